@@ -1,0 +1,305 @@
+"""ORACLE (test infrastructure, never shipped, never on the product path).
+
+CPU restatement of the reference's heatmap -> 3D lifting head, written as flat
+functions over a ``state_dict`` (the reference's own key names, SURVEY.md
+Appendix B) with plain torch CPU tensor ops.  Pinned against golden vectors
+captured from the reference's own modules (tests/golden/lift_fwd_*.npz,
+pu_chain_*.npz, fcblock.npz, loss_*.npz; generator tools/make_golden.py), see
+tests/test_oracle_golden.py.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline
+leg may import this file.
+
+Reference lines restated (all under /root/reference):
+  model/net_architecture.py:682-758   EgoTAPAutoEncoder.forward  -> lift_forward
+  model/net_architecture.py:370-415   PatchedHeatmapFeatureExtractorViT.forward -> pos_encoder
+  model/net_architecture.py:263-274   HeatmapFeatureExtractorFC.forward -> rot_encoder
+  model/net_architecture.py:513-576 + model/custom_cells.py:94-197  SkelNet/PU -> pu_chain
+  model/modeling_vit.py:128-157, 195, 226-252, 271, 319-344, 366-384, 608-609 -> vit_*
+  model/network_utils.py:123-142      make_fc_layer -> fc_block
+  utils/loss.py:54-85                 LossFuncCosSim / LossFuncMPJPE -> loss_*
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+UE_PARENTS = [0, 0, 1, 1, 2, 3, 4, 5, 2, 3, 8, 9, 10, 11, 12, 13]            # utils/util.py:51
+EC_PARENTS = [0, 0, 1, 2, 3, 4, 1, 6, 7, 8, 2, 10, 11, 12, 6, 14, 15, 16]   # utils/util.py:52
+
+
+@dataclass(frozen=True)
+class LiftPreset:
+    name: str
+    n_joints_hm: int          # J: heatmaps per eye (= PU chain length)
+    estimate_head: bool       # UE: extra head joint from global_mlp, appended LAST
+    hm_size: int = 64
+    hidden: int = 128         # ae_hidden_size
+    vit_dim: int = 1024
+    vit_heads: int = 8
+    vit_layers: int = 3
+    patch: int = 16
+
+    @property
+    def tokens(self):          # T = 2J (stereo)
+        return 2 * self.n_joints_hm
+
+    @property
+    def grid(self):            # heatmaps per side of the tiled ViT image (net_architecture.py:328)
+        return int(math.sqrt(self.tokens - 1)) + 1
+
+    @property
+    def ppd(self):             # patches per heatmap side
+        return self.hm_size // self.patch
+
+    @property
+    def side(self):            # patches per side of the ViT image
+        return self.grid * self.ppd
+
+    @property
+    def seq(self):
+        return self.side * self.side
+
+    @property
+    def out_joints(self):
+        return self.n_joints_hm + (1 if self.estimate_head else 0)
+
+    @property
+    def in_channels(self):     # 2J position + 4J sin/cos
+        return 6 * self.n_joints_hm
+
+
+UE = LiftPreset("UnrealEgo", 15, True)
+EC = LiftPreset("EgoCap", 17, False)
+
+
+def preset_by_name(name: str, hm_size: int = 64) -> LiftPreset:
+    base = {"UnrealEgo": UE, "EgoCap": EC}[name]
+    return LiftPreset(base.name, base.n_joints_hm, base.estimate_head, hm_size)
+
+
+# ---------------------------------------------------------------------------
+def layer_norm(x, w, b, eps=1e-12):
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def gelu_erf(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def fc_block(x, sd, prefix, training=False, momentum=0.1, eps=1e-5):
+    """LeakyReLU_0.2(BatchNorm1d(x W^T + b)); network_utils.py:123-142.
+
+    training=True uses batch statistics and returns the updated running stats
+    (unbiased variance, momentum 0.1) as torch's BatchNorm1d does.
+    """
+    z = x @ sd[prefix + ".fc.weight"].T + sd[prefix + ".fc.bias"]
+    g, beta = sd[prefix + ".bn.weight"], sd[prefix + ".bn.bias"]
+    if training:
+        mean = z.mean(dim=0)
+        var_b = ((z - mean) ** 2).mean(dim=0)
+        n = z.shape[0]
+        new_rm = (1 - momentum) * sd[prefix + ".bn.running_mean"] + momentum * mean
+        new_rv = (1 - momentum) * sd[prefix + ".bn.running_var"] + momentum * var_b * n / (n - 1)
+        y = (z - mean) / torch.sqrt(var_b + eps) * g + beta
+        return F.leaky_relu(y, 0.2), (new_rm, new_rv)
+    mean, var = sd[prefix + ".bn.running_mean"], sd[prefix + ".bn.running_var"]
+    y = (z - mean) / torch.sqrt(var + eps) * g + beta
+    return F.leaky_relu(y, 0.2)
+
+
+def tile_to_patches(pos_hm, p: LiftPreset):
+    """[B,T,hm,hm] -> ([B, seq, patch*patch], dummy_mask[seq]).
+
+    Heatmap i sits at grid cell (i // grid, i % grid) of a (grid*hm)^2 image whose
+    unused cells are zero (net_architecture.py:375-383); the image is cut in
+    row-major 16x16 patches (modeling_vit.py:195).
+    """
+    B, T = pos_hm.shape[:2]
+    G, hm, ps, S = p.grid, p.hm_size, p.patch, p.side
+    cells = torch.zeros(B, G * G, hm, hm, dtype=pos_hm.dtype)
+    cells[:, :T] = pos_hm
+    img = cells.view(B, G, G, hm, hm).permute(0, 1, 3, 2, 4).reshape(B, G * hm, G * hm)
+    patches = img.view(B, S, ps, S, ps).permute(0, 1, 3, 2, 4).reshape(B, S * S, ps * ps)
+    cell_of_patch = (torch.arange(S)[:, None] // p.ppd) * G + (torch.arange(S)[None, :] // p.ppd)
+    dummy = (cell_of_patch >= T).reshape(-1)
+    return patches, dummy
+
+
+def vit_embed(pos_hm, sd, p: LiftPreset, pre="pos_heatmap_encoder.vit."):
+    patches, dummy = tile_to_patches(pos_hm, p)
+    w = sd[pre + "embeddings.patch_embeddings.projection.weight"].reshape(p.vit_dim, -1)
+    b = sd[pre + "embeddings.patch_embeddings.projection.bias"]
+    emb = patches @ w.T + b
+    mask_tok = sd[pre + "embeddings.mask_token"].reshape(-1)
+    emb = torch.where(dummy[None, :, None], mask_tok[None, None, :], emb)
+    return emb + sd[pre + "embeddings.position_embeddings"]
+
+
+def vit_layer(x, sd, pre, heads):
+    B, N, D = x.shape
+    dh = D // heads
+    h = layer_norm(x, sd[pre + "layernorm_before.weight"], sd[pre + "layernorm_before.bias"])
+    a = pre + "attention.attention."
+    q = (h @ sd[a + "query.weight"].T + sd[a + "query.bias"]).view(B, N, heads, dh).transpose(1, 2)
+    k = (h @ sd[a + "key.weight"].T + sd[a + "key.bias"]).view(B, N, heads, dh).transpose(1, 2)
+    v = (h @ sd[a + "value.weight"].T + sd[a + "value.bias"]).view(B, N, heads, dh).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    ctx = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, N, D)
+    x = x + ctx @ sd[pre + "attention.output.dense.weight"].T + sd[pre + "attention.output.dense.bias"]
+    h = layer_norm(x, sd[pre + "layernorm_after.weight"], sd[pre + "layernorm_after.bias"])
+    h = gelu_erf(h @ sd[pre + "intermediate.dense.weight"].T + sd[pre + "intermediate.dense.bias"])
+    return x + h @ sd[pre + "output.dense.weight"].T + sd[pre + "output.dense.bias"]
+
+
+def pos_encoder(pos_hm, sd, p: LiftPreset, trace=None, training=False):
+    """[B,T,hm,hm] -> [B*T, hidden]  (T tokens in [L_1..L_J, R_1..R_J] order)."""
+    pre = "pos_heatmap_encoder."
+    x = vit_embed(pos_hm, sd, p)
+    if trace is not None:
+        trace["emb"] = x
+    for i in range(p.vit_layers):
+        x = vit_layer(x, sd, f"{pre}vit.encoder.layer.{i}.", p.vit_heads)
+        if trace is not None:
+            trace[f"layer{i}"] = x
+    x = layer_norm(x, sd[pre + "vit.layernorm.weight"], sd[pre + "vit.layernorm.bias"])
+    if trace is not None:
+        trace["final_ln"] = x
+    B, T, G, q, S, D = pos_hm.shape[0], p.tokens, p.grid, p.ppd, p.side, p.vit_dim
+    # heatmap i <- its q x q patches, flattened (patch-row, patch-col, channel); net_architecture.py:388-402
+    grid = x.view(B, G, q, G, q, D).permute(0, 1, 3, 2, 4, 5).reshape(B, G * G, q * q * D)
+    z = grid[:, :T].reshape(B * T, q * q * D)
+    stats = {}
+    for name in ("fc1", "fc2", "fc3"):
+        z = fc_block(z, sd, pre + name, training)
+        if training:
+            z, stats[pre + name] = z
+    return (z, stats) if training else z
+
+
+def rot_relayout(rot_hm, p: LiftPreset):
+    """[B,4J,hm,hm] (L_cos[J], L_sin[J], R_cos[J], R_sin[J]) -> [B*2J, 2*hm*hm]
+    rows ordered [L_1..L_J, R_1..R_J], each row = (cos map | sin map); net_architecture.py:690-694."""
+    B, J, hm = rot_hm.shape[0], p.n_joints_hm, p.hm_size
+    return rot_hm.view(B, 2, 2, J, hm * hm).permute(0, 1, 3, 2, 4).reshape(B * 2 * J, 2 * hm * hm)
+
+
+def rot_encoder(rot_hm, sd, p: LiftPreset, training=False):
+    z = rot_relayout(rot_hm, p)
+    stats = {}
+    for name in ("fc1", "fc2", "fc3"):
+        z = fc_block(z, sd, "rot_heatmap_encoder." + name, training)
+        if training:
+            z, stats["rot_heatmap_encoder." + name] = z
+    return (z, stats) if training else z
+
+
+def stereo_interleave(z, B, p: LiftPreset):
+    """[B*2J, h] (eye-major) -> [B, J, 2h] with joint j = [left_j | right_j]; net_architecture.py:699-705."""
+    J, h = p.n_joints_hm, z.shape[-1]
+    return z.view(B, 2, J, h).transpose(1, 2).reshape(B, J, 2 * h)
+
+
+def _pu_cell(x, b, h, c, sd, pre, hidden):
+    f = x @ sd[pre + "x2f.weight"].T + sd[pre + "x2f.bias"]
+    h = torch.sigmoid(f[:, :hidden]) * h
+    g = x @ sd[pre + "x2h.weight"].T + sd[pre + "x2h.bias"] + h @ sd[pre + "h2h.weight"].T + sd[pre + "h2h.bias"]
+    if b is not None:
+        b = torch.sigmoid(f[:, hidden:]) * b
+        g = g + b @ sd[pre + "b2h.weight"].T + sd[pre + "b2h.bias"]
+    fg, ig, cg, og = g.chunk(4, dim=1)     # forget, input, cell, output: custom_cells.py:109
+    c = c * torch.sigmoid(fg) + torch.sigmoid(ig) * torch.tanh(cg)
+    return torch.sigmoid(og) * torch.tanh(c), c
+
+
+def pu_chain(x_seq, b_seq, sd, pre="skel_sequential_layer.lstm_custom.layers.", hidden=512, tree_parents=None):
+    """x_seq, b_seq: [J, B, 256] -> [J, B, 512].
+
+    The reference's PropagationUnit writes its new state into the caller's
+    tensors (custom_cells.py:190-191), so SkelNet's per-joint state lists alias
+    ONE tensor and the recurrence is a chain over joint index, a 2-layer
+    modified LSTM.  ``tree_parents`` (kinematic parent list)
+    computes what a real tree propagation would give -- the WRONG answer, kept
+    only so a test can show the fixtures discriminate the two.
+    """
+    J, B = x_seq.shape[:2]
+    zero = torch.zeros(B, hidden, dtype=x_seq.dtype)
+    if tree_parents is None:
+        h0, c0, h1, c1 = zero, zero, zero, zero
+        out = []
+        for t in range(J):
+            h0, c0 = _pu_cell(x_seq[t], b_seq[t], h0, c0, sd, pre + "0.", hidden)
+            h1, c1 = _pu_cell(h0, None, h1, c1, sd, pre + "1.", hidden)
+            out.append(h1)
+        return torch.stack(out)
+    states = [(zero, zero, zero, zero)]
+    out = []
+    for i in range(1, len(tree_parents)):
+        h0, c0, h1, c1 = states[tree_parents[i]]
+        h0, c0 = _pu_cell(x_seq[i - 1], b_seq[i - 1], h0, c0, sd, pre + "0.", hidden)
+        h1, c1 = _pu_cell(h0, None, h1, c1, sd, pre + "1.", hidden)
+        states.append((h0, c0, h1, c1))
+        out.append(h1)
+    return torch.stack(out)
+
+
+def pose_head(pos_j, skel, sd, p: LiftPreset):
+    """pos_j [B,J,256], skel [J,B,512] -> [B, out_joints, 3]; net_architecture.py:732-751."""
+    B, J = pos_j.shape[0], p.n_joints_hm
+    skel_b = skel.transpose(0, 1)                                  # [B,J,512]
+    feat = torch.cat([pos_j, skel_b], dim=-1)                      # [B,J,768]
+    pose = feat @ sd["pose_mlp.pose_fcs.0.weight"].T + sd["pose_mlp.pose_fcs.0.bias"]
+    if p.estimate_head:
+        other = skel_b.reshape(B, -1) @ sd["global_mlp.pose_fcs.0.weight"].T + sd["global_mlp.pose_fcs.0.bias"]
+        pose = pose + other[:, None, :3]
+        pose = torch.cat([pose, other[:, None, 3:]], dim=1)         # head joint LAST
+    return pose
+
+
+def lift_forward(hm, sd, p: LiftPreset, trace=None):
+    """hm [B, 6J, hm, hm] -> pose [B, out_joints, 3] (eval mode)."""
+    B, J = hm.shape[0], p.n_joints_hm
+    pos = pos_encoder(hm[:, : 2 * J], sd, p, trace)
+    rot = rot_encoder(hm[:, 2 * J:], sd, p)
+    pos_j = stereo_interleave(pos, B, p)
+    rot_j = stereo_interleave(rot, B, p)
+    skel = pu_chain(pos_j.transpose(0, 1), rot_j.transpose(0, 1), sd)
+    pose = pose_head(pos_j, skel, sd, p)
+    if trace is not None:
+        trace["pos_embed"] = pos.reshape(B, -1)
+        trace["rot_embed"] = rot.reshape(B, -1)
+        trace["skel_embed"] = skel
+    return pose
+
+
+# ---------------------------------------------------------------------------
+def loss_mpjpe(pred, gt):
+    return torch.linalg.norm(gt - pred, dim=-1).mean()
+
+
+def loss_cos_sim(pred, gt, p: LiftPreset, eps=1e-8):
+    """Sum over bones of cos(bone_pred, bone_gt), mean over batch; utils/loss.py:54-77."""
+    parents = UE_PARENTS if p.estimate_head else EC_PARENTS
+    if not p.estimate_head:      # EgoCap: zero root prepended, first bone dropped afterwards
+        z = torch.zeros(pred.shape[0], 1, 3, dtype=pred.dtype)
+        pred, gt = torch.cat([z, pred], 1), torch.cat([z, gt], 1)
+    bp = (pred - pred[:, parents])[:, 1:]
+    bg = (gt - gt[:, parents])[:, 1:]
+    # nn.CosineSimilarity semantics: x.y / (max(|x|, eps) * max(|y|, eps))
+    cos = (bp * bg).sum(-1) / (bp.norm(dim=-1).clamp_min(eps) * bg.norm(dim=-1).clamp_min(eps))
+    if not p.estimate_head:
+        cos = cos[:, 1:]
+    return cos.sum(dim=1).mean()
+
+
+def to_torch_sd(np_sd, dtype=torch.float32):
+    out = {}
+    for k, v in np_sd.items():
+        t = torch.from_numpy(v)
+        out[k] = t.to(dtype) if t.is_floating_point() else t
+    return out

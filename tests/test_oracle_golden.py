@@ -1,0 +1,101 @@
+"""Pins the oracle (oracle/lift_ref.py) against golden vectors captured from the
+reference's own modules (tools/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from egotap_amd import spec
+from egotap_amd.synthetic import synth_state_dict, synth_input, synth_tensor
+from oracle import lift_ref as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def _sample(t, stride=997):
+    return t.reshape(-1)[::stride].numpy()
+
+
+@pytest.mark.parametrize("tag,preset", [("ue", "UnrealEgo"), ("ec", "EgoCap")])
+def test_state_spec_matches_reference(tag, preset):
+    g = _load(f"lift_fwd_{tag}_b2.npz")
+    p = spec.lift_preset(preset)
+    ours = spec.lift_state_spec(p)
+    assert [k for k, _ in ours] == list(g["state_keys"])
+    assert ["x".join(str(d) for d in shp) for _, shp in ours] == list(g["state_shapes"])
+    params = [k for k, _ in ours if not spec.is_buffer(k)]
+    assert params == list(g["param_keys"])
+    n_params = sum(int(np.prod(shp)) for k, shp in ours if not spec.is_buffer(k))
+    assert n_params == {"ue": 96_984_585, "ec": 96_938_499}[tag] or n_params > 96_000_000
+
+
+@pytest.mark.parametrize("tag,preset", [("ue", "UnrealEgo"), ("ec", "EgoCap")])
+def test_lift_forward_matches_reference(tag, preset):
+    g = _load(f"lift_fwd_{tag}_b2.npz")
+    p = spec.lift_preset(preset)
+    sd = O.to_torch_sd(synth_state_dict(spec.lift_state_spec(p)))
+    hm = torch.from_numpy(synth_input(f"hm_{tag}", (2, p.in_channels, 64, 64)))
+    trace = {}
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        pose = O.lift_forward(hm, sd, p, trace)
+    assert tuple(pose.shape) == (2, p.out_joints, 3)
+    np.testing.assert_allclose(pose.numpy(), g["pose"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(trace["pos_embed"].numpy(), g["pos_embed"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(trace["rot_embed"].numpy(), g["rot_embed"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(trace["skel_embed"].numpy(), g["skel_embed"], atol=1e-5, rtol=0)
+    for k in ("emb", "layer0", "layer1", "layer2", "final_ln"):
+        np.testing.assert_allclose(_sample(trace[k]), g[k + "_sample"], atol=2e-5, rtol=1e-5)
+        s = trace[k].double()
+        np.testing.assert_allclose([s.sum().item(), s.abs().sum().item()], g[k + "_stats"], rtol=1e-5)
+    assert bool(g["rot_is_zero"]) and bool(g["indep_is_zero"]) and bool(g["out_hm_is_zero"])
+
+
+@pytest.mark.parametrize("tag,preset", [("ue", "UnrealEgo"), ("ec", "EgoCap")])
+def test_pu_chain_is_chain_not_tree(tag, preset):
+    g = _load(f"pu_chain_{tag}.npz")
+    p = spec.lift_preset(preset)
+    full = spec.lift_state_spec(p)
+    sd = O.to_torch_sd(synth_state_dict([(k, s) for k, s in full if k.startswith("skel_sequential_layer.")]))
+    J = p.n_joints_hm
+    x = torch.from_numpy(synth_input(f"pu_x_{tag}", (J, 3, 256), -1.0, 1.0))
+    b = torch.from_numpy(synth_input(f"pu_b_{tag}", (J, 3, 256), -1.0, 1.0))
+    chain = O.pu_chain(x, b, sd)
+    np.testing.assert_allclose(chain.numpy(), g["out"], atol=1e-6, rtol=0)
+    parents = O.UE_PARENTS if preset == "UnrealEgo" else O.EC_PARENTS
+    tree = O.pu_chain(x, b, sd, tree_parents=parents)
+    assert tree.shape == chain.shape
+    assert float((tree - torch.from_numpy(g["out"])).abs().max()) > 1e-2   # the tree is the WRONG answer
+
+
+def test_fc_block_eval_and_train():
+    g = _load("fcblock.npz")
+    keys = [("fcblock.fc.weight", (64, 96)), ("fcblock.fc.bias", (64,)), ("fcblock.bn.weight", (64,)),
+            ("fcblock.bn.bias", (64,)), ("fcblock.bn.running_mean", (64,)), ("fcblock.bn.running_var", (64,))]
+    sd = {k: torch.from_numpy(synth_tensor(k, s)) for k, s in keys}
+    x = torch.from_numpy(synth_input("fcblock_x", (24, 96), -1.0, 1.0))
+    y = O.fc_block(x, sd, "fcblock")
+    np.testing.assert_allclose(y.numpy(), g["y_eval"], atol=1e-6)
+    y, (rm, rv) = O.fc_block(x, sd, "fcblock", training=True)
+    np.testing.assert_allclose(y.numpy(), g["y_train"], atol=2e-6)
+    np.testing.assert_allclose(rm.numpy(), g["running_mean"], atol=1e-6)
+    np.testing.assert_allclose(rv.numpy(), g["running_var"], atol=1e-6)
+    assert int(g["num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("tag,preset,nj", [("ue", "UnrealEgo", 16), ("ec", "EgoCap", 17)])
+def test_losses(tag, preset, nj):
+    g = _load(f"loss_{tag}.npz")
+    p = spec.lift_preset(preset)
+    pred = torch.from_numpy(synth_input(f"loss_pred_{tag}", (5, nj, 3), -20.0, 20.0)).requires_grad_(True)
+    gt = torch.from_numpy(synth_input(f"loss_gt_{tag}", (5, nj, 3), -20.0, 20.0))
+    mp, cs = O.loss_mpjpe(pred, gt), O.loss_cos_sim(pred, gt, p)
+    np.testing.assert_allclose(mp.item(), g["mpjpe"], rtol=1e-6)
+    np.testing.assert_allclose(cs.item(), g["cos_sim"], rtol=1e-5)
+    (grad,) = torch.autograd.grad(0.1 * mp + (-0.01) * 0.1 * cs, pred)
+    np.testing.assert_allclose(grad.numpy(), g["dtotal_dpred"], atol=1e-7)

@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules on CPU.
+
+Runs only in the build container (needs /root/reference).  Nothing from the
+reference is copied: its modules are imported in place, their parameters are
+overwritten with the hash-RNG weights of ``egotap_amd.synthetic`` (so no weight
+is ever stored), they are run on synthetic inputs and the outputs are saved as
+small fixtures.  The GPU box only ever sees the fixtures.
+
+Shims applied before the import (each fills a hole left by a package that is
+missing or newer here than the reference pins; none touches reference
+arithmetic) -- SURVEY.md section 8(c):
+  1. transformers.pytorch_utils.find_pruneable_heads_and_indices (removed in
+     transformers 5; only used by the never-called prune_heads)
+  2. ViTModel.get_head_mask -> [None] * num_layers (4.33 semantics for None)
+  3. sys.modules['torchvision'(.models)] -> stub whose resnet18 is this repo's
+     own ResNet-18 restatement (oracle/hm_ref.py); torchvision is not installed
+  4. empty skimage / skimage.draw / cv2 stubs (transitive imports, never run)
+  5. torch.Tensor.cuda -> .to(device or 'cpu') (the wrapper hard-codes .cuda())
+
+usage: python tools/make_golden.py [--only lift,pu,fc,loss,hm]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+GOLD = os.path.join(REPO, "tests", "golden")
+
+from egotap_amd.synthetic import synth_tensor, synth_input  # noqa: E402
+
+
+# --------------------------------------------------------------------------
+def apply_shims():
+    import transformers.pytorch_utils as tpu
+
+    if not hasattr(tpu, "find_pruneable_heads_and_indices"):
+        tpu.find_pruneable_heads_and_indices = lambda *a, **k: None
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tv.models = tvm
+    try:
+        from oracle import hm_ref
+
+        tvm.resnet18 = lambda pretrained=False, **k: hm_ref.ResNet18Holder()
+    except Exception:  # lifting-head fixtures do not need a backbone
+        pass
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tvm
+    for n in ("skimage", "skimage.draw", "cv2"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules["skimage.draw"].line_aa = None
+    torch.Tensor.cuda = lambda self, device=None, **k: self.to(device or "cpu")
+    sys.path.insert(0, REF)
+    import model.modeling_vit as mv
+
+    if not hasattr(mv.ViTModel, "get_head_mask"):
+        mv.ViTModel.get_head_mask = lambda self, head_mask, n, *a, **k: [None] * n
+    else:
+        try:
+            mv.ViTModel.get_head_mask(object.__new__(mv.ViTModel), None, 1)
+        except Exception:
+            mv.ViTModel.get_head_mask = lambda self, head_mask, n, *a, **k: [None] * n
+
+
+def make_opt(preset: str, hm: int = 64):
+    o = types.SimpleNamespace()
+    o.joint_preset = preset
+    nj = 15 if preset == "UnrealEgo" else 17
+    o.num_heatmap = nj
+    o.num_rot_heatmap = nj
+    o.heatmap_type = "sin"
+    o.ae_hidden_size = 128
+    o.patched_heatmap_ae = True
+    o.skel_layer = "PU"
+    o.load_size_heatmap = [hm, hm]
+    o.estimate_head = preset == "UnrealEgo"
+    o.stereo = True
+    o.init_ImageNet = False
+    o.model_name = "resnet18"
+    return o
+
+
+def load_synth(module: torch.nn.Module, salt: str = ""):
+    """Overwrite every parameter and buffer with its hash-RNG value."""
+    sd = module.state_dict()
+    new = {k: torch.from_numpy(synth_tensor(salt + k, tuple(v.shape))) for k, v in sd.items()}
+    module.load_state_dict(new, strict=True)
+
+
+def sample(t: torch.Tensor, stride: int = 997) -> np.ndarray:
+    return t.detach().reshape(-1)[::stride].to(torch.float32).numpy().copy()
+
+
+def stats(t: torch.Tensor) -> np.ndarray:
+    d = t.detach().double()
+    return np.array([d.sum().item(), d.abs().sum().item()], dtype=np.float64)
+
+
+# --------------------------------------------------------------------------
+def gen_lift(tag: str, preset: str, batch: int = 2):
+    import model.net_architecture as na
+
+    torch.manual_seed(0)
+    opt = make_opt(preset)
+    net = na.EgoTAPAutoEncoder(opt, input_channel_scale=2)
+    load_synth(net)
+    net.eval()
+    nj = opt.num_heatmap
+    hm = torch.from_numpy(synth_input(f"hm_{tag}", (batch, 6 * nj, 64, 64)))
+
+    cap = {}
+
+    def hook(name):
+        def f(mod, inp, out):
+            cap[name] = out[0] if isinstance(out, tuple) else out
+        return f
+
+    vit = net.pos_heatmap_encoder.vit
+    hs = [vit.embeddings.register_forward_hook(hook("emb"))]
+    for i, layer in enumerate(vit.encoder.layer):
+        hs.append(layer.register_forward_hook(hook(f"layer{i}")))
+    hs.append(vit.layernorm.register_forward_hook(hook("final_ln")))
+    hs.append(net.pos_heatmap_encoder.register_forward_hook(hook("pos_embed")))
+    hs.append(net.rot_heatmap_encoder.register_forward_hook(hook("rot_embed")))
+    with torch.no_grad():
+        pose, rot, indep, out_hm = net(hm)
+    for h in hs:
+        h.remove()
+    out = {
+        "preset": np.array(preset),
+        "batch": np.array(batch),
+        "pose": pose.detach().numpy(),
+        "pos_embed": cap["pos_embed"].detach().numpy(),
+        "rot_embed": cap["rot_embed"].detach().numpy(),
+        "skel_embed": net.skel_embed.detach().numpy(),
+        "rot_is_zero": np.array(float(rot.abs().max()) == 0.0 and tuple(rot.shape) == (batch, 3 * nj)),
+        "indep_is_zero": np.array(float(indep.abs().max()) == 0.0 and tuple(indep.shape) == (batch, 6 * nj)),
+        "out_hm_is_zero": np.array(float(out_hm.abs().max()) == 0.0 and tuple(out_hm.shape) == tuple(hm.shape)),
+    }
+    ref_sd = net.state_dict()
+    out["state_keys"] = np.array(list(ref_sd.keys()))
+    out["state_shapes"] = np.array(["x".join(str(d) for d in v.shape) for v in ref_sd.values()])
+    out["param_keys"] = np.array([k for k, _ in net.named_parameters()])
+    for k in ("emb", "layer0", "layer1", "layer2", "final_ln"):
+        out[k + "_sample"] = sample(cap[k])
+        out[k + "_stats"] = stats(cap[k])
+    np.savez_compressed(os.path.join(GOLD, f"lift_fwd_{tag}_b{batch}.npz"), **out)
+    print(f"lift_fwd_{tag}: pose[0,:2] =", pose[0, :2].tolist())
+
+
+def gen_pu():
+    import model.net_architecture as na
+
+    for tag, preset in (("ue", "UnrealEgo"), ("ec", "EgoCap")):
+        opt = make_opt(preset)
+        skel = na.SkelNet(opt, input_size=256, bridge_size=256, num_layers=2, batch_first=False, layer_type="PU")
+        load_synth(skel, salt="skel_sequential_layer.")
+        skel.eval()
+        nj = opt.num_heatmap
+        x = torch.from_numpy(synth_input(f"pu_x_{tag}", (nj, 3, 256), -1.0, 1.0))
+        b = torch.from_numpy(synth_input(f"pu_b_{tag}", (nj, 3, 256), -1.0, 1.0))
+        with torch.no_grad():
+            y = skel(input=x, bridge=b)
+        np.savez_compressed(os.path.join(GOLD, f"pu_chain_{tag}.npz"), out=y.numpy())
+        print(f"pu_chain_{tag}:", tuple(y.shape), float(y.abs().mean()))
+
+
+def gen_fcblock():
+    import model.network_utils as nu
+
+    blk = nu.make_fc_layer(96, 64)
+    load_synth(blk, salt="fcblock.")
+    x = torch.from_numpy(synth_input("fcblock_x", (24, 96), -1.0, 1.0))
+    blk.eval()
+    with torch.no_grad():
+        y_eval = blk(x)
+    blk.train()
+    with torch.no_grad():
+        y_train = blk(x)
+    np.savez_compressed(
+        os.path.join(GOLD, "fcblock.npz"),
+        y_eval=y_eval.numpy(),
+        y_train=y_train.numpy(),
+        running_mean=blk.bn.running_mean.numpy(),
+        running_var=blk.bn.running_var.numpy(),
+        num_batches_tracked=blk.bn.num_batches_tracked.numpy(),
+    )
+    print("fcblock ok")
+
+
+def gen_loss():
+    import utils.loss as L
+
+    for tag, preset, nj, head in (("ue", "UnrealEgo", 16, True), ("ec", "EgoCap", 17, False)):
+        pred = torch.from_numpy(synth_input(f"loss_pred_{tag}", (5, nj, 3), -20.0, 20.0)).requires_grad_(True)
+        gt = torch.from_numpy(synth_input(f"loss_gt_{tag}", (5, nj, 3), -20.0, 20.0))
+        mp = L.LossFuncMPJPE()(pred, gt)
+        cs = L.LossFuncCosSim(joint_preset=preset, estimate_head=head)(pred, gt)
+        total = 0.1 * mp + (-0.01) * 0.1 * cs
+        (g,) = torch.autograd.grad(total, pred)
+        np.savez_compressed(
+            os.path.join(GOLD, f"loss_{tag}.npz"),
+            mpjpe=mp.detach().numpy(), cos_sim=cs.detach().numpy(), dtotal_dpred=g.numpy(),
+        )
+        print(f"loss_{tag}:", float(mp), float(cs))
+
+
+def gen_hm():
+    """E1-E9: the reference's HeatMap_UnrealEgo_Shared with OUR ResNet-18 restatement
+    standing in for torchvision (parity of the backbone itself is unpinned)."""
+    import model.net_architecture as na
+
+    for tag, n_pos, n_rot in (("pos", 15, 0), ("rot", 0, 15)):
+        opt = make_opt("UnrealEgo")
+        opt.num_heatmap, opt.num_rot_heatmap = n_pos, n_rot
+        net = na.HeatMap_UnrealEgo_Shared(opt, "resnet18", input_channel_scale=2)
+        load_synth(net, salt=f"hm_{tag}.")
+        net.eval()
+        left = torch.from_numpy(synth_input("rgb_left", (1, 3, 256, 256), -2.0, 2.0))
+        right = torch.from_numpy(synth_input("rgb_right", (1, 3, 256, 256), -2.0, 2.0))
+        cap = {}
+
+        def hook(name):
+            def f(mod, inp, out):
+                cap[name] = out
+            return f
+
+        ab = net.after_backbone
+        hs = [getattr(ab, n).register_forward_hook(hook(n)) for n in
+              ("layer4_1x1", "layer3_1x1", "conv_up3", "conv_up2", "conv_up1")]
+        hs.append(net.backbone.backbone.register_forward_hook(hook("pyramid")))
+        with torch.no_grad():
+            y = net(left, right)
+        for h in hs:
+            h.remove()
+        out = {"out_sample": sample(y, 97), "out_stats": stats(y), "out_shape": np.array(y.shape),
+               "out_ch0": y[0, 0].numpy(), "out_last": y[0, -1].numpy()}
+        for k in ("layer4_1x1", "layer3_1x1", "conv_up3", "conv_up2", "conv_up1"):
+            out[k + "_sample"] = sample(cap[k], 997)
+            out[k + "_stats"] = stats(cap[k])
+        for i, t in enumerate(cap["pyramid"][1:], start=0):   # layer0..layer4 of the RIGHT eye (last call)
+            out[f"pyr{i}_sample"] = sample(t, 997)
+            out[f"pyr{i}_stats"] = stats(t)
+        np.savez_compressed(os.path.join(GOLD, f"hm_full_{tag}.npz"), **out)
+        print(f"hm_full_{tag}:", tuple(y.shape), float(y.abs().mean()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="lift,pu,fc,loss,hm")
+    args = ap.parse_args()
+    which = set(args.only.split(","))
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    apply_shims()
+    if "lift" in which:
+        gen_lift("ue", "UnrealEgo")
+        gen_lift("ec", "EgoCap")
+    if "pu" in which:
+        gen_pu()
+    if "fc" in which:
+        gen_fcblock()
+    if "loss" in which:
+        gen_loss()
+    if "hm" in which:
+        gen_hm()
+
+
+if __name__ == "__main__":
+    main()
