@@ -1,0 +1,171 @@
+// Fused softmax attention, fp32 on the matrix cores (modeling_vit.py:226-252):
+//   ctx[b, n, h*128:(h+1)*128] = softmax(Q_h K_h^T / sqrt(128)) V_h,   no mask, no dropout.
+// Q, K, V are read in place from the fused QKV GEMM output [B*N, 3*D] (no permute copies) and the
+// [B, heads, N, N] score tensor of the reference (2.7 GB per layer at B = 256) is never materialised.
+//
+// One wave = 32 query rows; a workgroup of NW waves shares 32-key K/V tiles through LDS.
+//   S^T = K_tile Q^T : 32x32 MFMA tile with the KEY on the accumulator row and the QUERY on the lane
+//         column, so the online-softmax state (running max / sum) is one scalar per lane and the
+//         accumulator registers are, as they stand, the B operand of the next product:
+//   O^T += V_tile^T P^T : four 32(d) x 32(q) MFMA tiles, A operand = V read row-wise from LDS.
+// The MFMA k index is permuted like in gemm_f32.h so Q lives in 64 registers loaded as float4 and
+// each K fragment is one ds_read_b128 (K rows padded to 132 floats: conflict free).
+#pragma once
+#include "common.h"
+#include <math.h>
+
+template <int NW>
+struct AttnCfg {
+    static constexpr int DH = 128, KT = 32, KLD = DH + 4, THREADS = 64 * NW;
+    static constexpr int TILE_FLOATS = KT * KLD + KT * DH;
+    static constexpr int OUT_FLOATS = NW * 32 * KLD;
+    static constexpr int LDS_BYTES = 4 * (TILE_FLOATS > OUT_FLOATS ? TILE_FLOATS : OUT_FLOATS);
+};
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* __restrict__ QKV,
+                                                                 float* __restrict__ CTX, int N, int heads,
+                                                                 int qgroups, float scale_log2e) {
+    using Cfg = AttnCfg<NW>;
+    constexpr int DH = Cfg::DH, KT = Cfg::KT, KLD = Cfg::KLD, THREADS = Cfg::THREADS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                 // [32][132]
+    float* Vs = smem + KT * KLD;      // [32][128]
+
+    // blocks that share an L2 (same blockIdx % 8) get a contiguous run of (batch, head) pairs
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, x8 = bid & 7;
+    const int lin = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (bid >> 3);
+    const int bh = lin / qgroups, qg = lin - bh * qgroups;
+    const int b = bh / heads, h = bh - b * heads;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int D = heads * DH;
+    const long ld = 3L * D;
+    const float* base = QKV + (long)b * N * ld + h * DH;     // q of token 0 of this (b, h)
+    const int qb = qg * NW + wid;                              // 32-row query block of this wave
+    const bool valid = qb * 32 < N;                            // wave-uniform
+
+    float qreg[64];
+    {
+        const float* qp = base + (long)(min(qb * 32, N - 32) + l31) * ld + 4 * lh;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4 v = *(const f32x4*)(qp + 8 * t);
+            qreg[4 * t + 0] = v[0]; qreg[4 * t + 1] = v[1]; qreg[4 * t + 2] = v[2]; qreg[4 * t + 3] = v[3];
+        }
+    }
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = N / KT;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();   // every wave is done with the previous tile
+        {   // K then V through registers (two short phases keep the staging at 16 float4 per lane)
+            const float* kp = base + (long)(kt * KT) * ld + D;
+            constexpr int PER = KT * (DH / 4) / THREADS;
+            f32x4 st[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
+                st[i] = *(const f32x4*)(kp + (long)row * ld + c4 * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
+                *(f32x4*)(Ks + row * KLD + c4 * 4) = st[i];
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
+                st[i] = *(const f32x4*)(kp + (long)row * ld + D + c4 * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
+                *(f32x4*)(Vs + row * DH + c4 * 4) = st[i];
+            }
+        }
+        __syncthreads();
+        if (valid) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const float* kf = Ks + l31 * KLD + 4 * lh;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const f32x4 a = *(const f32x4*)(kf + 8 * t);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], qreg[4 * t + u], s, 0, 0, 0);
+            }
+            // online softmax; the 32 keys of this tile sit in 16 registers x 2 lane halves
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f((m_run - m_new) * scale_log2e);
+            const float mneg = -m_new * scale_log2e;
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = exp2f(fmaf(s[r], scale_log2e, mneg));
+                psum += s[r];
+            }
+            l_run = l_run * alpha + psum;     // per lane-half partial sum; halves are added at the end
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            // O^T += V^T P^T : step r contracts keys key(r,0), key(r,1)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* vf = Vs + ((r & 3) + 8 * (r >> 2) + 4 * lh) * DH + l31;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[dt * 32], s[r], o[dt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();   // K/V tiles are dead: reuse the LDS to turn O^T into row-major rows
+    if (valid) {
+        const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+        float* Os = smem + wid * 32 * KLD;     // [32 q][132]
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = o[dt][4 * g + c] * inv;
+                *(f32x4*)(Os + l31 * KLD + dt * 32 + 8 * g + 4 * lh) = v;
+            }
+        // same wave reads back what it wrote: no barrier needed, only LDS completion (compiler waits)
+        float* out = CTX + ((long)b * N + qb * 32) * D + h * DH;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 2 + lh;
+            const f32x4 v = *(const f32x4*)(Os + row * KLD + l31 * 4);
+            *(f32x4*)(out + (long)row * D + l31 * 4) = v;
+        }
+    }
+}
+
+static hipError_t attention_f32_launch(const float* QKV, float* CTX, int B, int N, int heads, hipStream_t stream) {
+    constexpr int NW = 2;
+    using Cfg = AttnCfg<NW>;
+    if (B <= 0) return hipSuccess;
+    if (N % 32 != 0) return hipErrorInvalidValue;
+    auto kern = attention_f32_kernel<NW>;
+    const int qgroups = (N / 32 + NW - 1) / NW;
+    const float scale_log2e = 1.4426950408889634f / sqrtf(128.0f);
+    hipLaunchKernelGGL(kern, dim3(B * heads * qgroups), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, QKV, CTX, N, heads,
+                       qgroups, scale_log2e);
+    return hipGetLastError();
+}

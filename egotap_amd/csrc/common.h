@@ -1,0 +1,78 @@
+// Shared host/device helpers for the egotap_amd HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "egotap.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define EGOTAP_WAVE 64
+
+// thread-local error text returned by egotap_last_error()
+void egotap_set_error(const char* fmt, ...);
+
+#define EGO_CHECK(cond, ...)                  \
+    do {                                      \
+        if (!(cond)) {                        \
+            egotap_set_error(__VA_ARGS__);    \
+            return EGOTAP_ERR_INVALID;        \
+        }                                     \
+    } while (0)
+
+#define EGO_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            egotap_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),    \
+                             __FILE__, __LINE__);                                      \
+            return EGOTAP_ERR_HIP;                                                     \
+        }                                                                              \
+    } while (0)
+
+
+// A vector of N floats that may be split over up to three equally long
+// segments (the ViT keeps query/key/value as three nn.Linear; we run them as
+// one GEMM without packing, so weights stay the caller's live tensors).
+struct SegVec {
+    const float* p[3];
+    int seg;  // floats per segment
+    __device__ __forceinline__ float at(int n) const { return p[n / seg][n % seg]; }
+};
+
+// [N,K] row-major weight (nn.Linear layout) split the same way along N.
+struct SegMat {
+    const float* p[3];
+    int seg;  // rows per segment
+    long ld;  // row stride (floats)
+    __device__ __forceinline__ const float* row(int n) const { return p[n / seg] + (long)(n % seg) * ld; }
+};
+
+static inline SegVec segvec1(const float* p, int n) {
+    SegVec v;
+    v.p[0] = p; v.p[1] = p; v.p[2] = p; v.seg = n > 0 ? n : 1;
+    return v;
+}
+static inline SegMat segmat1(const float* p, int n, long ld) {
+    SegMat v;
+    v.p[0] = p; v.p[1] = p; v.p[2] = p; v.seg = n > 0 ? n : 1; v.ld = ld;
+    return v;
+}
+
+// XCD-aware block -> tile map.  Blocks are dealt round-robin over the 8 XCDs
+// (blockIdx % 8 labels the group that shares an L2), so give every group a
+// contiguous chunk of a grouped tile order: inside a group of GM tile-rows
+// walk M fastest, then N.  Bijective for any grid size; placement affects
+// speed only (cdna_hip_programming.md T1).
+__device__ __forceinline__ void xcd_tile(int bid, int nblk, int tiles_m, int tiles_n, int GM, int& tm, int& tn) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    const int per_group = GM * tiles_n;
+    const int g = lin / per_group;
+    const int first = g * GM;
+    const int gsz = min(tiles_m - first, GM);
+    const int in = lin - g * per_group;
+    tm = first + in % gsz;
+    tn = in / gsz;
+}

@@ -1,0 +1,519 @@
+// C ABI of libegotap_hip.so (include/egotap.h): handle, parameter binding, the lifting-head forward
+// (EgoTAPAutoEncoder.forward, model/net_architecture.py:682-758) as a sequence of HIP launches on the
+// caller's stream, single-operator entry points and the GEMM timing hook.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "attention_f32.h"
+#include "common.h"
+#include "gemm_f32.h"
+#include "layernorm.h"
+#include "pu_chain.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+void egotap_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* egotap_last_error(void) { return g_err; }
+extern "C" int egotap_abi_version(void) { return EGOTAP_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------------ tiles
+using TileA = GemmCfg<128, 128, 32, 2, 2, 2>;   // 4 waves, 64x64 per wave, 2 blocks/CU
+using TileB = GemmCfg<256, 128, 32, 4, 2, 2>;   // 8 waves, 64x64 per wave, 1 block/CU
+using TileC = GemmCfg<128, 256, 32, 2, 4, 2>;   // 8 waves, 64x64 per wave, 1 block/CU
+using TileD = GemmCfg<256, 256, 16, 4, 2, 2>;   // 8 waves, 64x128 per wave, 1 block/CU
+using TileE = GemmCfg<256, 128, 16, 2, 2, 2>;   // 4 waves, 128x64 per wave, 2 blocks/CU
+using TileF = GemmCfg<64, 64, 32, 2, 2, 2>;     // 4 waves, 32x32 per wave (small problems)
+using TileG = GemmCfg<256, 128, 32, 2, 2, 1>;   // 4 waves, 128x64 per wave, 1 block/CU
+
+extern "C" const char* egotap_gemm_tile_name(int tile) {
+    switch (tile) {
+        case 0: case 1: return "128x128x32/4w";
+        case 2: return "256x128x32/8w";
+        case 3: return "128x256x32/8w";
+        case 4: return "256x256x16/8w";
+        case 5: return "256x128x16/4w";
+        case 6: return "64x64x32/4w";
+        case 7: return "256x128x32/4w";
+        default: return nullptr;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ handle
+struct Param {
+    void* ptr = nullptr;
+    int64_t numel = 0;
+    int dtype = EGOTAP_F32;
+};
+
+struct LiftParams {   // resolved raw pointers of net_AutoEncoder
+    const float *mask_tok, *pos_emb, *patch_w, *patch_b;
+    struct Layer {
+        const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *o_w, *o_b, *up_w, *up_b, *dn_w, *dn_b;
+        const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    } layer[8];
+    const float *lnf_g, *lnf_b;
+    struct Fc { const float *w, *b, *g, *beta, *mean, *var; } pos_fc[3], rot_fc[3];
+    const float *x2f0_w, *x2f0_b, *x2h0_w, *x2h0_b, *b2h0_w, *b2h0_b, *h2h0_w, *h2h0_b;
+    const float *x2f1_w, *x2f1_b, *x2h1_w, *x2h1_b, *h2h1_w, *h2h1_b;
+    const float *pose_w, *pose_b, *glob_w, *glob_b;
+};
+
+struct egotap_handle_s {
+    egotap_config cfg;
+    // derived (spec.py LiftPreset)
+    int J, T, grid, ppd, side, seq, C, D, H, hid, out_joints;
+    std::unordered_map<std::string, int64_t> expect[EGOTAP_NET_COUNT];   // key -> numel (forward-needed keys)
+    std::unordered_map<std::string, Param> bound[EGOTAP_NET_COUNT];
+    bool lift_resolved = false;
+    LiftParams lp;
+    int debug_stop = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;   // start/stop pairs
+    size_t ev_used = 0;
+    double flops = 0.0;
+};
+typedef egotap_handle_s Handle;
+
+static int isqrt_floor(int v) {
+    int r = 0;
+    while ((r + 1) * (r + 1) <= v) ++r;
+    return r;
+}
+
+static void lift_expect(Handle* h) {
+    auto& e = h->expect[EGOTAP_NET_LIFT];
+    const int64_t D = h->D, H = h->H, hid = h->hid, x = 2 * hid;
+    const std::string v = "pos_heatmap_encoder.vit.";
+    e[v + "embeddings.mask_token"] = D;
+    e[v + "embeddings.position_embeddings"] = (int64_t)h->seq * D;
+    e[v + "embeddings.patch_embeddings.projection.weight"] = D * h->cfg.patch * h->cfg.patch;
+    e[v + "embeddings.patch_embeddings.projection.bias"] = D;
+    auto lin = [&](const std::string& p, int64_t n_out, int64_t n_in) {
+        e[p + ".weight"] = n_out * n_in;
+        e[p + ".bias"] = n_out;
+    };
+    for (int i = 0; i < h->cfg.vit_layers; ++i) {
+        const std::string l = v + "encoder.layer." + std::to_string(i) + ".";
+        lin(l + "attention.attention.query", D, D);
+        lin(l + "attention.attention.key", D, D);
+        lin(l + "attention.attention.value", D, D);
+        lin(l + "attention.output.dense", D, D);
+        lin(l + "intermediate.dense", 4 * D, D);
+        lin(l + "output.dense", D, 4 * D);
+        e[l + "layernorm_before.weight"] = D; e[l + "layernorm_before.bias"] = D;
+        e[l + "layernorm_after.weight"] = D;  e[l + "layernorm_after.bias"] = D;
+    }
+    e[v + "layernorm.weight"] = D; e[v + "layernorm.bias"] = D;
+    auto fcb = [&](const std::string& p, int64_t n_in, int64_t n_out) {
+        lin(p + ".fc", n_out, n_in);
+        e[p + ".bn.weight"] = n_out; e[p + ".bn.bias"] = n_out;
+        e[p + ".bn.running_mean"] = n_out; e[p + ".bn.running_var"] = n_out;
+    };
+    const int64_t k_pos = (int64_t)h->ppd * h->ppd * D, k_rot = 2LL * h->cfg.hm_size * h->cfg.hm_size;
+    fcb("pos_heatmap_encoder.fc1", k_pos, 2048); fcb("pos_heatmap_encoder.fc2", 2048, 512); fcb("pos_heatmap_encoder.fc3", 512, hid);
+    fcb("rot_heatmap_encoder.fc1", k_rot, 2048); fcb("rot_heatmap_encoder.fc2", 2048, 512); fcb("rot_heatmap_encoder.fc3", 512, hid);
+    const std::string c = "skel_sequential_layer.lstm_custom.layers.";
+    lin(c + "0.x2f", H + x, x); lin(c + "0.x2h", 4 * H, x); lin(c + "0.b2h", 4 * H, x); lin(c + "0.h2h", 4 * H, H);
+    lin(c + "1.x2f", H, H); lin(c + "1.x2h", 4 * H, H); lin(c + "1.h2h", 4 * H, H);
+    lin("pose_mlp.pose_fcs.0", 3, x + H);
+    if (h->cfg.estimate_head) lin("global_mlp.pose_fcs.0", 6, (int64_t)h->J * H);
+}
+
+extern "C" int egotap_create(const egotap_config* cfg, egotap_handle* out) {
+    EGO_CHECK(cfg && out, "egotap_create: null argument");
+    EGO_CHECK(cfg->struct_bytes == (int32_t)sizeof(egotap_config), "egotap_create: egotap_config is %d bytes, library expects %d",
+              cfg->struct_bytes, (int)sizeof(egotap_config));
+    EGO_CHECK(cfg->n_joints_hm >= 1 && cfg->n_joints_hm <= 64, "n_joints_hm out of range");
+    EGO_CHECK(cfg->patch == 16, "patch size must be 16 (net_architecture.py:326)");
+    EGO_CHECK(cfg->hm_size > 0 && cfg->hm_size % 16 == 0, "hm_size must be a positive multiple of 16 (net_architecture.py:327)");
+    EGO_CHECK(cfg->vit_dim == 1024 && cfg->vit_heads == 8, "ViT hidden size / heads are fixed at 1024 / 8 (net_architecture.py:340-348)");
+    EGO_CHECK(cfg->vit_layers >= 1 && cfg->vit_layers <= 8, "vit_layers out of range");
+    EGO_CHECK(cfg->pu_hidden == 512 && cfg->hidden == 128, "hidden sizes are fixed at ae_hidden_size 128 / PU 512 in this build");
+    Handle* h = new Handle();
+    h->cfg = *cfg;
+    h->J = cfg->n_joints_hm;
+    h->T = 2 * h->J;
+    h->grid = isqrt_floor(h->T - 1) + 1;
+    h->ppd = cfg->hm_size / cfg->patch;
+    h->side = h->grid * h->ppd;
+    h->seq = h->side * h->side;
+    h->C = 6 * h->J;
+    h->D = cfg->vit_dim;
+    h->H = cfg->pu_hidden;
+    h->hid = cfg->hidden;
+    h->out_joints = h->J + (cfg->estimate_head ? 1 : 0);
+    lift_expect(h);
+    *out = h;
+    return EGOTAP_OK;
+}
+
+extern "C" void egotap_destroy(egotap_handle h) {
+    if (!h) return;
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    delete h;
+}
+
+extern "C" int egotap_bind_param(egotap_handle h, int net, const char* key, void* dev_ptr, int64_t numel, int dtype) {
+    EGO_CHECK(h && key, "egotap_bind_param: null argument");
+    EGO_CHECK(net >= 0 && net < EGOTAP_NET_COUNT, "egotap_bind_param: bad net id %d", net);
+    EGO_CHECK(dev_ptr != nullptr || numel == 0, "egotap_bind_param(%s): null device pointer", key);
+    auto it = h->expect[net].find(key);
+    if (it != h->expect[net].end()) {
+        EGO_CHECK(dtype == EGOTAP_F32, "egotap_bind_param(%s): expected f32", key);
+        EGO_CHECK(it->second == numel, "egotap_bind_param(%s): %lld elements, expected %lld", key, (long long)numel,
+                  (long long)it->second);
+        EGO_CHECK(((uintptr_t)dev_ptr & 15) == 0, "egotap_bind_param(%s): pointer must be 16-byte aligned", key);
+    }
+    Param p;
+    p.ptr = dev_ptr; p.numel = numel; p.dtype = dtype;
+    h->bound[net][key] = p;   // keys the forward never reads (pooler, cls_token, num_batches_tracked) are kept but unused
+    if (net == EGOTAP_NET_LIFT) h->lift_resolved = false;
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_unbound_count(egotap_handle h, int net, int* count) {
+    EGO_CHECK(h && count, "egotap_unbound_count: null argument");
+    EGO_CHECK(net >= 0 && net < EGOTAP_NET_COUNT, "bad net id %d", net);
+    int n = 0;
+    for (auto& kv : h->expect[net])
+        if (!h->bound[net].count(kv.first)) ++n;
+    *count = n;
+    return EGOTAP_OK;
+}
+
+static const float* P(Handle* h, int net, const std::string& key, bool& ok) {
+    auto it = h->bound[net].find(key);
+    if (it == h->bound[net].end()) {
+        if (ok) egotap_set_error("parameter '%s' is not bound", key.c_str());
+        ok = false;
+        return nullptr;
+    }
+    return (const float*)it->second.ptr;
+}
+
+static int lift_resolve(Handle* h) {
+    if (h->lift_resolved) return EGOTAP_OK;
+    bool ok = true;
+    const int N = EGOTAP_NET_LIFT;
+    LiftParams& p = h->lp;
+    const std::string v = "pos_heatmap_encoder.vit.";
+    p.mask_tok = P(h, N, v + "embeddings.mask_token", ok);
+    p.pos_emb = P(h, N, v + "embeddings.position_embeddings", ok);
+    p.patch_w = P(h, N, v + "embeddings.patch_embeddings.projection.weight", ok);
+    p.patch_b = P(h, N, v + "embeddings.patch_embeddings.projection.bias", ok);
+    for (int i = 0; i < h->cfg.vit_layers; ++i) {
+        const std::string l = v + "encoder.layer." + std::to_string(i) + ".";
+        auto& L = p.layer[i];
+        L.q_w = P(h, N, l + "attention.attention.query.weight", ok); L.q_b = P(h, N, l + "attention.attention.query.bias", ok);
+        L.k_w = P(h, N, l + "attention.attention.key.weight", ok);   L.k_b = P(h, N, l + "attention.attention.key.bias", ok);
+        L.v_w = P(h, N, l + "attention.attention.value.weight", ok); L.v_b = P(h, N, l + "attention.attention.value.bias", ok);
+        L.o_w = P(h, N, l + "attention.output.dense.weight", ok);    L.o_b = P(h, N, l + "attention.output.dense.bias", ok);
+        L.up_w = P(h, N, l + "intermediate.dense.weight", ok);       L.up_b = P(h, N, l + "intermediate.dense.bias", ok);
+        L.dn_w = P(h, N, l + "output.dense.weight", ok);             L.dn_b = P(h, N, l + "output.dense.bias", ok);
+        L.ln1_g = P(h, N, l + "layernorm_before.weight", ok);        L.ln1_b = P(h, N, l + "layernorm_before.bias", ok);
+        L.ln2_g = P(h, N, l + "layernorm_after.weight", ok);         L.ln2_b = P(h, N, l + "layernorm_after.bias", ok);
+    }
+    p.lnf_g = P(h, N, v + "layernorm.weight", ok);
+    p.lnf_b = P(h, N, v + "layernorm.bias", ok);
+    const char* encs[2] = {"pos_heatmap_encoder", "rot_heatmap_encoder"};
+    for (int e = 0; e < 2; ++e)
+        for (int i = 0; i < 3; ++i) {
+            const std::string f = std::string(encs[e]) + ".fc" + std::to_string(i + 1);
+            LiftParams::Fc& fc = e == 0 ? p.pos_fc[i] : p.rot_fc[i];
+            fc.w = P(h, N, f + ".fc.weight", ok);        fc.b = P(h, N, f + ".fc.bias", ok);
+            fc.g = P(h, N, f + ".bn.weight", ok);        fc.beta = P(h, N, f + ".bn.bias", ok);
+            fc.mean = P(h, N, f + ".bn.running_mean", ok); fc.var = P(h, N, f + ".bn.running_var", ok);
+        }
+    const std::string c = "skel_sequential_layer.lstm_custom.layers.";
+    p.x2f0_w = P(h, N, c + "0.x2f.weight", ok); p.x2f0_b = P(h, N, c + "0.x2f.bias", ok);
+    p.x2h0_w = P(h, N, c + "0.x2h.weight", ok); p.x2h0_b = P(h, N, c + "0.x2h.bias", ok);
+    p.b2h0_w = P(h, N, c + "0.b2h.weight", ok); p.b2h0_b = P(h, N, c + "0.b2h.bias", ok);
+    p.h2h0_w = P(h, N, c + "0.h2h.weight", ok); p.h2h0_b = P(h, N, c + "0.h2h.bias", ok);
+    p.x2f1_w = P(h, N, c + "1.x2f.weight", ok); p.x2f1_b = P(h, N, c + "1.x2f.bias", ok);
+    p.x2h1_w = P(h, N, c + "1.x2h.weight", ok); p.x2h1_b = P(h, N, c + "1.x2h.bias", ok);
+    p.h2h1_w = P(h, N, c + "1.h2h.weight", ok); p.h2h1_b = P(h, N, c + "1.h2h.bias", ok);
+    p.pose_w = P(h, N, "pose_mlp.pose_fcs.0.weight", ok); p.pose_b = P(h, N, "pose_mlp.pose_fcs.0.bias", ok);
+    p.glob_w = p.glob_b = nullptr;
+    if (h->cfg.estimate_head) {
+        p.glob_w = P(h, N, "global_mlp.pose_fcs.0.weight", ok);
+        p.glob_b = P(h, N, "global_mlp.pose_fcs.0.bias", ok);
+    }
+    if (!ok) return EGOTAP_ERR_UNBOUND;
+    h->lift_resolved = true;
+    return EGOTAP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ timing
+extern "C" int egotap_timing_enable(egotap_handle h, int enable) {
+    EGO_CHECK(h, "null handle");
+    h->timing = enable != 0;
+    return EGOTAP_OK;
+}
+extern "C" int egotap_timing_read(egotap_handle h, int* launches, double* total_ms, double* total_flops) {
+    EGO_CHECK(h && launches && total_ms && total_flops, "null argument");
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        EGO_HIP(hipEventSynchronize(h->ev[i + 1]));
+        float t = 0.f;
+        EGO_HIP(hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]));
+        ms += t;
+    }
+    *launches = (int)(h->ev_used / 2);
+    *total_ms = ms;
+    *total_flops = h->flops;
+    h->ev_used = 0;
+    h->flops = 0.0;
+    return EGOTAP_OK;
+}
+
+struct GemmTimer {   // brackets one GEMM launch when the handle's timing hook is on
+    Handle* h;
+    hipStream_t s;
+    bool on;
+    GemmTimer(Handle* h_, hipStream_t s_, double flops) : h(h_), s(s_), on(h_ && h_->timing) {
+        if (!on) return;
+        if (h->ev_used + 2 > h->ev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            h->ev.push_back(a);
+            h->ev.push_back(b);
+        }
+        (void)hipEventRecord(h->ev[h->ev_used], s);
+        h->flops += flops;
+    }
+    ~GemmTimer() {
+        if (!on) return;
+        (void)hipEventRecord(h->ev[h->ev_used + 1], s);
+        h->ev_used += 2;
+    }
+};
+
+template <class Cfg, class AL, class Epi>
+static hipError_t gemm(Handle* h, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K,
+                       hipStream_t s) {
+    GemmTimer t(h, s, 2.0 * M * N * K);
+    return gemm_f32_launch<Cfg, AL, Epi>(al, W, epi, C, ldc, M, N, K, s);
+}
+
+// ------------------------------------------------------------------------------------------------ workspace
+struct LiftWs {
+    size_t X, Y, QKV, CTX, HID, Z1, Z2, POSZ, ROTZ, F0, G0, HS0, F1, G1, HS1, C0, C1, ZERO, total;
+};
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+static LiftWs lift_ws(const Handle* h, int B) {
+    LiftWs w;
+    const size_t M = (size_t)B * h->seq, D = h->D, BT = (size_t)B * h->T, JB = (size_t)h->J * B, H = h->H;
+    size_t o = 0;
+    auto take = [&](size_t floats) { size_t r = o; o = al256(o + floats * 4); return r; };
+    w.X = take(M * D); w.Y = take(M * D); w.QKV = take(M * 3 * D); w.CTX = take(M * D); w.HID = take(M * 4 * D);
+    w.Z1 = take(BT * 2048); w.Z2 = take(BT * 512); w.POSZ = take(BT * h->hid); w.ROTZ = take(BT * h->hid);
+    w.F0 = take(JB * (H + 2 * h->hid)); w.G0 = take(JB * 4 * H); w.HS0 = take(JB * H);
+    w.F1 = take(JB * H); w.G1 = take(JB * 4 * H); w.HS1 = take(JB * H);
+    w.C0 = take((size_t)B * H); w.C1 = take((size_t)B * H); w.ZERO = take((size_t)B * H);
+    w.total = o;
+    return w;
+}
+
+extern "C" int egotap_lift_workspace_bytes(egotap_handle h, int B, size_t* bytes) {
+    EGO_CHECK(h && bytes, "null argument");
+    EGO_CHECK(B >= 0, "negative batch");
+    *bytes = lift_ws(h, B > 0 ? B : 1).total;
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_lift_intermediate(egotap_handle h, int B, const char* name, size_t* offset, int64_t* numel) {
+    EGO_CHECK(h && name && offset && numel, "null argument");
+    const LiftWs w = lift_ws(h, B > 0 ? B : 1);
+    const int64_t M = (int64_t)B * h->seq;
+    if (!strcmp(name, "tokens")) { *offset = w.Y; *numel = M * h->D; }
+    else if (!strcmp(name, "x")) { *offset = w.X; *numel = M * h->D; }
+    else if (!strcmp(name, "pos_embed")) { *offset = w.POSZ; *numel = (int64_t)B * h->T * h->hid; }
+    else if (!strcmp(name, "rot_embed")) { *offset = w.ROTZ; *numel = (int64_t)B * h->T * h->hid; }
+    else if (!strcmp(name, "skel_embed")) { *offset = w.HS1; *numel = (int64_t)h->J * B * h->H; }
+    else { egotap_set_error("unknown intermediate '%s'", name); return EGOTAP_ERR_INVALID; }
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_lift_debug_stop(egotap_handle h, int stage) {
+    EGO_CHECK(h, "null handle");
+    h->debug_stop = stage;   // 0: full forward; 1: after embeddings; 2+i: after ViT layer i  ("x" holds the state)
+    return EGOTAP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+static hipError_t launch_ln(const float* x, float* y, const float* g, const float* b, int rows, float eps, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const int blocks = min((rows + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL(layernorm_f32_kernel<1024>, dim3(blocks), dim3(256), 0, s, x, y, g, b, rows, eps);
+    return hipGetLastError();
+}
+
+extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, float* pose, void* ws, size_t ws_bytes,
+                                   void* stream) {
+    EGO_CHECK(h, "null handle");
+    if (B == 0) return EGOTAP_OK;
+    EGO_CHECK(B > 0 && hm && pose && ws, "egotap_lift_forward: null argument or negative batch");
+    EGO_CHECK(((uintptr_t)hm & 15) == 0 && ((uintptr_t)ws & 255) == 0, "hm must be 16-byte and ws 256-byte aligned");
+    int rc = lift_resolve(h);
+    if (rc != EGOTAP_OK) return rc;
+    const LiftWs w = lift_ws(h, B);
+    if (ws_bytes < w.total) {
+        egotap_set_error("workspace too small: %zu bytes given, %zu needed for B=%d", ws_bytes, w.total, B);
+        return EGOTAP_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const LiftParams& p = h->lp;
+    char* base = (char*)ws;
+    auto F = [&](size_t off) { return (float*)(base + off); };
+    float *X = F(w.X), *Y = F(w.Y), *QKV = F(w.QKV), *CTX = F(w.CTX), *HID = F(w.HID);
+    float *Z1 = F(w.Z1), *Z2 = F(w.Z2), *POSZ = F(w.POSZ), *ROTZ = F(w.ROTZ);
+    float *F0 = F(w.F0), *G0 = F(w.G0), *HS0 = F(w.HS0), *F1 = F(w.F1), *G1 = F(w.G1), *HS1 = F(w.HS1);
+    float *C0 = F(w.C0), *C1 = F(w.C1), *ZERO = F(w.ZERO);
+    const int D = h->D, M = B * h->seq, BT = B * h->T, J = h->J, H = h->H, hid = h->hid, JB = J * B;
+    const int S = h->cfg.hm_size, HW = S * S;
+    using Tile = TileA;
+
+    // H1+H2: tile -> patch embed -> mask token -> + position embeddings
+    {
+        ALoadPatch al{hm, h->C, S, h->seq, h->side, h->ppd, h->grid, h->T};
+        EpiPatch ep{p.patch_b, p.mask_tok, p.pos_emb, D, h->seq, h->side, h->ppd, h->grid, h->T};
+        EGO_HIP((gemm<Tile>(h, al, segmat1(p.patch_w, D, 256), ep, X, D, M, D, 256, s)));
+    }
+    if (h->debug_stop == 1) return EGOTAP_OK;
+    // H3-H8: pre-LN transformer layers
+    for (int i = 0; i < h->cfg.vit_layers; ++i) {
+        const auto& L = p.layer[i];
+        EGO_HIP(launch_ln(X, Y, L.ln1_g, L.ln1_b, M, 1e-12f, s));
+        {
+            SegMat Wqkv; Wqkv.p[0] = L.q_w; Wqkv.p[1] = L.k_w; Wqkv.p[2] = L.v_w; Wqkv.seg = D; Wqkv.ld = D;
+            SegVec bqkv; bqkv.p[0] = L.q_b; bqkv.p[1] = L.k_b; bqkv.p[2] = L.v_b; bqkv.seg = D;
+            EGO_HIP((gemm<Tile>(h, ALoadPlain{Y, D}, Wqkv, EpiBias{bqkv}, QKV, 3L * D, M, 3 * D, D, s)));
+        }
+        EGO_HIP(attention_f32_launch(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
+        EGO_HIP((gemm<Tile>(h, ALoadPlain{CTX, D}, segmat1(L.o_w, D, D), EpiBiasRes{segvec1(L.o_b, D), X, D}, X, D, M, D, D, s)));
+        EGO_HIP(launch_ln(X, Y, L.ln2_g, L.ln2_b, M, 1e-12f, s));
+        EGO_HIP((gemm<Tile>(h, ALoadPlain{Y, D}, segmat1(L.up_w, 4 * D, D), EpiBiasGelu{segvec1(L.up_b, 4 * D)}, HID, 4L * D, M, 4 * D, D, s)));
+        EGO_HIP((gemm<Tile>(h, ALoadPlain{HID, 4L * D}, segmat1(L.dn_w, D, 4L * D), EpiBiasRes{segvec1(L.dn_b, D), X, D}, X, D, M, D, 4 * D, s)));
+        if (h->debug_stop == 2 + i) return EGOTAP_OK;
+    }
+    EGO_HIP(launch_ln(X, Y, p.lnf_g, p.lnf_b, M, 1e-12f, s));
+    // H9-H10: per-heatmap regroup folded into fc1's A loader; fc blocks with folded BatchNorm + LeakyReLU
+    auto bn = [](const LiftParams::Fc& f) { return EpiBnLrelu{f.b, f.g, f.beta, f.mean, f.var, 1e-5f, 0.2f}; };
+    {
+        const int K1 = h->ppd * h->ppd * D;
+        ALoadTokens al{Y, h->T, D, h->seq, h->side, h->ppd, h->grid};
+        EGO_HIP((gemm<Tile>(h, al, segmat1(p.pos_fc[0].w, 2048, K1), bn(p.pos_fc[0]), Z1, 2048, BT, 2048, K1, s)));
+        EGO_HIP((gemm<Tile>(h, ALoadPlain{Z1, 2048}, segmat1(p.pos_fc[1].w, 512, 2048), bn(p.pos_fc[1]), Z2, 512, BT, 512, 2048, s)));
+        EGO_HIP((gemm<Tile>(h, ALoadPlain{Z2, 512}, segmat1(p.pos_fc[2].w, hid, 512), bn(p.pos_fc[2]), POSZ, hid, BT, hid, 512, s)));
+    }
+    // H11-H12: rotation (cos/sin) heatmaps straight from the input tensor
+    {
+        ALoadRot al{hm, h->C, J, HW};
+        EGO_HIP((gemm<Tile>(h, al, segmat1(p.rot_fc[0].w, 2048, 2L * HW), bn(p.rot_fc[0]), Z1, 2048, BT, 2048, 2 * HW, s)));
+        EGO_HIP((gemm<Tile>(h, ALoadPlain{Z1, 2048}, segmat1(p.rot_fc[1].w, 512, 2048), bn(p.rot_fc[1]), Z2, 512, BT, 512, 2048, s)));
+        EGO_HIP((gemm<Tile>(h, ALoadPlain{Z2, 512}, segmat1(p.rot_fc[2].w, hid, 512), bn(p.rot_fc[2]), ROTZ, hid, BT, hid, 512, s)));
+    }
+    // H13-H14: propagation units.  State-independent projections of all J steps as GEMMs (rows time-major t*B+b) ...
+    const int x = 2 * hid, NF0 = H + x;
+    ALoadStereo xs{POSZ, B, J, hid};
+    EGO_HIP((gemm<Tile>(h, xs, segmat1(p.x2f0_w, NF0, x), EpiBias{segvec1(p.x2f0_b, NF0)}, F0, NF0, JB, NF0, x, s)));
+    EGO_HIP((gemm<Tile>(h, xs, segmat1(p.x2h0_w, 4 * H, x), EpiBias{segvec1(p.x2h0_b, 4 * H)}, G0, 4L * H, JB, 4 * H, x, s)));
+    {
+        ALoadStereoGated bs{ALoadStereo{ROTZ, B, J, hid}, F0, NF0, H};
+        EGO_HIP((gemm<Tile>(h, bs, segmat1(p.b2h0_w, 4 * H, x), EpiBiasRes{segvec1(p.b2h0_b, 4 * H), G0, 4L * H}, G0, 4L * H, JB, 4 * H, x, s)));
+    }
+    // ... then the two J-step recurrences (layer 0 never reads layer-1 state, so the layers run one after the other)
+    EGO_HIP(hipMemsetAsync(C0, 0, (size_t)(w.ZERO - w.C0) + (size_t)B * H * 4, s));   // C0, C1, ZERO are contiguous
+    const dim3 pgrid((B + 31) / 32, H / 32);
+    for (int t = 0; t < J; ++t) {
+        const float* hprev = t == 0 ? ZERO : HS0 + (size_t)(t - 1) * B * H;
+        hipLaunchKernelGGL(pu_step_kernel, pgrid, dim3(256), 0, s, F0 + (size_t)t * B * NF0, NF0, G0 + (size_t)t * B * 4 * H,
+                           p.h2h0_w, p.h2h0_b, hprev, C0, HS0 + (size_t)t * B * H, B, H);
+    }
+    EGO_HIP(hipGetLastError());
+    EGO_HIP((gemm<Tile>(h, ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
+    EGO_HIP((gemm<Tile>(h, ALoadPlain{HS0, H}, segmat1(p.x2h1_w, 4 * H, H), EpiBias{segvec1(p.x2h1_b, 4 * H)}, G1, 4L * H, JB, 4 * H, H, s)));
+    for (int t = 0; t < J; ++t) {
+        const float* hprev = t == 0 ? ZERO : HS1 + (size_t)(t - 1) * B * H;
+        hipLaunchKernelGGL(pu_step_kernel, pgrid, dim3(256), 0, s, F1 + (size_t)t * B * H, H, G1 + (size_t)t * B * 4 * H,
+                           p.h2h1_w, p.h2h1_b, hprev, C1, HS1 + (size_t)t * B * H, B, H);
+    }
+    EGO_HIP(hipGetLastError());
+    // H15: per-joint pose head (+ global offset and head joint for UnrealEgo)
+    hipLaunchKernelGGL(pose_head_kernel, dim3(B), dim3(256), 0, s, POSZ, HS1, p.pose_w, p.pose_b, p.glob_w, p.glob_b, pose, B,
+                       J, hid, H, h->cfg.estimate_head);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ single operators
+template <class Cfg>
+static hipError_t linear_tile(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int epi,
+                              const float* r, const float* g, const float* beta, const float* mean, const float* var,
+                              hipStream_t s) {
+    const ALoadPlain al{x, K};
+    const SegMat W = segmat1(w, N, K);
+    switch (epi) {
+        case 0: return gemm_f32_launch<Cfg>(al, W, EpiBias{segvec1(b, N)}, y, N, M, N, K, s);
+        case 1: return gemm_f32_launch<Cfg>(al, W, EpiBiasRes{segvec1(b, N), r, N}, y, N, M, N, K, s);
+        case 2: return gemm_f32_launch<Cfg>(al, W, EpiBiasGelu{segvec1(b, N)}, y, N, M, N, K, s);
+        case 3: return gemm_f32_launch<Cfg>(al, W, EpiBnLrelu{b, g, beta, mean, var, 1e-5f, 0.2f}, y, N, M, N, K, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+extern "C" int egotap_linear_f32(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int epi,
+                                 const float* r, const float* g, const float* beta, const float* mean, const float* var,
+                                 int tile, void* stream) {
+    EGO_CHECK(x && w && b && y, "egotap_linear_f32: null argument");
+    EGO_CHECK(M >= 0 && N > 0 && K > 0, "egotap_linear_f32: bad shape");
+    EGO_CHECK(epi >= 0 && epi <= 3, "egotap_linear_f32: epi must be 0..3");
+    EGO_CHECK(epi != 1 || r, "egotap_linear_f32: residual pointer missing");
+    EGO_CHECK(epi != 3 || (g && beta && mean && var), "egotap_linear_f32: BatchNorm pointers missing");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (tile != 0 && tile != 1 && epi != 0) { egotap_set_error("non-default tiles are built for epi 0 only"); return EGOTAP_ERR_INVALID; }
+    switch (tile) {
+        case 0: case 1: e = linear_tile<TileA>(x, w, b, y, M, N, K, epi, r, g, beta, mean, var, s); break;
+        case 2: e = gemm_f32_launch<TileB>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
+        case 3: e = gemm_f32_launch<TileC>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
+        case 4: e = gemm_f32_launch<TileD>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
+        case 5: e = gemm_f32_launch<TileE>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
+        case 6: e = gemm_f32_launch<TileF>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
+        case 7: e = gemm_f32_launch<TileG>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
+        default: egotap_set_error("unknown tile id %d", tile); return EGOTAP_ERR_INVALID;
+    }
+    if (e == hipErrorInvalidValue) {
+        egotap_set_error("egotap_linear_f32: N=%d / K=%d not a multiple of the tile (%s)", N, K, egotap_gemm_tile_name(tile));
+        return EGOTAP_ERR_INVALID;
+    }
+    EGO_HIP(e);
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_layernorm_f32(const float* x, float* y, const float* gamma, const float* beta, int rows, int dim,
+                                    float eps, void* stream) {
+    EGO_CHECK(x && y && gamma && beta, "egotap_layernorm_f32: null argument");
+    EGO_CHECK(dim == 1024, "egotap_layernorm_f32: dim must be 1024 (ViT hidden size)");
+    EGO_HIP(launch_ln(x, y, gamma, beta, rows, eps, (hipStream_t)stream));
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_attention_f32(const float* qkv, float* ctx, int B, int N, int heads, void* stream) {
+    EGO_CHECK(qkv && ctx, "egotap_attention_f32: null argument");
+    EGO_CHECK(N > 0 && N % 32 == 0, "egotap_attention_f32: sequence length must be a multiple of 32");
+    EGO_CHECK(heads > 0, "egotap_attention_f32: heads must be positive");
+    EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, (hipStream_t)stream));
+    return EGOTAP_OK;
+}

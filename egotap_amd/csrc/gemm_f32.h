@@ -1,0 +1,293 @@
+// fp32 GEMM on the gfx950 matrix cores:  C[M,N] = epi( A[M,K] * W[N,K]^T ).
+//
+// * v_mfma_f32_32x32x2_f32 (exact f32, one rounding per product, 64 FLOP/clk/SIMD;
+//   157.3 TFLOP/s chip peak) -- the north star pins fp32 at 1e-4, so no bf16.
+// * A is produced by a LOADER functor, so the reference's reshuffles (tiling the
+//   heatmaps into the ViT image, regrouping tokens per heatmap, the stereo
+//   cos/sin interleave) are index math inside the load, never a copy.
+// * W is nn.Linear's [N,K] layout, up to three row segments (fused Q|K|V).
+// * The epilogue functor fuses bias / residual / exact GELU / folded
+//   BatchNorm1d + LeakyReLU / position-embedding + mask-token.
+//
+// Tiling: BM x BN block, BK-deep slabs double buffered in LDS (rows padded by 4
+// floats so the ds_read_b128 fragment reads are bank-conflict free), register
+// staged prefetch of the next slab under the MFMAs of the current one, one
+// barrier per slab.  Each wave owns a (BM/WM) x (BN/WN) sub-tile = TM x TN MFMA
+// tiles of 32x32.  The MFMA k index is permuted (lane half h, step 4t+u reads
+// k = 8t+4h+u for both operands) so every fragment read is one 16-byte LDS read
+// feeding four MFMAs.
+#pragma once
+#include "common.h"
+
+// ----------------------------------------------------------------------------- A loaders
+struct ALoadPlain {
+    const float* A;
+    long lda;
+    struct Row { const float* p; };
+    __device__ __forceinline__ Row row(int m) const { return Row{A + (long)m * lda}; }
+    __device__ __forceinline__ f32x4 load(const Row& r, int k) const { return *(const f32x4*)(r.p + k); }
+};
+
+// ViT patch embedding input: token (b, pr, pc) of the tiled (grid*hm)^2 image, K = 16*16
+// pixels of one patch.  Reference: net_architecture.py:375-383 + modeling_vit.py:195.
+struct ALoadPatch {
+    const float* hm;   // [B, C, S, S] heatmaps, position channels first
+    int C, S, seq, side, ppd, grid, T;
+    struct Row { const float* p; };   // nullptr: dummy cell (zeros)
+    __device__ __forceinline__ Row row(int m) const {
+        const int b = m / seq, tok = m - b * seq;
+        const int pr = tok / side, pc = tok - pr * side;
+        const int cell = (pr / ppd) * grid + pc / ppd;
+        if (cell >= T) return Row{nullptr};
+        return Row{hm + ((long)(b * C + cell) * S + (pr % ppd) * 16) * S + (pc % ppd) * 16};
+    }
+    __device__ __forceinline__ f32x4 load(const Row& r, int k) const {
+        if (r.p == nullptr) return f32x4{0.f, 0.f, 0.f, 0.f};
+        return *(const f32x4*)(r.p + (k >> 4) * S + (k & 15));
+    }
+};
+
+// fc1 of the position encoder: row (b, i) = the ppd x ppd patch tokens of heatmap i,
+// flattened (patch-row, patch-col, channel).  Reference: net_architecture.py:388-406.
+struct ALoadTokens {
+    const float* Y;    // [B*seq, D] final-LayerNorm tokens
+    int T, D, seq, side, ppd, grid;
+    struct Row { const float* p; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int b = m / T, i = m - b * T;
+        return Row{Y + ((long)b * seq + (long)(ppd * (i / grid)) * side + ppd * (i % grid)) * D};
+    }
+    __device__ __forceinline__ f32x4 load(const Row& r, int k) const {
+        const int s = k / D, c = k - s * D;
+        const int prl = s / ppd, pcl = s - prl * ppd;
+        return *(const f32x4*)(r.p + (long)(prl * side + pcl) * D + c);
+    }
+};
+
+// fc1 of the rotation encoder: row (b, eye*J + j) = [cos map | sin map] of limb j of that eye.
+// Reference: net_architecture.py:690-694 (channel order L_cos, L_sin, R_cos, R_sin after 2J position maps).
+struct ALoadRot {
+    const float* hm;   // [B, C, S, S]
+    int C, J, HW;      // HW = S*S
+    struct Row { const float* p; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int T = 2 * J;
+        const int b = m / T, t = m - b * T;
+        const int eye = t / J, j = t - eye * J;
+        return Row{hm + (long)(b * C + 2 * J + eye * 2 * J + j) * HW};
+    }
+    __device__ __forceinline__ f32x4 load(const Row& r, int k) const {
+        const int cs = k / HW;
+        return *(const f32x4*)(r.p + (long)cs * J * HW + (k - cs * HW));
+    }
+};
+
+// Propagation-unit inputs, time-major rows m = t*B + b: [left_t | right_t] features of
+// joint t from Z[(b*2 + eye)*J + t, hid].  Reference: net_architecture.py:699-705, 722-723.
+struct ALoadStereo {
+    const float* Z;
+    int B, J, hid;
+    struct Row { const float* p; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int t = m / B, b = m - t * B;
+        return Row{Z + ((long)b * 2 * J + t) * hid};
+    }
+    __device__ __forceinline__ f32x4 load(const Row& r, int k) const {
+        const int eye = k / hid;
+        return *(const f32x4*)(r.p + (long)eye * J * hid + (k - eye * hid));
+    }
+};
+
+// Bridge operand of PU layer 0: b' = sigmoid(F[m, fcol0 + k]) * bridge(m, k)   (custom_cells.py:102).
+struct ALoadStereoGated {
+    ALoadStereo z;
+    const float* F;    // [J*B, ldf] x2f output
+    int ldf, fcol0;
+    struct Row { ALoadStereo::Row r; const float* f; };
+    __device__ __forceinline__ Row row(int m) const { return Row{z.row(m), F + (long)m * ldf + fcol0}; }
+    __device__ __forceinline__ f32x4 load(const Row& r, int k) const {
+        f32x4 v = z.load(r.r, k);
+        const f32x4 g = *(const f32x4*)(r.f + k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= 1.0f / (1.0f + expf(-g[i]));
+        return v;
+    }
+};
+
+// ----------------------------------------------------------------------------- epilogues
+struct EpiBias {          // C = acc + bias
+    SegVec bias;
+    struct Col { float b; };
+    __device__ __forceinline__ Col col(int n) const { return Col{bias.at(n)}; }
+    __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const { return acc + c.b; }
+};
+struct EpiBiasRes {       // C = acc + bias + R[m, n]   (R may alias C)
+    SegVec bias;
+    const float* R;
+    long ldr;
+    struct Col { float b; };
+    __device__ __forceinline__ Col col(int n) const { return Col{bias.at(n)}; }
+    __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const {
+        return acc + c.b + R[(long)m * ldr + n];
+    }
+};
+struct EpiBiasGelu {      // exact erf GELU (modeling_vit.py:320-327, hidden_act='gelu')
+    SegVec bias;
+    struct Col { float b; };
+    __device__ __forceinline__ Col col(int n) const { return Col{bias.at(n)}; }
+    __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const {
+        const float x = acc + c.b;
+        return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    }
+};
+struct EpiBnLrelu {       // LeakyReLU_0.2(BatchNorm1d_eval(acc + bias))  (network_utils.py:123-142)
+    const float *bias, *gamma, *beta, *mean, *var;
+    float eps, slope;
+    struct Col { float b, mu, sc, sh; };
+    __device__ __forceinline__ Col col(int n) const {
+        return Col{bias[n], mean[n], gamma[n] / sqrtf(var[n] + eps), beta[n]};
+    }
+    __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const {
+        const float y = (acc + c.b - c.mu) * c.sc + c.sh;
+        return y > 0.f ? y : slope * y;
+    }
+};
+struct EpiPatch {         // (dummy ? mask_token : acc + bias) + position_embeddings   (modeling_vit.py:137-153)
+    const float *bias, *mask_tok, *pos;
+    int D, seq, side, ppd, grid, T;
+    struct Col { float b, mt; };
+    __device__ __forceinline__ Col col(int n) const { return Col{bias[n], mask_tok[n]}; }
+    __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const {
+        const int tok = m % seq;
+        const int pr = tok / side, pc = tok - pr * side;
+        const bool dummy = (pr / ppd) * grid + pc / ppd >= T;
+        return (dummy ? c.mt : acc + c.b) + pos[(long)tok * D + n];
+    }
+};
+
+// ----------------------------------------------------------------------------- kernel
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_>
+struct GemmCfg {
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_;
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int LDK = BK + 4;                 // padded LDS row (floats)
+    static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static constexpr int A_V4 = BM * BK / 4 / THREADS; // float4 per thread per slab
+    static constexpr int B_V4 = BN * BK / 4 / THREADS;
+    static constexpr int ROWS_PER_PASS = THREADS / (BK / 4);
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * LDK * 4;
+    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "wave tile must be a multiple of 32x32");
+    static_assert(BK % 8 == 0, "BK multiple of 8");
+    static_assert((BM * BK / 4) % THREADS == 0 && (BN * BK / 4) % THREADS == 0, "staging must divide evenly");
+};
+
+template <class Cfg, class ALoad, class Epi>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_kernel(
+    ALoad al, SegMat W, Epi epi, float* C, long ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, LDK = Cfg::LDK;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, A_V4 = Cfg::A_V4, B_V4 = Cfg::B_V4, RPP = Cfg::ROWS_PER_PASS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                        // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;         // [2][BN][LDK]
+
+    int tm, tn;
+    xcd_tile(blockIdx.x, gridDim.x, tiles_m, tiles_n, 8, tm, tn);
+    const int bm = tm * BM, bn = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / Cfg::WN, wn = wid % Cfg::WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // staging assignment: thread -> (row r0 + i*RPP, float4 column c4)
+    const int c4 = tid % (BK / 4), r0 = tid / (BK / 4);
+    typename ALoad::Row arow[A_V4];
+    const float* brow[B_V4];
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) arow[i] = al.row(min(bm + r0 + i * RPP, M - 1));
+#pragma unroll
+    for (int i = 0; i < B_V4; ++i) brow[i] = W.row(bn + r0 + i * RPP);
+
+    f32x4 pa[A_V4], pb[B_V4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) pa[i] = al.load(arow[i], k0 + c4 * 4);
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) pb[i] = *(const f32x4*)(brow[i] + k0 + c4 * 4);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) *(f32x4*)(As + (buf * BM + r0 + i * RPP) * LDK + c4 * 4) = pa[i];
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) *(f32x4*)(Bs + (buf * BN + r0 + i * RPP) * LDK + c4 * 4) = pb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KT = K / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) gload((kt + 1) * BK);
+        const float* Ab = As + (buf * BM + wm * (TM * 32) + l31) * LDK + 4 * lh;
+        const float* Bb = Bs + (buf * BN + wn * (TN * 32) + l31) * LDK + 4 * lh;
+#pragma unroll
+        for (int t = 0; t < BK / 8; ++t) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(Ab + i * 32 * LDK + 8 * t);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(Bb + j * 32 * LDK + 8 * t);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[j][u], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: acc reg r of lane l is C[32x32 tile row (r&3) + 8*(r>>2) + 4*(l>>5)][col l&31]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = bn + wn * (TN * 32) + j * 32 + l31;
+        const typename Epi::Col cc = epi.col(n);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mbase = bm + wm * (TM * 32) + i * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m < M) C[(long)m * ldc + n] = epi.apply(acc[i][j][r], cc, m, n);
+            }
+        }
+    }
+}
+
+// host launcher; returns hipError_t (no allocation, no sync: capture safe)
+template <class Cfg, class ALoad, class Epi>
+static hipError_t gemm_f32_launch(const ALoad& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N,
+                                  int K, hipStream_t stream) {
+    if (M <= 0) return hipSuccess;
+    if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0) return hipErrorInvalidValue;
+    auto kern = gemm_f32_kernel<Cfg, ALoad, Epi>;
+    static bool attr_done = false;     // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, al, W, epi, C, ldc, M,
+                       N, K, tiles_m, tiles_n);
+    return hipGetLastError();
+}

@@ -1,0 +1,128 @@
+"""ctypes binding of libegotap_hip.so (include/egotap.h).  No CPU fallback: if the HIP library is
+missing or fails to load, everything here raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+ERR_NAMES = {1: "EGOTAP_ERR_INVALID", 2: "EGOTAP_ERR_HIP", 3: "EGOTAP_ERR_UNBOUND", 4: "EGOTAP_ERR_WORKSPACE"}
+NET_LIFT, NET_HM_POS, NET_HM_ROT = 0, 1, 2
+F32, I64 = 0, 1
+
+
+class EgotapConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "struct_bytes", "n_joints_hm", "estimate_head", "hm_size", "hidden", "vit_dim", "vit_heads", "vit_layers",
+        "patch", "pu_hidden")]
+
+
+class EgotapError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_PROTOS = {
+    "egotap_abi_version": (C.c_int, []),
+    "egotap_last_error": (C.c_char_p, []),
+    "egotap_create": (C.c_int, [C.POINTER(EgotapConfig), C.POINTER(C.c_void_p)]),
+    "egotap_destroy": (None, [C.c_void_p]),
+    "egotap_bind_param": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int64, C.c_int]),
+    "egotap_unbound_count": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "egotap_lift_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
+    "egotap_lift_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_lift_intermediate": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
+    "egotap_lift_debug_stop": (C.c_int, [C.c_void_p, C.c_int]),
+    "egotap_linear_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
+    "egotap_gemm_tile_name": (C.c_char_p, [C.c_int]),
+    "egotap_layernorm_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "egotap_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "egotap_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "egotap_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+
+def exported_symbols():
+    """names declared in include/egotap.h that the library must export"""
+    return sorted(_PROTOS)
+
+
+def load(build_if_missing: bool = True):
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if build_if_missing and not os.path.exists(path):
+        path = _build.build()
+    if not os.path.exists(path):
+        raise EgotapError(f"{path} is missing: build it with `python -m egotap_amd.build` (hipcc, gfx950)")
+    lib = C.CDLL(path)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.egotap_abi_version() != 1:
+        raise EgotapError("libegotap_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().egotap_last_error().decode("utf-8", "replace")
+        raise EgotapError(f"{ERR_NAMES.get(rc, rc)}: {msg}")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ----------------------------------------------------------------------------------------- single operators
+def _need_cuda_f32(*ts):
+    import torch
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise EgotapError("egotap_amd ops need contiguous float32 tensors on the GPU (no CPU fallback)")
+
+
+def linear(x, w, b, epi: str = "bias", residual=None, bn=None, tile: int = 0):
+    """y = epi(x @ w.T + b) on the fp32 MFMA GEMM.  epi: bias | residual | gelu | bn_lrelu."""
+    import torch
+    code = {"bias": 0, "residual": 1, "gelu": 2, "bn_lrelu": 3}[epi]
+    M, K = x.shape
+    N = w.shape[0]
+    g = beta = mean = var = None
+    if bn is not None:
+        g, beta, mean, var = bn
+    _need_cuda_f32(x, w, b, residual, g, beta, mean, var)
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    check(load().egotap_linear_f32(_ptr(x), _ptr(w), _ptr(b), _ptr(y), M, N, K, code, _ptr(residual), _ptr(g), _ptr(beta),
+                                   _ptr(mean), _ptr(var), tile, _stream()))
+    return y
+
+
+def layernorm(x, gamma, beta, eps: float = 1e-12):
+    import torch
+    _need_cuda_f32(x, gamma, beta)
+    y = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    check(load().egotap_layernorm_f32(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), rows, x.shape[-1], eps, _stream()))
+    return y
+
+
+def attention(qkv, B: int, N: int, heads: int):
+    """qkv [B*N, 3*heads*128] (q|k|v) -> ctx [B*N, heads*128]"""
+    import torch
+    _need_cuda_f32(qkv)
+    ctx = torch.empty((B * N, heads * 128), device=qkv.device, dtype=torch.float32)
+    check(load().egotap_attention_f32(_ptr(qkv), _ptr(ctx), B, N, heads, _stream()))
+    return ctx

@@ -1,0 +1,192 @@
+"""Host-side mirror of the reference's network modules for the hot path.
+
+Same class names, constructor arguments, forward signatures and ``state_dict`` keys as
+``model/net_architecture.py`` in the reference, so ``train.py``/``test.py``-style callers and released
+checkpoints work unchanged -- but the modules hold parameters only: every forward goes through the
+C ABI of libegotap_hip.so (hand-written HIP for gfx950).  There is no PyTorch compute fallback; without
+the HIP library or off the GPU these modules raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import lib as _lib
+from . import spec as _spec
+
+
+class _Node(nn.Module):
+    """Parameter container; the tree of _Nodes reproduces the reference's dotted state_dict keys."""
+
+    def forward(self, *a, **k):  # pragma: no cover - containers are never called
+        raise RuntimeError("parameter container: compute happens in libegotap_hip.so")
+
+
+def _build_tree(root: nn.Module, entries):
+    """Register (key, shape) entries as nn.Parameter / buffers under nested _Node children of root."""
+    for key, shape in entries:
+        parts = key.split(".")
+        mod = root
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, _Node())
+            mod = mod._modules[p]
+        leaf = parts[-1]
+        if leaf == "num_batches_tracked":
+            mod.register_buffer(leaf, torch.zeros(shape, dtype=torch.long))
+        elif _spec.is_buffer(key):
+            mod.register_buffer(leaf, torch.ones(shape) if leaf == "running_var" else torch.zeros(shape))
+        else:
+            mod.register_parameter(leaf, nn.Parameter(torch.zeros(shape)))
+
+
+def _kaiming_init_(module: nn.Module):
+    """init_net(net, 'kaiming') of the reference (network_utils.py:37-58): kaiming-normal (fan_in) on every
+    Conv/Linear weight, zero bias; everything else keeps its constructor default.  Uses torch's RNG."""
+    for name, p in module.named_parameters():
+        leaf = name.rsplit(".", 1)[-1]
+        with torch.no_grad():
+            if leaf == "weight" and p.dim() >= 2:
+                nn.init.kaiming_normal_(p, a=0, mode="fan_in")
+            elif leaf == "weight":            # LayerNorm / BatchNorm1d gain
+                p.fill_(1.0)
+            elif leaf == "bias":
+                p.zero_()
+            elif leaf in ("cls_token", "position_embeddings"):
+                nn.init.trunc_normal_(p, mean=0.0, std=0.02)
+            elif leaf == "mask_token":
+                p.zero_()
+
+
+class EgoTAPAutoEncoder(nn.Module):
+    """Heatmaps -> 3D pose lifting head (reference: model/net_architecture.py:579-758).
+
+    forward(input[B, 6J, S, S]) -> (pose[B, J(+1), 3], rot zeros[B, 3J], indep_pos zeros[B, 6J],
+    reconstructed-heatmap zeros[B, 6J, S, S]) -- the last three are all-zero in the reference too
+    (net_architecture.py:718-719, 756); they are returned as cached / broadcast zeros, not re-allocated.
+    """
+
+    def __init__(self, opt, input_channel_scale: int = 2, fc_dim: int = 16384):
+        super().__init__()
+        if input_channel_scale != 2:
+            raise NotImplementedError("only the stereo presets (UnrealEgo, EgoCap) are built")
+        if not getattr(opt, "patched_heatmap_ae", True) or getattr(opt, "skel_layer", "PU") != "PU":
+            raise NotImplementedError("only --patched_heatmap_ae --skel_layer PU (the shipped configuration) is built")
+        if getattr(opt, "heatmap_type", "sin") != "sin":
+            raise NotImplementedError("only --heatmap_type sin is built")
+        hm = list(getattr(opt, "load_size_heatmap", [64, 64]))
+        if hm[0] != hm[1]:
+            raise ValueError("load_size_heatmap must be square")
+        self.preset = _spec.lift_preset(opt.joint_preset, hm[0], getattr(opt, "ae_hidden_size", 128))
+        if opt.num_heatmap != self.preset.n_joints_hm or opt.num_rot_heatmap != self.preset.n_joints_hm:
+            raise ValueError("num_heatmap / num_rot_heatmap must match the joint preset")
+        p = self.preset
+        self.joint_preset = opt.joint_preset
+        self.hidden_size = p.hidden
+        self.num_joints = p.out_joints
+        self.num_pos_heatmap = self.num_rot_heatmap = p.n_joints_hm
+        self.channels_heatmap = p.in_channels
+        self.W = self.H = p.hm_size
+        self.rot_dim = 3 * p.n_joints_hm
+        _build_tree(self, _spec.lift_state_spec(p))
+        _kaiming_init_(self)
+        self._handle = None
+        self._bound_sig = None
+        self._ws = None
+        self._zeros = {}
+
+    # -- C-ABI plumbing ---------------------------------------------------------------------------
+    def _ensure_handle(self):
+        if self._handle is None:
+            p = self.preset
+            cfg = _lib.EgotapConfig(C.sizeof(_lib.EgotapConfig), p.n_joints_hm, int(p.estimate_head), p.hm_size, p.hidden,
+                                    p.vit_dim, p.vit_heads, p.vit_layers, p.patch, p.pu_hidden)
+            h = C.c_void_p()
+            _lib.check(_lib.load().egotap_create(C.byref(cfg), C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def _bind(self, device):
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        sig = tuple((k, t.data_ptr()) for k, t in sd.items())
+        if sig == self._bound_sig:
+            return
+        lib, h = _lib.load(), self._ensure_handle()
+        for k, t in sd.items():
+            if t.device != device:
+                raise _lib.EgotapError(f"parameter {k} is on {t.device}, input on {device}")
+            if t.dtype == torch.float32:
+                if not t.is_contiguous():
+                    raise _lib.EgotapError(f"parameter {k} must be contiguous")
+                _lib.check(lib.egotap_bind_param(h, _lib.NET_LIFT, k.encode(), C.c_void_p(t.data_ptr()), t.numel(), _lib.F32))
+            elif t.dtype == torch.long:
+                _lib.check(lib.egotap_bind_param(h, _lib.NET_LIFT, k.encode(), C.c_void_p(t.data_ptr()), t.numel(), _lib.I64))
+            else:
+                raise _lib.EgotapError(f"parameter {k}: dtype {t.dtype} not supported (fp32 path)")
+        n = C.c_int()
+        _lib.check(lib.egotap_unbound_count(h, _lib.NET_LIFT, C.byref(n)))
+        if n.value:
+            raise _lib.EgotapError(f"{n.value} parameters the forward needs are not bound")
+        self._bound_sig = sig
+
+    def _workspace(self, B, device):
+        lib, h = _lib.load(), self._ensure_handle()
+        need = C.c_size_t()
+        _lib.check(lib.egotap_lift_workspace_bytes(h, B, C.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != device:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def intermediate(self, name: str, B: int):
+        """View of an intermediate of the LAST forward inside the workspace (parity tests)."""
+        off, n = C.c_size_t(), C.c_int64()
+        _lib.check(_lib.load().egotap_lift_intermediate(self._ensure_handle(), B, name.encode(), C.byref(off), C.byref(n)))
+        return self._ws[off.value: off.value + 4 * n.value].view(torch.float32)
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.load().egotap_destroy(self._handle)
+        except Exception:
+            pass
+
+    # -- reference API ----------------------------------------------------------------------------
+    def predict_pose(self, input, input_rgb_left=None, input_rgb_right=None):
+        return self.forward(input, input_rgb_left, input_rgb_right, pose_only=True)
+
+    def forward(self, input, input_rgb_left=None, input_rgb_right=None, pose_only=False):
+        p = self.preset
+        if self.training:
+            raise NotImplementedError(
+                "egotap_amd builds the eval-mode forward in this round; call .eval() "
+                "(training: BatchNorm batch statistics + backward kernels are the next scope row)")
+        if not input.is_cuda:
+            raise _lib.EgotapError("EgoTAPAutoEncoder runs on the GPU only (no CPU fallback); move the input to cuda")
+        if input.dim() != 4 or input.shape[1] != p.in_channels or input.shape[2] != p.hm_size or input.shape[3] != p.hm_size:
+            raise ValueError(f"expected input [B, {p.in_channels}, {p.hm_size}, {p.hm_size}], got {tuple(input.shape)}")
+        hm = input.detach()
+        if hm.dtype != torch.float32:
+            hm = hm.float()
+        hm = hm.contiguous()
+        B = hm.shape[0]
+        dev = hm.device
+        pose = torch.empty((B, p.out_joints, 3), dtype=torch.float32, device=dev)
+        if B > 0:
+            with torch.cuda.device(dev):
+                self._bind(dev)
+                ws = self._workspace(B, dev)
+                _lib.check(_lib.load().egotap_lift_forward(
+                    self._ensure_handle(), C.c_void_p(hm.data_ptr()), B, C.c_void_p(pose.data_ptr()),
+                    C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        if pose_only:
+            return pose
+        key = (B, str(dev))
+        if key not in self._zeros:
+            z = torch.zeros((), dtype=torch.float32, device=dev)
+            self._zeros = {key: (torch.zeros((B, self.rot_dim), device=dev), torch.zeros((B, 6 * p.n_joints_hm), device=dev),
+                                 z.expand(B, p.in_channels, p.hm_size, p.hm_size))}
+        rot, indep, out_hm = self._zeros[key]
+        return pose, rot, indep, out_hm

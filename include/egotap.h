@@ -1,0 +1,109 @@
+/* egotap.h -- C ABI of libegotap_hip.so: EgoTAP's heatmap -> 3D lifting hot path on MI355X (gfx950).
+ *
+ * The reference (tho-kn/EgoTAP) is pure Python/PyTorch and has no FFI of its own; the boundary it
+ * offers is the nn.Module call.  Each entry point below names the reference interface it replaces
+ * (paths under the reference repo).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Contract
+ *   - plain pointers and sizes only; every pointer marked "device" is a HIP device pointer owned
+ *     by the caller (PyTorch allocates params, activations, workspace); the library borrows them.
+ *   - no device allocation, no synchronisation, no internal streams: all work is enqueued on the
+ *     caller's stream (pass torch.cuda.current_stream().cuda_stream as a void*).  Graph-capture safe.
+ *   - every function returns 0 on success, an EGOTAP_ERR_* code otherwise; the message is in
+ *     egotap_last_error() (thread local).  No C++ exception crosses the ABI.
+ *   - a handle is not thread-safe; data parallelism = one process + one handle per GPU.
+ */
+#ifndef EGOTAP_H
+#define EGOTAP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGOTAP_ABI_VERSION 1
+
+enum { EGOTAP_OK = 0, EGOTAP_ERR_INVALID = 1, EGOTAP_ERR_HIP = 2, EGOTAP_ERR_UNBOUND = 3, EGOTAP_ERR_WORKSPACE = 4 };
+
+/* which of the wrapper's three networks a parameter belongs to
+ * (model/egotap_autoencoder_model.py:109-111: net_AutoEncoder, net_HeatMap, net_RotHeatMap) */
+enum { EGOTAP_NET_LIFT = 0, EGOTAP_NET_HM_POS = 1, EGOTAP_NET_HM_ROT = 2, EGOTAP_NET_COUNT = 3 };
+
+enum { EGOTAP_F32 = 0, EGOTAP_I64 = 1 };
+
+/* Options that shape the networks; mirrors the reference flags
+ * --joint_preset/--num_heatmap/--ae_hidden_size/--load_size_heatmap (options/base_options.py:52-66,
+ * options/dataset_options.py:29-41) and the fixed ViT/PU sizes of model/net_architecture.py:340-348, 650. */
+typedef struct egotap_config {
+    int32_t struct_bytes;   /* sizeof(egotap_config), for ABI checking */
+    int32_t n_joints_hm;    /* heatmaps per eye: 15 UnrealEgo, 17 EgoCap */
+    int32_t estimate_head;  /* 1: UnrealEgo (head joint + global offset from global_mlp), 0: EgoCap */
+    int32_t hm_size;        /* heatmap side (64; 128 for 512x512 RGB) */
+    int32_t hidden;         /* --ae_hidden_size (128) */
+    int32_t vit_dim;        /* 1024 */
+    int32_t vit_heads;      /* 8 */
+    int32_t vit_layers;     /* 3 */
+    int32_t patch;          /* 16 */
+    int32_t pu_hidden;      /* 512 */
+} egotap_config;
+
+typedef struct egotap_handle_s* egotap_handle;
+
+/* library */
+int egotap_abi_version(void);
+const char* egotap_last_error(void);
+
+/* replaces network.define_AutoEncoder / define_HeatMap (model/network.py:11-33): host-side state only */
+int egotap_create(const egotap_config* cfg, egotap_handle* out);
+void egotap_destroy(egotap_handle h);
+
+/* replaces nn.Module parameter ownership: bind one state_dict entry (the reference's own key,
+ * SURVEY.md Appendix B, e.g. "pos_heatmap_encoder.vit.encoder.layer.0.attention.attention.query.weight")
+ * to a device pointer.  numel and dtype are checked against the expected shape. */
+int egotap_bind_param(egotap_handle h, int net, const char* state_dict_key, void* dev_ptr, int64_t numel, int dtype);
+/* number of state_dict entries the forward of `net` needs that are not bound yet (0 = ready) */
+int egotap_unbound_count(egotap_handle h, int net, int* count);
+
+/* EgoTAPAutoEncoder.forward / predict_pose (model/net_architecture.py:679-758), eval mode:
+ *   hm    device f32 [B, 6*n_joints_hm, hm_size, hm_size]  (L pos, R pos, L cos, L sin, R cos, R sin)
+ *   pose  device f32 [B, n_joints_hm + estimate_head, 3]   (head joint last)
+ *   ws    device scratch of at least egotap_lift_workspace_bytes(B), 256-byte aligned
+ * The reference's three all-zero outputs (rot, indep_pos, reconstructed heatmaps; :718-719, 756) are
+ * not computed here: the host mirror returns cached zeros. */
+int egotap_lift_workspace_bytes(egotap_handle h, int B, size_t* bytes);
+int egotap_lift_forward(egotap_handle h, const float* hm, int B, float* pose, void* ws, size_t ws_bytes, void* stream);
+
+/* where an intermediate lives inside ws after egotap_lift_forward (for parity tests):
+ * name in {"tokens","pos_embed","rot_embed","skel_embed"}; offset in bytes, numel in floats */
+int egotap_lift_intermediate(egotap_handle h, int B, const char* name, size_t* offset, int64_t* numel);
+
+/* debugging aid for parity tests: 0 = full forward (default); 1 = return after the embeddings;
+ * 2+i = return after ViT layer i.  The state is then readable as intermediate "x". */
+int egotap_lift_debug_stop(egotap_handle h, int stage);
+
+/* ---- single operators (same kernels the forward uses; exported for unit tests and reuse) ---- */
+/* y = epi(x W^T + b): nn.Linear (+ residual / exact GELU / BatchNorm1d-eval + LeakyReLU 0.2).
+ * epi: 0 bias, 1 bias + residual r[M,N], 2 bias + GELU(erf), 3 bias + BN(eval) + LeakyReLU (bn = gamma,beta,mean,var; eps 1e-5)
+ * tile: 0 default, else a tile-shape id (see egotap_gemm_tile_name) */
+int egotap_linear_f32(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int epi,
+                      const float* r, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                      const float* bn_var, int tile, void* stream);
+const char* egotap_gemm_tile_name(int tile);
+/* nn.LayerNorm over the last dim (1024), modeling_vit.py:357-358 */
+int egotap_layernorm_f32(const float* x, float* y, const float* gamma, const float* beta, int rows, int dim, float eps,
+                         void* stream);
+/* ViTSelfAttention core (modeling_vit.py:233-252) on a fused [B*N, 3*heads*128] q|k|v buffer -> ctx [B*N, heads*128] */
+int egotap_attention_f32(const float* qkv, float* ctx, int B, int N, int heads, void* stream);
+
+/* ---- measurement hooks (bench.py roofline) ---- */
+/* when enabled, every GEMM launch of the handle is bracketed by HIP events on the caller's stream */
+int egotap_timing_enable(egotap_handle h, int enable);
+/* synchronises the recorded events; returns launches, summed milliseconds and summed algorithmic FLOPs
+ * of the fp32 GEMM kernel since the last reset, then resets */
+int egotap_timing_read(egotap_handle h, int* launches, double* total_ms, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGOTAP_H */

@@ -1,0 +1,105 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/egotap.h declares,
+and its host-side argument checking behaves (no kernel is launched here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from egotap_amd import lib as L
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(REPO, "include", "egotap.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(egotap_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_library_agree():
+    lib = L.load()
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in egotap.h but not exported"
+    assert sorted(L.exported_symbols()) == names
+    assert lib.egotap_abi_version() == 1
+
+
+def _cfg(**kw):
+    base = dict(n_joints_hm=15, estimate_head=1, hm_size=64, hidden=128, vit_dim=1024, vit_heads=8, vit_layers=3,
+                patch=16, pu_hidden=512)
+    base.update(kw)
+    return L.EgotapConfig(C.sizeof(L.EgotapConfig), *[base[k] for k in (
+        "n_joints_hm", "estimate_head", "hm_size", "hidden", "vit_dim", "vit_heads", "vit_layers", "patch", "pu_hidden")])
+
+
+def test_create_rejects_bad_config():
+    lib = L.load()
+    h = C.c_void_p()
+    bad = _cfg(hm_size=60)
+    assert lib.egotap_create(C.byref(bad), C.byref(h)) == 1
+    assert b"multiple of 16" in lib.egotap_last_error()
+    bad = _cfg()
+    bad.struct_bytes = 4
+    assert lib.egotap_create(C.byref(bad), C.byref(h)) == 1
+
+
+def test_bind_checks_shape_and_reports_unbound():
+    lib = L.load()
+    h = C.c_void_p()
+    cfg = _cfg()
+    assert lib.egotap_create(C.byref(cfg), C.byref(h)) == 0
+    n = C.c_int()
+    assert lib.egotap_unbound_count(h, L.NET_LIFT, C.byref(n)) == 0
+    assert n.value == 4 + 3 * 16 + 2 + 2 * 3 * 6 + 14 + 2 + 2    # forward-needed keys of the UE lifting head
+    key = b"pos_heatmap_encoder.vit.layernorm.weight"
+    fake = C.c_void_p(0x1000)
+    assert lib.egotap_bind_param(h, L.NET_LIFT, key, fake, 1000, L.F32) == 1
+    assert b"expected 1024" in lib.egotap_last_error()
+    assert lib.egotap_bind_param(h, L.NET_LIFT, key, C.c_void_p(0x1004), 1024, L.F32) == 1   # misaligned
+    assert lib.egotap_bind_param(h, L.NET_LIFT, key, fake, 1024, L.F32) == 0
+    assert lib.egotap_unbound_count(h, L.NET_LIFT, C.byref(n)) == 0
+    before = n.value
+    # forward with unbound parameters must fail loudly, before any launch
+    ws = C.c_size_t()
+    assert lib.egotap_lift_workspace_bytes(h, 2, C.byref(ws)) == 0 and ws.value > 0
+    rc = lib.egotap_lift_forward(h, C.c_void_p(0x1000), 2, C.c_void_p(0x2000), C.c_void_p(0x10000), ws.value, None)
+    assert rc == 3 and b"not bound" in lib.egotap_last_error()
+    assert before > 0
+    lib.egotap_destroy(h)
+
+
+def test_workspace_grows_with_batch():
+    lib = L.load()
+    h = C.c_void_p()
+    cfg = _cfg()
+    assert lib.egotap_create(C.byref(cfg), C.byref(h)) == 0
+    a, b = C.c_size_t(), C.c_size_t()
+    lib.egotap_lift_workspace_bytes(h, 1, C.byref(a))
+    lib.egotap_lift_workspace_bytes(h, 256, C.byref(b))
+    assert 200 * a.value < b.value < 260 * a.value
+    assert b.value < 8 << 30
+    lib.egotap_destroy(h)
+
+
+def test_module_mirror_has_reference_state_dict():
+    import types
+    import numpy as np
+    from egotap_amd import networks, spec
+    g = np.load(os.path.join(REPO, "tests", "golden", "lift_fwd_ue_b2.npz"))
+    opt = types.SimpleNamespace(joint_preset="UnrealEgo", num_heatmap=15, num_rot_heatmap=15, heatmap_type="sin",
+                                ae_hidden_size=128, patched_heatmap_ae=True, skel_layer="PU", load_size_heatmap=[64, 64])
+    net = networks.EgoTAPAutoEncoder(opt, input_channel_scale=2)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(g["state_keys"])
+    assert ["x".join(str(d) for d in v.shape) for v in sd.values()] == list(g["state_shapes"])
+    assert [k for k, _ in net.named_parameters()] == list(g["param_keys"])
+    net.eval()
+    import torch
+    with pytest.raises(L.EgotapError):
+        net(torch.zeros(1, 90, 64, 64))          # CPU tensor: no fallback, must raise
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1, 90, 64, 64))

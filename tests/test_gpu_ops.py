@@ -1,0 +1,118 @@
+"""GPU parity of the single HIP operators (through the C ABI) against float64 CPU math."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g, dtype=torch.float64) * (hi - lo) + lo).float()
+
+
+def _close(got, ref64, atol, rtol=1e-5):
+    got = got.detach().cpu().double()
+    err = (got - ref64).abs()
+    tol = atol + rtol * ref64.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e} (max ref {ref64.abs().max().item():.3e})"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (576, 1024, 256), (1, 128, 64), (130, 256, 96), (1152, 3072, 1024),
+                                    (77, 512, 2048)])
+def test_linear_bias(M, N, K):
+    from egotap_amd import lib
+    x, w, b = _rand((M, K), 1), _rand((N, K), 2, -0.1, 0.1), _rand((N,), 3)
+    y = lib.linear(x.cuda(), w.cuda(), b.cuda())
+    ref = x.double() @ w.double().T + b.double()
+    _close(y, ref, atol=2e-6 * math.sqrt(K))
+
+
+def test_linear_identity_asymmetric():
+    """A = I against an asymmetric W catches a transposed C write (cdna_hip_programming.md section 3)."""
+    from egotap_amd import lib
+    K = 128
+    x = torch.eye(K)
+    w = torch.arange(256 * K, dtype=torch.float32).reshape(256, K) * 0.5
+    y = lib.linear(x.cuda(), w.cuda(), torch.zeros(256).cuda()).cpu()
+    assert torch.equal(y, w.T.contiguous())
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 6, 7])
+def test_linear_tiles_agree(tile):
+    from egotap_amd import lib
+    M, N, K = 700, 512, 160
+    x, w, b = _rand((M, K), 11), _rand((N, K), 12, -0.1, 0.1), _rand((N,), 13)
+    ref = x.double() @ w.double().T + b.double()
+    y = lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=tile)
+    _close(y, ref, atol=3e-5)
+
+
+def test_linear_epilogues():
+    from egotap_amd import lib
+    M, N, K = 200, 256, 512
+    x, w, b = _rand((M, K), 21), _rand((N, K), 22, -0.05, 0.05), _rand((N,), 23)
+    z = x.double() @ w.double().T + b.double()
+    r = _rand((M, N), 24)
+    _close(lib.linear(x.cuda(), w.cuda(), b.cuda(), "residual", residual=r.cuda()), z + r.double(), 3e-5)
+    gel = 0.5 * z * (1.0 + torch.erf(z / math.sqrt(2.0)))
+    _close(lib.linear(x.cuda(), w.cuda(), b.cuda(), "gelu"), gel, 3e-5)
+    g, beta, mean, var = _rand((N,), 25, 0.5, 1.5), _rand((N,), 26), _rand((N,), 27, -0.2, 0.2), _rand((N,), 28, 0.5, 1.5)
+    bn = (z - mean.double()) / torch.sqrt(var.double() + 1e-5) * g.double() + beta.double()
+    bn = torch.where(bn > 0, bn, 0.2 * bn)
+    _close(lib.linear(x.cuda(), w.cuda(), b.cuda(), "bn_lrelu", bn=tuple(t.cuda() for t in (g, beta, mean, var))), bn, 5e-5)
+    # residual in place (the transformer's x += ...): output buffer aliases the residual
+    xr = r.cuda().clone()
+    import ctypes as C
+    L = lib.load()
+    xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+    lib.check(L.egotap_linear_f32(C.c_void_p(xc.data_ptr()), C.c_void_p(wc.data_ptr()), C.c_void_p(bc.data_ptr()),
+                                  C.c_void_p(xr.data_ptr()), M, N, K, 1, C.c_void_p(xr.data_ptr()), None, None, None, None, 0,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    _close(xr, z + r.double(), 3e-5)
+
+
+def test_linear_rejects_bad_shapes():
+    from egotap_amd import lib
+    x, w, b = torch.zeros(4, 40).cuda(), torch.zeros(128, 40).cuda(), torch.zeros(128).cuda()
+    with pytest.raises(lib.EgotapError):
+        lib.linear(x, w, b)                      # K = 40 not a multiple of 32
+    with pytest.raises(lib.EgotapError):
+        lib.linear(torch.zeros(4, 64), w, b)     # CPU tensor
+
+
+@pytest.mark.parametrize("rows", [1, 5, 576, 4099])
+def test_layernorm(rows):
+    from egotap_amd import lib
+    x, g, b = _rand((rows, 1024), 31, -3, 3), _rand((1024,), 32, 0.5, 1.5), _rand((1024,), 33)
+    xd = x.double()
+    mu = xd.mean(-1, keepdim=True)
+    var = ((xd - mu) ** 2).mean(-1, keepdim=True)
+    ref = (xd - mu) / torch.sqrt(var + 1e-12) * g.double() + b.double()
+    _close(lib.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-12), ref, 3e-6)
+
+
+@pytest.mark.parametrize("B,N,heads", [(1, 32, 1), (2, 576, 8), (1, 64, 2), (3, 96, 8)])
+def test_attention(B, N, heads):
+    from egotap_amd import lib
+    D = heads * 128
+    qkv = _rand((B * N, 3 * D), 41, -2, 2)
+    q, k, v = [t.reshape(B, N, heads, 128).transpose(1, 2).double() for t in qkv.split(D, dim=1)]
+    s = q @ k.transpose(-1, -2) / math.sqrt(128.0)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * N, D)
+    _close(lib.attention(qkv.cuda(), B, N, heads), ref, 3e-6)
+
+
+def test_attention_rescale_branch():
+    """Force the running max to jump at a late key tile (online-softmax rescale path)."""
+    from egotap_amd import lib
+    B, N, heads, D = 1, 128, 1, 128
+    qkv = _rand((N, 3 * D), 51, -0.5, 0.5)
+    qkv[7, :128] = 3.0                    # query 7 ...
+    qkv[100, 128:256] = 3.0               # ... strongly matches key 100 (4th key tile)
+    q, k, v = [t.reshape(B, N, heads, 128).transpose(1, 2).double() for t in qkv.split(D, dim=1)]
+    s = q @ k.transpose(-1, -2) / math.sqrt(128.0)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(N, D)
+    _close(lib.attention(qkv.cuda(), B, N, heads), ref, 3e-6)
