@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: stereo frames/s of the heatmap -> 3D lift (BASELINE.json configs[1]:
+UnrealEgo 16-joint lifting, batch 256 per GPU, fp32, forward only) on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps 10 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path (EgoTAPAutoEncoder.forward through the C ABI / HIP kernels) over one
+batch of 256 synthetic stereo heatmap sets already resident in HBM.  The batch shards by sample with no
+data-path collective, so N GPUs run N shards: weak scaling; value = N*256*K / max-rank time.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 256 CUs @ 2.4 GHz
+
+
+def lift_flops_per_frame(p) -> float:
+    """Algorithmic FLOPs (2 per MAC, matmul only) of one lifting-head forward: SURVEY.md 8(d)."""
+    N, D, T, J, H = p.seq, p.vit_dim, p.tokens, p.n_joints_hm, p.pu_hidden
+    patch = 2 * N * 256 * D
+    vit = p.vit_layers * (24 * N * D * D + 4 * N * N * D)
+    pos_fc = 2 * T * (p.ppd * p.ppd * D * 2048 + 2048 * 512 + 512 * p.hidden)
+    rot_fc = 2 * T * (2 * p.hm_size ** 2 * 2048 + 2048 * 512 + 512 * p.hidden)
+    x = 2 * p.hidden
+    pu = 2 * J * (x * (H + x) + 2 * x * 4 * H + H * 4 * H + H * H + 2 * H * 4 * H)
+    head = 2 * J * (x + H) * 3 + (2 * J * H * 6 if p.estimate_head else 0)
+    return float(patch + vit + pos_fc + rot_fc + pu + head)
+
+
+def host_cores() -> int:
+    """CPU cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    env = os.environ.get("EGOTAP_CPU_THREADS")
+    if env:
+        n = int(env)
+    return n
+
+
+def cpu_baseline(p, sd_np, batch: int, reps: int):
+    """The oracle (CPU restatement of the reference, plain torch ops) timed on the host cores."""
+    import torch
+    from egotap_amd.synthetic import synth_input
+    from oracle import lift_ref as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = O.to_torch_sd(sd_np)
+    hm = torch.from_numpy(synth_input("hm_cpu_baseline", (batch, p.in_channels, p.hm_size, p.hm_size)))
+    with torch.no_grad():
+        O.lift_forward(hm[:2], sd, p)      # warm-up
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = O.lift_forward(hm, sd, p)
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": batch / med, "unit": "stereo frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/lift_ref.lift_forward, B={batch}, fp32, {reps} timed passes (median), torch CPU threads={cores}"}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="stereo frames per GPU per step (BASELINE: 256)")
+    ap.add_argument("--preset", default="UnrealEgo")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket GEMM launches with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from egotap_amd import lib, spec
+    from egotap_amd.synthetic import synth_input, synth_state_dict
+    from egotap_amd.options import preset_defaults as make_opt
+    from egotap_amd import networks
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    p = spec.lift_preset(args.preset)
+    sd_np = synth_state_dict(spec.lift_state_spec(p))
+    net = networks.EgoTAPAutoEncoder(make_opt(args.preset), input_channel_scale=2)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    net = net.to(dev).eval()
+    B = args.batch
+    hm = torch.from_numpy(synth_input(f"hm_bench_rank{rank}", (B, p.in_channels, p.hm_size, p.hm_size))).to(dev)
+
+    L = lib.load()
+    h = net._ensure_handle()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        pose = net.predict_pose(hm)
+    barrier()
+    timing = not args.no_kernel_timing
+    lib.check(L.egotap_timing_enable(h, int(timing)))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pose = net.predict_pose(hm)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    barrier()
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    roof = None
+    if timing:
+        n, ms, fl = C.c_int(), C.c_double(), C.c_double()
+        lib.check(L.egotap_timing_read(h, C.byref(n), C.byref(ms), C.byref(fl)))
+        detail = json.loads(L.egotap_timing_detail(h).decode())
+        lib.check(L.egotap_timing_enable(h, 0))
+        by_kernel = {}
+        for d in detail:
+            k = by_kernel.setdefault(d["kernel"], {"launches": 0, "ms": 0.0, "flops": 0.0})
+            k["launches"] += d["launches"]; k["ms"] += d["ms"]; k["flops"] += d["flops"]
+        achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        roof = {
+            "bound": "mfma", "kernel": "gemm_f32_kernel (all instantiations, v_mfma_f32_32x32x2_f32)",
+            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches": n.value, "avg_launch_ms": round(ms.value / max(n.value, 1), 4),
+            "gemm_share_of_step_time": round(ms.value * 1e-3 / (elapsed if world == 1 else elapsed), 4),
+            "by_kernel": {k: {"launches": v["launches"], "avg_ms": round(v["ms"] / v["launches"], 4),
+                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in by_kernel.items()},
+            "by_role": {d["role"]: {"avg_ms": round(d["ms"] / d["launches"], 4),
+                                    "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)} for d in detail},
+        }
+
+    cpu = None
+    gpu_vs_oracle = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, ref = cpu_baseline(p, sd_np, args.cpu_batch, 3)
+        # parity spot check on the same inputs the CPU leg used (first frames)
+        hm_c = torch.from_numpy(synth_input("hm_cpu_baseline", (args.cpu_batch, p.in_channels, p.hm_size, p.hm_size))).to(dev)
+        got = net.predict_pose(hm_c).cpu()
+        gpu_vs_oracle = float((got - ref).abs().max())
+
+    if rank == 0:
+        frames = world * B * args.steps
+        fps = frames / elapsed
+        flops_frame = lift_flops_per_frame(p)
+        line = {
+            "metric": "stereo frames/sec (2D->3D lift, B=256, 256x256)", "value": round(fps, 1), "unit": "stereo frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.preset} 16-joint lifting head (heatmaps [B,90,64,64] -> joints [B,16,3]), "
+                                   f"forward only, fp32, batch {B} per GPU, inputs resident in HBM",
+                       "batch_per_gpu": B, "global_batch": world * B, "heatmap": p.hm_size, "rgb": 4 * p.hm_size,
+                       "parallelism": f"dp{world} (batch shards, no collective)"},
+            "flops_per_frame": flops_frame,
+            "end_to_end_tflops_per_gpu": round(fps * flops_frame / world / 1e12, 2),
+            "end_to_end_frac_of_f32_mfma_peak": round(fps * flops_frame / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "roofline": roof, "cpu_baseline": cpu, "max_abs_diff_vs_oracle": gpu_vs_oracle,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

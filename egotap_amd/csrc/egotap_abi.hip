@@ -34,6 +34,10 @@ using TileD = GemmCfg<256, 256, 16, 4, 2, 2>;   // 8 waves, 64x128 per wave, 1 b
 using TileE = GemmCfg<256, 128, 16, 2, 2, 2>;   // 4 waves, 128x64 per wave, 2 blocks/CU
 using TileF = GemmCfg<64, 64, 32, 2, 2, 2>;     // 4 waves, 32x32 per wave (small problems)
 using TileG = GemmCfg<256, 128, 32, 2, 2, 1>;   // 4 waves, 128x64 per wave, 1 block/CU
+using PipeA = PipeCfg<128, 128, 16, 2, 2, 2>;   // pipelined: 3 x 20 KiB slabs, 2 blocks/CU
+using PipeB = PipeCfg<128, 128, 32, 2, 2, 1>;   // pipelined: 3 x 36 KiB slabs, 1 block/CU
+using PipeC = PipeCfg<256, 128, 16, 4, 2, 2>;   // pipelined, 8 waves: 3 x 30 KiB slabs, 1 block/CU
+using PipeD = PipeCfg<256, 256, 16, 4, 2, 2>;   // pipelined, 8 waves 64x128 per wave: 3 x 40 KiB slabs
 
 extern "C" const char* egotap_gemm_tile_name(int tile) {
     switch (tile) {
@@ -44,6 +48,10 @@ extern "C" const char* egotap_gemm_tile_name(int tile) {
         case 5: return "256x128x16/4w";
         case 6: return "64x64x32/4w";
         case 7: return "256x128x32/4w";
+        case 8: return "pipe128x128x16/4w";
+        case 9: return "pipe128x128x32/4w";
+        case 10: return "pipe256x128x16/8w";
+        case 11: return "pipe256x256x16/8w";
         default: return nullptr;
     }
 }
@@ -80,8 +88,10 @@ struct egotap_handle_s {
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;   // start/stop pairs
+    struct Rec { const char* role; const char* kernel; double flops; };
+    std::vector<Rec> rec;         // one per recorded pair
     size_t ev_used = 0;
-    double flops = 0.0;
+    std::string detail;           // JSON written by egotap_timing_read
 };
 typedef egotap_handle_s Handle;
 
@@ -262,26 +272,46 @@ extern "C" int egotap_timing_enable(egotap_handle h, int enable) {
 }
 extern "C" int egotap_timing_read(egotap_handle h, int* launches, double* total_ms, double* total_flops) {
     EGO_CHECK(h && launches && total_ms && total_flops, "null argument");
-    double ms = 0.0;
-    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
-        EGO_HIP(hipEventSynchronize(h->ev[i + 1]));
+    struct Agg { std::string role, kernel; int n = 0; double ms = 0, flops = 0; };
+    std::vector<Agg> aggs;
+    double ms = 0.0, fl = 0.0;
+    const size_t pairs = h->ev_used / 2;
+    for (size_t i = 0; i < pairs; ++i) {
+        EGO_HIP(hipEventSynchronize(h->ev[2 * i + 1]));
         float t = 0.f;
-        EGO_HIP(hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]));
+        EGO_HIP(hipEventElapsedTime(&t, h->ev[2 * i], h->ev[2 * i + 1]));
         ms += t;
+        fl += h->rec[i].flops;
+        Agg* a = nullptr;
+        for (auto& x : aggs)
+            if (x.role == h->rec[i].role) { a = &x; break; }
+        if (!a) { aggs.emplace_back(); a = &aggs.back(); a->role = h->rec[i].role; a->kernel = h->rec[i].kernel; }
+        a->n += 1; a->ms += t; a->flops += h->rec[i].flops;
     }
-    *launches = (int)(h->ev_used / 2);
+    std::string js = "[";
+    for (size_t i = 0; i < aggs.size(); ++i) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "%s{\"role\": \"%s\", \"kernel\": \"%s\", \"launches\": %d, \"ms\": %.6f, \"flops\": %.6e}",
+                 i ? ", " : "", aggs[i].role.c_str(), aggs[i].kernel.c_str(), aggs[i].n, aggs[i].ms, aggs[i].flops);
+        js += buf;
+    }
+    js += "]";
+    h->detail = js;
+    *launches = (int)pairs;
     *total_ms = ms;
-    *total_flops = h->flops;
+    *total_flops = fl;
     h->ev_used = 0;
-    h->flops = 0.0;
+    h->rec.clear();
     return EGOTAP_OK;
 }
+extern "C" const char* egotap_timing_detail(egotap_handle h) { return h ? h->detail.c_str() : ""; }
 
 struct GemmTimer {   // brackets one GEMM launch when the handle's timing hook is on
     Handle* h;
     hipStream_t s;
     bool on;
-    GemmTimer(Handle* h_, hipStream_t s_, double flops) : h(h_), s(s_), on(h_ && h_->timing) {
+    GemmTimer(Handle* h_, hipStream_t s_, const char* role, const char* kernel, double flops)
+        : h(h_), s(s_), on(h_ && h_->timing) {
         if (!on) return;
         if (h->ev_used + 2 > h->ev.size()) {
             hipEvent_t a, b;
@@ -290,7 +320,7 @@ struct GemmTimer {   // brackets one GEMM launch when the handle's timing hook i
             h->ev.push_back(b);
         }
         (void)hipEventRecord(h->ev[h->ev_used], s);
-        h->flops += flops;
+        h->rec.push_back({role, kernel, flops});
     }
     ~GemmTimer() {
         if (!on) return;
@@ -299,11 +329,39 @@ struct GemmTimer {   // brackets one GEMM launch when the handle's timing hook i
     }
 };
 
+template <class AL> struct AlName;
+template <> struct AlName<ALoadPlain> { static constexpr const char* v = "ALoadPlain"; };
+template <> struct AlName<ALoadPatch> { static constexpr const char* v = "ALoadPatch"; };
+template <> struct AlName<ALoadTokens> { static constexpr const char* v = "ALoadTokens"; };
+template <> struct AlName<ALoadRot> { static constexpr const char* v = "ALoadRot"; };
+template <> struct AlName<ALoadStereo> { static constexpr const char* v = "ALoadStereo"; };
+template <> struct AlName<ALoadStereoGated> { static constexpr const char* v = "ALoadStereoGated"; };
+template <class E> struct EpiName;
+template <> struct EpiName<EpiBias> { static constexpr const char* v = "EpiBias"; };
+template <> struct EpiName<EpiBiasRes> { static constexpr const char* v = "EpiBiasRes"; };
+template <> struct EpiName<EpiBiasGelu> { static constexpr const char* v = "EpiBiasGelu"; };
+template <> struct EpiName<EpiBnLrelu> { static constexpr const char* v = "EpiBnLrelu"; };
+template <> struct EpiName<EpiPatch> { static constexpr const char* v = "EpiPatch"; };
+
 template <class Cfg, class AL, class Epi>
-static hipError_t gemm(Handle* h, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K,
-                       hipStream_t s) {
-    GemmTimer t(h, s, 2.0 * M * N * K);
+static hipError_t gemm(Handle* h, const char* role, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc,
+                       int M, int N, int K, hipStream_t s) {
+    static const std::string kname = std::string("gemm_f32_kernel<") + std::to_string(Cfg::BM) + "x" +
+                                     std::to_string(Cfg::BN) + "x" + std::to_string(Cfg::BK) + "," + AlName<AL>::v + "," +
+                                     EpiName<Epi>::v + ">";
+    GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
     return gemm_f32_launch<Cfg, AL, Epi>(al, W, epi, C, ldc, M, N, K, s);
+}
+
+// large GEMMs (ViT projections, fc1): 256x256 tile, 3-stage pipelined kernel -- fewest global-load
+// instructions per MFMA (each costs the matrix pipe ~56 cycles, tools/mfma_probe.hip), DESIGN.md section 4
+template <class AL, class Epi>
+static hipError_t gemm_big(Handle* h, const char* role, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc,
+                           int M, int N, int K, hipStream_t s) {
+    using Cfg = PipeD;
+    static const std::string kname = std::string("gemm_f32_pipe_kernel<256x256x16,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
+    GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
+    return gemm_f32_pipe_launch<Cfg, AL, Epi>(al, W, epi, C, ldc, M, N, K, s);
 }
 
 // ------------------------------------------------------------------------------------------------ workspace
@@ -388,7 +446,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     {
         ALoadPatch al{hm, h->C, S, h->seq, h->side, h->ppd, h->grid, h->T};
         EpiPatch ep{p.patch_b, p.mask_tok, p.pos_emb, D, h->seq, h->side, h->ppd, h->grid, h->T};
-        EGO_HIP((gemm<Tile>(h, al, segmat1(p.patch_w, D, 256), ep, X, D, M, D, 256, s)));
+        EGO_HIP((gemm_big(h, "patch_embed", al, segmat1(p.patch_w, D, 256), ep, X, D, M, D, 256, s)));
     }
     if (h->debug_stop == 1) return EGOTAP_OK;
     // H3-H8: pre-LN transformer layers
@@ -398,13 +456,13 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
         {
             SegMat Wqkv; Wqkv.p[0] = L.q_w; Wqkv.p[1] = L.k_w; Wqkv.p[2] = L.v_w; Wqkv.seg = D; Wqkv.ld = D;
             SegVec bqkv; bqkv.p[0] = L.q_b; bqkv.p[1] = L.k_b; bqkv.p[2] = L.v_b; bqkv.seg = D;
-            EGO_HIP((gemm<Tile>(h, ALoadPlain{Y, D}, Wqkv, EpiBias{bqkv}, QKV, 3L * D, M, 3 * D, D, s)));
+            EGO_HIP((gemm_big(h, "qkv", ALoadPlain{Y, D}, Wqkv, EpiBias{bqkv}, QKV, 3L * D, M, 3 * D, D, s)));
         }
         EGO_HIP(attention_f32_launch(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
-        EGO_HIP((gemm<Tile>(h, ALoadPlain{CTX, D}, segmat1(L.o_w, D, D), EpiBiasRes{segvec1(L.o_b, D), X, D}, X, D, M, D, D, s)));
+        EGO_HIP((gemm_big(h, "attn_out", ALoadPlain{CTX, D}, segmat1(L.o_w, D, D), EpiBiasRes{segvec1(L.o_b, D), X, D}, X, D, M, D, D, s)));
         EGO_HIP(launch_ln(X, Y, L.ln2_g, L.ln2_b, M, 1e-12f, s));
-        EGO_HIP((gemm<Tile>(h, ALoadPlain{Y, D}, segmat1(L.up_w, 4 * D, D), EpiBiasGelu{segvec1(L.up_b, 4 * D)}, HID, 4L * D, M, 4 * D, D, s)));
-        EGO_HIP((gemm<Tile>(h, ALoadPlain{HID, 4L * D}, segmat1(L.dn_w, D, 4L * D), EpiBiasRes{segvec1(L.dn_b, D), X, D}, X, D, M, D, 4 * D, s)));
+        EGO_HIP((gemm_big(h, "mlp_up", ALoadPlain{Y, D}, segmat1(L.up_w, 4 * D, D), EpiBiasGelu{segvec1(L.up_b, 4 * D)}, HID, 4L * D, M, 4 * D, D, s)));
+        EGO_HIP((gemm_big(h, "mlp_down", ALoadPlain{HID, 4L * D}, segmat1(L.dn_w, D, 4L * D), EpiBiasRes{segvec1(L.dn_b, D), X, D}, X, D, M, D, 4 * D, s)));
         if (h->debug_stop == 2 + i) return EGOTAP_OK;
     }
     EGO_HIP(launch_ln(X, Y, p.lnf_g, p.lnf_b, M, 1e-12f, s));
@@ -413,25 +471,25 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     {
         const int K1 = h->ppd * h->ppd * D;
         ALoadTokens al{Y, h->T, D, h->seq, h->side, h->ppd, h->grid};
-        EGO_HIP((gemm<Tile>(h, al, segmat1(p.pos_fc[0].w, 2048, K1), bn(p.pos_fc[0]), Z1, 2048, BT, 2048, K1, s)));
-        EGO_HIP((gemm<Tile>(h, ALoadPlain{Z1, 2048}, segmat1(p.pos_fc[1].w, 512, 2048), bn(p.pos_fc[1]), Z2, 512, BT, 512, 2048, s)));
-        EGO_HIP((gemm<Tile>(h, ALoadPlain{Z2, 512}, segmat1(p.pos_fc[2].w, hid, 512), bn(p.pos_fc[2]), POSZ, hid, BT, hid, 512, s)));
+        EGO_HIP((gemm_big(h, "pos_fc1", al, segmat1(p.pos_fc[0].w, 2048, K1), bn(p.pos_fc[0]), Z1, 2048, BT, 2048, K1, s)));
+        EGO_HIP((gemm<Tile>(h, "pos_fc2", ALoadPlain{Z1, 2048}, segmat1(p.pos_fc[1].w, 512, 2048), bn(p.pos_fc[1]), Z2, 512, BT, 512, 2048, s)));
+        EGO_HIP((gemm<Tile>(h, "pos_fc3", ALoadPlain{Z2, 512}, segmat1(p.pos_fc[2].w, hid, 512), bn(p.pos_fc[2]), POSZ, hid, BT, hid, 512, s)));
     }
     // H11-H12: rotation (cos/sin) heatmaps straight from the input tensor
     {
         ALoadRot al{hm, h->C, J, HW};
-        EGO_HIP((gemm<Tile>(h, al, segmat1(p.rot_fc[0].w, 2048, 2L * HW), bn(p.rot_fc[0]), Z1, 2048, BT, 2048, 2 * HW, s)));
-        EGO_HIP((gemm<Tile>(h, ALoadPlain{Z1, 2048}, segmat1(p.rot_fc[1].w, 512, 2048), bn(p.rot_fc[1]), Z2, 512, BT, 512, 2048, s)));
-        EGO_HIP((gemm<Tile>(h, ALoadPlain{Z2, 512}, segmat1(p.rot_fc[2].w, hid, 512), bn(p.rot_fc[2]), ROTZ, hid, BT, hid, 512, s)));
+        EGO_HIP((gemm_big(h, "rot_fc1", al, segmat1(p.rot_fc[0].w, 2048, 2L * HW), bn(p.rot_fc[0]), Z1, 2048, BT, 2048, 2 * HW, s)));
+        EGO_HIP((gemm<Tile>(h, "rot_fc2", ALoadPlain{Z1, 2048}, segmat1(p.rot_fc[1].w, 512, 2048), bn(p.rot_fc[1]), Z2, 512, BT, 512, 2048, s)));
+        EGO_HIP((gemm<Tile>(h, "rot_fc3", ALoadPlain{Z2, 512}, segmat1(p.rot_fc[2].w, hid, 512), bn(p.rot_fc[2]), ROTZ, hid, BT, hid, 512, s)));
     }
     // H13-H14: propagation units.  State-independent projections of all J steps as GEMMs (rows time-major t*B+b) ...
     const int x = 2 * hid, NF0 = H + x;
     ALoadStereo xs{POSZ, B, J, hid};
-    EGO_HIP((gemm<Tile>(h, xs, segmat1(p.x2f0_w, NF0, x), EpiBias{segvec1(p.x2f0_b, NF0)}, F0, NF0, JB, NF0, x, s)));
-    EGO_HIP((gemm<Tile>(h, xs, segmat1(p.x2h0_w, 4 * H, x), EpiBias{segvec1(p.x2h0_b, 4 * H)}, G0, 4L * H, JB, 4 * H, x, s)));
+    EGO_HIP((gemm<Tile>(h, "pu0_x2f", xs, segmat1(p.x2f0_w, NF0, x), EpiBias{segvec1(p.x2f0_b, NF0)}, F0, NF0, JB, NF0, x, s)));
+    EGO_HIP((gemm<Tile>(h, "pu0_x2h", xs, segmat1(p.x2h0_w, 4 * H, x), EpiBias{segvec1(p.x2h0_b, 4 * H)}, G0, 4L * H, JB, 4 * H, x, s)));
     {
         ALoadStereoGated bs{ALoadStereo{ROTZ, B, J, hid}, F0, NF0, H};
-        EGO_HIP((gemm<Tile>(h, bs, segmat1(p.b2h0_w, 4 * H, x), EpiBiasRes{segvec1(p.b2h0_b, 4 * H), G0, 4L * H}, G0, 4L * H, JB, 4 * H, x, s)));
+        EGO_HIP((gemm<Tile>(h, "pu0_b2h", bs, segmat1(p.b2h0_w, 4 * H, x), EpiBiasRes{segvec1(p.b2h0_b, 4 * H), G0, 4L * H}, G0, 4L * H, JB, 4 * H, x, s)));
     }
     // ... then the two J-step recurrences (layer 0 never reads layer-1 state, so the layers run one after the other)
     EGO_HIP(hipMemsetAsync(C0, 0, (size_t)(w.ZERO - w.C0) + (size_t)B * H * 4, s));   // C0, C1, ZERO are contiguous
@@ -442,8 +500,8 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
                            p.h2h0_w, p.h2h0_b, hprev, C0, HS0 + (size_t)t * B * H, B, H);
     }
     EGO_HIP(hipGetLastError());
-    EGO_HIP((gemm<Tile>(h, ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
-    EGO_HIP((gemm<Tile>(h, ALoadPlain{HS0, H}, segmat1(p.x2h1_w, 4 * H, H), EpiBias{segvec1(p.x2h1_b, 4 * H)}, G1, 4L * H, JB, 4 * H, H, s)));
+    EGO_HIP((gemm<Tile>(h, "pu1_x2f", ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
+    EGO_HIP((gemm<Tile>(h, "pu1_x2h", ALoadPlain{HS0, H}, segmat1(p.x2h1_w, 4 * H, H), EpiBias{segvec1(p.x2h1_b, 4 * H)}, G1, 4L * H, JB, 4 * H, H, s)));
     for (int t = 0; t < J; ++t) {
         const float* hprev = t == 0 ? ZERO : HS1 + (size_t)(t - 1) * B * H;
         hipLaunchKernelGGL(pu_step_kernel, pgrid, dim3(256), 0, s, F1 + (size_t)t * B * H, H, G1 + (size_t)t * B * 4 * H,
@@ -492,6 +550,10 @@ extern "C" int egotap_linear_f32(const float* x, const float* w, const float* b,
         case 5: e = gemm_f32_launch<TileE>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
         case 6: e = gemm_f32_launch<TileF>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
         case 7: e = gemm_f32_launch<TileG>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
+        case 8: e = gemm_f32_pipe_launch<PipeA>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
+        case 9: e = gemm_f32_pipe_launch<PipeB>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
+        case 10: e = gemm_f32_pipe_launch<PipeC>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
+        case 11: e = gemm_f32_pipe_launch<PipeD>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
         default: egotap_set_error("unknown tile id %d", tile); return EGOTAP_ERR_INVALID;
     }
     if (e == hipErrorInvalidValue) {

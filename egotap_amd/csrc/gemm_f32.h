@@ -18,6 +18,7 @@
 // feeding four MFMAs.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 // ----------------------------------------------------------------------------- A loaders
 struct ALoadPlain {
@@ -271,6 +272,171 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_kernel(
             }
         }
     }
+}
+
+// ----------------------------------------------------------------------------- pipelined kernel
+// Same tiling and numerics as gemm_f32_kernel (identical k order, bit-identical results) but with
+// the per-slab bubbles removed, which the first version lost ~22 % of the MFMA pipe to
+// (SQ_VALU_MFMA_BUSY_CYCLES 0.78; its two co-resident waves per SIMD run the same program in
+// lockstep, so their ds_read / ds_write / barrier gaps coincide):
+//   * THREE LDS slabs: slab kt+1 is already published while slab kt is computed, so the first
+//     fragments of the next slab are read BEFORE the barrier, which drops off the critical path;
+//   * fragments are double buffered in registers: the ds_reads of group t+1 are issued ahead of
+//     the 4*TM*TN MFMAs of group t (sched_barrier keeps the compiler from sinking them);
+//   * global loads run two slabs ahead in two register sets (a slab is only BK=16 deep, so a
+//     set is 4 float4), the LDS write of slab kt+2 sits in the middle of slab kt's MFMAs.
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_>
+struct PipeCfg : GemmCfg<BM_, BN_, BK_, WM_, WN_, MINW_> {
+    using Base = GemmCfg<BM_, BN_, BK_, WM_, WN_, MINW_>;
+    static constexpr int NS = 3;
+    static constexpr int LDS_BYTES = NS * (BM_ + BN_) * Base::LDK * 4;
+    static_assert((BK_ / 8) % 2 == 0, "need an even number of 8-deep fragment groups per slab");
+};
+
+template <class Cfg, class ALoad, class Epi>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_pipe_kernel(
+    ALoad al, SegMat W, Epi epi, float* C, long ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, LDK = Cfg::LDK, NS = Cfg::NS;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, A_V4 = Cfg::A_V4, B_V4 = Cfg::B_V4, RPP = Cfg::ROWS_PER_PASS;
+    constexpr int G = BK / 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                         // [NS][BM][LDK]
+    float* Bs = smem + NS * BM * LDK;         // [NS][BN][LDK]
+
+    int tm, tn;
+    xcd_tile(blockIdx.x, gridDim.x, tiles_m, tiles_n, 8, tm, tn);
+    const int bm = tm * BM, bn = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / Cfg::WN, wn = wid % Cfg::WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int c4 = tid % (BK / 4), r0 = tid / (BK / 4);
+    typename ALoad::Row arow[A_V4];
+    const float* brow[B_V4];
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) arow[i] = al.row(min(bm + r0 + i * RPP, M - 1));
+#pragma unroll
+    for (int i = 0; i < B_V4; ++i) brow[i] = W.row(bn + r0 + i * RPP);
+
+    f32x4 ga[2][A_V4], gb[2][B_V4];          // two global-load register sets
+    f32x4 fa[2][TM], fb[2][TN];              // two fragment register sets
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KT = K / BK;
+    const int a_off = (wm * (TM * 32) + l31) * LDK + 4 * lh;
+    const int b_off = (wn * (TN * 32) + l31) * LDK + 4 * lh;
+
+#define GLOAD(SET, SLAB)                                                                             \
+    {                                                                                                \
+        const int k0_ = (SLAB) * BK + c4 * 4;                                                        \
+        _Pragma("unroll") for (int i = 0; i < A_V4; ++i) ga[SET][i] = al.load(arow[i], k0_);         \
+        _Pragma("unroll") for (int i = 0; i < B_V4; ++i) gb[SET][i] = *(const f32x4*)(brow[i] + k0_); \
+    }
+#define LSTORE(SET, BUF)                                                                                         \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < A_V4; ++i)                                                         \
+            *(f32x4*)(As + ((BUF) * BM + r0 + i * RPP) * LDK + c4 * 4) = ga[SET][i];                             \
+        _Pragma("unroll") for (int i = 0; i < B_V4; ++i)                                                         \
+            *(f32x4*)(Bs + ((BUF) * BN + r0 + i * RPP) * LDK + c4 * 4) = gb[SET][i];                             \
+    }
+#define FRAGS(FSET, BUF, T)                                                                                      \
+    {                                                                                                            \
+        const float* ap_ = As + (BUF) * BM * LDK + a_off + 8 * (T);                                              \
+        const float* bp_ = Bs + (BUF) * BN * LDK + b_off + 8 * (T);                                              \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[FSET][i] = *(const f32x4*)(ap_ + i * 32 * LDK);        \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[FSET][j] = *(const f32x4*)(bp_ + j * 32 * LDK);        \
+    }
+#define MFMAS(FSET)                                                                                              \
+    {                                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                            \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                           \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                           \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[FSET][i][u], fb[FSET][j][u], acc[i][j], 0, 0, 0); \
+    }
+
+    // prologue: slabs 0 and 1 into LDS, slab 2 in flight, first fragments of slab 0 in registers
+    GLOAD(0, 0)
+    if (KT > 1) GLOAD(1, 1)
+    LSTORE(0, 0)
+    if (KT > 2) GLOAD(0, 2)
+    if (KT > 1) LSTORE(1, 1)
+    __syncthreads();
+    FRAGS(0, 0, 0)
+
+    int buf = 0;   // LDS slab of iteration kt
+    auto body = [&](auto PT, int kt) {
+        constexpr int P = decltype(PT)::value;      // parity of kt: register set of slab kt+2 (same parity) is P
+        const int b1 = buf + 1 >= NS ? buf + 1 - NS : buf + 1;
+        const int b2 = b1 + 1 >= NS ? b1 + 1 - NS : b1 + 1;
+        if (kt + 3 < KT) GLOAD(P ^ 1, kt + 3)
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+            // prefetch the fragments of the next group (next slab after the last group)
+            if (t + 1 < G) {
+                FRAGS((t + 1) & 1, buf, t + 1)
+            } else if (kt + 1 < KT) {
+                FRAGS(0, b1, 0)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            MFMAS(t & 1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == G / 2 - 1 && kt + 2 < KT) {
+                LSTORE(P, b2)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        buf = b1;
+    };
+    int kt = 0;
+    for (; kt + 1 < KT; kt += 2) {
+        body(std::integral_constant<int, 0>{}, kt);
+        body(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    if (kt < KT) body(std::integral_constant<int, 0>{}, kt);
+#undef GLOAD
+#undef LSTORE
+#undef FRAGS
+#undef MFMAS
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = bn + wn * (TN * 32) + j * 32 + l31;
+        const typename Epi::Col cc = epi.col(n);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mbase = bm + wm * (TM * 32) + i * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m < M) C[(long)m * ldc + n] = epi.apply(acc[i][j][r], cc, m, n);
+            }
+        }
+    }
+}
+
+template <class Cfg, class ALoad, class Epi>
+static hipError_t gemm_f32_pipe_launch(const ALoad& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N,
+                                       int K, hipStream_t stream) {
+    if (M <= 0) return hipSuccess;
+    if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0) return hipErrorInvalidValue;
+    auto kern = gemm_f32_pipe_kernel<Cfg, ALoad, Epi>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, al, W, epi, C, ldc, M,
+                       N, K, tiles_m, tiles_n);
+    return hipGetLastError();
 }
 
 // host launcher; returns hipError_t (no allocation, no sync: capture safe)

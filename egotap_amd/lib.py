@@ -41,6 +41,7 @@ _PROTOS = {
     "egotap_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "egotap_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "egotap_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "egotap_timing_detail": (C.c_char_p, [C.c_void_p]),
 }
 
 
@@ -53,6 +54,9 @@ def load(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime: import it first so this process has exactly one libamdhip64
+    # (loading ours before torch's gives two runtimes and "no ROCm-capable device" at the first launch)
+    import torch  # noqa: F401
     path = _build.LIB
     if build_if_missing and not os.path.exists(path):
         path = _build.build()

@@ -102,6 +102,9 @@ int egotap_timing_enable(egotap_handle h, int enable);
 /* synchronises the recorded events; returns launches, summed milliseconds and summed algorithmic FLOPs
  * of the fp32 GEMM kernel since the last reset, then resets */
 int egotap_timing_read(egotap_handle h, int* launches, double* total_ms, double* total_flops);
+/* JSON array written by the last egotap_timing_read: one object per GEMM role
+ * {"role","kernel","launches","ms","flops"}; the pointer stays valid until the next read */
+const char* egotap_timing_detail(egotap_handle h);
 
 #ifdef __cplusplus
 }

@@ -8,10 +8,8 @@ from egotap_amd.synthetic import synth_state_dict, synth_input
 
 
 def make_opt(preset="UnrealEgo", hm=64):
-    nj = 15 if preset == "UnrealEgo" else 17
-    return types.SimpleNamespace(joint_preset=preset, num_heatmap=nj, num_rot_heatmap=nj, heatmap_type="sin",
-                                 ae_hidden_size=128, patched_heatmap_ae=True, skel_layer="PU", load_size_heatmap=[hm, hm],
-                                 estimate_head=preset == "UnrealEgo", stereo=True, model_name="resnet18", init_ImageNet=False)
+    from egotap_amd.options import preset_defaults
+    return preset_defaults(preset, hm)
 
 
 _cache = {}

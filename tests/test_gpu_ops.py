@@ -40,7 +40,7 @@ def test_linear_identity_asymmetric():
     assert torch.equal(y, w.T.contiguous())
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 6, 7])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11])
 def test_linear_tiles_agree(tile):
     from egotap_amd import lib
     M, N, K = 700, 512, 160

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Digest gpurun_out/prof (written by tools/profile_bench.sh on the GPU box) into profiles/<tag>_*.
+
+usage: python tools/summarize_prof.py r01
+Copies the rocprofv3 kernel stats CSV and writes a markdown summary with per-kernel average
+duration, HBM bytes per launch (FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md, WRITE_SIZE as is;
+both in KiB), effective clock (GRBM_GUI_ACTIVE / 8 / duration) and matrix-pipe utilisation
+(SQ_VALU_MFMA_BUSY_CYCLES / (clock cycles x 1024 SIMDs))."""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(REPO, "gpurun_out", "prof")
+
+
+def rows(pat):
+    out = []
+    for f in glob.glob(os.path.join(SRC, pat)):
+        out += list(csv.DictReader(open(f)))
+    return out
+
+
+def short(name):
+    name = name.replace("void ", "")
+    cut = name.find(">(")
+    if cut > 0:
+        name = name[:cut + 1]
+    cut = name.find("(")
+    if cut > 0 and "<" not in name[:cut]:
+        name = name[:cut]
+    return name.replace("GemmCfg", "").replace("PipeCfg", "Pipe")
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    dst = os.path.join(REPO, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = rows("trace/*/*_kernel_stats.csv")
+    for f in glob.glob(os.path.join(SRC, "trace/*/*_kernel_stats.csv")):
+        shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    pm = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    for x in rows("pmc_mfma/*/*_counter_collection.csv"):
+        k = short(x["Kernel_Name"])
+        pm[k][x["Counter_Name"]] += float(x["Counter_Value"])
+        if x["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            pm[k]["ns"] += int(x["End_Timestamp"]) - int(x["Start_Timestamp"])
+            cnt[k] += 1
+    fetch, write = collections.defaultdict(list), collections.defaultdict(list)
+    for x in rows("pmc_fetch/*/*_counter_collection.csv"):
+        fetch[short(x["Kernel_Name"])].append(float(x["Counter_Value"]))
+    for x in rows("pmc_write/*/*_counter_collection.csv"):
+        write[short(x["Kernel_Name"])].append(float(x["Counter_Value"]))
+    lines = [f"# rocprofv3 summary {tag}", "",
+             "Command: `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (B = 256, UnrealEgo lifting head, fp32) under",
+             "`rocprofv3 --kernel-trace --stats` (durations) and separate `--pmc` passes (FETCH_SIZE; WRITE_SIZE; "
+             "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY).",
+             "HBM read MB = FETCH_SIZE[KiB] x 2 / 1024 (gfx950 counts 64 B per 128-B request), write MB = WRITE_SIZE[KiB] / 1024.", "",
+             "| kernel | calls | avg ms | % time | HBM read MB/launch | HBM write MB/launch | clock GHz | MFMA busy |",
+             "|---|---|---|---|---|---|---|---|"]
+    for s in stats:
+        k = short(s["Name"])
+        avg = float(s["AverageNs"]) / 1e6
+        fr = 2 * sum(fetch[k]) / max(len(fetch[k]), 1) / 1024 if fetch[k] else float("nan")
+        wr = sum(write[k]) / max(len(write[k]), 1) / 1024 if write[k] else float("nan")
+        v = pm.get(k)
+        clk = v["GRBM_GUI_ACTIVE"] / 8 / v["ns"] if v and v["ns"] else float("nan")
+        busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8 * 1024) if v and v["GRBM_GUI_ACTIVE"] else float("nan")
+        lines.append(f"| `{k}` | {s['Calls']} | {avg:.4f} | {float(s['Percentage']):.2f} | {fr:.1f} | {wr:.1f} | {clk:.2f} | {busy:.3f} |")
+    open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
