@@ -123,3 +123,63 @@ LIFT_DEAD_KEYS = (
     "pos_heatmap_encoder.vit.pooler.dense.weight",
     "pos_heatmap_encoder.vit.pooler.dense.bias",
 )
+
+
+# ----------------------------------------------------------------------------------------- heatmap estimator
+HM_STAGES = ((64, 1), (128, 2), (256, 2), (512, 2))    # torchvision resnet18: (channels, stride of first block)
+
+
+def _bn2d(pre, c):
+    return [(pre + ".weight", (c,)), (pre + ".bias", (c,)), (pre + ".running_mean", (c,)),
+            (pre + ".running_var", (c,)), (pre + ".num_batches_tracked", ())]
+
+
+def resnet18_spec():
+    """[(key, shape)] of torchvision.models.resnet18().state_dict() (public architecture; 122 entries)."""
+    s = [("conv1.weight", (64, 3, 7, 7))] + _bn2d("bn1", 64)
+    cin = 64
+    for i, (c, stride) in enumerate(HM_STAGES, start=1):
+        for b in range(2):
+            pre = f"layer{i}.{b}"
+            bc_in = cin if b == 0 else c
+            s += [(pre + ".conv1.weight", (c, bc_in, 3, 3))] + _bn2d(pre + ".bn1", c)
+            s += [(pre + ".conv2.weight", (c, c, 3, 3))] + _bn2d(pre + ".bn2", c)
+            if b == 0 and (stride != 1 or cin != c):
+                s += [(pre + ".downsample.0.weight", (c, bc_in, 1, 1))] + _bn2d(pre + ".downsample.1", c)
+        cin = c
+    s += [("fc.weight", (1000, 512)), ("fc.bias", (1000,))]
+    return s
+
+
+def hm_state_spec(n_hm_per_eye: int):
+    """[(key, shape, alias_of)] of HeatMap_UnrealEgo_Shared(resnet18, stereo).state_dict() in the reference's order.
+
+    Encoder_Block registers the ResNet and, again, its slices layer0..layer4 (net_architecture.py:58, 68-73), so
+    every backbone tensor appears under two keys; alias_of names the canonical key of the shared tensor.
+    n_hm_per_eye = num_heatmap + 2 * num_rot_heatmap of that net (15 for the position net, 30 for the sin/cos net).
+    """
+    rs = resnet18_spec()
+    root = "backbone.backbone."
+    out = [(root + "backbone." + k, shp, None) for k, shp in rs]
+
+    def dup(prefix_new, prefix_old):
+        for k, shp in rs:
+            if k.startswith(prefix_old):
+                out.append((root + prefix_new + k[len(prefix_old):], shp, root + "backbone." + k))
+
+    dup("layer0.0.", "conv1.")
+    dup("layer0.1.", "bn1.")
+    dup("layer1.1.", "layer1.")
+    dup("layer2.", "layer2.")
+    dup("layer3.", "layer3.")
+    dup("layer4.", "layer4.")
+    a = "after_backbone."
+
+    def conv(name, cout, cin, k):
+        return [(a + name + ".weight", (cout, cin, k, k), None), (a + name + ".bias", (cout,), None)]
+
+    out += conv("layer1_1x1.0", 128, 128, 1) + conv("layer2_1x1.0", 256, 256, 1)
+    out += conv("layer3_1x1.0", 516, 512, 1) + conv("layer4_1x1.0", 1024, 1024, 1)
+    out += conv("conv_up3.0", 1024, 1540, 3) + conv("conv_up2.0", 512, 1280, 3) + conv("conv_up1.0", 512, 640, 3)
+    out += conv("conv_heatmap", 2 * n_hm_per_eye, 512, 1)
+    return out

@@ -112,3 +112,21 @@ def synth_input(name: str, shape, lo: float = 0.0, hi: float = 1.0) -> np.ndarra
     n = int(np.prod(shape))
     u = uniform01("input:" + name, n)
     return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+def synth_hm_state_dict(n_hm_per_eye: int, salt: str):
+    """Hash-RNG state_dict of a heatmap estimator.  Backbone tensors appear under two keys in the reference's
+    state_dict (spec.hm_state_spec); load_state_dict writes them in key order, so the value that survives is the one
+    generated from the LATER (alias) key -- reproduced here so weights equal what tools/make_golden.py loaded."""
+    from . import spec
+    entries = spec.hm_state_spec(n_hm_per_eye)
+    last_key_of = {}
+    for key, shape, alias in entries:
+        last_key_of[alias or key] = key
+    out = {}
+    for key, shape, alias in entries:
+        canon = alias or key
+        if canon not in out:
+            out[canon] = synth_tensor(salt + last_key_of[canon], shape)
+        out[key] = out[canon]
+    return out

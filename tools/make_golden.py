@@ -242,7 +242,11 @@ def gen_hm():
             y = net(left, right)
         for h in hs:
             h.remove()
-        out = {"out_sample": sample(y, 97), "out_stats": stats(y), "out_shape": np.array(y.shape),
+        ref_sd = net.state_dict()
+        out = {"state_keys": np.array(list(ref_sd.keys())),
+               "state_shapes": np.array(["x".join(str(d) for d in v.shape) for v in ref_sd.values()]),
+               "param_keys": np.array([k for k, _ in net.named_parameters()]),
+               "out_sample": sample(y, 97), "out_stats": stats(y), "out_shape": np.array(y.shape),
                "out_ch0": y[0, 0].numpy(), "out_last": y[0, -1].numpy()}
         for k in ("layer4_1x1", "layer3_1x1", "conv_up3", "conv_up2", "conv_up1"):
             out[k + "_sample"] = sample(cap[k], 997)
