@@ -1,0 +1,355 @@
+// NCHW fp32 convolution (3x3 pad 1 / 1x1, stride 1 or 2) as an implicit GEMM on the gfx950 matrix cores, with
+// the BatchNorm(eval) / bias, residual add and ReLU of the reference fused into the epilogue:
+//   HeatMap_UnrealEgo_Shared: torchvision BasicBlock convs + the U-Net decoder's convrelu blocks
+//   (model/net_architecture.py:53-173, model/network_utils.py:144-148).
+//
+//   D[co][pixel] = sum_k W[co][k] * X[k][pixel],  k = (ci, ky, kx)
+// * A operand = weights.  PyTorch's [Cout][Cin][3][3] layout IS a row-major [Cout][K] matrix, so a slab of CI_S
+//   input channels is a contiguous run of CI_S*TAPS floats per output channel: staged by float4, read back as
+//   ds_read_b128 fragments exactly like gemm_f32.h (lane half h takes the second half of the slab's channels).
+// * B operand = the input, NEVER im2col'ed: the block stages the raw input rows of its pixel tile (+ halo) once
+//   per slab into LDS in NCHW order and every (ci, ky, kx) tap is a ds_read_b32 at a compile-time offset from the
+//   lane's pixel address.  Global->LDS traffic per MFMA is therefore weights-dominated (~0.043 vector-memory
+//   instructions per MFMA for a 128 x 256 tile; each costs the matrix pipe ~56 cycles, tools/mfma_probe.hip).
+// * Pixel tile = 256 consecutive pixels in (image, y, x) order = R full rows of width W (W = 128..8), spanning
+//   G = R/H whole images when the map is smaller than the tile; x halos are always outside the image (zeros that
+//   are written once), y halos are loaded or zero.
+// * Output: accumulator row = co, lane = pixel -> every store instruction writes 128-byte row segments of NCHW.
+//   The output (and residual) image stride is a parameter, so results land directly in channel slices of the
+//   decoder's concat buffers and of the lifting head's input tensor (no torch.cat, no chunk).
+#pragma once
+#include "common.h"
+
+template <int TAPS_, int STRIDE_, int LOG2W_, int CO_T_, int WCO_, int WPX_, int CI_S_>
+struct ConvCfg {
+    static constexpr int TAPS = TAPS_, STRIDE = STRIDE_, LOG2W = LOG2W_, CO_T = CO_T_, WCO = WCO_, WPX = WPX_, CI_S = CI_S_;
+    static constexpr int KS = TAPS == 9 ? 3 : 1, PAD = (KS - 1) / 2;
+    static constexpr int W = 1 << LOG2W;                 // output width == height (square maps)
+    static constexpr int WIN = W * STRIDE;               // input width == height
+    static constexpr int PX_T = 256;
+    static constexpr int R = PX_T / W;                   // output rows per tile
+    static constexpr int G = R > W ? R / W : 1;          // whole images per tile when the map is small
+    static constexpr int RSEG = R > W ? W : R;           // output rows per image segment
+    static constexpr int RI = (RSEG - 1) * STRIDE + KS;  // staged input rows per segment
+    static constexpr int COL0 = TAPS == 9 ? 4 : 0;       // column of x = 0 inside a staged row (16-byte aligned)
+    static constexpr int ROWW = WIN + (TAPS == 9 ? 8 : 0);
+    static constexpr int CHS = G * RI * ROWW;            // staged floats per input channel
+    static constexpr int KH = CI_S / 2 * TAPS;           // k per lane half per slab
+    static constexpr int NT = KH / 4;
+    static constexpr int LDK = 2 * KH + 4;               // padded weight row (floats)
+    static constexpr int A_FLOATS = CO_T * LDK, B_FLOATS = CI_S * CHS;
+    static constexpr int STAGE = A_FLOATS + B_FLOATS;
+    static constexpr int LDS_BYTES = 2 * STAGE * 4;
+    static constexpr int THREADS = 64 * WCO * WPX;
+    static constexpr int TCO = CO_T / WCO / 32, TPX = PX_T / WPX / 32;
+    static constexpr int A_V4 = CO_T * (2 * KH / 4);     // float4 per weight slab
+    static constexpr int B_V4 = CI_S * G * RI * (WIN / 4);
+    static constexpr int A_IT = (A_V4 + THREADS - 1) / THREADS, B_IT = (B_V4 + THREADS - 1) / THREADS;
+    static_assert(KH % 4 == 0 && CI_S % 2 == 0, "slab must split in two halves of a multiple of 4 k");
+    static_assert(CO_T % (32 * WCO) == 0 && PX_T % (32 * WPX) == 0, "wave tile must be 32x32 MFMA tiles");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(WIN % 4 == 0, "rows are staged by float4");
+};
+
+struct ConvArgs {
+    const float* in;        // [Nimg][Cin][HIN][WIN] with image stride in_istride (floats)
+    const float* w;         // [Cout][Cin][KS][KS]
+    float* out;             // image stride out_istride, channel stride H*W
+    const float* res;       // optional residual, image stride res_istride, same channel layout as out
+    // per-output-channel affine: BatchNorm (gamma, beta, mean, var; eps 1e-5) when gamma != nullptr, else bias
+    const float *gamma, *beta, *mean, *var, *bias;
+    long in_istride, out_istride, res_istride;
+    int Nimg, Cin, Cout, relu;
+    int tiles_co, tiles_px;
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::THREADS) void conv_f32_kernel(ConvArgs a) {
+    constexpr int TAPS = Cfg::TAPS, STRIDE = Cfg::STRIDE, KS = Cfg::KS, PAD = Cfg::PAD, W = Cfg::W, WIN = Cfg::WIN;
+    constexpr int G = Cfg::G, RSEG = Cfg::RSEG, RI = Cfg::RI, COL0 = Cfg::COL0, ROWW = Cfg::ROWW, CHS = Cfg::CHS;
+    constexpr int CI_S = Cfg::CI_S, KH = Cfg::KH, NT = Cfg::NT, LDK = Cfg::LDK, CO_T = Cfg::CO_T;
+    constexpr int TCO = Cfg::TCO, TPX = Cfg::TPX, THREADS = Cfg::THREADS, STAGE = Cfg::STAGE, A_FLOATS = Cfg::A_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    int tpx, tco;   // consecutive blocks of one XCD walk pixel tiles of one output-channel tile (weights stay in L2)
+    xcd_tile(blockIdx.x, gridDim.x, a.tiles_px, a.tiles_co, 32, tpx, tco);
+    const int co0 = tco * CO_T;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wco = wid / Cfg::WPX, wpx = wid % Cfg::WPX;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // tile origin: image n0 (segments g -> image n0 + g), first output row y0
+    int n0, y0;
+    if (G == 1) {
+        const int gr0 = tpx * Cfg::R;
+        n0 = gr0 / W;
+        y0 = gr0 - n0 * W;
+    } else {
+        n0 = tpx * G;
+        y0 = 0;
+    }
+    const int yin0 = y0 * STRIDE - PAD;
+    const long ch_in = (long)WIN * WIN;
+
+    // zero both input stages once: x halos are never written again
+    for (int i = tid; i < Cfg::B_FLOATS; i += THREADS) {
+        smem[A_FLOATS + i] = 0.f;
+        smem[STAGE + A_FLOATS + i] = 0.f;
+    }
+
+    f32x4 pa[Cfg::A_IT], pb[Cfg::B_IT];
+    const long wrow = (long)a.Cin * TAPS;     // floats per output channel
+    auto gload = [&](int slab) {
+        const int c0 = slab * CI_S;
+#pragma unroll
+        for (int it = 0; it < Cfg::A_IT; ++it) {
+            const int idx = tid + it * THREADS;
+            const int row = idx / (2 * KH / 4), f4 = idx - row * (2 * KH / 4);
+            const long koff = (long)c0 * TAPS + f4 * 4;
+            const bool ok = idx < Cfg::A_V4 && co0 + row < a.Cout && koff < wrow;
+            pa[it] = ok ? *(const f32x4*)(a.w + (long)(co0 + row) * wrow + koff) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int it = 0; it < Cfg::B_IT; ++it) {
+            const int idx = tid + it * THREADS;
+            const int c4 = idx % (WIN / 4);
+            int rest = idx / (WIN / 4);
+            const int rr = rest % RI;
+            rest /= RI;
+            const int g = rest % G, cl = rest / G;
+            const int y = yin0 + rr, n = n0 + g, ci = c0 + cl;
+            const bool ok = idx < Cfg::B_V4 && y >= 0 && y < WIN && n < a.Nimg && ci < a.Cin;
+            pb[it] = ok ? *(const f32x4*)(a.in + (long)n * a.in_istride + (long)ci * ch_in + (long)y * WIN + c4 * 4)
+                        : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + A_FLOATS;
+#pragma unroll
+        for (int it = 0; it < Cfg::A_IT; ++it) {
+            const int idx = tid + it * THREADS;
+            const int row = idx / (2 * KH / 4), f4 = idx - row * (2 * KH / 4);
+            if (idx < Cfg::A_V4) *(f32x4*)(As + row * LDK + f4 * 4) = pa[it];
+        }
+#pragma unroll
+        for (int it = 0; it < Cfg::B_IT; ++it) {
+            const int idx = tid + it * THREADS;
+            const int c4 = idx % (WIN / 4);
+            const int rest = idx / (WIN / 4);     // = (cl * G + g) * RI + rr
+            if (idx < Cfg::B_V4) *(f32x4*)(Bs + rest * ROWW + COL0 + c4 * 4) = pb[it];
+        }
+    };
+
+    // per px-tile lane address inside a staged channel (floats), lane half h reads the slab's second half
+    int laneb[TPX];
+#pragma unroll
+    for (int j = 0; j < TPX; ++j) {
+        const int p = (wpx * TPX + j) * 32 + l31;
+        const int g = p / (RSEG * W), rem = p - g * (RSEG * W);
+        const int yy = rem / W, x = rem - yy * W;
+        laneb[j] = lh * (CI_S / 2) * CHS + (g * RI + yy * STRIDE) * ROWW + x * STRIDE + COL0 - PAD;
+    }
+    const int a_off = (wco * TCO * 32 + l31) * LDK + lh * KH;
+
+    f32x16 acc[TCO][TPX];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TPX; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nslab = (a.Cin + CI_S - 1) / CI_S;
+    gload(0);
+    __syncthreads();          // zero fill done before the first staged rows land
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslab) gload(s + 1);
+        const float* As = smem + buf * STAGE + a_off;
+        const float* Bs = smem + buf * STAGE + A_FLOATS;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 af[TCO];
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) af[i] = *(const f32x4*)(As + i * 32 * LDK + 4 * t);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int jj = 4 * t + u;                       // k index inside the lane half (compile time)
+                const int cl = jj / TAPS, tap = jj - cl * TAPS;
+                const int off = cl * CHS + (tap / KS) * ROWW + (tap % KS);
+                float bv[TPX];
+#pragma unroll
+                for (int j = 0; j < TPX; ++j) bv[j] = Bs[laneb[j] + off];
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                    for (int j = 0; j < TPX; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][u], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (s + 1 < nslab) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: accumulator register r of lane l = D[co = 32x32 row (r&3) + 8*(r>>2) + 4*(l>>5)][pixel l&31]
+    const long ch_out = (long)W * W;
+#pragma unroll
+    for (int i = 0; i < TCO; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (co >= a.Cout) continue;
+            float sc = 1.f, sh;
+            if (a.gamma) {
+                sc = a.gamma[co] / sqrtf(a.var[co] + 1e-5f);
+                sh = a.beta[co] - a.mean[co] * sc;
+            } else {
+                sh = a.bias[co];
+            }
+#pragma unroll
+            for (int j = 0; j < TPX; ++j) {
+                const int p = (wpx * TPX + j) * 32 + l31;
+                const int g = p / (RSEG * W), rem = p - g * (RSEG * W);
+                const int n = n0 + g;
+                if (n >= a.Nimg) continue;
+                const long pix = (long)y0 * W + rem;       // (y0 + yy) * W + x
+                float v = acc[i][j][r] * sc + sh;
+                if (a.res) v += a.res[(long)n * a.res_istride + co * ch_out + pix];
+                if (a.relu) v = fmaxf(v, 0.f);
+                a.out[(long)n * a.out_istride + co * ch_out + pix] = v;
+            }
+        }
+    }
+}
+
+template <class Cfg>
+static hipError_t conv_f32_launch(ConvArgs a, hipStream_t stream) {
+    if (a.Nimg <= 0) return hipSuccess;
+    if ((a.Cin * Cfg::TAPS) % 4 != 0) return hipErrorInvalidValue;
+    auto kern = conv_f32_kernel<Cfg>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    a.tiles_co = (a.Cout + Cfg::CO_T - 1) / Cfg::CO_T;
+    const long px = (long)a.Nimg * Cfg::W * Cfg::W;
+    a.tiles_px = Cfg::G == 1 ? (int)(px / Cfg::PX_T) : (a.Nimg + Cfg::G - 1) / Cfg::G;
+    hipLaunchKernelGGL(kern, dim3(a.tiles_co * a.tiles_px), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------- ResNet stem and the glue kernels
+// conv 7x7 stride 2 pad 3 (3 -> 64) + BatchNorm(eval) + ReLU, torchvision resnet18.conv1/bn1/relu via
+// net_architecture.py:69.  K = 147 is too ragged for the MFMA tiling and only 1 % of the FLOPs: direct VALU
+// convolution, 16 x 16 output pixels per block (one per thread), all 64 channels per thread, weights through
+// wave-uniform (scalar) loads from a [tap][co] transposed copy in LDS.
+// Two input pointers: image n = 2*b + eye reads eye ? right : left (the stereo pair is never concatenated).
+__global__ __launch_bounds__(256) void stem_conv7_kernel(const float* __restrict__ left, const float* __restrict__ right,
+                                                         const float* __restrict__ w, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ mean,
+                                                         const float* __restrict__ var, float* __restrict__ out, int HIN) {
+    constexpr int TO = 16, TI = TO * 2 + 5;            // 37 x 37 input patch per channel
+    __shared__ float xs[3 * TI * TI];                   // 16.4 KB
+    __shared__ float ws[147 * 64];                      // [tap][co], 37.6 KB
+    const int HO = HIN / 2;
+    const int tiles = HO / TO;
+    const int n = blockIdx.z, ty = blockIdx.y, tx = blockIdx.x;
+    const float* src = ((n & 1) ? right : left) + (long)(n >> 1) * 3 * HIN * HIN;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 147 * 64; i += 256) {
+        const int co = i / 147, tap = i - co * 147;
+        ws[tap * 64 + co] = w[i];
+    }
+    const int iy0 = ty * TO * 2 - 3, ix0 = tx * TO * 2 - 3;
+    for (int i = tid; i < 3 * TI * TI; i += 256) {
+        const int c = i / (TI * TI), rem = i - c * TI * TI, yy = rem / TI, xx = rem - yy * TI;
+        const int y = iy0 + yy, x = ix0 + xx;
+        xs[i] = (y >= 0 && y < HIN && x >= 0 && x < HIN) ? src[((long)c * HIN + y) * HIN + x] : 0.f;
+    }
+    __syncthreads();
+    const int oy = tid >> 4, ox = tid & 15;
+    float acc[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) acc[c] = 0.f;
+    for (int c = 0; c < 3; ++c)
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const float xv = xs[(c * TI + oy * 2 + ky) * TI + ox * 2 + kx];
+                const float* wp = ws + ((c * 7 + ky) * 7 + kx) * 64;
+#pragma unroll
+                for (int co = 0; co < 64; ++co) acc[co] = fmaf(xv, wp[co], acc[co]);
+            }
+    const int y = ty * TO + oy, x = tx * TO + ox;
+    float* dst = out + (long)n * 64 * HO * HO + (long)y * HO + x;
+#pragma unroll
+    for (int co = 0; co < 64; ++co) {
+        const float sc = gamma[co] / sqrtf(var[co] + 1e-5f);
+        const float v = acc[co] * sc + (beta[co] - mean[co] * sc);
+        dst[(long)co * HO * HO] = fmaxf(v, 0.f);
+    }
+    (void)tiles;
+}
+
+// MaxPool2d(3, stride 2, pad 1) on [N*C] planes of HIN x HIN (torchvision resnet18.maxpool)
+__global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
+                                                         int HIN) {
+    const int HO = HIN / 2;
+    const long total = planes * HO * HO;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % HO), y = (int)((i / HO) % HO);
+        const long pl = i / ((long)HO * HO);
+        const float* p = in + pl * HIN * HIN;
+        float m = -INFINITY;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = 2 * y + dy, xx = 2 * x + dx;
+                if (yy >= 0 && yy < HIN && xx >= 0 && xx < HIN) m = fmaxf(m, p[(long)yy * HIN + xx]);
+            }
+        out[i] = m;
+    }
+}
+
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (net_architecture.py:126), written into a
+// channel slice of the next concat buffer: out[n][c] at out + n*out_istride + c*4*HIN*HIN.
+// One thread = four consecutive x of one output row (float4 store); NO grid-stride loop: with a loop hipcc emits a
+// peeled and an unrolled copy of the body that round differently, and a pixel's value then depends on the batch size.
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C,
+                                                         int HIN, long in_istride, long out_istride) {
+    const int HO = 2 * HIN, Q = HO / 4;
+    const float scale = (float)(HIN - 1) / (float)(HO - 1);
+    const long total = (long)N * C * HO * Q;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int xq = (int)(i % Q), y = (int)((i / Q) % HO);
+    const long nc = i / ((long)HO * Q);
+    const int c = (int)(nc % C);
+    const long n = nc / C;
+    const float sy = scale * y;
+    const int y0 = (int)sy;
+    const int y1 = y0 + (y0 < HIN - 1 ? 1 : 0);
+    const float ly = sy - y0, hy = 1.f - ly;
+    const float* p = in + n * in_istride + (long)c * HIN * HIN;
+    const float* r0 = p + (long)y0 * HIN;
+    const float* r1 = p + (long)y1 * HIN;
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = xq * 4 + k;
+        const float sx = scale * x;
+        const int x0 = (int)sx;
+        const int x1 = x0 + (x0 < HIN - 1 ? 1 : 0);
+        const float lx = sx - x0, hx = 1.f - lx;
+        v[k] = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+    }
+    *(f32x4*)(out + n * out_istride + (long)c * HO * HO + (long)y * HO + xq * 4) = v;
+}

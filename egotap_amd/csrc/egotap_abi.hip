@@ -11,6 +11,7 @@
 
 #include "attention_f32.h"
 #include "common.h"
+#include "conv_f32.h"
 #include "gemm_f32.h"
 #include "layernorm.h"
 #include "pu_chain.h"
@@ -76,6 +77,14 @@ struct LiftParams {   // resolved raw pointers of net_AutoEncoder
     const float *pose_w, *pose_b, *glob_w, *glob_b;
 };
 
+struct HmParams {   // resolved raw pointers of one heatmap estimator (net_HeatMap / net_RotHeatMap)
+    struct Bn { const float *g, *b, *m, *v; };
+    const float* stem_w; Bn stem_bn;
+    struct Block { const float *w1, *w2, *wd; Bn bn1, bn2, bnd; } blk[4][2];
+    struct Cv { const float *w, *b; } l1x1[4], up[3], head;   // layerK_1x1 (K=1..4), conv_up1..3, conv_heatmap
+    int n_out;   // output channels of conv_heatmap (2 * heatmaps per eye)
+};
+
 struct egotap_handle_s {
     egotap_config cfg;
     // derived (spec.py LiftPreset)
@@ -84,6 +93,8 @@ struct egotap_handle_s {
     std::unordered_map<std::string, Param> bound[EGOTAP_NET_COUNT];
     bool lift_resolved = false;
     LiftParams lp;
+    bool hm_resolved[EGOTAP_NET_COUNT] = {false, false, false};
+    HmParams hp[EGOTAP_NET_COUNT];
     int debug_stop = 0;
     // timing
     bool timing = false;
@@ -140,6 +151,35 @@ static void lift_expect(Handle* h) {
     if (h->cfg.estimate_head) lin("global_mlp.pose_fcs.0", 6, (int64_t)h->J * H);
 }
 
+static const int HM_CH[4] = {64, 128, 256, 512};
+
+static void hm_expect(Handle* h, int net, int n_out) {
+    auto& e = h->expect[net];
+    const std::string bb = "backbone.backbone.backbone.";
+    auto bn = [&](const std::string& p, int64_t c) {
+        e[p + ".weight"] = c; e[p + ".bias"] = c; e[p + ".running_mean"] = c; e[p + ".running_var"] = c;
+    };
+    e[bb + "conv1.weight"] = 64 * 3 * 49;
+    bn(bb + "bn1", 64);
+    int cin = 64;
+    for (int i = 0; i < 4; ++i) {
+        const int c = HM_CH[i];
+        for (int b = 0; b < 2; ++b) {
+            const std::string p = bb + "layer" + std::to_string(i + 1) + "." + std::to_string(b);
+            const int bc = b == 0 ? cin : c;
+            e[p + ".conv1.weight"] = (int64_t)c * bc * 9; bn(p + ".bn1", c);
+            e[p + ".conv2.weight"] = (int64_t)c * c * 9;  bn(p + ".bn2", c);
+            if (b == 0 && i > 0) { e[p + ".downsample.0.weight"] = (int64_t)c * bc; bn(p + ".downsample.1", c); }
+        }
+        cin = c;
+    }
+    const std::string a = "after_backbone.";
+    auto cv = [&](const std::string& n, int64_t co, int64_t ci, int k) { e[a + n + ".weight"] = co * ci * k * k; e[a + n + ".bias"] = co; };
+    cv("layer1_1x1.0", 128, 128, 1); cv("layer2_1x1.0", 256, 256, 1); cv("layer3_1x1.0", 516, 512, 1); cv("layer4_1x1.0", 1024, 1024, 1);
+    cv("conv_up3.0", 1024, 1540, 3); cv("conv_up2.0", 512, 1280, 3); cv("conv_up1.0", 512, 640, 3);
+    cv("conv_heatmap", n_out, 512, 1);
+}
+
 extern "C" int egotap_create(const egotap_config* cfg, egotap_handle* out) {
     EGO_CHECK(cfg && out, "egotap_create: null argument");
     EGO_CHECK(cfg->struct_bytes == (int32_t)sizeof(egotap_config), "egotap_create: egotap_config is %d bytes, library expects %d",
@@ -164,6 +204,10 @@ extern "C" int egotap_create(const egotap_config* cfg, egotap_handle* out) {
     h->hid = cfg->hidden;
     h->out_joints = h->J + (cfg->estimate_head ? 1 : 0);
     lift_expect(h);
+    hm_expect(h, EGOTAP_NET_HM_POS, 2 * h->J);        // num_heatmap per eye, stereo
+    hm_expect(h, EGOTAP_NET_HM_ROT, 4 * h->J);        // cos + sin per limb per eye
+    h->hp[EGOTAP_NET_HM_POS].n_out = 2 * h->J;
+    h->hp[EGOTAP_NET_HM_ROT].n_out = 4 * h->J;
     *out = h;
     return EGOTAP_OK;
 }
@@ -189,6 +233,7 @@ extern "C" int egotap_bind_param(egotap_handle h, int net, const char* key, void
     p.ptr = dev_ptr; p.numel = numel; p.dtype = dtype;
     h->bound[net][key] = p;   // keys the forward never reads (pooler, cls_token, num_batches_tracked) are kept but unused
     if (net == EGOTAP_NET_LIFT) h->lift_resolved = false;
+    else h->hm_resolved[net] = false;
     return EGOTAP_OK;
 }
 
@@ -512,6 +557,237 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     hipLaunchKernelGGL(pose_head_kernel, dim3(B), dim3(256), 0, s, POSZ, HS1, p.pose_w, p.pose_b, p.glob_w, p.glob_b, pose, B,
                        J, hid, H, h->cfg.estimate_head);
     EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ heatmap estimator
+static int hm_resolve(Handle* h, int net) {
+    if (h->hm_resolved[net]) return EGOTAP_OK;
+    bool ok = true;
+    HmParams& p = h->hp[net];
+    const std::string bb = "backbone.backbone.backbone.";
+    auto bn = [&](const std::string& k) {
+        return HmParams::Bn{P(h, net, k + ".weight", ok), P(h, net, k + ".bias", ok), P(h, net, k + ".running_mean", ok),
+                            P(h, net, k + ".running_var", ok)};
+    };
+    p.stem_w = P(h, net, bb + "conv1.weight", ok);
+    p.stem_bn = bn(bb + "bn1");
+    for (int i = 0; i < 4; ++i)
+        for (int b = 0; b < 2; ++b) {
+            const std::string k = bb + "layer" + std::to_string(i + 1) + "." + std::to_string(b);
+            auto& B = p.blk[i][b];
+            B.w1 = P(h, net, k + ".conv1.weight", ok); B.bn1 = bn(k + ".bn1");
+            B.w2 = P(h, net, k + ".conv2.weight", ok); B.bn2 = bn(k + ".bn2");
+            B.wd = nullptr;
+            if (b == 0 && i > 0) { B.wd = P(h, net, k + ".downsample.0.weight", ok); B.bnd = bn(k + ".downsample.1"); }
+        }
+    const std::string a = "after_backbone.";
+    for (int k = 0; k < 4; ++k) {
+        const std::string n = a + "layer" + std::to_string(k + 1) + "_1x1.0";
+        p.l1x1[k] = {P(h, net, n + ".weight", ok), P(h, net, n + ".bias", ok)};
+    }
+    for (int k = 0; k < 3; ++k) {
+        const std::string n = a + "conv_up" + std::to_string(k + 1) + ".0";
+        p.up[k] = {P(h, net, n + ".weight", ok), P(h, net, n + ".bias", ok)};
+    }
+    p.head = {P(h, net, a + "conv_heatmap.weight", ok), P(h, net, a + "conv_heatmap.bias", ok)};
+    if (!ok) return EGOTAP_ERR_UNBOUND;
+    h->hm_resolved[net] = true;
+    return EGOTAP_OK;
+}
+
+//                      taps stride log2W CO_T WCO WPX CI_S
+using C3s1_64_co64  = ConvCfg<9, 1, 6,  64, 2, 4, 8>;
+using C3s1_64       = ConvCfg<9, 1, 6, 128, 2, 4, 8>;
+using C3s1_32       = ConvCfg<9, 1, 5, 128, 2, 4, 8>;
+using C3s1_16       = ConvCfg<9, 1, 4, 128, 2, 4, 8>;
+using C3s1_8        = ConvCfg<9, 1, 3, 128, 2, 4, 8>;
+using C3s2_32       = ConvCfg<9, 2, 5,  64, 2, 4, 8>;
+using C3s2_16       = ConvCfg<9, 2, 4,  64, 2, 4, 8>;
+using C3s2_8        = ConvCfg<9, 2, 3,  64, 2, 4, 8>;
+using C1s1_64       = ConvCfg<1, 1, 6,  64, 2, 4, 32>;
+using C1s1_32       = ConvCfg<1, 1, 5, 128, 2, 4, 32>;
+using C1s1_16       = ConvCfg<1, 1, 4, 128, 2, 4, 32>;
+using C1s1_8        = ConvCfg<1, 1, 3, 128, 2, 4, 32>;
+using C1s2_32       = ConvCfg<1, 2, 5,  64, 2, 4, 8>;
+using C1s2_16       = ConvCfg<1, 2, 4,  64, 2, 4, 8>;
+using C1s2_8        = ConvCfg<1, 2, 3,  64, 2, 4, 8>;
+
+template <class Cfg>
+static hipError_t conv(Handle* h, const char* role, const ConvArgs& a, hipStream_t s) {
+    static const std::string kname = std::string("conv_f32_kernel<") + (Cfg::TAPS == 9 ? "3x3" : "1x1") + ",s" +
+                                     std::to_string(Cfg::STRIDE) + ",W" + std::to_string(Cfg::W) + ",co" +
+                                     std::to_string(Cfg::CO_T) + ">";
+    GemmTimer t(h, s, role, kname.c_str(), 2.0 * a.Cout * a.Cin * Cfg::TAPS * (double)a.Nimg * Cfg::W * Cfg::W);
+    return conv_f32_launch<Cfg>(a, s);
+}
+
+// dispatch on (taps, stride, output width); wout in {64, 32, 16, 8}
+static hipError_t conv_any(Handle* h, const char* role, int taps, int stride, int wout, const ConvArgs& a, hipStream_t s) {
+    if (taps == 9 && stride == 1) {
+        if (wout == 64) return a.Cout <= 64 ? conv<C3s1_64_co64>(h, role, a, s) : conv<C3s1_64>(h, role, a, s);
+        if (wout == 32) return conv<C3s1_32>(h, role, a, s);
+        if (wout == 16) return conv<C3s1_16>(h, role, a, s);
+        if (wout == 8) return conv<C3s1_8>(h, role, a, s);
+    } else if (taps == 9 && stride == 2) {
+        if (wout == 32) return conv<C3s2_32>(h, role, a, s);
+        if (wout == 16) return conv<C3s2_16>(h, role, a, s);
+        if (wout == 8) return conv<C3s2_8>(h, role, a, s);
+    } else if (taps == 1 && stride == 1) {
+        if (wout == 64) return conv<C1s1_64>(h, role, a, s);
+        if (wout == 32) return conv<C1s1_32>(h, role, a, s);
+        if (wout == 16) return conv<C1s1_16>(h, role, a, s);
+        if (wout == 8) return conv<C1s1_8>(h, role, a, s);
+    } else if (taps == 1 && stride == 2) {
+        if (wout == 32) return conv<C1s2_32>(h, role, a, s);
+        if (wout == 16) return conv<C1s2_16>(h, role, a, s);
+        if (wout == 8) return conv<C1s2_8>(h, role, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+struct HmWs {
+    size_t L0, P0, S[4][4] /* per stage: Ta, Tb, Td, L */, U4, CAT3, X3, CAT2, X2, CAT1, X1, total;
+};
+static HmWs hm_ws(const Handle* h, int B) {
+    HmWs w;
+    const size_t N2 = 2 * (size_t)B, S0 = (size_t)h->cfg.hm_size * 4;   // RGB side
+    size_t o = 0;
+    auto take = [&](size_t floats) { size_t r = o; o = al256(o + floats * 4); return r; };
+    w.L0 = take(N2 * 64 * (S0 / 2) * (S0 / 2));
+    w.P0 = take(N2 * 64 * (S0 / 4) * (S0 / 4));
+    for (int i = 0; i < 4; ++i) {
+        const size_t side = S0 / (4u << i), fl = N2 * HM_CH[i] * side * side;
+        for (int k = 0; k < 4; ++k) w.S[i][k] = take(fl);
+    }
+    const size_t s8 = S0 / 32, s16 = S0 / 16, s32 = S0 / 8, s64 = S0 / 4;
+    w.U4 = take((size_t)B * 1024 * s8 * s8);
+    w.CAT3 = take((size_t)B * 1540 * s16 * s16); w.X3 = take((size_t)B * 1024 * s16 * s16);
+    w.CAT2 = take((size_t)B * 1280 * s32 * s32); w.X2 = take((size_t)B * 512 * s32 * s32);
+    w.CAT1 = take((size_t)B * 640 * s64 * s64);  w.X1 = take((size_t)B * 512 * s64 * s64);
+    w.total = o;
+    return w;
+}
+
+extern "C" int egotap_hm_workspace_bytes(egotap_handle h, int B, size_t* bytes) {
+    EGO_CHECK(h && bytes, "null argument");
+    EGO_CHECK(B >= 0, "negative batch");
+    *bytes = hm_ws(h, B > 0 ? B : 1).total;
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_hm_intermediate(egotap_handle h, int B, const char* name, size_t* offset, int64_t* numel) {
+    EGO_CHECK(h && name && offset && numel, "null argument");
+    const HmWs w = hm_ws(h, B > 0 ? B : 1);
+    const int64_t N2 = 2LL * B, S0 = h->cfg.hm_size * 4;
+    auto sq = [](int64_t v) { return v * v; };
+    if (!strcmp(name, "layer0")) { *offset = w.L0; *numel = N2 * 64 * sq(S0 / 2); }
+    else if (!strcmp(name, "layer1")) { *offset = w.S[0][3]; *numel = N2 * 64 * sq(S0 / 4); }
+    else if (!strcmp(name, "layer2")) { *offset = w.S[1][3]; *numel = N2 * 128 * sq(S0 / 8); }
+    else if (!strcmp(name, "layer3")) { *offset = w.S[2][3]; *numel = N2 * 256 * sq(S0 / 16); }
+    else if (!strcmp(name, "layer4")) { *offset = w.S[3][3]; *numel = N2 * 512 * sq(S0 / 32); }
+    else if (!strcmp(name, "u4")) { *offset = w.U4; *numel = (int64_t)B * 1024 * sq(S0 / 32); }
+    else if (!strcmp(name, "cat3")) { *offset = w.CAT3; *numel = (int64_t)B * 1540 * sq(S0 / 16); }
+    else if (!strcmp(name, "cat2")) { *offset = w.CAT2; *numel = (int64_t)B * 1280 * sq(S0 / 8); }
+    else if (!strcmp(name, "cat1")) { *offset = w.CAT1; *numel = (int64_t)B * 640 * sq(S0 / 4); }
+    else if (!strcmp(name, "conv_up3")) { *offset = w.X3; *numel = (int64_t)B * 1024 * sq(S0 / 16); }
+    else if (!strcmp(name, "conv_up2")) { *offset = w.X2; *numel = (int64_t)B * 512 * sq(S0 / 8); }
+    else if (!strcmp(name, "conv_up1")) { *offset = w.X1; *numel = (int64_t)B * 512 * sq(S0 / 4); }
+    else { egotap_set_error("unknown intermediate '%s'", name); return EGOTAP_ERR_INVALID; }
+    return EGOTAP_OK;
+}
+
+// HeatMap_UnrealEgo_Shared.forward(left, right) (model/net_architecture.py:32-36, 45-51, 75-85, 139-173), eval mode.
+extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, const float* right, int B, float* out,
+                                 int64_t out_image_stride, void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(h, "null handle");
+    EGO_CHECK(net == EGOTAP_NET_HM_POS || net == EGOTAP_NET_HM_ROT, "egotap_hm_forward: net must be EGOTAP_NET_HM_POS or _ROT");
+    if (B == 0) return EGOTAP_OK;
+    EGO_CHECK(B > 0 && left && right && out && ws, "egotap_hm_forward: null argument or negative batch");
+    EGO_CHECK((((uintptr_t)left | (uintptr_t)right | (uintptr_t)out) & 15) == 0 && ((uintptr_t)ws & 255) == 0, "pointers must be 16-byte (ws: 256-byte) aligned");
+    const int S0 = h->cfg.hm_size * 4, s64 = S0 / 4, s32 = S0 / 8, s16 = S0 / 16, s8 = S0 / 32;
+    EGO_CHECK(s64 == 64, "this build instantiates the conv kernels for 256x256 RGB (64x64 heatmaps) only");
+    int rc = hm_resolve(h, net);
+    if (rc != EGOTAP_OK) return rc;
+    const HmWs w = hm_ws(h, B);
+    if (ws_bytes < w.total) {
+        egotap_set_error("workspace too small: %zu bytes given, %zu needed for B=%d", ws_bytes, w.total, B);
+        return EGOTAP_ERR_WORKSPACE;
+    }
+    const HmParams& p = h->hp[net];
+    EGO_CHECK(out_image_stride >= (int64_t)p.n_out * s64 * s64, "out_image_stride smaller than the output image");
+    hipStream_t s = (hipStream_t)stream;
+    char* base = (char*)ws;
+    auto F = [&](size_t off) { return (float*)(base + off); };
+    const int N2 = 2 * B;
+
+    // E1: stem conv7x7/2 + BN + ReLU on image n = 2b + eye (the L/R channel concat of every pyramid level is then a view)
+    hipLaunchKernelGGL(stem_conv7_kernel, dim3(S0 / 32, S0 / 32, N2), dim3(256), 0, s, left, right, p.stem_w, p.stem_bn.g,
+                       p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, F(w.L0), S0);
+    EGO_HIP(hipGetLastError());
+    // E2: maxpool 3x3/2
+    hipLaunchKernelGGL(maxpool3s2_kernel, dim3(2048), dim3(256), 0, s, F(w.L0), F(w.P0), (long)N2 * 64, S0 / 2);
+    EGO_HIP(hipGetLastError());
+    // E3: four stages of two BasicBlocks
+    const float* x = F(w.P0);
+    int cin = 64;
+    const int sides[4] = {s64, s32, s16, s8};
+    static const char* r1[4][2] = {{"hm.l1.0.conv1", "hm.l1.1.conv1"}, {"hm.l2.0.conv1", "hm.l2.1.conv1"}, {"hm.l3.0.conv1", "hm.l3.1.conv1"}, {"hm.l4.0.conv1", "hm.l4.1.conv1"}};
+    static const char* r2[4][2] = {{"hm.l1.0.conv2", "hm.l1.1.conv2"}, {"hm.l2.0.conv2", "hm.l2.1.conv2"}, {"hm.l3.0.conv2", "hm.l3.1.conv2"}, {"hm.l4.0.conv2", "hm.l4.1.conv2"}};
+    static const char* rd[4] = {"", "hm.l2.down", "hm.l3.down", "hm.l4.down"};
+    for (int i = 0; i < 4; ++i) {
+        const int c = HM_CH[i], side = sides[i];
+        const long ist_in = (long)cin * (i == 0 ? side : 2 * side) * (i == 0 ? side : 2 * side);
+        const long ist = (long)c * side * side;
+        float *Ta = F(w.S[i][0]), *Tb = F(w.S[i][1]), *Td = F(w.S[i][2]), *L = F(w.S[i][3]);
+        for (int b = 0; b < 2; ++b) {
+            const auto& K = p.blk[i][b];
+            const float* xin = b == 0 ? x : Tb;
+            const int stride = (b == 0 && i > 0) ? 2 : 1;
+            const int bc = b == 0 ? cin : c;
+            const long xin_ist = b == 0 ? ist_in : ist;
+            ConvArgs a1{xin, K.w1, Ta, nullptr, K.bn1.g, K.bn1.b, K.bn1.m, K.bn1.v, nullptr, xin_ist, ist, 0, N2, bc, c, 1, 0, 0};
+            EGO_HIP(conv_any(h, r1[i][b], 9, stride, side, a1, s));
+            const float* idt = xin;
+            long idt_ist = xin_ist;
+            if (K.wd) {
+                ConvArgs ad{xin, K.wd, Td, nullptr, K.bnd.g, K.bnd.b, K.bnd.m, K.bnd.v, nullptr, xin_ist, ist, 0, N2, bc, c, 0, 0, 0};
+                EGO_HIP(conv_any(h, rd[i], 1, 2, side, ad, s));
+                idt = Td;
+                idt_ist = ist;
+            }
+            float* y = b == 0 ? Tb : L;
+            ConvArgs a2{Ta, K.w2, y, idt, K.bn2.g, K.bn2.b, K.bn2.m, K.bn2.v, nullptr, ist, ist, idt_ist, N2, c, c, 1, 0, 0};
+            EGO_HIP(conv_any(h, r2[i][b], 9, 1, side, a2, s));
+        }
+        x = L;
+        cin = c;
+    }
+    // E4-E9: decoder on the channel-concatenated pyramids ([2B, C, s, s] viewed as [B, 2C, s, s])
+    const float *L1 = F(w.S[0][3]), *L2 = F(w.S[1][3]), *L3 = F(w.S[2][3]), *L4 = F(w.S[3][3]);
+    float *U4 = F(w.U4), *CAT3 = F(w.CAT3), *X3 = F(w.X3), *CAT2 = F(w.CAT2), *X2 = F(w.X2), *CAT1 = F(w.CAT1), *X1 = F(w.X1);
+    auto up = [&](const float* in, float* o, int C, int hin, long ist_in, long ist_out) {
+        const long threads = (long)B * C * (2 * hin) * (2 * hin / 4);
+        hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, in, o, B, C, hin, ist_in, ist_out);
+        return hipGetLastError();
+    };
+    auto biasconv = [&](const char* role, int taps, int side, const float* in, long in_ist, const HmParams::Cv& cv, int Cin, int Cout,
+                        float* o, long o_ist, int relu) {
+        ConvArgs a{in, cv.w, o, nullptr, nullptr, nullptr, nullptr, nullptr, cv.b, in_ist, o_ist, 0, B, Cin, Cout, relu, 0, 0};
+        return conv_any(h, role, taps, 1, side, a, s);
+    };
+    const long p8 = (long)s8 * s8, p16 = (long)s16 * s16, p32 = (long)s32 * s32, p64 = (long)s64 * s64;
+    EGO_HIP(biasconv("hm.layer4_1x1", 1, s8, L4, 1024 * p8, p.l1x1[3], 1024, 1024, U4, 1024 * p8, 1));
+    EGO_HIP(up(U4, CAT3, 1024, s8, 1024 * p8, 1540 * p16));
+    EGO_HIP(biasconv("hm.layer3_1x1", 1, s16, L3, 512 * p16, p.l1x1[2], 512, 516, CAT3 + 1024 * p16, 1540 * p16, 1));
+    EGO_HIP(biasconv("hm.conv_up3", 9, s16, CAT3, 1540 * p16, p.up[2], 1540, 1024, X3, 1024 * p16, 1));
+    EGO_HIP(up(X3, CAT2, 1024, s16, 1024 * p16, 1280 * p32));
+    EGO_HIP(biasconv("hm.layer2_1x1", 1, s32, L2, 256 * p32, p.l1x1[1], 256, 256, CAT2 + 1024 * p32, 1280 * p32, 1));
+    EGO_HIP(biasconv("hm.conv_up2", 9, s32, CAT2, 1280 * p32, p.up[1], 1280, 512, X2, 512 * p32, 1));
+    EGO_HIP(up(X2, CAT1, 512, s32, 512 * p32, 640 * p64));
+    EGO_HIP(biasconv("hm.layer1_1x1", 1, s64, L1, 128 * p64, p.l1x1[0], 128, 128, CAT1 + 512 * p64, 640 * p64, 1));
+    EGO_HIP(biasconv("hm.conv_up1", 9, s64, CAT1, 640 * p64, p.up[0], 640, 512, X1, 512 * p64, 1));
+    EGO_HIP(biasconv("hm.conv_heatmap", 1, s64, X1, 512 * p64, p.head, 512, p.n_out, out, out_image_stride, 0));
     return EGOTAP_OK;
 }
 

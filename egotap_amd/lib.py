@@ -35,6 +35,10 @@ _PROTOS = {
     "egotap_lift_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egotap_lift_intermediate": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "egotap_lift_debug_stop": (C.c_int, [C.c_void_p, C.c_int]),
+    "egotap_hm_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
+    "egotap_hm_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
+    "egotap_hm_intermediate": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "egotap_linear_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
     "egotap_gemm_tile_name": (C.c_char_p, [C.c_int]),
     "egotap_layernorm_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),

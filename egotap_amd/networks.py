@@ -190,3 +190,147 @@ class EgoTAPAutoEncoder(nn.Module):
                                  z.expand(B, p.in_channels, p.hm_size, p.hm_size))}
         rot, indep, out_hm = self._zeros[key]
         return pose, rot, indep, out_hm
+
+
+class HeatMap_UnrealEgo_Shared(nn.Module):
+    """Stereo heatmap estimator (reference: model/net_architecture.py:25-173 over torchvision resnet18).
+
+    forward(left[B,3,256,256], right[B,3,256,256]) -> [B, 2*n_hm, 64, 64] (left maps then right maps).
+    The state_dict has the reference's 258 keys, including the duplicate ``backbone.backbone.layerK.*`` views of
+    the ResNet tensors (the same nn.Parameter objects registered under both paths, as in the reference).
+    ``forward_into(left, right, out)`` writes the result into a channel slice of a larger tensor instead
+    (used by the wrapper to build the lifting head's input without torch.cat).
+    """
+
+    def __init__(self, opt, model_name: str = "resnet18", input_channel_scale: int = 2):
+        super().__init__()
+        if model_name != "resnet18":
+            raise NotImplementedError("only the resnet18 backbone (the shipped configuration) is built")
+        if input_channel_scale != 2:
+            raise NotImplementedError("only the stereo presets are built")
+        limb = {"none": 0, "sin": 2, "limb": 1}[getattr(opt, "heatmap_type", "none")]
+        self.num_heatmap = opt.num_heatmap + opt.num_rot_heatmap * limb
+        hm = list(getattr(opt, "load_size_heatmap", [64, 64]))
+        self.hm_size = hm[0]
+        self.preset = _spec.lift_preset(opt.joint_preset, hm[0], getattr(opt, "ae_hidden_size", 128))
+        J = self.preset.n_joints_hm
+        if self.num_heatmap == J:
+            self._net = _lib.NET_HM_POS
+        elif self.num_heatmap == 2 * J:
+            self._net = _lib.NET_HM_ROT
+        else:
+            raise ValueError("heatmap estimator must be the position net (num_rot_heatmap=0) or the sin/cos net (num_heatmap=0)")
+        entries = _spec.hm_state_spec(self.num_heatmap)
+        _build_tree(self, [(k, s) for k, s, a in entries if a is None])
+        for k, s, a in entries:                      # aliases: same Parameter / buffer object under a second path
+            if a is None:
+                continue
+            src_mod, src_leaf = self._locate(a)
+            parts = k.split(".")
+            mod = self
+            for part in parts[:-1]:
+                if part not in mod._modules:
+                    mod.add_module(part, _Node())
+                mod = mod._modules[part]
+            if src_leaf in src_mod._parameters:
+                mod.register_parameter(parts[-1], src_mod._parameters[src_leaf])
+            else:
+                mod.register_buffer(parts[-1], src_mod._buffers[src_leaf])
+        _kaiming_init_(self)
+        self._handle = None
+        self._bound_sig = None
+        self._ws = None
+
+    def _locate(self, key):
+        parts = key.split(".")
+        mod = self
+        for part in parts[:-1]:
+            mod = mod._modules[part]
+        return mod, parts[-1]
+
+    def _ensure_handle(self):
+        if self._handle is None:
+            p = self.preset
+            cfg = _lib.EgotapConfig(C.sizeof(_lib.EgotapConfig), p.n_joints_hm, int(p.estimate_head), p.hm_size, p.hidden,
+                                    p.vit_dim, p.vit_heads, p.vit_layers, p.patch, p.pu_hidden)
+            h = C.c_void_p()
+            _lib.check(_lib.load().egotap_create(C.byref(cfg), C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def _bind(self, device):
+        sd = self.state_dict(keep_vars=True)
+        sig = tuple((k, t.data_ptr()) for k, t in sd.items())
+        if sig == self._bound_sig:
+            return
+        lib, h = _lib.load(), self._ensure_handle()
+        for k, t in sd.items():
+            if t.device != device:
+                raise _lib.EgotapError(f"parameter {k} is on {t.device}, input on {device}")
+            dt = _lib.F32 if t.dtype == torch.float32 else (_lib.I64 if t.dtype == torch.long else None)
+            if dt is None or not t.is_contiguous():
+                raise _lib.EgotapError(f"parameter {k}: need contiguous fp32 (or int64 counters)")
+            _lib.check(lib.egotap_bind_param(h, self._net, k.encode(), C.c_void_p(t.data_ptr()), t.numel(), dt))
+        n = C.c_int()
+        _lib.check(lib.egotap_unbound_count(h, self._net, C.byref(n)))
+        if n.value:
+            raise _lib.EgotapError(f"{n.value} parameters the forward needs are not bound")
+        self._bound_sig = sig
+
+    def _workspace(self, B, device):
+        need = C.c_size_t()
+        _lib.check(_lib.load().egotap_hm_workspace_bytes(self._ensure_handle(), B, C.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != device:
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def intermediate(self, name: str, B: int):
+        off, n = C.c_size_t(), C.c_int64()
+        _lib.check(_lib.load().egotap_hm_intermediate(self._ensure_handle(), B, name.encode(), C.byref(off), C.byref(n)))
+        return self._ws[off.value: off.value + 4 * n.value].view(torch.float32)
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.load().egotap_destroy(self._handle)
+        except Exception:
+            pass
+
+    def forward_into(self, left, right, out, channel_offset: int = 0, workspace=None):
+        """Write this net's [B, 2*n_hm, S, S] output into out[:, channel_offset : channel_offset + 2*n_hm]."""
+        if self.training:
+            raise NotImplementedError("egotap_amd builds the eval-mode forward (folded BatchNorm); call .eval()")
+        for t in (left, right, out):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise _lib.EgotapError("heatmap estimator needs contiguous float32 CUDA tensors (no CPU fallback)")
+        B, S = left.shape[0], 4 * self.hm_size
+        if tuple(left.shape) != (B, 3, S, S) or tuple(right.shape) != (B, 3, S, S):
+            raise ValueError(f"expected left/right [B, 3, {S}, {S}], got {tuple(left.shape)} / {tuple(right.shape)}")
+        n_out = 2 * self.num_heatmap
+        if out.dim() != 4 or out.shape[0] != B or out.shape[2] != self.hm_size or out.shape[3] != self.hm_size \
+                or channel_offset + n_out > out.shape[1]:
+            raise ValueError("output tensor does not hold the requested channel slice")
+        if B == 0:
+            return out
+        dev = left.device
+        with torch.cuda.device(dev):
+            self._bind(dev)
+            ws = workspace if workspace is not None else self._workspace(B, dev)
+            self._ws = ws
+            hw = self.hm_size * self.hm_size
+            _lib.check(_lib.load().egotap_hm_forward(
+                self._ensure_handle(), self._net, C.c_void_p(left.data_ptr()), C.c_void_p(right.data_ptr()), B,
+                C.c_void_p(out.data_ptr() + 4 * channel_offset * hw), out.shape[1] * hw, C.c_void_p(ws.data_ptr()),
+                ws.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return out
+
+    def forward(self, *inputs):
+        if len(inputs) != 2:
+            raise NotImplementedError("stereo input (left, right) expected")
+        left, right = (t.detach().float().contiguous() for t in inputs)
+        if not left.is_cuda:
+            raise _lib.EgotapError("HeatMap_UnrealEgo_Shared runs on the GPU only (no CPU fallback)")
+        out = torch.empty((left.shape[0], 2 * self.num_heatmap, self.hm_size, self.hm_size), dtype=torch.float32,
+                          device=left.device)
+        return self.forward_into(left, right, out)

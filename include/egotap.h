@@ -78,6 +78,19 @@ int egotap_lift_forward(egotap_handle h, const float* hm, int B, float* pose, vo
  * name in {"tokens","pos_embed","rot_embed","skel_embed"}; offset in bytes, numel in floats */
 int egotap_lift_intermediate(egotap_handle h, int B, const char* name, size_t* offset, int64_t* numel);
 
+/* HeatMap_UnrealEgo_Shared.forward(left, right) (model/net_architecture.py:25-173; resnet18 backbone), eval mode:
+ *   net    EGOTAP_NET_HM_POS (2*n_joints_hm output channels) or EGOTAP_NET_HM_ROT (4*n_joints_hm)
+ *   left, right  device f32 [B, 3, 4*hm_size, 4*hm_size]
+ *   out    device f32, channel 0 of this net's output; image b starts at out + b*out_image_stride (floats), so the
+ *          result can be written straight into a channel slice of the lifting head's input
+ *          (torch.cat of egotap_autoencoder_model.py:195-216 is never materialised)
+ *   ws     device scratch of at least egotap_hm_workspace_bytes(B), 256-byte aligned (shared by both nets) */
+int egotap_hm_workspace_bytes(egotap_handle h, int B, size_t* bytes);
+int egotap_hm_forward(egotap_handle h, int net, const float* left, const float* right, int B, float* out,
+                      int64_t out_image_stride, void* ws, size_t ws_bytes, void* stream);
+/* name in {"layer0".."layer4" (backbone pyramid, images interleaved n = 2b + eye), "conv_up3","conv_up2","conv_up1"} */
+int egotap_hm_intermediate(egotap_handle h, int B, const char* name, size_t* offset, int64_t* numel);
+
 /* debugging aid for parity tests: 0 = full forward (default); 1 = return after the embeddings;
  * 2+i = return after ViT layer i.  The state is then readable as intermediate "x". */
 int egotap_lift_debug_stop(egotap_handle h, int stage);

@@ -26,3 +26,21 @@ def lift_net(preset="UnrealEgo", hm=64, device="cuda"):
         net = net.to(device).eval()
         _cache[key] = (net, sd_np, p)
     return _cache[key]
+
+
+def hm_net(which="pos", device="cuda"):
+    """HeatMap_UnrealEgo_Shared (position or sin/cos net) with hash-RNG weights on the GPU, eval mode."""
+    from egotap_amd.synthetic import synth_hm_state_dict
+    key = ("hm", which, device)
+    if key not in _cache:
+        opt = make_opt("UnrealEgo")
+        if which == "pos":
+            opt.num_rot_heatmap = 0
+        else:
+            opt.num_heatmap = 0
+        net = networks.HeatMap_UnrealEgo_Shared(opt, "resnet18", input_channel_scale=2)
+        sd_np = synth_hm_state_dict(net.num_heatmap, f"hm_{which}.")
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+        net = net.to(device).eval()
+        _cache[key] = (net, sd_np)
+    return _cache[key]
