@@ -1,0 +1,173 @@
+"""Host-side mirror of the reference's model wrapper for the hot path.
+
+``create_model(opt)`` / ``EgoTAPAutoEncoderModel`` keep the surface ``test.py`` / ``utils/evaluate.py`` touch
+(reference: model/models.py:2-17, model/egotap_autoencoder_model.py:13-350, model/base_model.py): ``set_input``,
+``forward(evaluate=)``, ``evaluate(dict)``, ``set_eval_mode``, ``eval_key``, ``load_networks`` / ``save_networks``,
+the ``pred_*`` attributes.  The three networks run through libegotap_hip.so; this file is plumbing only.
+Training (``optimize_parameters``) is the next scope row and raises.
+"""
+from __future__ import annotations
+
+import copy
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import networks
+
+
+def create_model(opt):
+    if getattr(opt, "model", "egotap_autoencoder") != "egotap_autoencoder":
+        raise ValueError("Model [%s] not recognized." % opt.model)
+    model = EgoTAPAutoEncoderModel()
+    model.initialize(opt)
+    return model
+
+
+def batch_procrustes(S1: torch.Tensor, S2: torch.Tensor) -> torch.Tensor:
+    """Similarity-align S1 [B,J,3] onto S2 [B,J,3] (scale, rotation, translation); restates
+    utils/util.py:328-379 (batch_compute_similarity_transform_torch) for the PA-MPJPE metric."""
+    X1, X2 = S1.transpose(1, 2), S2.transpose(1, 2)                  # [B,3,J]
+    mu1, mu2 = X1.mean(dim=-1, keepdim=True), X2.mean(dim=-1, keepdim=True)
+    Y1, Y2 = X1 - mu1, X2 - mu2
+    var1 = (Y1 ** 2).sum(dim=(1, 2))
+    K = Y1 @ Y2.transpose(1, 2)
+    U, _, Vh = torch.linalg.svd(K)
+    V = Vh.transpose(1, 2)
+    Z = torch.eye(3, device=S1.device, dtype=S1.dtype).repeat(S1.shape[0], 1, 1)
+    Z[:, -1, -1] = torch.sign(torch.det(U @ V.transpose(1, 2)))
+    R = V @ Z @ U.transpose(1, 2)
+    scale = torch.diagonal(R @ K, dim1=1, dim2=2).sum(-1) / var1
+    t = mu2 - scale[:, None, None] * (R @ mu1)
+    return (scale[:, None, None] * (R @ X1) + t).transpose(1, 2)
+
+
+def mpjpe(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    """LossFuncMPJPE (utils/loss.py:79-85)."""
+    return torch.linalg.norm(gt - pred, dim=-1).mean()
+
+
+class EgoTAPAutoEncoderModel(nn.Module):
+    def name(self):
+        return "EgoTAP AutoEncoder model"
+
+    def initialize(self, opt):
+        self.opt = opt
+        self.gpu_ids = getattr(opt, "gpu_ids", [0])
+        self.isTrain = getattr(opt, "isTrain", False)
+        self.save_dir = os.path.join(getattr(opt, "log_dir", "./log"), getattr(opt, "experiment_name", "experiment"))
+        self.device = torch.device("cuda:{}".format(self.gpu_ids[0])) if self.gpu_ids else torch.device("cuda:0")
+        self.loss_names = ["pose", "cos_sim"] if self.isTrain else []
+        self.model_names = ["HeatMap", "RotHeatMap", "AutoEncoder"]
+        self.visual_names, self.visual_pose_names = [], ["pred_pose", "gt_pose"]
+        self.eval_key = "mpjpe"
+        self.cm2mm = 10
+        self.stereo = getattr(opt, "stereo", True)
+        self.input_channel_scale = 2 if self.stereo else 1
+        if not self.stereo:
+            raise NotImplementedError("only the stereo presets are built")
+        pos_opt, rot_opt = copy.deepcopy(opt), copy.deepcopy(opt)      # egotap_autoencoder_model.py:104-107
+        pos_opt.num_rot_heatmap = 0
+        rot_opt.num_heatmap = 0
+        self.net_HeatMap = networks.HeatMap_UnrealEgo_Shared(pos_opt, getattr(opt, "model_name", "resnet18"), 2)
+        self.net_RotHeatMap = networks.HeatMap_UnrealEgo_Shared(rot_opt, getattr(opt, "model_name", "resnet18"), 2)
+        self.net_AutoEncoder = networks.EgoTAPAutoEncoder(opt, input_channel_scale=2)
+        self.optimizers, self.schedulers = [], []
+        self.to(self.device)
+        self._hm_ws = None
+
+    # ---- data --------------------------------------------------------------------------------------------------
+    def set_input(self, data):
+        """Keys of dataloader/data_loader.py:166-215; only the ones the eval path reads are required."""
+        self.data = data
+        dev = self.device
+        self.input_rgb_left = data["input_rgb_left"].to(dev, non_blocking=True)
+        self.input_rgb_right = data["input_rgb_right"].to(dev, non_blocking=True)
+        for k in ("gt_heatmap_left", "gt_heatmap_right", "gt_limb_heatmap_left", "gt_limb_heatmap_right"):
+            setattr(self, k, data[k].to(dev, non_blocking=True) if k in data else None)
+        self.gt_pose = data["gt_local_pose"].to(dev, non_blocking=True) if "gt_local_pose" in data else None
+
+    # ---- forward -----------------------------------------------------------------------------------------------
+    def forward_heatmap(self):
+        p = self.net_AutoEncoder.preset
+        J = p.n_joints_hm
+        if getattr(self.opt, "use_gt_heatmap", False):
+            cat = torch.cat((self.gt_heatmap_left, self.gt_heatmap_right, self.gt_limb_heatmap_left,
+                             self.gt_limb_heatmap_right), dim=1).float().contiguous()
+        else:
+            left = self.input_rgb_left.float().contiguous()
+            right = self.input_rgb_right.float().contiguous()
+            B = left.shape[0]
+            cat = torch.empty((B, p.in_channels, p.hm_size, p.hm_size), dtype=torch.float32, device=left.device)
+            ws = self.net_HeatMap._workspace(B, left.device)          # one scratch shared by both estimators
+            self.net_HeatMap.forward_into(left, right, cat, 0, workspace=ws)
+            self.net_RotHeatMap.forward_into(left, right, cat, 2 * J, workspace=ws)
+        self.pred_heatmap_cat = cat
+        self.pred_heatmap_left, self.pred_heatmap_right = cat[:, :J], cat[:, J:2 * J]
+        self.pred_limb_heatmap_left, self.pred_limb_heatmap_right = cat[:, 2 * J:4 * J], cat[:, 4 * J:]
+
+    def forward(self, evaluate=False):
+        if not evaluate and self.net_AutoEncoder.training:
+            raise NotImplementedError("training forward/backward is the next scope row; use evaluate()")
+        self.forward_heatmap()
+        self.pred_pose, self.pred_rot, self.pred_indep_pos, rec = self.net_AutoEncoder(
+            self.pred_heatmap_cat, self.input_rgb_left, self.input_rgb_right)
+        J = self.net_AutoEncoder.preset.n_joints_hm
+        self.pred_heatmap_rec_cat = rec
+        self.pred_heatmap_left_rec, self.pred_heatmap_right_rec = rec[:, :J], rec[:, J:2 * J]
+        self.pred_limb_heatmap_left_rec, self.pred_limb_heatmap_right_rec = rec[:, 2 * J:4 * J], rec[:, 4 * J:]
+
+    def optimize_parameters(self):
+        raise NotImplementedError("egotap_amd round 1 builds the eval path; the training step is the next scope row")
+
+    def set_eval_mode(self):
+        self.net_AutoEncoder.eval()
+        self.net_HeatMap.eval()
+        self.net_RotHeatMap.eval()
+
+    def evaluate(self, runnning_average_dict):
+        self.set_eval_mode()
+        with torch.no_grad():
+            self.forward(evaluate=True)
+            aligned = batch_procrustes(self.pred_pose, self.gt_pose)
+            err = torch.linalg.norm(self.gt_pose - self.pred_pose, dim=-1).mean(dim=-1) * self.cm2mm
+            pa = torch.linalg.norm(self.gt_pose - aligned, dim=-1).mean(dim=-1) * self.cm2mm
+        for i in range(self.pred_pose.shape[0]):
+            runnning_average_dict.update(dict(mpjpe=err[i], pa_mpjpe=pa[i]))
+        return self.pred_pose, self.pred_heatmap_cat, runnning_average_dict
+
+    # ---- checkpoints (base_model.py:64-148 file naming) --------------------------------------------------------
+    def save_networks(self, which_epoch=None, checkpoint_path=None):
+        if which_epoch is None and checkpoint_path is None:
+            raise ValueError("which_epoch and checkpoint_path cannot be both None")
+        which_epoch = "checkpoint" if which_epoch is None else which_epoch
+        checkpoint_path = self.save_dir if checkpoint_path is None else checkpoint_path
+        os.makedirs(checkpoint_path, exist_ok=True)
+        for name in self.model_names:
+            net = getattr(self, "net_" + name)
+            sd = OrderedDict((k, v.detach().cpu()) for k, v in net.state_dict().items())
+            torch.save(sd, os.path.join(checkpoint_path, "%s_net_%s.pth" % (which_epoch, name)))
+
+    def load_networks(self, which_epoch=None, net=None, path_to_trained_weights=None, checkpoint_path=None):
+        if path_to_trained_weights is not None:
+            sd = torch.load(path_to_trained_weights, map_location="cpu")
+            sd = OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in sd.items())
+            net.load_state_dict(sd)
+            return
+        if which_epoch is None and checkpoint_path is None:
+            raise ValueError("which_epoch and checkpoint_path cannot be both None")
+        which_epoch = "checkpoint" if which_epoch is None else which_epoch
+        checkpoint_path = self.save_dir if checkpoint_path is None else checkpoint_path
+        for name in self.model_names:
+            n = getattr(self, "net_" + name)
+            n.load_state_dict(torch.load(os.path.join(checkpoint_path, "%s_net_%s.pth" % (which_epoch, name)), map_location="cpu"))
+            n.eval() if not self.isTrain else n.train()
+
+    def get_current_errors(self):
+        return OrderedDict((n, getattr(self, "loss_" + n).item()) for n in self.loss_names if hasattr(self, "loss_" + n))
+
+    def update_learning_rate(self):
+        for s in self.schedulers:
+            s.step()

@@ -297,6 +297,23 @@ def loss_cos_sim(pred, gt, p: LiftPreset, eps=1e-8):
     return cos.sum(dim=1).mean()
 
 
+def procrustes_align(s1, s2):
+    """Batched similarity transform of s1 [B,J,3] onto s2 (utils/util.py:328-379), for PA-MPJPE."""
+    x1, x2 = s1.transpose(1, 2), s2.transpose(1, 2)
+    mu1, mu2 = x1.mean(-1, keepdim=True), x2.mean(-1, keepdim=True)
+    y1, y2 = x1 - mu1, x2 - mu2
+    var1 = (y1 ** 2).sum(dim=(1, 2))
+    k = y1 @ y2.transpose(1, 2)
+    u, _, vh = torch.linalg.svd(k)
+    v = vh.transpose(1, 2)
+    z = torch.eye(3, dtype=s1.dtype).repeat(s1.shape[0], 1, 1)
+    z[:, 2, 2] = torch.sign(torch.det(u @ v.transpose(1, 2)))
+    r = v @ z @ u.transpose(1, 2)
+    scale = torch.diagonal(r @ k, dim1=1, dim2=2).sum(-1) / var1
+    t = mu2 - scale[:, None, None] * (r @ mu1)
+    return (scale[:, None, None] * (r @ x1) + t).transpose(1, 2)
+
+
 def to_torch_sd(np_sd, dtype=torch.float32):
     out = {}
     for k, v in np_sd.items():

@@ -1,0 +1,76 @@
+"""GPU parity of the whole hot path through the wrapper mirror (RGB -> two heatmap estimators -> lifting head ->
+joints + metrics) against the oracle chain on the same synthetic inputs."""
+import numpy as np
+import pytest
+import torch
+
+from egotap_amd.synthetic import synth_hm_state_dict, synth_input, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+class _Avg(dict):
+    def update(self, d):
+        for k, v in d.items():
+            self.setdefault(k, []).append(float(v))
+
+
+def _model():
+    from egotap_amd import models, spec
+    from egotap_amd.options import preset_defaults
+    opt = preset_defaults("UnrealEgo")
+    m = models.create_model(opt)
+    p = spec.lift_preset("UnrealEgo")
+    sds = {"AutoEncoder": synth_state_dict(spec.lift_state_spec(p)),
+           "HeatMap": synth_hm_state_dict(15, "hm_pos."), "RotHeatMap": synth_hm_state_dict(30, "hm_rot.")}
+    for name, sd in sds.items():
+        getattr(m, "net_" + name).load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m, sds, p
+
+
+def test_wrapper_evaluate_matches_oracle_chain():
+    from oracle import hm_ref as H, lift_ref as O
+    m, sds, p = _model()
+    B = 2
+    data = {"input_rgb_left": torch.from_numpy(synth_input("w_rgb_l", (B, 3, 256, 256), -2.0, 2.0)),
+            "input_rgb_right": torch.from_numpy(synth_input("w_rgb_r", (B, 3, 256, 256), -2.0, 2.0)),
+            "gt_local_pose": torch.from_numpy(synth_input("w_gt", (B, 16, 3), -1.0, 1.0))}
+    m.set_input(data)
+    avg = _Avg()
+    pose, hm_cat, avg = m.evaluate(avg)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        pos = H.hm_forward(data["input_rgb_left"], data["input_rgb_right"], H.to_torch_sd(sds["HeatMap"]))
+        rot = H.hm_forward(data["input_rgb_left"], data["input_rgb_right"], H.to_torch_sd(sds["RotHeatMap"]))
+        cat = torch.cat([pos, rot], dim=1)
+        ref = O.lift_forward(cat, O.to_torch_sd(sds["AutoEncoder"]), p)
+        aligned = O.procrustes_align(ref, data["gt_local_pose"])
+    assert tuple(hm_cat.shape) == (B, 90, 64, 64)
+    np.testing.assert_allclose(hm_cat.cpu().numpy(), cat.numpy(), atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(pose.cpu().numpy(), ref.numpy(), atol=1e-4, rtol=0)
+    ref_mpjpe = [float(torch.linalg.norm(data["gt_local_pose"][i] - ref[i], dim=-1).mean() * 10) for i in range(B)]
+    ref_pa = [float(torch.linalg.norm(data["gt_local_pose"][i] - aligned[i], dim=-1).mean() * 10) for i in range(B)]
+    np.testing.assert_allclose(avg["mpjpe"], ref_mpjpe, rtol=1e-4)
+    np.testing.assert_allclose(avg["pa_mpjpe"], ref_pa, rtol=1e-3)
+    # attributes the reference's callers read
+    assert m.pred_heatmap_left.shape == (B, 15, 64, 64) and m.pred_limb_heatmap_right.shape == (B, 30, 64, 64)
+    assert float(m.pred_heatmap_rec_cat.abs().max()) == 0.0 and m.eval_key == "mpjpe"
+    with pytest.raises(NotImplementedError):
+        m.optimize_parameters()
+
+
+def test_wrapper_gt_heatmap_path():
+    m, sds, p = _model()
+    m.opt.use_gt_heatmap = True
+    B = 3
+    hm = torch.from_numpy(synth_input("w_hm", (B, 90, 64, 64)))
+    data = {"input_rgb_left": torch.zeros(B, 3, 256, 256), "input_rgb_right": torch.zeros(B, 3, 256, 256),
+            "gt_heatmap_left": hm[:, :15], "gt_heatmap_right": hm[:, 15:30], "gt_limb_heatmap_left": hm[:, 30:60],
+            "gt_limb_heatmap_right": hm[:, 60:], "gt_local_pose": torch.zeros(B, 16, 3)}
+    m.set_input(data)
+    m.set_eval_mode()
+    with torch.no_grad():
+        m.forward(evaluate=True)
+    direct = m.net_AutoEncoder.predict_pose(hm.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(m.pred_pose, direct)

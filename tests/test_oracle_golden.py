@@ -99,3 +99,11 @@ def test_losses(tag, preset, nj):
     np.testing.assert_allclose(cs.item(), g["cos_sim"], rtol=1e-5)
     (grad,) = torch.autograd.grad(0.1 * mp + (-0.01) * 0.1 * cs, pred)
     np.testing.assert_allclose(grad.numpy(), g["dtotal_dpred"], atol=1e-7)
+
+
+def test_procrustes_matches_reference():
+    g = _load("procrustes.npz")
+    s1 = torch.from_numpy(synth_input("procrustes_s1", (6, 16, 3), -30.0, 30.0))
+    s2 = torch.from_numpy(synth_input("procrustes_s2", (6, 16, 3), -30.0, 30.0))
+    s2[:3] = s1[:3] * 1.7 + 0.3 * s2[:3]
+    np.testing.assert_allclose(O.procrustes_align(s1, s2).numpy(), g["s1_hat"], atol=2e-4, rtol=1e-4)

@@ -214,6 +214,17 @@ def gen_loss():
         print(f"loss_{tag}:", float(mp), float(cs))
 
 
+def gen_procrustes():
+    import utils.util as U
+
+    s1 = torch.from_numpy(synth_input("procrustes_s1", (6, 16, 3), -30.0, 30.0))
+    s2 = torch.from_numpy(synth_input("procrustes_s2", (6, 16, 3), -30.0, 30.0))
+    s2[:3] = s1[:3] * 1.7 + 0.3 * s2[:3]          # partly correlated pairs (well-conditioned rotations)
+    out = U.batch_compute_similarity_transform_torch(s1, s2)
+    np.savez_compressed(os.path.join(GOLD, "procrustes.npz"), s1_hat=out.numpy())
+    print("procrustes ok", tuple(out.shape))
+
+
 def gen_hm():
     """E1-E9: the reference's HeatMap_UnrealEgo_Shared with OUR ResNet-18 restatement
     standing in for torchvision (parity of the backbone itself is unpinned)."""
@@ -260,7 +271,7 @@ def gen_hm():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="lift,pu,fc,loss,hm")
+    ap.add_argument("--only", default="lift,pu,fc,loss,hm,procrustes")
     args = ap.parse_args()
     which = set(args.only.split(","))
     os.makedirs(GOLD, exist_ok=True)
@@ -277,6 +288,8 @@ def main():
         gen_loss()
     if "hm" in which:
         gen_hm()
+    if "procrustes" in which:
+        gen_procrustes()
 
 
 if __name__ == "__main__":
