@@ -39,6 +39,27 @@ def lift_flops_per_frame(p) -> float:
     return float(patch + vit + pos_fc + rot_fc + pu + head)
 
 
+def hm_flops_per_frame(n_out: int, rgb: int = 256) -> float:
+    """Algorithmic FLOPs of one heatmap estimator (both eyes), resnet18 U-Net of net_architecture.py:25-173."""
+    f = 0.0
+    s = rgb // 2
+    f += 2 * 2.0 * 147 * 64 * s * s                                   # stem, two eyes
+    cin, s = 64, rgb // 4
+    for i, c in enumerate((64, 128, 256, 512)):
+        if i > 0:
+            s //= 2
+        px = 2.0 * s * s                                               # two eyes
+        f += 2 * 9 * cin * c * px + 3 * 2 * 9 * c * c * px             # 4 convs 3x3
+        if i > 0:
+            f += 2 * cin * c * px                                      # 1x1 downsample
+        cin = c
+    s8, s16, s32, s64 = rgb // 32, rgb // 16, rgb // 8, rgb // 4
+    f += 2.0 * 1024 * 1024 * s8 * s8 + 2.0 * 512 * 516 * s16 * s16 + 2.0 * 256 * 256 * s32 * s32 + 2.0 * 128 * 128 * s64 * s64
+    f += 2.0 * 9 * 1540 * 1024 * s16 * s16 + 2.0 * 9 * 1280 * 512 * s32 * s32 + 2.0 * 9 * 640 * 512 * s64 * s64
+    f += 2.0 * 512 * n_out * s64 * s64
+    return f
+
+
 def host_cores() -> int:
     """CPU cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
     n = os.cpu_count() or 1
@@ -89,6 +110,69 @@ def cpu_baseline(p, sd_np, batch: int, reps: int):
             "sample": f"oracle/lift_ref.lift_forward, B={batch}, fp32, {reps} timed passes (median), torch CPU threads={cores}"}, out
 
 
+def bench_full(args, p, dev, rank, world, barrier, lib, L):
+    """Secondary measurement: the whole path from RGB (two heatmap estimators + lifting head), same batch."""
+    import torch
+    import torch.distributed as dist
+    from egotap_amd import models, spec
+    from egotap_amd.options import preset_defaults
+    from egotap_amd.synthetic import synth_hm_state_dict, synth_input, synth_state_dict
+    opt = preset_defaults(args.preset)
+    opt.gpu_ids = [dev.index]
+    m = models.create_model(opt)
+    J = p.n_joints_hm
+    for name, sd in (("AutoEncoder", synth_state_dict(spec.lift_state_spec(p))), ("HeatMap", synth_hm_state_dict(J, "hm_pos.")),
+                     ("RotHeatMap", synth_hm_state_dict(2 * J, "hm_rot."))):
+        getattr(m, "net_" + name).load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    B = args.batch
+    S = 4 * p.hm_size
+    # uniform RGB in the ImageNet-normalised range; one 8-frame block repeated (generation cost only)
+    blk = min(B, 8)
+    l = torch.from_numpy(synth_input(f"rgb_l_rank{rank}", (blk, 3, S, S), -2.0, 2.0)).to(dev).repeat((B + blk - 1) // blk, 1, 1, 1)[:B].contiguous()
+    r = torch.from_numpy(synth_input(f"rgb_r_rank{rank}", (blk, 3, S, S), -2.0, 2.0)).to(dev).repeat((B + blk - 1) // blk, 1, 1, 1)[:B].contiguous()
+    m.set_input({"input_rgb_left": l, "input_rgb_right": r})
+    m.set_eval_mode()
+    h = m.net_HeatMap._ensure_handle()
+    with torch.no_grad():
+        m.forward(evaluate=True)
+        barrier()
+        lib.check(L.egotap_timing_enable(h, 1))
+        lib.check(L.egotap_timing_enable(m.net_RotHeatMap._ensure_handle(), 1))
+        t0 = time.perf_counter()
+        for _ in range(args.full_steps):
+            m.forward(evaluate=True)
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+    barrier()
+    from egotap_amd import parallel
+    elapsed = parallel.max_over_ranks(elapsed, dev)
+    roles = {}
+    tot_ms = tot_fl = 0.0
+    for net in (m.net_HeatMap, m.net_RotHeatMap):
+        n, ms, fl = C.c_int(), C.c_double(), C.c_double()
+        lib.check(L.egotap_timing_read(net._ensure_handle(), C.byref(n), C.byref(ms), C.byref(fl)))
+        lib.check(L.egotap_timing_enable(net._ensure_handle(), 0))
+        tot_ms += ms.value
+        tot_fl += fl.value
+        for d in json.loads(L.egotap_timing_detail(net._ensure_handle()).decode()):
+            a = roles.setdefault(d["role"], {"ms": 0.0, "flops": 0.0, "launches": 0, "kernel": d["kernel"]})
+            a["ms"] += d["ms"]; a["flops"] += d["flops"]; a["launches"] += d["launches"]
+    flops_frame = lift_flops_per_frame(p) + hm_flops_per_frame(2 * J, S) + hm_flops_per_frame(4 * J, S)
+    fps = world * B * args.full_steps / elapsed
+    conv_tf = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    return {
+        "value": round(fps, 1), "unit": "stereo frames/s", "ms_per_step": round(1e3 * elapsed / args.full_steps, 2),
+        "steps": args.full_steps, "flops_per_frame": flops_frame,
+        "end_to_end_tflops_per_gpu": round(fps * flops_frame / world / 1e12, 2),
+        "end_to_end_frac_of_f32_mfma_peak": round(fps * flops_frame / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+        "conv_roofline": {"bound": "mfma", "kernel": "conv_f32_kernel (all instantiations)", "achieved": round(conv_tf, 2),
+                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(conv_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                          "conv_share_of_step_time": round(tot_ms * 1e-3 / elapsed, 4)},
+        "by_role": {k: {"kernel": v["kernel"], "avg_ms": round(v["ms"] / v["launches"], 4),
+                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in roles.items()},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,6 +183,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--lift-only", action="store_true", help="skip the secondary full-pipeline (RGB -> joints) measurement")
+    ap.add_argument("--full-steps", type=int, default=3)
     args = ap.parse_args()
 
     import torch
@@ -119,9 +205,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    from egotap_amd import parallel
+    parallel.init_from_env("nccl", dev)      # "nccl" is RCCL on ROCm; no-op for one rank
 
     p = spec.lift_preset(args.preset)
     sd_np = synth_state_dict(spec.lift_state_spec(p))
@@ -135,10 +220,7 @@ def main():
     h = net._ensure_handle()
 
     def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        parallel.barrier(dev)
 
     for _ in range(max(args.warmup, 1)):
         pose = net.predict_pose(hm)
@@ -151,10 +233,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed = parallel.max_over_ranks(elapsed, dev)
 
     roof = None
     if timing:
@@ -178,6 +257,10 @@ def main():
             "by_role": {d["role"]: {"avg_ms": round(d["ms"] / d["launches"], 4),
                                     "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)} for d in detail},
         }
+
+    full = None
+    if not args.lift_only:
+        full = bench_full(args, p, dev, rank, world, barrier, lib, L)
 
     cpu = None
     gpu_vs_oracle = None
@@ -204,6 +287,7 @@ def main():
             "end_to_end_tflops_per_gpu": round(fps * flops_frame / world / 1e12, 2),
             "end_to_end_frac_of_f32_mfma_peak": round(fps * flops_frame / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roof, "cpu_baseline": cpu, "max_abs_diff_vs_oracle": gpu_vs_oracle,
+            "full_pipeline_from_rgb": full,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -1,0 +1,68 @@
+"""Data-parallel plumbing of the hot path: one process per GPU, batch shards, no data-path collective.
+
+Samples are independent in eval (BatchNorm uses running statistics), so inference needs no exchange step
+(SURVEY.md 8(e)); the only collectives are the measurement barrier / max-over-ranks and an optional gather of the
+[B, J, 3] poses.  ``torch.distributed`` backend "nccl" is RCCL on ROCm; the same code runs on "gloo" for CPU tests.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, rank: int, world: int):
+    """Contiguous [lo, hi) slice of ``total`` samples for ``rank``; sizes differ by at most one."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend: str | None = None, device: torch.device | None = None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run); no-op for world 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def barrier(device: torch.device | None = None):
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value: float, device: torch.device | None = None) -> float:
+    """Slowest rank's time: what whole-job throughput is computed from."""
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_poses(pose: torch.Tensor, counts=None) -> torch.Tensor:
+    """All ranks' [b_r, J, 3] poses concatenated in rank order (equal shard sizes unless ``counts`` is given)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return pose
+    world = dist.get_world_size()
+    if counts is None:
+        out = [torch.empty_like(pose) for _ in range(world)]
+        dist.all_gather(out, pose.contiguous())
+        return torch.cat(out, dim=0)
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(pose.shape[1:]), dtype=pose.dtype, device=pose.device)
+    pad[: pose.shape[0]] = pose
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)

@@ -1,0 +1,55 @@
+"""World-size-2 gloo test (CPU) of the data-parallel plumbing bench.py and the wrapper rely on: disjoint batch
+shards that cover the batch, max-over-ranks timing, rank-ordered pose gather.  The per-rank 'model' here is the
+oracle's pose head on a shard (the HIP path needs a GPU; its sharding logic is what is under test)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from egotap_amd import parallel as P
+
+
+def test_shard_bounds_cover_and_balance():
+    for total in (0, 1, 7, 256, 8192):
+        for world in (1, 2, 3, 8):
+            spans = [P.shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        P.shard_bounds(4, 2, 2)
+
+
+def _worker(rank, world, port, total, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    r, w = P.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    lo, hi = P.shard_bounds(total, rank, world)
+    g = torch.Generator().manual_seed(1234)
+    full = torch.rand(total, 16, 3, generator=g)              # every rank can regenerate the whole batch
+    mine = full[lo:hi] * 2.0 + 1.0                              # "forward" of this rank's shard
+    P.barrier()
+    slowest = P.max_over_ranks(0.5 + rank)                      # rank 1 is slower
+    counts = [P.shard_bounds(total, k, world)[1] - P.shard_bounds(total, k, world)[0] for k in range(world)]
+    allp = P.gather_poses(mine, counts)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.concatenate([[slowest], allp.reshape(-1).numpy()]))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    total = 7                                                   # ragged: shards of 4 and 3
+    mp.spawn(_worker, args=(2, port, total, str(tmp_path)), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(1234)
+    ref = (torch.rand(total, 16, 3, generator=g) * 2.0 + 1.0).reshape(-1).numpy()
+    for rank in range(2):
+        got = np.load(tmp_path / f"r{rank}.npy")
+        assert got[0] == 1.5                                    # max over ranks
+        np.testing.assert_array_equal(got[1:], ref)             # same gathered batch on every rank, rank order
