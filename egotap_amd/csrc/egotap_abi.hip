@@ -53,6 +53,7 @@ extern "C" const char* egotap_gemm_tile_name(int tile) {
         case 9: return "pipe128x128x32/4w";
         case 10: return "pipe256x128x16/8w";
         case 11: return "pipe256x256x16/8w";
+        case 12: return "persist256x256x16/8w";
         default: return nullptr;
     }
 }
@@ -400,13 +401,23 @@ static hipError_t gemm(Handle* h, const char* role, const AL& al, const SegMat& 
 
 // large GEMMs (ViT projections, fc1): 256x256 tile, 3-stage pipelined kernel -- fewest global-load
 // instructions per MFMA (each costs the matrix pipe ~56 cycles, tools/mfma_probe.hip), DESIGN.md section 4
+static int device_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
 template <class AL, class Epi>
 static hipError_t gemm_big(Handle* h, const char* role, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc,
                            int M, int N, int K, hipStream_t s) {
     using Cfg = PipeD;
-    static const std::string kname = std::string("gemm_f32_pipe_kernel<256x256x16,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
+    static const std::string kname = std::string("gemm_f32_persist_kernel<256x256x16,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
     GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
-    return gemm_f32_pipe_launch<Cfg, AL, Epi>(al, W, epi, C, ldc, M, N, K, s);
+    return gemm_f32_persist_launch<Cfg, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
 }
 
 // ------------------------------------------------------------------------------------------------ workspace
@@ -830,6 +841,7 @@ extern "C" int egotap_linear_f32(const float* x, const float* w, const float* b,
         case 9: e = gemm_f32_pipe_launch<PipeB>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
         case 10: e = gemm_f32_pipe_launch<PipeC>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
         case 11: e = gemm_f32_pipe_launch<PipeD>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
+        case 12: e = gemm_f32_persist_launch<PipeD>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
         default: egotap_set_error("unknown tile id %d", tile); return EGOTAP_ERR_INVALID;
     }
     if (e == hipErrorInvalidValue) {

@@ -121,6 +121,11 @@ struct EpiBias {          // C = acc + bias
     struct Col { float b; };
     __device__ __forceinline__ Col col(int n) const { return Col{bias.at(n)}; }
     __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const { return acc + c.b; }
+    struct Col4 { f32x4 b; };
+    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{f32x4{bias.at(n0), bias.at(n0 + 1), bias.at(n0 + 2), bias.at(n0 + 3)}}; }
+    static constexpr bool HAS_RES = false;
+    __device__ __forceinline__ f32x4 res4(int m, int n0) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ f32x4 apply4(f32x4 acc, const Col4& c, f32x4 res, int m, int n0) const { return acc + c.b; }
 };
 struct EpiBiasRes {       // C = acc + bias + R[m, n]   (R may alias C)
     SegVec bias;
@@ -131,6 +136,11 @@ struct EpiBiasRes {       // C = acc + bias + R[m, n]   (R may alias C)
     __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const {
         return acc + c.b + R[(long)m * ldr + n];
     }
+    struct Col4 { f32x4 b; };
+    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{f32x4{bias.at(n0), bias.at(n0 + 1), bias.at(n0 + 2), bias.at(n0 + 3)}}; }
+    static constexpr bool HAS_RES = true;
+    __device__ __forceinline__ f32x4 res4(int m, int n0) const { return *(const f32x4*)(R + (long)m * ldr + n0); }
+    __device__ __forceinline__ f32x4 apply4(f32x4 acc, const Col4& c, f32x4 res, int m, int n0) const { return acc + c.b + res; }
 };
 struct EpiBiasGelu {      // exact erf GELU (modeling_vit.py:320-327, hidden_act='gelu')
     SegVec bias;
@@ -139,6 +149,19 @@ struct EpiBiasGelu {      // exact erf GELU (modeling_vit.py:320-327, hidden_act
     __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const {
         const float x = acc + c.b;
         return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    }
+    struct Col4 { f32x4 b; };
+    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{f32x4{bias.at(n0), bias.at(n0 + 1), bias.at(n0 + 2), bias.at(n0 + 3)}}; }
+    static constexpr bool HAS_RES = false;
+    __device__ __forceinline__ f32x4 res4(int m, int n0) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ f32x4 apply4(f32x4 acc, const Col4& c, f32x4 res, int m, int n0) const {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x = acc[i] + c.b[i];
+            o[i] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        }
+        return o;
     }
 };
 struct EpiBnLrelu {       // LeakyReLU_0.2(BatchNorm1d_eval(acc + bias))  (network_utils.py:123-142)
@@ -152,6 +175,16 @@ struct EpiBnLrelu {       // LeakyReLU_0.2(BatchNorm1d_eval(acc + bias))  (netwo
         const float y = (acc + c.b - c.mu) * c.sc + c.sh;
         return y > 0.f ? y : slope * y;
     }
+    struct Col4 { Col c[4]; };
+    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{{col(n0), col(n0 + 1), col(n0 + 2), col(n0 + 3)}}; }
+    static constexpr bool HAS_RES = false;
+    __device__ __forceinline__ f32x4 res4(int m, int n0) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ f32x4 apply4(f32x4 acc, const Col4& c, f32x4 res, int m, int n0) const {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = apply(acc[i], c.c[i], m, n0 + i);
+        return o;
+    }
 };
 struct EpiPatch {         // (dummy ? mask_token : acc + bias) + position_embeddings   (modeling_vit.py:137-153)
     const float *bias, *mask_tok, *pos;
@@ -163,6 +196,16 @@ struct EpiPatch {         // (dummy ? mask_token : acc + bias) + position_embedd
         const int pr = tok / side, pc = tok - pr * side;
         const bool dummy = (pr / ppd) * grid + pc / ppd >= T;
         return (dummy ? c.mt : acc + c.b) + pos[(long)tok * D + n];
+    }
+    struct Col4 { f32x4 b, mt; };
+    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{*(const f32x4*)(bias + n0), *(const f32x4*)(mask_tok + n0)}; }
+    static constexpr bool HAS_RES = true;     // the position embedding row plays the residual's role
+    __device__ __forceinline__ f32x4 res4(int m, int n0) const { return *(const f32x4*)(pos + (long)(m % seq) * D + n0); }
+    __device__ __forceinline__ f32x4 apply4(f32x4 acc, const Col4& c, f32x4 res, int m, int n0) const {
+        const int tok = m % seq;
+        const int pr = tok / side, pc = tok - pr * side;
+        const bool dummy = (pr / ppd) * grid + pc / ppd >= T;
+        return (dummy ? c.mt : acc + c.b) + res;
     }
 };
 
@@ -436,6 +479,213 @@ static hipError_t gemm_f32_pipe_launch(const ALoad& al, const SegMat& W, const E
     const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, al, W, epi, C, ldc, M,
                        N, K, tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------- persistent kernel
+// gemm_f32_pipe_kernel's slab pipeline run as ONE block per CU that walks its share of the tiles: the slab stream
+// simply continues into the next tile (its first slabs are loaded / staged under the tail of the current one), so
+// the per-tile prologue (exposed first-slab latency, ~3 slab times) disappears, and the C tile is stored as whole
+// 128-byte row segments with global_store_dwordx4 after a per-wave transpose through a private LDS patch
+// (4x fewer store instructions than the accumulator-shaped dword stores; a vector-memory instruction costs the
+// matrix pipe ~56 cycles).  Tile order: blocks with equal blockIdx % 8 share an L2; they take consecutive tiles of a
+// contiguous chunk of the grouped order in lockstep, so co-resident blocks share A / W panels.  Same k order as the
+// other kernels: bit-identical results.
+template <class Cfg, class ALoad, class Epi>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_persist_kernel(
+    ALoad al, SegMat W, Epi epi, float* C, long ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, LDK = Cfg::LDK, NS = Cfg::NS;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, A_V4 = Cfg::A_V4, B_V4 = Cfg::B_V4, RPP = Cfg::ROWS_PER_PASS;
+    constexpr int G = BK / 8, ELD = 36;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + NS * BM * LDK;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float* Es = smem + NS * (BM + BN) * LDK + wid * 32 * ELD;      // this wave's 32 x 32 transpose patch
+    const int wm = wid / Cfg::WN, wn = wid % Cfg::WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int c4 = tid % (BK / 4), r0 = tid / (BK / 4);
+
+    // tiles of this block
+    const int ntiles = tiles_m * tiles_n, nb = gridDim.x, x8 = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int nbx = (nb >> 3) + (x8 < (nb & 7) ? 1 : 0);
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int lo = x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8;
+    const int cnt = q8 + (x8 < r8 ? 1 : 0);
+    const int my_n = cnt > jb ? (cnt - jb + nbx - 1) / nbx : 0;
+    const int KT = K / BK;
+    const int total = my_n * KT;
+    if (total == 0) return;
+    auto tile_of = [&](int i, int& tm, int& tn) __attribute__((always_inline)) {
+        const int lin = lo + jb + i * nbx;
+        const int per_group = 8 * tiles_n;
+        const int g = lin / per_group, first = g * 8;
+        const int gsz = min(tiles_m - first, 8);
+        const int in = lin - g * per_group;
+        tm = first + in % gsz;
+        tn = in / gsz;
+    };
+
+    typename ALoad::Row arow[A_V4];
+    const float* brow[B_V4];
+    int l_tile = 0, l_kt = 0;           // load position
+    auto set_rows = [&](int i) __attribute__((always_inline)) {
+        int tm, tn;
+        tile_of(i, tm, tn);
+#pragma unroll
+        for (int v = 0; v < A_V4; ++v) arow[v] = al.row(min(tm * BM + r0 + v * RPP, M - 1));
+#pragma unroll
+        for (int v = 0; v < B_V4; ++v) brow[v] = W.row(tn * BN + r0 + v * RPP);
+    };
+    set_rows(0);
+
+    f32x4 ga[A_V4], gb[B_V4];            // ONE global-load staging set: loads are issued right after the LDS write that
+                                         // frees it and have a whole slab time (~3 us) to land
+    f32x4 fa[2][TM], fb[2][TN];
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int a_off = (wm * (TM * 32) + l31) * LDK + 4 * lh;
+    const int b_off = (wn * (TN * 32) + l31) * LDK + 4 * lh;
+
+#define GLOAD()                                                                                      \
+    {                                                                                                \
+        const int k0_ = l_kt * BK + c4 * 4;                                                          \
+        _Pragma("unroll") for (int i = 0; i < A_V4; ++i) ga[i] = al.load(arow[i], k0_);              \
+        _Pragma("unroll") for (int i = 0; i < B_V4; ++i) gb[i] = *(const f32x4*)(brow[i] + k0_);     \
+        if (++l_kt == KT) {                                                                          \
+            l_kt = 0;                                                                                \
+            if (++l_tile < my_n) set_rows(l_tile);                                                   \
+        }                                                                                            \
+    }
+#define LSTORE(BUF)                                                                                              \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < A_V4; ++i)                                                         \
+            *(f32x4*)(As + ((BUF) * BM + r0 + i * RPP) * LDK + c4 * 4) = ga[i];                                  \
+        _Pragma("unroll") for (int i = 0; i < B_V4; ++i)                                                         \
+            *(f32x4*)(Bs + ((BUF) * BN + r0 + i * RPP) * LDK + c4 * 4) = gb[i];                                  \
+    }
+#define FRAGS(FSET, BUF, T)                                                                                      \
+    {                                                                                                            \
+        const float* ap_ = As + (BUF) * BM * LDK + a_off + 8 * (T);                                              \
+        const float* bp_ = Bs + (BUF) * BN * LDK + b_off + 8 * (T);                                              \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[FSET][i] = *(const f32x4*)(ap_ + i * 32 * LDK);        \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[FSET][j] = *(const f32x4*)(bp_ + j * 32 * LDK);        \
+    }
+#define MFMAS(FSET)                                                                                              \
+    {                                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                            \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                           \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                           \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[FSET][i][u], fb[FSET][j][u], acc[i][j], 0, 0, 0); \
+    }
+
+    // prologue: slabs 0 and 1 staged, slab 2 in flight, first fragments of slab 0 in registers
+    GLOAD()
+    LSTORE(0)
+    if (total > 1) {
+        GLOAD()
+        LSTORE(1)
+    }
+    if (total > 2) GLOAD()
+    __syncthreads();
+    FRAGS(0, 0, 0)
+
+    int buf = 0, c_tile = 0, c_kt = 0;
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        // per 32x32 MFMA tile: accumulators -> this wave's LDS patch -> row-major float4 -> epilogue -> dwordx4 stores.
+        // The residual rows of tile q+1 are requested BEFORE the stores of tile q are issued, so the wait for them is
+        // a counted vmcnt(4) and never drains the stores (vmcnt is in-order and counts stores on gfx950).
+        int tm, tn;
+        tile_of(c_tile, tm, tn);
+        const int er = lane >> 3, ec = (lane & 7) * 4;            // float4 #lane of an 8-row stripe
+        const int nb0 = tn * BN + wn * (TN * 32) + ec, mb0 = tm * BM + wm * (TM * 32) + er;
+        f32x4 rs[4];
+        if (Epi::HAS_RES) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) rs[s4] = epi.res4(min(mb0 + s4 * 8, M - 1), nb0);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n0 = nb0 + j * 32;
+            const typename Epi::Col4 cc = epi.col4(n0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = mb0 + i * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ELD + l31] = acc[i][j][r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                f32x4 o[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    o[s4] = epi.apply4(*(const f32x4*)(Es + (s4 * 8 + er) * ELD + ec), cc, rs[s4], mb + s4 * 8, n0);
+                if (Epi::HAS_RES && (j * TM + i + 1 < TM * TN)) {
+                    const int qn = j * TM + i + 1, jn = qn / TM, in = qn % TM;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) rs[s4] = epi.res4(min(mb0 + in * 32 + s4 * 8, M - 1), nb0 + jn * 32);
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    if (mb + s4 * 8 < M) *(f32x4*)(C + (long)(mb + s4 * 8) * ldc + n0) = o[s4];
+            }
+        }
+    };
+    for (int gs = 0; gs < total; ++gs) {
+        const int b1 = buf + 1 >= NS ? buf + 1 - NS : buf + 1;
+        const int b2 = b1 + 1 >= NS ? b1 + 1 - NS : b1 + 1;
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+            if (t + 1 < G) {
+                FRAGS((t + 1) & 1, buf, t + 1)
+            } else if (gs + 1 < total) {
+                FRAGS(0, b1, 0)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            MFMAS(t & 1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == G / 2 - 1) {
+                if (gs + 2 < total) LSTORE(b2)          // slab gs+2 (requested one slab ago) -> the free LDS slab
+                if (gs + 3 < total) GLOAD()             // request slab gs+3 into the registers just freed
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        buf = b1;
+        if (++c_kt == KT) {
+            epilogue();
+            c_kt = 0;
+            ++c_tile;
+        }
+    }
+#undef GLOAD
+#undef LSTORE
+#undef FRAGS
+#undef MFMAS
+}
+
+template <class Cfg, class ALoad, class Epi>
+static hipError_t gemm_f32_persist_launch(const ALoad& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N,
+                                          int K, int num_cu, hipStream_t stream) {
+    if (M <= 0) return hipSuccess;
+    if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0) return hipErrorInvalidValue;
+    auto kern = gemm_f32_persist_kernel<Cfg, ALoad, Epi>;
+    constexpr int LDS = Cfg::LDS_BYTES + (Cfg::THREADS / 64) * 32 * 36 * 4;
+    static_assert(LDS <= 160 * 1024, "LDS budget (3 slabs + per-wave transpose patches)");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
+    const int ntiles = tiles_m * tiles_n;
+    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), LDS, stream, al, W, epi, C, ldc, M, N, K, tiles_m, tiles_n);
     return hipGetLastError();
 }
 

@@ -40,7 +40,7 @@ def test_linear_identity_asymmetric():
     assert torch.equal(y, w.T.contiguous())
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12])
 def test_linear_tiles_agree(tile):
     from egotap_amd import lib
     M, N, K = 700, 512, 160
@@ -116,3 +116,15 @@ def test_attention_rescale_branch():
     s = q @ k.transpose(-1, -2) / math.sqrt(128.0)
     ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(N, D)
     _close(lib.attention(qkv.cuda(), B, N, heads), ref, 3e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 16), (300, 512, 48), (1153, 768, 1024), (5000, 256, 32), (2304, 1024, 64)])
+def test_linear_persistent_tile_many_shapes(M, N, K):
+    """persistent 256x256 kernel: tiles < CUs, ragged M, short K (fewer slabs than pipeline stages), many tiles per block"""
+    from egotap_amd import lib
+    x, w, b = _rand((M, K), 61), _rand((N, K), 62, -0.1, 0.1), _rand((N,), 63)
+    ref = x.double() @ w.double().T + b.double()
+    y = lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=12)
+    _close(y, ref, atol=2e-6 * math.sqrt(K) + 1e-6)
+    y1 = lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=8)
+    assert torch.equal(y, y1)            # same k order as the 128x128 pipelined kernel: bit-identical
