@@ -12,7 +12,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
-LIB = os.path.join(PKG, "libegotap_hip.so")
+LIB = os.environ.get("EGOTAP_LIB") or os.path.join(PKG, "libegotap_hip.so")   # EGOTAP_LIB: experiment builds
 SOURCES = ["egotap_abi.hip"]
 
 

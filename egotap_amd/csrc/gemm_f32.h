@@ -504,7 +504,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_persist_kern
     float* Es = smem + NS * (BM + BN) * LDK + wid * 32 * ELD;      // this wave's 32 x 32 transpose patch
     const int wm = wid / Cfg::WN, wn = wid % Cfg::WN;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int c4 = tid % (BK / 4), r0 = tid / (BK / 4);
+    // staging assignment: the 64 lanes of a wave cover (64 / CH) rows x CH float4 chunks with the ROW on the low lane
+    // bits, so the 8-lane groups of a ds_write_b128 hit 8 different rows (stride LDK = 20 floats: 8 distinct bank
+    // quads) -- chunk-on-low-bits was a 2-way conflict on every staging write (SQ_LDS_BANK_CONFLICT): +2-3 % TFLOP/s.
+    constexpr int CH = BK / 4, RW = 64 / CH;
+    const int c4 = lane / RW, r0 = wid * RW + lane % RW;
 
     // tiles of this block
     const int ntiles = tiles_m * tiles_n, nb = gridDim.x, x8 = blockIdx.x & 7, jb = blockIdx.x >> 3;
@@ -620,18 +624,16 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_persist_kern
                 for (int r = 0; r < 16; ++r) Es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ELD + l31] = acc[i][j][r];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-                f32x4 o[4];
+                const bool more = Epi::HAS_RES && (j * TM + i + 1 < TM * TN);
+                const int qn = j * TM + i + 1, jn = qn / TM, in = qn % TM;
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-                    o[s4] = epi.apply4(*(const f32x4*)(Es + (s4 * 8 + er) * ELD + ec), cc, rs[s4], mb + s4 * 8, n0);
-                if (Epi::HAS_RES && (j * TM + i + 1 < TM * TN)) {
-                    const int qn = j * TM + i + 1, jn = qn / TM, in = qn % TM;
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) rs[s4] = epi.res4(min(mb0 + in * 32 + s4 * 8, M - 1), nb0 + jn * 32);
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    // one row group at a time (few live registers): result, then the NEXT tile's residual request,
+                    // then the store -- load/store alternate, so the next tile waits with a counted vmcnt(7)
+                    const f32x4 o = epi.apply4(*(const f32x4*)(Es + (s4 * 8 + er) * ELD + ec), cc, rs[s4], mb + s4 * 8, n0);
+                    if (more) rs[s4] = epi.res4(min(mb0 + in * 32 + s4 * 8, M - 1), nb0 + jn * 32);
+                    if (mb + s4 * 8 < M) *(f32x4*)(C + (long)(mb + s4 * 8) * ldc + n0) = o;
                 }
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-                    if (mb + s4 * 8 < M) *(f32x4*)(C + (long)(mb + s4 * 8) * ldc + n0) = o[s4];
             }
         }
     };
@@ -645,13 +647,16 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_persist_kern
             } else if (gs + 1 < total) {
                 FRAGS(0, b1, 0)
             }
-            __builtin_amdgcn_sched_barrier(0);
+#ifndef EGOTAP_SB_VARIANT
+#define EGOTAP_SB_VARIANT 0
+#endif
+            if (EGOTAP_SB_VARIANT != 2) __builtin_amdgcn_sched_barrier(0);
             MFMAS(t & 1)
-            __builtin_amdgcn_sched_barrier(0);
+            if (EGOTAP_SB_VARIANT == 0) __builtin_amdgcn_sched_barrier(0);
             if (t == G / 2 - 1) {
                 if (gs + 2 < total) LSTORE(b2)          // slab gs+2 (requested one slab ago) -> the free LDS slab
                 if (gs + 3 < total) GLOAD()             // request slab gs+3 into the registers just freed
-                __builtin_amdgcn_sched_barrier(0);
+                if (EGOTAP_SB_VARIANT == 0) __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
