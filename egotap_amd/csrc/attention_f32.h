@@ -25,7 +25,7 @@ struct AttnCfg {
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* __restrict__ QKV,
                                                                  float* __restrict__ CTX, int N, int heads,
-                                                                 int qgroups, float scale_log2e) {
+                                                                 int qgroups, float scale_log2e, float* __restrict__ LSE) {
     using Cfg = AttnCfg<NW>;
     constexpr int DH = Cfg::DH, KT = Cfg::KT, KLD = Cfg::KLD, THREADS = Cfg::THREADS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -135,7 +135,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
     }
     __syncthreads();   // K/V tiles are dead: reuse the LDS to turn O^T into row-major rows
     if (valid) {
-        const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        // training: log-sum-exp of the scaled scores (natural log) per query row, for the flash-style backward
+        if (LSE != nullptr && lh == 0) LSE[((long)b * heads + h) * N + qb * 32 + l31] = m_run * (scale_log2e * 0.6931471805599453f) + logf(l_tot);
         float* Os = smem + wid * 32 * KLD;     // [32 q][132]
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
@@ -157,7 +160,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
     }
 }
 
-static hipError_t attention_f32_launch(const float* QKV, float* CTX, int B, int N, int heads, hipStream_t stream) {
+static hipError_t attention_f32_launch(const float* QKV, float* CTX, int B, int N, int heads, hipStream_t stream,
+                                       float* LSE = nullptr) {
     constexpr int NW = 2;
     using Cfg = AttnCfg<NW>;
     if (B <= 0) return hipSuccess;
@@ -166,6 +170,6 @@ static hipError_t attention_f32_launch(const float* QKV, float* CTX, int B, int 
     const int qgroups = (N / 32 + NW - 1) / NW;
     const float scale_log2e = 1.4426950408889634f / sqrtf(128.0f);
     hipLaunchKernelGGL(kern, dim3(B * heads * qgroups), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, QKV, CTX, N, heads,
-                       qgroups, scale_log2e);
+                       qgroups, scale_log2e, LSE);
     return hipGetLastError();
 }

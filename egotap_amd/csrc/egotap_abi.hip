@@ -553,7 +553,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     for (int t = 0; t < J; ++t) {
         const float* hprev = t == 0 ? ZERO : HS0 + (size_t)(t - 1) * B * H;
         hipLaunchKernelGGL(pu_step_kernel, pgrid, dim3(256), 0, s, F0 + (size_t)t * B * NF0, NF0, G0 + (size_t)t * B * 4 * H,
-                           p.h2h0_w, p.h2h0_b, hprev, C0, HS0 + (size_t)t * B * H, B, H);
+                           p.h2h0_w, p.h2h0_b, hprev, C0, C0, HS0 + (size_t)t * B * H, nullptr, B, H);
     }
     EGO_HIP(hipGetLastError());
     EGO_HIP((gemm<Tile>(h, "pu1_x2f", ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
@@ -561,7 +561,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     for (int t = 0; t < J; ++t) {
         const float* hprev = t == 0 ? ZERO : HS1 + (size_t)(t - 1) * B * H;
         hipLaunchKernelGGL(pu_step_kernel, pgrid, dim3(256), 0, s, F1 + (size_t)t * B * H, H, G1 + (size_t)t * B * 4 * H,
-                           p.h2h1_w, p.h2h1_b, hprev, C1, HS1 + (size_t)t * B * H, B, H);
+                           p.h2h1_w, p.h2h1_b, hprev, C1, C1, HS1 + (size_t)t * B * H, nullptr, B, H);
     }
     EGO_HIP(hipGetLastError());
     // H15: per-joint pose head (+ global offset and head joint for UnrealEgo)
@@ -865,5 +865,515 @@ extern "C" int egotap_attention_f32(const float* qkv, float* ctx, int B, int N, 
     EGO_CHECK(N > 0 && N % 32 == 0, "egotap_attention_f32: sequence length must be a multiple of 32");
     EGO_CHECK(heads > 0, "egotap_attention_f32: heads must be positive");
     EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, (hipStream_t)stream));
+    return EGOTAP_OK;
+}
+
+// ================================================================================================ training operators
+// Building blocks of the training step (egotap_autoencoder_model.py:299-323), called by the autograd glue in
+// egotap_amd/autograd.py.  Each takes caller-owned device buffers and the caller's stream.
+#include "attention_bwd_f32.h"
+#include "gemm_tn_f32.h"
+#include "train_ops.h"
+
+using TnBig = TnCfg<256, 256, 16, 4, 2>;     // 8 waves, 64x128 per wave
+using TnSmall = TnCfg<128, 128, 16, 2, 2>;   // 4 waves, 64x64 per wave
+
+enum { LD_PLAIN = 0, LD_PATCH = 1, LD_TOKENS = 2, LD_ROT = 3, LD_STEREO = 4, LD_STEREO_GATED = 5 };
+enum { TE_NONE = 0, TE_BIAS = 1, TE_BIAS_RES = 2, TE_BIAS_GELU_SAVE = 3, TE_ACCUM = 4, TE_GELU_GRAD = 5, TE_PATCH = 6 };
+
+template <class AL, class Epi>
+static hipError_t nt_any(const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K, hipStream_t s) {
+    if (N % 256 == 0 && K % 16 == 0 && M >= 1024) return gemm_f32_persist_launch<PipeD, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
+    if (N % 128 == 0 && K % 32 == 0) return gemm_f32_launch<TileA, AL, Epi>(al, W, epi, C, ldc, M, N, K, s);
+    return hipErrorInvalidValue;
+}
+
+template <class AL>
+static hipError_t nt_epi(const AL& al, const float* w, const float* b, float* y, int M, int N, int K, int epi, const float* r,
+                         float* z, const LiftParams* lp, Handle* h, hipStream_t s) {
+    const SegMat W = segmat1(w, N, K);
+    switch (epi) {
+        case TE_NONE: return nt_any(al, W, EpiNone{}, y, N, M, N, K, s);
+        case TE_BIAS: return nt_any(al, W, EpiBias{segvec1(b, N)}, y, N, M, N, K, s);
+        case TE_BIAS_RES: return nt_any(al, W, EpiBiasRes{segvec1(b, N), r, N}, y, N, M, N, K, s);
+        case TE_BIAS_GELU_SAVE: return nt_any(al, W, EpiBiasGeluSave{segvec1(b, N), z, N}, y, N, M, N, K, s);
+        case TE_ACCUM: return nt_any(al, W, EpiAccum{r, N}, y, N, M, N, K, s);
+        case TE_GELU_GRAD: return nt_any(al, W, EpiGeluGrad{r, N}, y, N, M, N, K, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// y[M,N] = epi(A(x) W^T (+ b)); `loader` gathers A from x exactly as the eval forward does; aux = gate source (F) for LD_STEREO_GATED.
+// r: residual / accumulate source / saved pre-activation (by epi); z: pre-activation output for TE_BIAS_GELU_SAVE.
+extern "C" int egotap_train_gemm_nt(egotap_handle h, int loader, const float* x, int64_t lda, const float* aux, const float* w, const float* b,
+                                    float* y, int M, int N, int K, int epi, const float* r, float* z, int Bsz, void* stream) {
+    EGO_CHECK(h && x && w && y, "egotap_train_gemm_nt: null argument");
+    if (lda <= 0) lda = K;
+    hipStream_t s = (hipStream_t)stream;
+    const int S = h->cfg.hm_size;
+    hipError_t e;
+    switch (loader) {
+        case LD_PLAIN: e = nt_epi(ALoadPlain{x, (long)lda}, w, b, y, M, N, K, epi, r, z, nullptr, h, s); break;
+        case LD_TOKENS: e = nt_epi(ALoadTokens{x, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, w, b, y, M, N, K, epi, r, z, nullptr, h, s); break;
+        case LD_ROT: e = nt_epi(ALoadRot{x, h->C, h->J, S * S}, w, b, y, M, N, K, epi, r, z, nullptr, h, s); break;
+        case LD_STEREO: e = nt_epi(ALoadStereo{x, Bsz, h->J, h->hid}, w, b, y, M, N, K, epi, r, z, nullptr, h, s); break;
+        case LD_STEREO_GATED:
+            e = nt_epi(ALoadStereoGated{ALoadStereo{x, Bsz, h->J, h->hid}, aux, h->H + 2 * h->hid, h->H}, w, b, y, M, N, K, epi, r, z, nullptr, h, s);
+            break;
+        default: egotap_set_error("egotap_train_gemm_nt: bad loader %d", loader); return EGOTAP_ERR_INVALID;
+    }
+    if (e == hipErrorInvalidValue) { egotap_set_error("egotap_train_gemm_nt: unsupported shape M=%d N=%d K=%d epi=%d", M, N, K, epi); return EGOTAP_ERR_INVALID; }
+    EGO_HIP(e);
+    return EGOTAP_OK;
+}
+
+// patch embedding forward in training (same kernel as eval): hm [B,C,S,S] -> x [B*seq, D]
+extern "C" int egotap_train_patch_fwd(egotap_handle h, const float* hm, int B, const float* w, const float* b, const float* mask_tok,
+                                      const float* pos, float* x, void* stream) {
+    EGO_CHECK(h && hm && w && b && mask_tok && pos && x, "egotap_train_patch_fwd: null argument");
+    const int S = h->cfg.hm_size, D = h->D, M = B * h->seq;
+    ALoadPatch al{hm, h->C, S, h->seq, h->side, h->ppd, h->grid, h->T};
+    EpiPatch ep{b, mask_tok, pos, D, h->seq, h->side, h->ppd, h->grid, h->T};
+    EGO_HIP((gemm_f32_persist_launch<PipeD, ALoadPatch, EpiPatch>(al, segmat1(w, D, 256), ep, x, D, M, D, 256, device_cu_count(), (hipStream_t)stream)));
+    return EGOTAP_OK;
+}
+
+template <class XL>
+static hipError_t tn_any(const float* dy, const XL& xl, float* dw, float* ws, size_t ws_bytes, int M, int N, int K, int acc, hipStream_t s,
+                         long ldy = 0) {
+    if (ldy <= 0) ldy = N;
+    if (N % 256 == 0 && K % 256 == 0) return gemm_tn_f32_launch<TnBig, XL>(dy, ldy, xl, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
+    if (N % 128 == 0 && K % 128 == 0) return gemm_tn_f32_launch<TnSmall, XL>(dy, ldy, xl, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
+    return hipErrorInvalidValue;
+}
+
+// dW[N,K] (+)= dY[M,N]^T A(x)[M,K]   (weight gradient; x goes through the forward's loader)
+extern "C" int egotap_train_gemm_tn(egotap_handle h, int loader, const float* dy, int64_t ldy, const float* x, const float* aux, float* dw, int M,
+                                    int N, int K, int accumulate, int Bsz, void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(h && dy && x && dw && ws, "egotap_train_gemm_tn: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = h->cfg.hm_size;
+    float* w = (float*)ws;
+    hipError_t e;
+    switch (loader) {
+        case LD_PLAIN: e = tn_any(dy, ALoadPlain{x, K}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
+        case LD_PATCH: e = tn_any(dy, ALoadPatch{x, h->C, S, h->seq, h->side, h->ppd, h->grid, h->T}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
+        case LD_TOKENS: e = tn_any(dy, ALoadTokens{x, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
+        case LD_ROT: e = tn_any(dy, ALoadRot{x, h->C, h->J, S * S}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
+        case LD_STEREO: e = tn_any(dy, ALoadStereo{x, Bsz, h->J, h->hid}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
+        case LD_STEREO_GATED:
+            e = tn_any(dy, ALoadStereoGated{ALoadStereo{x, Bsz, h->J, h->hid}, aux, h->H + 2 * h->hid, h->H}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy);
+            break;
+        default: egotap_set_error("egotap_train_gemm_tn: bad loader %d", loader); return EGOTAP_ERR_INVALID;
+    }
+    if (e == hipErrorInvalidValue) { egotap_set_error("egotap_train_gemm_tn: unsupported shape N=%d K=%d", N, K); return EGOTAP_ERR_INVALID; }
+    if (e == hipErrorOutOfMemory) { egotap_set_error("egotap_train_gemm_tn: workspace too small (%zu bytes) for N*K=%ld", ws_bytes, (long)N * K); return EGOTAP_ERR_WORKSPACE; }
+    EGO_HIP(e);
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_train_colsum(const float* y, int64_t ldy, float* out, int M, int N, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(y && out && ws, "egotap_train_colsum: null argument");
+    EGO_CHECK(N % 4 == 0, "egotap_train_colsum: N must be a multiple of 4");
+    EGO_HIP(colsum_f32_launch(y, ldy > 0 ? ldy : N, out, (float*)ws, ws_bytes, M, N, accumulate, (hipStream_t)stream));
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_train_transpose(const float* in, float* out, int R, int C, int64_t ldo, void* stream) {
+    EGO_CHECK(in && out, "egotap_train_transpose: null argument");
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, out, R, C, (long)(ldo > 0 ? ldo : R));
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_train_layernorm_fwd(const float* x, float* y, const float* g, const float* b, float* mean, float* rstd, int rows,
+                                          float eps, void* stream) {
+    EGO_CHECK(x && y && g && b && mean && rstd, "egotap_train_layernorm_fwd: null argument");
+    if (rows > 0) hipLaunchKernelGGL(layernorm_fwd_stats_kernel<1024>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, g, b, mean, rstd, rows, eps);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+// dx = LN'(dy) (+ dres); dgamma / dbeta (+)= column sums.  ws: >= ceil(rows/64) * 2 * 1024 floats
+extern "C" int egotap_train_layernorm_bwd(const float* x, const float* dy, const float* g, const float* mean, const float* rstd,
+                                          const float* dres, float* dx, float* dgamma, float* dbeta, int rows, int accumulate,
+                                          void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(x && dy && g && mean && rstd && dx && dgamma && dbeta && ws, "egotap_train_layernorm_bwd: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int rows_per_wave = 16, blocks = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
+    EGO_CHECK(ws_bytes >= (size_t)blocks * 2 * 1024 * 4, "egotap_train_layernorm_bwd: workspace too small");
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(layernorm_bwd_kernel<1024>, dim3(blocks), dim3(256), 0, s, x, dy, g, mean, rstd, dres, dx, part, rows, rows_per_wave);
+    EGO_HIP(hipGetLastError());
+    // part[block][2][1024] -> treat as 'blocks' slabs of 2048 floats: slab k = (dgamma_k | dbeta_k)
+    // reduce into a temporary pair laid out contiguously is not possible in place, so reduce the two halves separately:
+    // stride trick: slabs are 2048 apart, reduce_slabs_kernel assumes stride n -> run it on n = 2048 into a 2048 buffer at the end of ws
+    float* tmp = part + (size_t)blocks * 2048;
+    EGO_CHECK(ws_bytes >= ((size_t)blocks * 2048 + 2048) * 4, "egotap_train_layernorm_bwd: workspace too small");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(2), dim3(256), 0, s, part, tmp, 2048L, blocks, 0);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, tmp, dgamma, 1024L, 1, accumulate);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, tmp + 1024, dbeta, 1024L, 1, accumulate);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+// BatchNorm1d (training mode) + LeakyReLU(0.2) over z [R, C]: y, saved mean / rstd, running-stat update
+// (network_utils.py:123-142; momentum 0.1, unbiased running variance).  ws >= (2 * ceil(R/256) * C + 2C) floats
+extern "C" int egotap_train_bn_lrelu_fwd(const float* z, float* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                                         float* run_mean, float* run_var, int R, int C, float eps, float momentum, void* ws,
+                                         size_t ws_bytes, void* stream) {
+    EGO_CHECK(z && y && gamma && beta && mean && rstd && ws, "egotap_train_bn_lrelu_fwd: null argument");
+    EGO_CHECK(C % 4 == 0 && R > 1, "egotap_train_bn_lrelu_fwd: C must be a multiple of 4 and R > 1");
+    hipStream_t s = (hipStream_t)stream;
+    const int rpb = 256, gy = (R + rpb - 1) / rpb;
+    EGO_CHECK(ws_bytes >= ((size_t)gy * 2 * C + 2 * C) * 4, "egotap_train_bn_lrelu_fwd: workspace too small");
+    float* part = (float*)ws;
+    float* sums = part + (size_t)gy * 2 * C;
+    const dim3 grid((C / 4 + 63) / 64, gy);
+    hipLaunchKernelGGL(colstats_kernel<0>, grid, dim3(256), 0, s, z, nullptr, nullptr, nullptr, nullptr, part, R, C, rpb, 0.f);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((2 * C / 4 + 255) / 256), dim3(256), 0, s, part, sums, 2L * C, gy, 0);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, mean, C, R, 0, eps, momentum, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(colstats_kernel<0>, grid, dim3(256), 0, s, z, nullptr, nullptr, mean, nullptr, part, R, C, rpb, 0.f);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((2 * C / 4 + 255) / 256), dim3(256), 0, s, part, sums, 2L * C, gy, 0);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums + C, rstd, C, R, 1, eps, momentum, run_mean, run_var, mean);
+    const long n4 = (long)R * C / 4;
+    hipLaunchKernelGGL(bn_apply_lrelu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, z, y, mean, rstd, gamma, beta, n4, C, 0.2f);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_train_bn_lrelu_bwd(const float* z, const float* y, const float* dy, const float* gamma, const float* mean,
+                                         const float* rstd, float* dz, float* dgamma, float* dbeta, int R, int C, int accumulate,
+                                         void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(z && y && dy && gamma && mean && rstd && dz && dgamma && dbeta && ws, "egotap_train_bn_lrelu_bwd: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int rpb = 256, gy = (R + rpb - 1) / rpb;
+    EGO_CHECK(ws_bytes >= ((size_t)gy * 2 * C + 2 * C) * 4, "egotap_train_bn_lrelu_bwd: workspace too small");
+    float* part = (float*)ws;
+    float* sums = part + (size_t)gy * 2 * C;       // [0:C] = sum dyb (dbeta), [C:2C] = sum dyb*xhat (dgamma)
+    const dim3 grid((C / 4 + 63) / 64, gy);
+    hipLaunchKernelGGL(colstats_kernel<1>, grid, dim3(256), 0, s, z, y, dy, mean, rstd, part, R, C, rpb, 0.2f);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((2 * C / 4 + 255) / 256), dim3(256), 0, s, part, sums, 2L * C, gy, 0);
+    const long n4 = (long)R * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, z, y, dy, mean, rstd, gamma, sums, sums + C, dz, n4, C, R, 0.2f);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((C / 4 + 255) / 256), dim3(256), 0, s, sums, dbeta, (long)C, 1, accumulate);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((C / 4 + 255) / 256), dim3(256), 0, s, sums + C, dgamma, (long)C, 1, accumulate);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_train_attention_fwd(const float* qkv, float* ctx, float* lse, int B, int N, int heads, void* stream) {
+    EGO_CHECK(qkv && ctx && lse, "egotap_train_attention_fwd: null argument");
+    EGO_CHECK(N > 0 && N % 32 == 0 && heads > 0, "egotap_train_attention_fwd: bad shape");
+    EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, (hipStream_t)stream, lse));
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_train_attention_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* delta,
+                                          float* dqkv, int B, int N, int heads, void* stream) {
+    EGO_CHECK(qkv && ctx && dctx && lse && delta && dqkv, "egotap_train_attention_bwd: null argument");
+    EGO_CHECK(N > 0 && N % 32 == 0 && heads > 0, "egotap_train_attention_bwd: bad shape");
+    EGO_HIP(attention_bwd_f32_launch(qkv, ctx, dctx, lse, delta, dqkv, B, N, heads, (hipStream_t)stream));
+    return EGOTAP_OK;
+}
+
+// loss_pose, loss_cos_sim -> out[2]; d(loss_pose + loss_cos_sim)/d pred -> dpred.  partial: [B, 2] scratch.
+extern "C" int egotap_train_pose_loss(egotap_handle h, const float* pred, const float* gt, float* dpred, float* out, float* partial,
+                                      int B, float lambda_mpjpe, float lambda_cos_sim, void* stream) {
+    EGO_CHECK(h && pred && gt && dpred && out && partial, "egotap_train_pose_loss: null argument");
+    static const int ue[16] = {0, 0, 1, 1, 2, 3, 4, 5, 2, 3, 8, 9, 10, 11, 12, 13};                 // utils/util.py:51
+    static const int ec[18] = {0, 0, 1, 2, 3, 4, 1, 6, 7, 8, 2, 10, 11, 12, 6, 14, 15, 16};         // utils/util.py:52
+    LossArgs a;
+    a.pred = pred; a.gt = gt; a.dpred = dpred; a.partial = partial;
+    a.B = B; a.J = h->out_joints; a.estimate_head = h->cfg.estimate_head;
+    a.lam_pose = lambda_mpjpe; a.lam_cos = lambda_cos_sim * lambda_mpjpe;
+    const int n = a.estimate_head ? 16 : 18;
+    EGO_CHECK(a.J + (a.estimate_head ? 0 : 1) == n, "egotap_train_pose_loss: joint count does not match the preset's kinematic list");
+    for (int i = 0; i < 20; ++i) a.parents[i] = i < n ? (a.estimate_head ? ue[i] : ec[i]) : 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pose_loss_kernel, dim3(B), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(pose_loss_finish_kernel, dim3(1), dim3(64), 0, s, partial, out, B, a.J, a.lam_pose, a.lam_cos);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_train_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                  float weight_decay, int step, void* stream) {
+    EGO_CHECK(p && g && m && v && step >= 1, "egotap_train_adamw: bad argument");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2s);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_train_add_inplace(float* out, const float* in, int64_t n, void* stream) {
+    EGO_CHECK(out && in && n % 4 == 0, "egotap_train_add_inplace: bad argument");
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, in, (long)(n / 4));
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ PU chain + pose head (training)
+struct PuSaved { size_t F0, G0, HS0, C0, F1, G1, HS1, C1, ZERO, total; };
+static PuSaved pu_saved(const Handle* h, int B) {
+    PuSaved w;
+    const size_t JB = (size_t)h->J * B, H = h->H, NF0 = H + 2 * h->hid;
+    size_t o = 0;
+    auto take = [&](size_t floats) { size_t r = o; o = al256(o + floats * 4); return r; };
+    w.F0 = take(JB * NF0); w.G0 = take(JB * 4 * H); w.HS0 = take(JB * H); w.C0 = take(JB * H);
+    w.F1 = take(JB * H); w.G1 = take(JB * 4 * H); w.HS1 = take(JB * H); w.C1 = take(JB * H);
+    w.ZERO = take((size_t)B * H);
+    w.total = o;
+    return w;
+}
+extern "C" int egotap_train_pu_saved_bytes(egotap_handle h, int B, size_t* bytes, size_t* hs1_offset) {
+    EGO_CHECK(h && bytes && hs1_offset, "null argument");
+    const PuSaved w = pu_saved(h, B > 0 ? B : 1);
+    *bytes = w.total;
+    *hs1_offset = w.HS1;
+    return EGOTAP_OK;
+}
+
+// SkelNet(mode "PU") forward keeping what the backward needs: posz, rotz [B*2J, hid] -> saved[HS1] = skel_embed [J, B, H]
+extern "C" int egotap_train_pu_fwd(egotap_handle h, const float* posz, const float* rotz, int B, void* saved, size_t saved_bytes,
+                                   void* stream) {
+    EGO_CHECK(h && posz && rotz && saved, "egotap_train_pu_fwd: null argument");
+    int rc = lift_resolve(h);
+    if (rc != EGOTAP_OK) return rc;
+    const PuSaved w = pu_saved(h, B);
+    EGO_CHECK(saved_bytes >= w.total, "egotap_train_pu_fwd: saved buffer too small");
+    hipStream_t s = (hipStream_t)stream;
+    const LiftParams& p = h->lp;
+    char* base = (char*)saved;
+    auto F = [&](size_t off) { return (float*)(base + off); };
+    float *F0 = F(w.F0), *G0 = F(w.G0), *HS0 = F(w.HS0), *C0 = F(w.C0), *F1 = F(w.F1), *G1 = F(w.G1), *HS1 = F(w.HS1), *C1 = F(w.C1), *ZERO = F(w.ZERO);
+    const int J = h->J, H = h->H, hid = h->hid, JB = J * B, x = 2 * hid, NF0 = H + x;
+    using Tile = TileA;
+    ALoadStereo xs{posz, B, J, hid};
+    EGO_HIP((gemm<Tile>(h, "pu0_x2f", xs, segmat1(p.x2f0_w, NF0, x), EpiBias{segvec1(p.x2f0_b, NF0)}, F0, NF0, JB, NF0, x, s)));
+    EGO_HIP((gemm<Tile>(h, "pu0_x2h", xs, segmat1(p.x2h0_w, 4 * H, x), EpiBias{segvec1(p.x2h0_b, 4 * H)}, G0, 4L * H, JB, 4 * H, x, s)));
+    {
+        ALoadStereoGated bs{ALoadStereo{rotz, B, J, hid}, F0, NF0, H};
+        EGO_HIP((gemm<Tile>(h, "pu0_b2h", bs, segmat1(p.b2h0_w, 4 * H, x), EpiBiasRes{segvec1(p.b2h0_b, 4 * H), G0, 4L * H}, G0, 4L * H, JB, 4 * H, x, s)));
+    }
+    EGO_HIP(hipMemsetAsync(ZERO, 0, (size_t)B * H * 4, s));
+    const dim3 pgrid((B + 31) / 32, H / 32);
+    for (int t = 0; t < J; ++t) {       // G0 holds Gin on entry and the full gate pre-activations on exit (in place)
+        const float* hprev = t == 0 ? ZERO : HS0 + (size_t)(t - 1) * B * H;
+        const float* cprev = t == 0 ? ZERO : C0 + (size_t)(t - 1) * B * H;
+        float* g = G0 + (size_t)t * B * 4 * H;
+        hipLaunchKernelGGL(pu_step_kernel, pgrid, dim3(256), 0, s, F0 + (size_t)t * B * NF0, NF0, g, p.h2h0_w, p.h2h0_b, hprev, cprev,
+                           C0 + (size_t)t * B * H, HS0 + (size_t)t * B * H, g, B, H);
+    }
+    EGO_HIP(hipGetLastError());
+    EGO_HIP((gemm<Tile>(h, "pu1_x2f", ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
+    EGO_HIP((gemm<Tile>(h, "pu1_x2h", ALoadPlain{HS0, H}, segmat1(p.x2h1_w, 4 * H, H), EpiBias{segvec1(p.x2h1_b, 4 * H)}, G1, 4L * H, JB, 4 * H, H, s)));
+    for (int t = 0; t < J; ++t) {
+        const float* hprev = t == 0 ? ZERO : HS1 + (size_t)(t - 1) * B * H;
+        const float* cprev = t == 0 ? ZERO : C1 + (size_t)(t - 1) * B * H;
+        float* g = G1 + (size_t)t * B * 4 * H;
+        hipLaunchKernelGGL(pu_step_kernel, pgrid, dim3(256), 0, s, F1 + (size_t)t * B * H, H, g, p.h2h1_w, p.h2h1_b, hprev, cprev,
+                           C1 + (size_t)t * B * H, HS1 + (size_t)t * B * H, g, B, H);
+    }
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+struct PuBwdWs { size_t dG, dF, HP, dHS0, dXs, dBp, DHP, dHrec[2], dC[2], WT, part, total; };
+static PuBwdWs pu_bwd_ws(const Handle* h, int B) {
+    PuBwdWs w;
+    const size_t JB = (size_t)h->J * B, H = h->H, x = 2 * h->hid, NF0 = H + x, BH = (size_t)B * H;
+    size_t o = 0;
+    auto take = [&](size_t floats) { size_t r = o; o = al256(o + floats * 4); return r; };
+    w.dG = take(JB * 4 * H); w.dF = take(JB * NF0); w.HP = take(JB * H); w.dHS0 = take(JB * H); w.dXs = take(JB * x); w.dBp = take(JB * x);
+    w.DHP = take(BH); w.dHrec[0] = take(BH); w.dHrec[1] = take(BH); w.dC[0] = take(BH); w.dC[1] = take(BH);
+    w.WT = take(4 * H * H);                       // largest transposed weight: [H, 4H]
+    w.part = take(4 * H * NF0 * 8 + 64 * 4 * H);  // split-M slabs of the weight-gradient GEMMs + column-sum partials
+    w.total = o;
+    return w;
+}
+extern "C" int egotap_train_pu_bwd_ws_bytes(egotap_handle h, int B, size_t* bytes) {
+    EGO_CHECK(h && bytes, "null argument");
+    *bytes = pu_bwd_ws(h, B > 0 ? B : 1).total;
+    return EGOTAP_OK;
+}
+
+// Backward of egotap_train_pu_fwd.  dhs1: gradient w.r.t. skel_embed [J,B,H]; dposz is ACCUMULATED into (the pose head's
+// contribution is already there), drotz is written; grads[14] (state_dict order of skel_sequential_layer) are accumulated
+// when accumulate != 0, else overwritten.
+extern "C" int egotap_train_pu_bwd(egotap_handle h, const float* posz, const float* rotz, int B, const void* saved,
+                                   const float* dhs1, float* dposz, float* drotz, float* const* grads, int accumulate, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    EGO_CHECK(h && posz && rotz && saved && dhs1 && dposz && drotz && grads && ws, "egotap_train_pu_bwd: null argument");
+    int rc = lift_resolve(h);
+    if (rc != EGOTAP_OK) return rc;
+    const PuSaved sv = pu_saved(h, B);
+    const PuBwdWs w = pu_bwd_ws(h, B);
+    EGO_CHECK(ws_bytes >= w.total, "egotap_train_pu_bwd: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    const LiftParams& p = h->lp;
+    const char* sb = (const char*)saved;
+    auto SF = [&](size_t off) { return (const float*)(sb + off); };
+    char* wb = (char*)ws;
+    auto WF = [&](size_t off) { return (float*)(wb + off); };
+    const float *F0 = SF(sv.F0), *G0 = SF(sv.G0), *HS0 = SF(sv.HS0), *C0 = SF(sv.C0), *F1 = SF(sv.F1), *G1 = SF(sv.G1), *HS1 = SF(sv.HS1),
+                *C1 = SF(sv.C1), *ZERO = SF(sv.ZERO);
+    float *dG = WF(w.dG), *dF = WF(w.dF), *HP = WF(w.HP), *dHS0 = WF(w.dHS0), *dXs = WF(w.dXs), *dBp = WF(w.dBp), *DHP = WF(w.DHP), *WT = WF(w.WT),
+          *part = WF(w.part);
+    float* dHrec[2] = {WF(w.dHrec[0]), WF(w.dHrec[1])};
+    float* dC[2] = {WF(w.dC[0]), WF(w.dC[1])};
+    const size_t part_bytes = w.total - w.part;
+    const int J = h->J, H = h->H, hid = h->hid, JB = J * B, x = 2 * hid, NF0 = H + x;
+    const size_t BH = (size_t)B * H;
+    const int pw_blocks = (int)((BH + 255) / 256);
+    enum { X2F0_W, X2F0_B, X2H0_W, X2H0_B, B2H0_W, B2H0_B, H2H0_W, H2H0_B, X2F1_W, X2F1_B, X2H1_W, X2H1_B, H2H1_W, H2H1_B };
+    auto transpose = [&](const float* in, int R, int C) {
+        hipLaunchKernelGGL(transpose_f32_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, in, WT, R, C, (long)R);
+    };
+    auto nt = [&](const float* a, int M, int N, int K, float* y, const float* acc_src) -> hipError_t {   // y[M,N] = a[M,K] WT[N,K]^T (+ acc)
+        if (acc_src) return gemm_f32_launch<TileA>(ALoadPlain{a, K}, segmat1(WT, N, K), EpiAccum{acc_src, N}, y, N, M, N, K, s);
+        return gemm_f32_launch<TileA>(ALoadPlain{a, K}, segmat1(WT, N, K), EpiNone{}, y, N, M, N, K, s);
+    };
+    auto recurrence = [&](const float* Gpre, const float* Cs, const float* Hs, const float* Fs, int ldf, const float* Whh, const float* dh_ext) -> int {
+        transpose(Whh, 4 * H, H);                  // WT = Whh^T viewed as [H out][4H contract]
+        for (int t = J - 1; t >= 0; --t) {
+            const int cur = t & 1, nxt = cur ^ 1;
+            const float* cprev = t > 0 ? Cs + (size_t)(t - 1) * BH : ZERO;
+            const float* hprev = t > 0 ? Hs + (size_t)(t - 1) * BH : ZERO;
+            hipLaunchKernelGGL(pu_gates_bwd_kernel, dim3(pw_blocks), dim3(256), 0, s, Gpre + (size_t)t * B * 4 * H, cprev, Cs + (size_t)t * BH,
+                               dh_ext + (size_t)t * BH, t == J - 1 ? nullptr : dHrec[cur], t == J - 1 ? nullptr : dC[cur],
+                               dG + (size_t)t * B * 4 * H, dC[nxt], B, H);
+            EGO_HIP(nt(dG + (size_t)t * B * 4 * H, B, H, 4 * H, DHP, nullptr));
+            hipLaunchKernelGGL(pu_hp_bwd_kernel, dim3(pw_blocks), dim3(256), 0, s, DHP, Fs + (size_t)t * B * ldf, ldf, hprev, dHrec[nxt],
+                               dF + (size_t)t * B * ldf, ldf, HP + (size_t)t * BH, B, H);
+        }
+        EGO_HIP(hipGetLastError());
+        return EGOTAP_OK;
+    };
+    auto wgrad = [&](const float* dy, int N, int loader_plain_K, const float* xin, float* dwp) -> hipError_t {   // plain X [JB, K]
+        return tn_any(dy, ALoadPlain{xin, loader_plain_K}, dwp, part, part_bytes, JB, N, loader_plain_K, accumulate, s);
+    };
+    auto bias = [&](const float* dy, int N, float* dbp) -> hipError_t { return colsum_f32_launch(dy, N, dbp, part, part_bytes, JB, N, accumulate, s); };
+
+    // ---- layer 1
+    rc = recurrence(G1, C1, HS1, F1, H, p.h2h1_w, dhs1);
+    if (rc != EGOTAP_OK) return rc;
+    EGO_HIP(wgrad(dG, 4 * H, H, HP, grads[H2H1_W]));
+    EGO_HIP(bias(dG, 4 * H, grads[H2H1_B]));
+    EGO_HIP(wgrad(dG, 4 * H, H, HS0, grads[X2H1_W]));
+    EGO_HIP(bias(dG, 4 * H, grads[X2H1_B]));
+    EGO_HIP(wgrad(dF, H, H, HS0, grads[X2F1_W]));
+    EGO_HIP(bias(dF, H, grads[X2F1_B]));
+    transpose(p.x2h1_w, 4 * H, H);
+    EGO_HIP(nt(dG, JB, H, 4 * H, dHS0, nullptr));
+    transpose(p.x2f1_w, H, H);
+    EGO_HIP(nt(dF, JB, H, H, dHS0, dHS0));
+    // ---- layer 0 (its outputs only feed layer 1)
+    rc = recurrence(G0, C0, HS0, F0, NF0, p.h2h0_w, dHS0);
+    if (rc != EGOTAP_OK) return rc;
+    EGO_HIP(wgrad(dG, 4 * H, H, HP, grads[H2H0_W]));
+    EGO_HIP(bias(dG, 4 * H, grads[H2H0_B]));
+    // bridge branch: gates += b2h(sigmoid(fb) * bridge)
+    EGO_HIP(tn_any(dG, ALoadStereoGated{ALoadStereo{rotz, B, J, hid}, F0, NF0, H}, grads[B2H0_W], part, part_bytes, JB, 4 * H, x, accumulate, s));
+    EGO_HIP(bias(dG, 4 * H, grads[B2H0_B]));
+    transpose(p.b2h0_w, 4 * H, x);
+    EGO_HIP(nt(dG, JB, x, 4 * H, dBp, nullptr));
+    {
+        const long n = (long)JB * x;
+        hipLaunchKernelGGL(pu_bridge_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dBp, F0, NF0, H, rotz, dF, drotz, B, J, hid);
+    }
+    // input branch: gates += x2h(x), F = x2f(x)
+    EGO_HIP(tn_any(dG, ALoadStereo{posz, B, J, hid}, grads[X2H0_W], part, part_bytes, JB, 4 * H, x, accumulate, s));
+    EGO_HIP(bias(dG, 4 * H, grads[X2H0_B]));
+    EGO_HIP(tn_any(dF, ALoadStereo{posz, B, J, hid}, grads[X2F0_W], part, part_bytes, JB, NF0, x, accumulate, s));
+    EGO_HIP(bias(dF, NF0, grads[X2F0_B]));
+    transpose(p.x2h0_w, 4 * H, x);
+    EGO_HIP(nt(dG, JB, x, 4 * H, dXs, nullptr));
+    transpose(p.x2f0_w, NF0, x);
+    EGO_HIP(nt(dF, JB, x, NF0, dXs, dXs));
+    {
+        const long n = (long)JB * x;
+        hipLaunchKernelGGL(stereo_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dXs, dposz, B, J, hid, 1);
+    }
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+// pose head (training): forward = the eval kernel; backward: data gradients + weight gradients
+extern "C" int egotap_train_pose_head_fwd(egotap_handle h, const float* posz, const float* hs1, int B, float* pose, void* stream) {
+    EGO_CHECK(h && posz && hs1 && pose, "egotap_train_pose_head_fwd: null argument");
+    int rc = lift_resolve(h);
+    if (rc != EGOTAP_OK) return rc;
+    const LiftParams& p = h->lp;
+    hipLaunchKernelGGL(pose_head_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, posz, hs1, p.pose_w, p.pose_b, p.glob_w, p.glob_b, pose, B,
+                       h->J, h->hid, h->H, h->cfg.estimate_head);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+extern "C" int egotap_train_pose_head_bwd(egotap_handle h, const float* posz, const float* hs1, const float* dpose, int B, float* dposz,
+                                          float* dhs1, float* dWp, float* dbp, float* dWg, float* dbg, int accumulate, void* stream) {
+    EGO_CHECK(h && posz && hs1 && dpose && dposz && dhs1 && dWp && dbp, "egotap_train_pose_head_bwd: null argument");
+    int rc = lift_resolve(h);
+    if (rc != EGOTAP_OK) return rc;
+    const LiftParams& p = h->lp;
+    hipStream_t s = (hipStream_t)stream;
+    const int J = h->J, hid = h->hid, H = h->H, eh = h->cfg.estimate_head;
+    EGO_CHECK(!eh || (dWg && dbg), "egotap_train_pose_head_bwd: global_mlp gradient buffers missing");
+    hipLaunchKernelGGL(pose_head_bwd_data_kernel, dim3(B), dim3(256), 0, s, dpose, p.pose_w, p.glob_w, dposz, dhs1, B, J, hid, H, eh);
+    const int cols = 2 * hid + H + (eh ? J * H : 0) + 1;
+    hipLaunchKernelGGL(pose_head_bwd_weight_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, dpose, posz, hs1, dWp, dbp, dWg, dbg, B, J, hid,
+                       H, eh, accumulate);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+
+// patch-embedding bias / mask-token gradients from dpos[seq, D] = sum_b dx[b]: rows of real cells -> dbias, dummy cells -> dmask
+__global__ __launch_bounds__(256) void patch_split_kernel(const float* __restrict__ dpos, float* __restrict__ dbias, float* __restrict__ dmask,
+                                                          int D, int seq, int side, int ppd, int grid, int T, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= D) return;
+    float sb = 0.f, sm = 0.f;
+    for (int tok = 0; tok < seq; ++tok) {
+        const int pr = tok / side, pc = tok - pr * side;
+        const float v = dpos[(long)tok * D + n];
+        if ((pr / ppd) * grid + pc / ppd >= T) sm += v; else sb += v;
+    }
+    dbias[n] = (accumulate ? dbias[n] : 0.f) + sb;
+    dmask[n] = (accumulate ? dmask[n] : 0.f) + sm;
+}
+extern "C" int egotap_train_patch_split(egotap_handle h, const float* dpos, float* dbias, float* dmask, int accumulate, void* stream) {
+    EGO_CHECK(h && dpos && dbias && dmask, "egotap_train_patch_split: null argument");
+    hipLaunchKernelGGL(patch_split_kernel, dim3((h->D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dpos, dbias, dmask, h->D, h->seq,
+                       h->side, h->ppd, h->grid, h->T, accumulate);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+// input gradient of fc1 (position encoder): dA [B*T, ppd*ppd*D] (heatmap-major) -> dtokens [B*seq, D]; dummy tokens get zero
+__global__ __launch_bounds__(256) void tokens_scatter_kernel(const float* __restrict__ dA, float* __restrict__ dtok, int B, int T, int D,
+                                                             int seq, int side, int ppd, int grid) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index over [B*seq, D/4]
+    const int D4 = D / 4;
+    if (i >= (long)B * seq * D4) return;
+    const int c4 = (int)(i % D4);
+    const long bt = i / D4;
+    const int tok = (int)(bt % seq), b = (int)(bt / seq);
+    const int pr = tok / side, pc = tok - pr * side;
+    const int cell = (pr / ppd) * grid + pc / ppd;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (cell < T) {
+        const int sseg = (pr % ppd) * ppd + (pc % ppd);
+        v = *(const f32x4*)(dA + ((long)b * T + cell) * (long)(ppd * ppd) * D + (long)sseg * D + c4 * 4);
+    }
+    *(f32x4*)(dtok + bt * D + c4 * 4) = v;
+}
+extern "C" int egotap_train_tokens_scatter(egotap_handle h, const float* dA, float* dtok, int B, void* stream) {
+    EGO_CHECK(h && dA && dtok, "egotap_train_tokens_scatter: null argument");
+    const long n = (long)B * h->seq * (h->D / 4);
+    hipLaunchKernelGGL(tokens_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dA, dtok, B, h->T, h->D, h->seq,
+                       h->side, h->ppd, h->grid);
+    EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }

@@ -209,6 +209,74 @@ struct EpiPatch {         // (dummy ? mask_token : acc + bias) + position_embedd
     }
 };
 
+// ---- epilogues used by the training step -------------------------------------------------------------------
+struct EpiNone {          // C = acc (input-gradient GEMMs)
+    struct Col {};
+    __device__ __forceinline__ Col col(int n) const { return Col{}; }
+    __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const { return acc; }
+    struct Col4 {};
+    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{}; }
+    static constexpr bool HAS_RES = false;
+    __device__ __forceinline__ f32x4 res4(int m, int n0) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ f32x4 apply4(f32x4 acc, const Col4& c, f32x4 res, int m, int n0) const { return acc; }
+};
+struct EpiAccum {         // C = acc + R[m, n]  (R may alias C): gradient accumulation of a second branch
+    const float* R;
+    long ldr;
+    struct Col {};
+    __device__ __forceinline__ Col col(int n) const { return Col{}; }
+    __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const { return acc + R[(long)m * ldr + n]; }
+    struct Col4 {};
+    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{}; }
+    static constexpr bool HAS_RES = true;
+    __device__ __forceinline__ f32x4 res4(int m, int n0) const { return *(const f32x4*)(R + (long)m * ldr + n0); }
+    __device__ __forceinline__ f32x4 apply4(f32x4 acc, const Col4& c, f32x4 res, int m, int n0) const { return acc + res; }
+};
+struct EpiBiasGeluSave {  // z = acc + bias is stored to Z (kept for the backward), C = GELU(z)
+    SegVec bias;
+    float* Z;
+    long ldz;
+    struct Col { float b; };
+    __device__ __forceinline__ Col col(int n) const { return Col{bias.at(n)}; }
+    __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const {
+        const float x = acc + c.b;
+        Z[(long)m * ldz + n] = x;
+        return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    }
+    struct Col4 { f32x4 b; };
+    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{f32x4{bias.at(n0), bias.at(n0 + 1), bias.at(n0 + 2), bias.at(n0 + 3)}}; }
+    static constexpr bool HAS_RES = false;
+    __device__ __forceinline__ f32x4 res4(int m, int n0) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ f32x4 apply4(f32x4 acc, const Col4& c, f32x4 res, int m, int n0) const {
+        const f32x4 x = acc + c.b;
+        *(f32x4*)(Z + (long)m * ldz + n0) = x;
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = 0.5f * x[i] * (1.0f + erff(x[i] * 0.70710678118654752440f));
+        return o;
+    }
+};
+struct EpiGeluGrad {      // C = acc * gelu'(Z[m, n])   (input gradient of the MLP-down layer, fused with GELU backward)
+    const float* Z;
+    long ldz;
+    __device__ __forceinline__ static float dgelu(float z) {
+        return 0.5f * (1.0f + erff(z * 0.70710678118654752440f)) + z * expf(-0.5f * z * z) * 0.39894228040143267794f;
+    }
+    struct Col {};
+    __device__ __forceinline__ Col col(int n) const { return Col{}; }
+    __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const { return acc * dgelu(Z[(long)m * ldz + n]); }
+    struct Col4 {};
+    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{}; }
+    static constexpr bool HAS_RES = true;      // Z rows are fetched like a residual
+    __device__ __forceinline__ f32x4 res4(int m, int n0) const { return *(const f32x4*)(Z + (long)m * ldz + n0); }
+    __device__ __forceinline__ f32x4 apply4(f32x4 acc, const Col4& c, f32x4 res, int m, int n0) const {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = acc[i] * dgelu(res[i]);
+        return o;
+    }
+};
+
 // ----------------------------------------------------------------------------- kernel
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_>
 struct GemmCfg {

@@ -1,0 +1,220 @@
+// Weight-gradient GEMM ("TN"): dW[N,K] = sum_m dY[m,n] * X[m,k]  -- the backward of y = x W^T + b w.r.t. W
+// (autograd of nn.Linear / the patch-embedding conv; training step of egotap_autoencoder_model.py:299-323).
+//
+// Both operands are row-major with the CONTRACTED index m as the row, so a slab of BKM rows of dY and of X is staged
+// exactly as it lies in memory (coalesced float4 rows, no transposes of the big activations) and the MFMA fragments
+// are ds_read_b32 with the output row/column on the lane: A[i = n][k = m] = dY[m][n0 + lane], B[k = m][j] = X[m][k0 + lane].
+// X goes through the same loader functors as the forward GEMM, so the gathers (ViT patch tiling, per-heatmap token
+// regroup, stereo cos/sin interleave) cost nothing in the backward either.
+// M is huge (147 k tokens at B = 256) and N x K small, so the M range is SPLIT over blocks: grid = tiles x splits,
+// each block writes a partial [N,K] slab; reduce_slabs_kernel sums the slabs in a fixed order (bitwise reproducible,
+// no float atomics) and optionally accumulates into the existing gradient.
+#pragma once
+#include "common.h"
+#include "gemm_f32.h"
+
+template <int BN_, int BK_, int BKM_, int WN_, int WK_>
+struct TnCfg {
+    static constexpr int BN = BN_, BK = BK_, BKM = BKM_, WN = WN_, WK = WK_;
+    static constexpr int THREADS = 64 * WN * WK;
+    static constexpr int LDA = BN + 4, LDB = BK + 4;          // padded rows (floats): the two lane halves read rows m, m+1
+    static constexpr int TN = BN / WN / 32, TK = BK / WK / 32;
+    static constexpr int A_V4 = BKM * BN / 4 / THREADS, B_V4 = BKM * BK / 4 / THREADS;
+    static constexpr int LDS_BYTES = 2 * BKM * (LDA + LDB) * 4;
+    static_assert(BKM % 2 == 0 && (BKM * BN / 4) % THREADS == 0 && (BKM * BK / 4) % THREADS == 0, "staging must divide evenly");
+};
+
+template <class Cfg, class XLoad>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void gemm_tn_f32_kernel(const float* __restrict__ dY, long ldy, XLoad xl,
+                                                                        float* __restrict__ slabs, int M, int N, int K,
+                                                                        int tiles_n, int tiles_k, int splits) {
+    constexpr int BN = Cfg::BN, BK = Cfg::BK, BKM = Cfg::BKM, LDA = Cfg::LDA, LDB = Cfg::LDB;
+    constexpr int TN = Cfg::TN, TK = Cfg::TK, A_V4 = Cfg::A_V4, B_V4 = Cfg::B_V4, THREADS = Cfg::THREADS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                          // [2][BKM][LDA]   dY rows
+    float* Bs = smem + 2 * BKM * LDA;          // [2][BKM][LDB]   X rows
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wn = wid / Cfg::WK, wk = wid % Cfg::WK;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // block -> (tile, split); splits of one tile are consecutive so they share the L2-resident slab region
+    const int bid = blockIdx.x;
+    const int split = bid % splits, tile = bid / splits;
+    const int tn = tile % tiles_n, tk = tile / tiles_n;
+    const int n0 = tn * BN, k0 = tk * BK;
+    const int rows_per = ((M + splits - 1) / splits + BKM - 1) / BKM * BKM;
+    const int m_lo = split * rows_per, m_hi = min(M, m_lo + rows_per);
+    const int nslab = m_hi > m_lo ? (m_hi - m_lo + BKM - 1) / BKM : 0;
+
+    // staging: thread -> (row r, float4 column c) of each operand slab
+    constexpr int A_C4 = BN / 4, B_C4 = BK / 4;
+    f32x4 pa[A_V4], pb[B_V4];
+    auto gload = [&](int s) __attribute__((always_inline)) {
+        const int mb = m_lo + s * BKM;
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) {
+            const int idx = tid + i * THREADS, r = idx / A_C4, c = idx - r * A_C4;
+            const int m = mb + r;
+            pa[i] = m < m_hi ? *(const f32x4*)(dY + (long)m * ldy + n0 + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) {
+            const int idx = tid + i * THREADS, r = idx / B_C4, c = idx - r * B_C4;
+            const int m = mb + r;
+            pb[i] = m < m_hi ? xl.load(xl.row(m), k0 + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) {
+            const int idx = tid + i * THREADS, r = idx / A_C4, c = idx - r * A_C4;
+            *(f32x4*)(As + (buf * BKM + r) * LDA + c * 4) = pa[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) {
+            const int idx = tid + i * THREADS, r = idx / B_C4, c = idx - r * B_C4;
+            *(f32x4*)(Bs + (buf * BKM + r) * LDB + c * 4) = pb[i];
+        }
+    };
+
+    f32x16 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nslab > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslab) gload(s + 1);
+        const float* Ab = As + (buf * BKM + lh) * LDA + wn * (TN * 32) + l31;
+        const float* Bb = Bs + (buf * BKM + lh) * LDB + wk * (TK * 32) + l31;
+#pragma unroll
+        for (int p = 0; p < BKM / 2; ++p) {
+            float a[TN], b[TK];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) a[i] = Ab[2 * p * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TK; ++j) b[j] = Bb[2 * p * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nslab) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = slabs + (long)split * N * K;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+            const int kk = k0 + wk * (TK * 32) + j * 32 + l31;
+            const int nb = n0 + wn * (TN * 32) + i * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nb + (r & 3) + 8 * (r >> 2);
+                if (n < N && kk < K) out[(long)n * K + kk] = acc[i][j][r];
+            }
+        }
+}
+
+// dst[i] = (accumulate ? dst[i] : 0) + sum_s slabs[s][i], fixed summation order
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ dst, long n,
+                                                           int splits, int accumulate) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 s = accumulate ? *(const f32x4*)(dst + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < splits; ++k) s += *(const f32x4*)(slabs + (long)k * n + i);
+    *(f32x4*)(dst + i) = s;
+}
+
+// column sums (bias gradients): out[n] = (accumulate ? out[n] : 0) + sum_m Y[m][n].  Two stages, fixed order:
+// stage 1 writes one partial row per block into part[gridDim.y][N]; stage 2 is reduce_slabs_kernel over those rows.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ Y, long ldy, float* __restrict__ part,
+                                                             int M, int N, int rows_per_block) {
+    __shared__ f32x4 red[4][64];
+    const int c4 = blockIdx.x * 64 + (threadIdx.x & 63);      // float4 column
+    const int q = threadIdx.x >> 6;                            // 4 row phases per block
+    const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c4 * 4 < N)
+        for (int m = m_lo + q; m < m_hi; m += 4) s += *(const f32x4*)(Y + (long)m * ldy + c4 * 4);
+    red[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c4 * 4 < N) {
+        const int l = threadIdx.x & 63;
+        *(f32x4*)(part + (long)blockIdx.y * N + c4 * 4) = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    }
+}
+
+// out[C, ldo >= R] = in[R,C]^T (weights for the input-gradient GEMM; 32x32 tiles through LDS)
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C, long ldo) {
+    __shared__ float t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = by + ty + i * 8, c = bx + tx;
+        t[ty + i * 8][tx] = (r < R && c < C) ? in[(long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = bx + ty + i * 8, r = by + tx;
+        if (r < R && c < C) out[(long)c * ldo + r] = t[tx][ty + i * 8];
+    }
+}
+
+template <class Cfg, class XLoad>
+static hipError_t gemm_tn_f32_launch(const float* dY, long ldy, const XLoad& xl, float* dW, float* slabs, size_t slab_bytes,
+                                     int M, int N, int K, int num_cu, int accumulate, hipStream_t stream) {
+    if (N % 4 != 0 || K % 4 != 0) return hipErrorInvalidValue;
+    const int tiles_n = (N + Cfg::BN - 1) / Cfg::BN, tiles_k = (K + Cfg::BK - 1) / Cfg::BK;
+    if (N % Cfg::BN != 0 || K % Cfg::BK != 0) return hipErrorInvalidValue;
+    const int tiles = tiles_n * tiles_k;
+    int splits = (2 * num_cu + tiles - 1) / tiles;               // about two blocks per CU
+    const int max_by_rows = (M + 4 * Cfg::BKM - 1) / (4 * Cfg::BKM);
+    if (splits > max_by_rows) splits = max_by_rows;
+    if (splits < 1) splits = 1;
+    while ((size_t)splits * N * K * 4 > slab_bytes && splits > 1) --splits;
+    if ((size_t)splits * N * K * 4 > slab_bytes) return hipErrorOutOfMemory;
+    auto kern = gemm_tn_f32_kernel<Cfg, XLoad>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, dY, ldy, xl, slabs, M, N, K,
+                       tiles_n, tiles_k, splits);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long n = (long)N * K;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, slabs, dW, n, splits,
+                       accumulate);
+    return hipGetLastError();
+}
+
+static hipError_t colsum_f32_launch(const float* Y, long ldy, float* out, float* part, size_t part_bytes, int M, int N,
+                                    int accumulate, hipStream_t stream) {
+    if (N % 4 != 0) return hipErrorInvalidValue;
+    int rows_per_block = 512;
+    int gy = (M + rows_per_block - 1) / rows_per_block;
+    while ((size_t)gy * N * 4 > part_bytes && rows_per_block < (1 << 30)) {
+        rows_per_block *= 2;
+        gy = (M + rows_per_block - 1) / rows_per_block;
+    }
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N / 4 + 63) / 64, gy), dim3(256), 0, stream, Y, ldy, part, M, N, rows_per_block);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((N / 4 + 255) / 256)), dim3(256), 0, stream, part, out, (long)N, gy,
+                       accumulate);
+    return hipGetLastError();
+}

@@ -21,8 +21,9 @@ __global__ __launch_bounds__(256) void pu_step_kernel(const float* __restrict__ 
                                                       const float* __restrict__ Gin_t,
                                                       const float* __restrict__ Whh,
                                                       const float* __restrict__ bhh,
-                                                      const float* __restrict__ h_prev, float* __restrict__ c,
-                                                      float* __restrict__ h_out, int B, int H) {
+                                                      const float* __restrict__ h_prev, const float* c_prev,
+                                                      float* c_out, float* __restrict__ h_out,
+                                                      float* __restrict__ gpre_out, int B, int H) {
     __shared__ float red[3 * 4 * 16 * 64];   // partial accumulators of waves 1..3 (48 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -77,12 +78,14 @@ __global__ __launch_bounds__(256) void pu_step_kernel(const float* __restrict__ 
             }
             if (row < B) {
                 const float* gi = Gin_t + (long)row * 4 * H + unit;
-                const float fg = sigmoidf_(pre[0] + gi[0]);
-                const float ig = sigmoidf_(pre[1] + gi[H]);
-                const float cg = tanhf(pre[2] + gi[2 * H]);
-                const float og = sigmoidf_(pre[3] + gi[3 * H]);
-                const float cn = c[(long)row * H + unit] * fg + ig * cg;
-                c[(long)row * H + unit] = cn;
+                const float pf = pre[0] + gi[0], pi = pre[1] + gi[H], pc = pre[2] + gi[2 * H], po = pre[3] + gi[3 * H];
+                if (gpre_out) {      // training: keep the gate pre-activations for the backward pass
+                    float* gp = gpre_out + (long)row * 4 * H + unit;
+                    gp[0] = pf; gp[H] = pi; gp[2 * H] = pc; gp[3 * H] = po;
+                }
+                const float fg = sigmoidf_(pf), ig = sigmoidf_(pi), cg = tanhf(pc), og = sigmoidf_(po);
+                const float cn = c_prev[(long)row * H + unit] * fg + ig * cg;
+                c_out[(long)row * H + unit] = cn;
                 h_out[(long)row * H + unit] = og * tanhf(cn);
             }
         }
@@ -130,4 +133,169 @@ __global__ __launch_bounds__(256) void pose_head_kernel(const float* __restrict_
         if (lane == 0) pose[((long)b * (J + (estimate_head ? 1 : 0)) + j) * 3 + cdim] = s + bp[cdim] + other[cdim];
     }
     if (estimate_head && tid < 3) pose[((long)b * (J + 1) + J) * 3 + tid] = other[3 + tid];
+}
+
+
+// ----------------------------------------------------------------------------- backward of the propagation units
+// One recurrent step, reverse time.  Pointwise part A (LSTM gates): from the total gradient on h_t and c_t to the
+// gradient of the four gate pre-activations and of c_{t-1}.  The matrix part dhp = dG . Whh runs on the GEMM kernel
+// (transposed weights); pointwise part B turns dhp into the gradient of h_{t-1} and of the x2f "forget" logits.
+__global__ __launch_bounds__(256) void pu_gates_bwd_kernel(const float* __restrict__ gpre, const float* __restrict__ c_prev,
+                                                           const float* __restrict__ c_t, const float* __restrict__ dh_ext,
+                                                           const float* __restrict__ dh_rec, const float* __restrict__ dc_next,
+                                                           float* __restrict__ dG, float* __restrict__ dc_prev, int B, int H) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * H) return;
+    const int row = (int)(i / H), u = (int)(i - (long)row * H);
+    const float* gp = gpre + (long)row * 4 * H + u;
+    const float f = sigmoidf_(gp[0]), ig = sigmoidf_(gp[H]), g = tanhf(gp[2 * H]), o = sigmoidf_(gp[3 * H]);
+    const float tc = tanhf(c_t[i]);
+    float dh = 0.f;
+    if (dh_ext) dh += dh_ext[i];
+    if (dh_rec) dh += dh_rec[i];
+    float dc = dh * o * (1.0f - tc * tc);
+    if (dc_next) dc += dc_next[i];
+    float* dg = dG + (long)row * 4 * H + u;
+    dg[0] = dc * c_prev[i] * f * (1.0f - f);
+    dg[H] = dc * g * ig * (1.0f - ig);
+    dg[2 * H] = dc * ig * (1.0f - g * g);
+    dg[3 * H] = dh * tc * o * (1.0f - o);
+    dc_prev[i] = dc * f;
+}
+
+// hp = sigmoid(f) * h_prev :  dh_prev = dhp * sigmoid(f) ;  df = dhp * h_prev * sigmoid'(f) ;  also emits hp (the
+// operand of the h2h weight gradient)
+__global__ __launch_bounds__(256) void pu_hp_bwd_kernel(const float* __restrict__ dhp, const float* __restrict__ F_t, int ldf,
+                                                        const float* __restrict__ h_prev, float* __restrict__ dh_rec_prev,
+                                                        float* __restrict__ dF_t, int lddf, float* __restrict__ hp_out, int B, int H) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * H) return;
+    const int row = (int)(i / H), u = (int)(i - (long)row * H);
+    const float s = sigmoidf_(F_t[(long)row * ldf + u]);
+    const float hprev = h_prev[i], d = dhp[i];
+    dh_rec_prev[i] = d * s;
+    dF_t[(long)row * lddf + u] = d * hprev * s * (1.0f - s);
+    hp_out[i] = s * hprev;
+}
+
+// bridge gate of layer 0: b' = sigmoid(fb) * bridge ;  dfb = db' * bridge * sigmoid'(fb) (written into dF[:, H:]) ;
+// dbridge = db' * sigmoid(fb) scattered back to the eye-major embedding layout [(b*2 + eye)*J + t, hid]
+__global__ __launch_bounds__(256) void pu_bridge_bwd_kernel(const float* __restrict__ dbp, const float* __restrict__ F, int ldf,
+                                                            int fcol0, const float* __restrict__ rotz, float* __restrict__ dF,
+                                                            float* __restrict__ drotz, int B, int J, int hid) {
+    const int x = 2 * hid;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)J * B * x) return;
+    const int m = (int)(i / x), k = (int)(i - (long)m * x);
+    const int t = m / B, b = m - t * B, eye = k / hid, c = k - eye * hid;
+    const long zi = ((long)(b * 2 + eye) * J + t) * hid + c;
+    const float s = sigmoidf_(F[(long)m * ldf + fcol0 + k]);
+    const float d = dbp[i], br = rotz[zi];
+    dF[(long)m * ldf + fcol0 + k] = d * br * s * (1.0f - s);
+    drotz[zi] = d * s;
+}
+
+// dposz[(b*2+eye)*J + t, c] = dxs[t*B + b, eye*hid + c] + dpose_feat contribution (already in dposz if accumulate)
+__global__ __launch_bounds__(256) void stereo_scatter_kernel(const float* __restrict__ dxs, float* __restrict__ dz, int B, int J,
+                                                             int hid, int accumulate) {
+    const int x = 2 * hid;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)J * B * x) return;
+    const int m = (int)(i / x), k = (int)(i - (long)m * x);
+    const int t = m / B, b = m - t * B, eye = k / hid, c = k - eye * hid;
+    const long zi = ((long)(b * 2 + eye) * J + t) * hid + c;
+    dz[zi] = (accumulate ? dz[zi] : 0.f) + dxs[i];
+}
+
+// Pose head backward.  Data gradients: one block per sample.
+//   dpos[(b*2+eye)*J + j, c] = sum_k dpose'[b,j,k] Wp[k, eye*hid + c] ;  dskel[j,b,u] = sum_k dpose'[b,j,k] Wp[k, 2hid + u]
+//                              + sum_o dother[b,o] Wg[o, j*H + u]   with dother[0:3] = sum_j dpose[b,j,:], dother[3:6] = dpose[b,J,:]
+__global__ __launch_bounds__(256) void pose_head_bwd_data_kernel(const float* __restrict__ dpose, const float* __restrict__ Wp,
+                                                                 const float* __restrict__ Wg, float* __restrict__ dposz,
+                                                                 float* __restrict__ dhseq, int B, int J, int hid, int H,
+                                                                 int estimate_head) {
+    __shared__ float dp[64 * 3], dother[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int JO = J + (estimate_head ? 1 : 0);
+    for (int i = tid; i < JO * 3; i += 256) dp[i] = dpose[(long)b * JO * 3 + i];
+    __syncthreads();
+    if (tid < 6) {
+        float s = 0.f;
+        if (estimate_head) {
+            if (tid < 3) for (int j = 0; j < J; ++j) s += dp[j * 3 + tid];
+            else s = dp[J * 3 + tid - 3];
+        }
+        dother[tid] = s;
+    }
+    __syncthreads();
+    const int kin = 2 * hid + H;
+    for (int i = tid; i < J * kin; i += 256) {
+        const int j = i / kin, k = i - j * kin;
+        float s = dp[j * 3] * Wp[k] + dp[j * 3 + 1] * Wp[kin + k] + dp[j * 3 + 2] * Wp[2 * kin + k];
+        if (k < 2 * hid) {
+            const int eye = k / hid, c = k - eye * hid;
+            dposz[((long)(b * 2 + eye) * J + j) * hid + c] = s;
+        } else {
+            const int u = k - 2 * hid;
+            if (estimate_head)
+#pragma unroll
+                for (int o = 0; o < 6; ++o) s += dother[o] * Wg[(long)o * J * H + (long)j * H + u];
+            dhseq[((long)j * B + b) * H + u] = s;
+        }
+    }
+}
+
+// Pose head weight gradients (tiny N): one thread per weight column, fixed (b, j) order.
+__global__ __launch_bounds__(256) void pose_head_bwd_weight_kernel(const float* __restrict__ dpose, const float* __restrict__ posz,
+                                                                   const float* __restrict__ hseq, float* __restrict__ dWp,
+                                                                   float* __restrict__ dbp, float* __restrict__ dWg,
+                                                                   float* __restrict__ dbg, int B, int J, int hid, int H,
+                                                                   int estimate_head, int accumulate) {
+    const int kin = 2 * hid + H, JO = J + (estimate_head ? 1 : 0);
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col < kin) {                        // dWp[c][col] = sum_{b,j} dpose[b,j,c] * feat[b,j,col]
+        float s[3] = {0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b)
+            for (int j = 0; j < J; ++j) {
+                float f;
+                if (col < 2 * hid) {
+                    const int eye = col / hid, c = col - eye * hid;
+                    f = posz[((long)(b * 2 + eye) * J + j) * hid + c];
+                } else {
+                    f = hseq[((long)j * B + b) * H + col - 2 * hid];
+                }
+                const float* d = dpose + ((long)b * JO + j) * 3;
+                s[0] += d[0] * f; s[1] += d[1] * f; s[2] += d[2] * f;
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dWp[c * kin + col] = (accumulate ? dWp[c * kin + col] : 0.f) + s[c];
+    } else if (estimate_head && col < kin + J * H) {   // dWg[o][q] = sum_b dother[b,o] * skel_flat[b,q]
+        const int q = col - kin, j = q / H, u = q - j * H;
+        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b) {
+            const float f = hseq[((long)j * B + b) * H + u];
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+            for (int jj = 0; jj < J; ++jj) { const float* d = dpose + ((long)b * JO + jj) * 3; d0 += d[0]; d1 += d[1]; d2 += d[2]; }
+            const float* dh = dpose + ((long)b * JO + J) * 3;
+            s[0] += d0 * f; s[1] += d1 * f; s[2] += d2 * f; s[3] += dh[0] * f; s[4] += dh[1] * f; s[5] += dh[2] * f;
+        }
+#pragma unroll
+        for (int o = 0; o < 6; ++o) dWg[(long)o * J * H + q] = (accumulate ? dWg[(long)o * J * H + q] : 0.f) + s[o];
+    } else if (col == kin + (estimate_head ? J * H : 0)) {   // biases
+        float sp[3] = {0.f, 0.f, 0.f}, sg[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b) {
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+            for (int j = 0; j < J; ++j) { const float* d = dpose + ((long)b * JO + j) * 3; d0 += d[0]; d1 += d[1]; d2 += d[2]; }
+            sp[0] += d0; sp[1] += d1; sp[2] += d2;
+            if (estimate_head) {
+                const float* dh = dpose + ((long)b * JO + J) * 3;
+                sg[0] += d0; sg[1] += d1; sg[2] += d2; sg[3] += dh[0]; sg[4] += dh[1]; sg[5] += dh[2];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dbp[c] = (accumulate ? dbp[c] : 0.f) + sp[c];
+        if (estimate_head)
+#pragma unroll
+            for (int o = 0; o < 6; ++o) dbg[o] = (accumulate ? dbg[o] : 0.f) + sg[o];
+    }
 }

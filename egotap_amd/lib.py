@@ -46,6 +46,32 @@ _PROTOS = {
     "egotap_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "egotap_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egotap_timing_detail": (C.c_char_p, [C.c_void_p]),
+    # ---- training-step operators
+    "egotap_train_gemm_nt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "egotap_train_gemm_tn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_train_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_train_transpose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "egotap_train_add_inplace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "egotap_train_patch_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6),
+    "egotap_train_patch_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "egotap_train_tokens_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "egotap_train_layernorm_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_float, C.c_void_p]),
+    "egotap_train_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_train_bn_lrelu_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_train_bn_lrelu_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_train_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "egotap_train_attention_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "egotap_train_pu_saved_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "egotap_train_pu_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_train_pu_bwd_ws_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
+    "egotap_train_pu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_train_pose_head_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "egotap_train_pose_head_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
+    "egotap_train_pose_loss": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "egotap_train_adamw": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int, C.c_void_p]),
 }
 
 

@@ -109,6 +109,50 @@ int egotap_layernorm_f32(const float* x, float* y, const float* gamma, const flo
 /* ViTSelfAttention core (modeling_vit.py:233-252) on a fused [B*N, 3*heads*128] q|k|v buffer -> ctx [B*N, heads*128] */
 int egotap_attention_f32(const float* qkv, float* ctx, int B, int N, int heads, void* stream);
 
+/* ---- training-step operators (fp32), called by the autograd glue (egotap_amd/training.py) ------------------------------
+ * They implement the backward of the modules above plus loss / optimizer (egotap_autoencoder_model.py:284-323,
+ * utils/loss.py:54-85, network.py:72-78 AdamW).  All buffers are caller-owned device memory; reductions have a fixed order.
+ * loader: 0 plain, 1 ViT patch gather, 2 per-heatmap token regroup, 3 stereo cos/sin gather, 4 stereo joint features,
+ *         5 stereo joint features x sigmoid gate (aux).  epi: 0 none, 1 bias, 2 bias + residual r, 3 bias + GELU (stores
+ *         the pre-activation to z), 4 accumulate onto r, 5 multiply by GELU'(r). */
+int egotap_train_gemm_nt(egotap_handle h, int loader, const float* x, int64_t lda, const float* aux, const float* w, const float* b,
+                         float* y, int M, int N, int K, int epi, const float* r, float* z, int Bsz, void* stream);
+int egotap_train_gemm_tn(egotap_handle h, int loader, const float* dy, int64_t ldy, const float* x, const float* aux, float* dw, int M,
+                         int N, int K, int accumulate, int Bsz, void* ws, size_t ws_bytes, void* stream);
+int egotap_train_colsum(const float* y, int64_t ldy, float* out, int M, int N, int accumulate, void* ws, size_t ws_bytes, void* stream);
+int egotap_train_transpose(const float* in, float* out, int R, int C, int64_t ldo, void* stream);
+int egotap_train_add_inplace(float* out, const float* in, int64_t n, void* stream);
+int egotap_train_patch_fwd(egotap_handle h, const float* hm, int B, const float* w, const float* b, const float* mask_tok,
+                           const float* pos, float* x, void* stream);
+int egotap_train_patch_split(egotap_handle h, const float* dpos, float* dbias, float* dmask, int accumulate, void* stream);
+int egotap_train_tokens_scatter(egotap_handle h, const float* dA, float* dtok, int B, void* stream);
+int egotap_train_layernorm_fwd(const float* x, float* y, const float* g, const float* b, float* mean, float* rstd, int rows,
+                               float eps, void* stream);
+int egotap_train_layernorm_bwd(const float* x, const float* dy, const float* g, const float* mean, const float* rstd,
+                               const float* dres, float* dx, float* dgamma, float* dbeta, int rows, int accumulate,
+                               void* ws, size_t ws_bytes, void* stream);
+int egotap_train_bn_lrelu_fwd(const float* z, float* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                              float* run_mean, float* run_var, int R, int C, float eps, float momentum, void* ws,
+                              size_t ws_bytes, void* stream);
+int egotap_train_bn_lrelu_bwd(const float* z, const float* y, const float* dy, const float* gamma, const float* mean,
+                              const float* rstd, float* dz, float* dgamma, float* dbeta, int R, int C, int accumulate,
+                              void* ws, size_t ws_bytes, void* stream);
+int egotap_train_attention_fwd(const float* qkv, float* ctx, float* lse, int B, int N, int heads, void* stream);
+int egotap_train_attention_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* delta,
+                               float* dqkv, int B, int N, int heads, void* stream);
+int egotap_train_pu_saved_bytes(egotap_handle h, int B, size_t* bytes, size_t* hs1_offset);
+int egotap_train_pu_fwd(egotap_handle h, const float* posz, const float* rotz, int B, void* saved, size_t saved_bytes, void* stream);
+int egotap_train_pu_bwd_ws_bytes(egotap_handle h, int B, size_t* bytes);
+int egotap_train_pu_bwd(egotap_handle h, const float* posz, const float* rotz, int B, const void* saved, const float* dhs1,
+                        float* dposz, float* drotz, float* const* grads, int accumulate, void* ws, size_t ws_bytes, void* stream);
+int egotap_train_pose_head_fwd(egotap_handle h, const float* posz, const float* hs1, int B, float* pose, void* stream);
+int egotap_train_pose_head_bwd(egotap_handle h, const float* posz, const float* hs1, const float* dpose, int B, float* dposz,
+                               float* dhs1, float* dWp, float* dbp, float* dWg, float* dbg, int accumulate, void* stream);
+int egotap_train_pose_loss(egotap_handle h, const float* pred, const float* gt, float* dpred, float* out, float* partial,
+                           int B, float lambda_mpjpe, float lambda_cos_sim, void* stream);
+int egotap_train_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, int step, void* stream);
+
 /* ---- measurement hooks (bench.py roofline) ---- */
 /* when enabled, every GEMM launch of the handle is bracketed by HIP events on the caller's stream */
 int egotap_timing_enable(egotap_handle h, int enable);

@@ -297,6 +297,43 @@ def loss_cos_sim(pred, gt, p: LiftPreset, eps=1e-8):
     return cos.sum(dim=1).mean()
 
 
+def lift_forward_train(hm, sd, p: LiftPreset):
+    """Training-mode forward (BatchNorm1d batch statistics in the six FC blocks): returns (pose, {bn prefix: (new running
+    mean, new running var)}).  Differentiable with torch autograd w.r.t. every tensor of sd that requires grad."""
+    B, J = hm.shape[0], p.n_joints_hm
+    pos, st1 = pos_encoder(hm[:, : 2 * J], sd, p, None, training=True)
+    rot, st2 = rot_encoder(hm[:, 2 * J:], sd, p, training=True)
+    pos_j = stereo_interleave(pos, B, p)
+    rot_j = stereo_interleave(rot, B, p)
+    skel = pu_chain(pos_j.transpose(0, 1), rot_j.transpose(0, 1), sd)
+    st1.update(st2)
+    return pose_head(pos_j, skel, sd, p), st1
+
+
+def train_step(hm, gt, sd, p: LiftPreset, lam_mpjpe=0.1, lam_cos=-0.01, lr=1e-3, eps=1e-4, wd=0.0):
+    """One optimisation step of egotap_autoencoder_model.py:299-323 (fp32, no AMP): forward in train mode, loss =
+    lam_mpjpe * MPJPE + lam_cos * lam_mpjpe * CosSim, backward, AdamW (network.py:72-78; betas 0.9 / 0.999).
+    Returns dict(pose, loss_pose, loss_cos_sim, grads{key}, new_params{key}, bn{prefix: (rm, rv)})."""
+    dead = ("cls_token", "pooler.dense")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) and not any(d in k for d in dead)}
+    full = dict(sd)
+    full.update(leaves)
+    pose, bn = lift_forward_train(hm, full, p)
+    lp = loss_mpjpe(pose, gt) * lam_mpjpe
+    lc = loss_cos_sim(pose, gt, p) * lam_cos * lam_mpjpe
+    grads = dict(zip(leaves.keys(), torch.autograd.grad(lp + lc, list(leaves.values()), allow_unused=True)))
+    new = {}
+    for k, g in grads.items():
+        if g is None:
+            continue
+        m = 0.1 * g
+        v = 0.001 * g * g
+        w = leaves[k].detach() * (1 - lr * wd)
+        new[k] = w - (lr / (1 - 0.9)) * m / (v.sqrt() / math.sqrt(1 - 0.999) + eps)
+    return dict(pose=pose.detach(), loss_pose=lp.detach(), loss_cos_sim=lc.detach(), grads=grads, new_params=new, bn=bn)
+
+
 def procrustes_align(s1, s2):
     """Batched similarity transform of s1 [B,J,3] onto s2 (utils/util.py:328-379), for PA-MPJPE."""
     x1, x2 = s1.transpose(1, 2), s2.transpose(1, 2)

@@ -107,3 +107,35 @@ def test_procrustes_matches_reference():
     s2 = torch.from_numpy(synth_input("procrustes_s2", (6, 16, 3), -30.0, 30.0))
     s2[:3] = s1[:3] * 1.7 + 0.3 * s2[:3]
     np.testing.assert_allclose(O.procrustes_align(s1, s2).numpy(), g["s1_hat"], atol=2e-4, rtol=1e-4)
+
+
+def test_train_step_matches_reference():
+    """oracle training step (train-mode BN, loss, autograd, AdamW) against one optimize step of the reference modules"""
+    g = _load("train_step_ue_b2.npz")
+    p = spec.lift_preset("UnrealEgo")
+    sd = O.to_torch_sd(synth_state_dict(spec.lift_state_spec(p)))
+    hm = torch.from_numpy(synth_input("hm_train", (2, 90, 64, 64)))
+    gt = torch.from_numpy(synth_input("gt_train", (2, 16, 3), -1.0, 1.0))
+    torch.set_num_threads(8)
+    out = O.train_step(hm, gt, sd, p)
+    np.testing.assert_allclose(out["pose"].numpy(), g["pose"], atol=2e-5)
+    np.testing.assert_allclose(out["loss_pose"].item(), g["loss_pose"], rtol=1e-5)
+    np.testing.assert_allclose(out["loss_cos_sim"].item(), g["loss_cos_sim"], rtol=1e-3, atol=1e-7)
+    assert sorted(k for k, v in out["grads"].items() if v is not None) == sorted(g["grad_keys"])
+    assert set(g["no_grad_keys"]) == {"pos_heatmap_encoder.vit.embeddings.cls_token", "pos_heatmap_encoder.vit.pooler.dense.weight",
+                                      "pos_heatmap_encoder.vit.pooler.dense.bias"}
+    norms = dict(zip(g["grad_keys"], g["grad_norms"]))
+    for k, gr in out["grads"].items():
+        if gr is None:
+            continue
+        ref_s = g["g:" + k]
+        got_s = gr.reshape(-1)[:: max(1, gr.numel() // 257)].numpy()
+        scale = max(norms[k] / np.sqrt(gr.numel()), 1e-12)
+        assert np.abs(got_s - ref_s).max() <= 2e-3 * scale + 5e-9, k   # some gradients are mathematically zero (noise ~1e-9)
+        # key.bias gradients are mathematically zero (softmax is shift invariant): pure rounding noise, absolute check
+        np.testing.assert_allclose(float(gr.double().norm()), norms[k], rtol=2e-4, atol=1e-8, err_msg=k)
+        new_s = out["new_params"][k].reshape(-1)[:: max(1, gr.numel() // 257)].numpy()
+        np.testing.assert_allclose(new_s, g["p:" + k], atol=2e-5, err_msg=k)
+    for pre, (rm, rv) in out["bn"].items():
+        np.testing.assert_allclose(rm.detach().numpy(), g["buf:" + pre + ".bn.running_mean"], atol=1e-6)
+        np.testing.assert_allclose(rv.detach().numpy(), g["buf:" + pre + ".bn.running_var"], atol=1e-6)

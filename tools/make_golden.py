@@ -214,6 +214,49 @@ def gen_loss():
         print(f"loss_{tag}:", float(mp), float(cs))
 
 
+def gen_train():
+    """One training forward/backward of the reference lifting head (train-mode BatchNorm, MPJPE + cos-sim loss of
+    egotap_autoencoder_model.py:284-296) and one AdamW step (lr 1e-3, eps 1e-4, wd 0): gradients and updated values."""
+    import model.net_architecture as na
+    import utils.loss as L
+
+    opt = make_opt("UnrealEgo")
+    net = na.EgoTAPAutoEncoder(opt, input_channel_scale=2)
+    load_synth(net)
+    net.train()
+    B = 2
+    hm = torch.from_numpy(synth_input("hm_train", (B, 90, 64, 64)))
+    gt = torch.from_numpy(synth_input("gt_train", (B, 16, 3), -1.0, 1.0))
+    optim = torch.optim.AdamW(net.parameters(), lr=1e-3, eps=1e-4, weight_decay=0.0)
+    optim.zero_grad()
+    pose = net(hm)[0]
+    lam_m, lam_c = 0.1, -0.01
+    loss_pose = L.LossFuncMPJPE()(pose, gt) * lam_m
+    loss_cos = L.LossFuncCosSim(joint_preset="UnrealEgo", estimate_head=True)(pose, gt) * lam_c * lam_m
+    (loss_pose + loss_cos).backward()
+    out = {"pose": pose.detach().numpy(), "loss_pose": loss_pose.detach().numpy(), "loss_cos_sim": loss_cos.detach().numpy()}
+    names, norms, no_grad = [], [], []
+    for k, prm in net.named_parameters():
+        if prm.grad is None:
+            no_grad.append(k)
+            continue
+        names.append(k)
+        norms.append(float(prm.grad.double().norm()))
+        out["g:" + k] = prm.grad.reshape(-1)[:: max(1, prm.numel() // 257)].numpy().copy()
+    out["grad_keys"] = np.array(names)
+    out["grad_norms"] = np.array(norms)
+    out["no_grad_keys"] = np.array(no_grad)
+    for k, v in net.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"):
+            out["buf:" + k] = v.numpy().copy()
+    optim.step()
+    for k, prm in net.named_parameters():
+        if prm.grad is not None:
+            out["p:" + k] = prm.detach().reshape(-1)[:: max(1, prm.numel() // 257)].numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "train_step_ue_b2.npz"), **out)
+    print("train_step: losses", float(loss_pose), float(loss_cos), "params without grad:", no_grad)
+
+
 def gen_procrustes():
     import utils.util as U
 
@@ -271,7 +314,7 @@ def gen_hm():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="lift,pu,fc,loss,hm,procrustes")
+    ap.add_argument("--only", default="lift,pu,fc,loss,hm,procrustes,train")
     args = ap.parse_args()
     which = set(args.only.split(","))
     os.makedirs(GOLD, exist_ok=True)
@@ -290,6 +333,8 @@ def main():
         gen_hm()
     if "procrustes" in which:
         gen_procrustes()
+    if "train" in which:
+        gen_train()
 
 
 if __name__ == "__main__":
