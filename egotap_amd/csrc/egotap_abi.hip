@@ -1377,3 +1377,16 @@ extern "C" int egotap_train_tokens_scatter(egotap_handle h, const float* dA, flo
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+
+
+// fused Q|K|V projection (three nn.Linear of ViTSelfAttention, modeling_vit.py:212-214) into one [M, 3D] buffer
+extern "C" int egotap_train_qkv_fwd(const float* y, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
+                                    const float* bv, float* qkv, int M, int D, void* stream) {
+    EGO_CHECK(y && wq && bq && wk && bk && wv && bv && qkv, "egotap_train_qkv_fwd: null argument");
+    EGO_CHECK(D % 256 == 0, "egotap_train_qkv_fwd: hidden size must be a multiple of 256");
+    SegMat W; W.p[0] = wq; W.p[1] = wk; W.p[2] = wv; W.seg = D; W.ld = D;
+    SegVec b; b.p[0] = bq; b.p[1] = bk; b.p[2] = bv; b.seg = D;
+    EGO_HIP((gemm_f32_persist_launch<PipeD, ALoadPlain, EpiBias>(ALoadPlain{y, D}, W, EpiBias{b}, qkv, 3L * D, M, 3 * D, D, device_cu_count(),
+                                                                 (hipStream_t)stream)));
+    return EGOTAP_OK;
+}

@@ -698,9 +698,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_persist_kern
                 for (int s4 = 0; s4 < 4; ++s4) {
                     // one row group at a time (few live registers): result, then the NEXT tile's residual request,
                     // then the store -- load/store alternate, so the next tile waits with a counted vmcnt(7)
-                    const f32x4 o = epi.apply4(*(const f32x4*)(Es + (s4 * 8 + er) * ELD + ec), cc, rs[s4], mb + s4 * 8, n0);
+                    const bool ok = mb + s4 * 8 < M;      // an epilogue may have side effects (it stores the GELU
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};       // pre-activation): never run it for rows past M
+                    if (ok) o = epi.apply4(*(const f32x4*)(Es + (s4 * 8 + er) * ELD + ec), cc, rs[s4], mb + s4 * 8, n0);
                     if (more) rs[s4] = epi.res4(min(mb0 + in * 32 + s4 * 8, M - 1), nb0 + jn * 32);
-                    if (mb + s4 * 8 < M) *(f32x4*)(C + (long)(mb + s4 * 8) * ldc + n0) = o;
+                    if (ok) *(f32x4*)(C + (long)(mb + s4 * 8) * ldc + n0) = o;
                 }
             }
         }

@@ -159,14 +159,14 @@ class EgoTAPAutoEncoder(nn.Module):
 
     def forward(self, input, input_rgb_left=None, input_rgb_right=None, pose_only=False):
         p = self.preset
-        if self.training:
-            raise NotImplementedError(
-                "egotap_amd builds the eval-mode forward in this round; call .eval() "
-                "(training: BatchNorm batch statistics + backward kernels are the next scope row)")
         if not input.is_cuda:
             raise _lib.EgotapError("EgoTAPAutoEncoder runs on the GPU only (no CPU fallback); move the input to cuda")
         if input.dim() != 4 or input.shape[1] != p.in_channels or input.shape[2] != p.hm_size or input.shape[3] != p.hm_size:
             raise ValueError(f"expected input [B, {p.in_channels}, {p.hm_size}, {p.hm_size}], got {tuple(input.shape)}")
+        if self.training:
+            from .training import lift_train_forward          # training mode: batch-statistics BatchNorm, differentiable
+            pose = lift_train_forward(self, input)
+            return pose if pose_only else (pose,) + self._zero_outputs(input.shape[0], input.device)[1:]
         hm = input.detach()
         if hm.dtype != torch.float32:
             hm = hm.float()
@@ -183,13 +183,18 @@ class EgoTAPAutoEncoder(nn.Module):
                     C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         if pose_only:
             return pose
+        return (pose,) + self._zero_outputs(B, dev)[1:]
+
+    def _zero_outputs(self, B, dev):
+        """(None, rot, indep_pos, reconstructed heatmaps): the reference's all-zero outputs, cached / broadcast"""
+        p = self.preset
         key = (B, str(dev))
         if key not in self._zeros:
             z = torch.zeros((), dtype=torch.float32, device=dev)
             self._zeros = {key: (torch.zeros((B, self.rot_dim), device=dev), torch.zeros((B, 6 * p.n_joints_hm), device=dev),
                                  z.expand(B, p.in_channels, p.hm_size, p.hm_size))}
         rot, indep, out_hm = self._zeros[key]
-        return pose, rot, indep, out_hm
+        return None, rot, indep, out_hm
 
 
 class HeatMap_UnrealEgo_Shared(nn.Module):

@@ -1,0 +1,230 @@
+"""Training step of the lifting head on the HIP operators: PyTorch is autograd glue only.
+
+``LiftTrainFn`` is ONE torch.autograd.Function for the whole head (heatmaps + parameters -> pose): its forward runs
+the training-mode network through libegotap_hip.so keeping the activations, its backward walks the layers in reverse
+through the backward operators and hands every parameter gradient back to autograd, so ``loss.backward()`` /
+``optimizer.step()`` in the wrapper read exactly like the reference (model/egotap_autoencoder_model.py:299-323).
+``PoseLossFn`` is the loss (utils/loss.py:54-85), ``EgotapAdamW`` the optimizer (model/network.py:72-78) -- both HIP.
+
+The fp32 path only (the reference's optional fp16 autocast is not reproduced).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as _lib
+from . import spec as _spec
+from . import train_ops as T
+
+
+def _param_order(p):
+    return [k for k, _ in _spec.lift_state_spec(p) if not _spec.is_buffer(k) and k not in _spec.LIFT_DEAD_KEYS]
+
+
+class LiftTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, hm, *params):
+        p = net.preset
+        keys = _param_order(p)
+        P = dict(zip(keys, params))
+        dev = hm.device
+        h = net._ensure_handle()
+        net._bind(dev)
+        B, D, seq, heads, J, T_, hid = hm.shape[0], p.vit_dim, p.seq, p.vit_heads, p.n_joints_hm, p.tokens, p.hidden
+        M, BT = B * seq, B * T_
+        lib = _lib.load()
+        st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        v = "pos_heatmap_encoder.vit."
+        hm = hm.detach().float().contiguous()
+        saved = {"hm": hm}
+        x = torch.empty((M, D), dtype=torch.float32, device=dev)
+        _lib.check(lib.egotap_train_patch_fwd(h, T._p(hm), B, T._p(P[v + "embeddings.patch_embeddings.projection.weight"]),
+                                              T._p(P[v + "embeddings.patch_embeddings.projection.bias"]), T._p(P[v + "embeddings.mask_token"]),
+                                              T._p(P[v + "embeddings.position_embeddings"]), T._p(x), st()))
+        layers = []
+        for i in range(p.vit_layers):
+            l = f"{v}encoder.layer.{i}."
+            a = l + "attention.attention."
+            y1, m1, r1 = T.layernorm_fwd(x, P[l + "layernorm_before.weight"], P[l + "layernorm_before.bias"])
+            qkv = torch.empty((M, 3 * D), dtype=torch.float32, device=dev)
+            _lib.check(lib.egotap_train_qkv_fwd(T._p(y1), T._p(P[a + "query.weight"]), T._p(P[a + "query.bias"]), T._p(P[a + "key.weight"]),
+                                                T._p(P[a + "key.bias"]), T._p(P[a + "value.weight"]), T._p(P[a + "value.bias"]), T._p(qkv), M, D, st()))
+            ctx_, lse = T.attention_fwd(qkv, B, seq, heads)
+            xm = T.gemm_nt(h, ctx_, P[l + "attention.output.dense.weight"], P[l + "attention.output.dense.bias"], M, D, D, epi=T.TE_BIAS_RES, r=x)
+            y2, m2, r2 = T.layernorm_fwd(xm, P[l + "layernorm_after.weight"], P[l + "layernorm_after.bias"])
+            z = torch.empty((M, 4 * D), dtype=torch.float32, device=dev)
+            hid_ = T.gemm_nt(h, y2, P[l + "intermediate.dense.weight"], P[l + "intermediate.dense.bias"], M, 4 * D, D, epi=T.TE_BIAS_GELU_SAVE, z=z)
+            xo = T.gemm_nt(h, hid_, P[l + "output.dense.weight"], P[l + "output.dense.bias"], M, D, 4 * D, epi=T.TE_BIAS_RES, r=xm)
+            layers.append(dict(x=x, m1=m1, r1=r1, y1=y1, qkv=qkv, ctx=ctx_, lse=lse, xm=xm, m2=m2, r2=r2, y2=y2, z=z, hid=hid_))
+            x = xo
+        tokens, mf, rf = T.layernorm_fwd(x, P[v + "layernorm.weight"], P[v + "layernorm.bias"])
+        saved.update(layers=layers, xf=x, mf=mf, rf=rf, tokens=tokens)
+
+        def encoder(name, loader, src, k1):
+            acts = []
+            a_in, ld, K = src, loader, k1
+            for j, n_out in enumerate((2048, 512, hid), start=1):
+                f = f"{name}.fc{j}"
+                zz = T.gemm_nt(h, a_in, P[f + ".fc.weight"], P[f + ".fc.bias"], BT, n_out, K, loader=ld, epi=T.TE_BIAS)
+                bufs = dict(net.named_buffers())
+                yy, mean, rstd = T.bn_lrelu_fwd(zz, P[f + ".bn.weight"], P[f + ".bn.bias"], bufs[f + ".bn.running_mean"], bufs[f + ".bn.running_var"])
+                bufs[f + ".bn.num_batches_tracked"].add_(1)
+                acts.append(dict(a_in=a_in, z=zz, y=yy, mean=mean, rstd=rstd, loader=ld, K=K, N=n_out, name=f))
+                a_in, ld, K = yy, T.LD_PLAIN, n_out
+            return acts
+
+        pos_acts = encoder("pos_heatmap_encoder", T.LD_TOKENS, tokens, p.ppd * p.ppd * D)
+        rot_acts = encoder("rot_heatmap_encoder", T.LD_ROT, hm, 2 * p.hm_size * p.hm_size)
+        posz, rotz = pos_acts[-1]["y"], rot_acts[-1]["y"]
+        nb, off = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.egotap_train_pu_saved_bytes(h, B, C.byref(nb), C.byref(off)))
+        pu_saved = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+        _lib.check(lib.egotap_train_pu_fwd(h, T._p(posz), T._p(rotz), B, T._p(pu_saved), pu_saved.numel(), st()))
+        hs1 = pu_saved[off.value: off.value + 4 * J * B * p.pu_hidden].view(torch.float32)
+        pose = torch.empty((B, p.out_joints, 3), dtype=torch.float32, device=dev)
+        _lib.check(lib.egotap_train_pose_head_fwd(h, T._p(posz), T._p(hs1), B, T._p(pose), st()))
+        saved.update(pos_acts=pos_acts, rot_acts=rot_acts, pu_saved=pu_saved, hs1=hs1, P=P, keys=keys, net=net, B=B)
+        ctx.egotap = saved
+        return pose
+
+    @staticmethod
+    def backward(ctx, dpose):
+        S = ctx.egotap
+        net, P, keys, B = S["net"], S["P"], S["keys"], S["B"]
+        p = net.preset
+        h = net._ensure_handle()
+        dev = dpose.device
+        D, seq, heads, J, T_, hid, H = p.vit_dim, p.seq, p.vit_heads, p.n_joints_hm, p.tokens, p.hidden, p.pu_hidden
+        M, BT = B * seq, B * T_
+        lib = _lib.load()
+        st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        G = {k: torch.empty_like(P[k]) for k in keys}          # every entry is fully overwritten below
+        dpose = dpose.detach().float().contiguous()
+        v = "pos_heatmap_encoder.vit."
+        posz, rotz, hs1 = S["pos_acts"][-1]["y"], S["rot_acts"][-1]["y"], S["hs1"]
+        # pose head + propagation units
+        dposz, drotz = torch.empty_like(posz), torch.empty_like(rotz)
+        dhs1 = torch.empty(J * B * H, dtype=torch.float32, device=dev)
+        gw = G.get("global_mlp.pose_fcs.0.weight")
+        gb = G.get("global_mlp.pose_fcs.0.bias")
+        _lib.check(lib.egotap_train_pose_head_bwd(h, T._p(posz), T._p(hs1), T._p(dpose), B, T._p(dposz), T._p(dhs1),
+                                                  T._p(G["pose_mlp.pose_fcs.0.weight"]), T._p(G["pose_mlp.pose_fcs.0.bias"]), T._p(gw), T._p(gb), 0, st()))
+        wsb = C.c_size_t()
+        _lib.check(lib.egotap_train_pu_bwd_ws_bytes(h, B, C.byref(wsb)))
+        ws = torch.empty(wsb.value, dtype=torch.uint8, device=dev)
+        ptrs = (C.c_void_p * 14)()
+        c = "skel_sequential_layer.lstm_custom.layers."
+        for i, nme in enumerate(("0.x2f", "0.x2h", "0.b2h", "0.h2h", "1.x2f", "1.x2h", "1.h2h")):
+            ptrs[2 * i] = G[c + nme + ".weight"].data_ptr()
+            ptrs[2 * i + 1] = G[c + nme + ".bias"].data_ptr()
+        _lib.check(lib.egotap_train_pu_bwd(h, T._p(posz), T._p(rotz), B, T._p(S["pu_saved"]), T._p(dhs1), T._p(dposz), T._p(drotz), ptrs, 0,
+                                           T._p(ws), ws.numel(), st()))
+        del ws
+
+        def encoder_bwd(acts, dy):
+            """returns the gradient w.r.t. the gathered fc1 input rows (None for the rotation encoder: its input is data)"""
+            for j in (2, 1, 0):
+                a = acts[j]
+                f = a["name"]
+                dz = T.bn_lrelu_bwd(a["z"], a["y"], dy, P[f + ".bn.weight"], a["mean"], a["rstd"], G[f + ".bn.weight"], G[f + ".bn.bias"])
+                T.gemm_tn(h, dz, a["a_in"], G[f + ".fc.weight"], BT, a["N"], a["K"], loader=a["loader"])
+                T.colsum(dz, G[f + ".fc.bias"], BT, a["N"])
+                if j == 0 and a["loader"] == T.LD_ROT:
+                    return None
+                wt = T.transpose(P[f + ".fc.weight"])                     # [K, N]
+                dy = T.gemm_nt(h, dz, wt, None, BT, a["K"], a["N"], epi=T.TE_NONE)
+            return dy
+
+        encoder_bwd(S["rot_acts"], drotz)
+        dA = encoder_bwd(S["pos_acts"], dposz)                            # [B*T, ppd*ppd*D], heatmap-major
+        dtok = torch.empty((M, D), dtype=torch.float32, device=dev)
+        _lib.check(lib.egotap_train_tokens_scatter(h, T._p(dA), T._p(dtok), B, st()))
+        del dA
+        dx = T.layernorm_bwd(S["xf"], dtok, P[v + "layernorm.weight"], S["mf"], S["rf"], G[v + "layernorm.weight"], G[v + "layernorm.bias"])
+        del dtok
+        for i in reversed(range(p.vit_layers)):
+            L = S["layers"][i]
+            l = f"{v}encoder.layer.{i}."
+            a = l + "attention.attention."
+            # MLP
+            T.gemm_tn(h, dx, L["hid"], G[l + "output.dense.weight"], M, D, 4 * D)
+            T.colsum(dx, G[l + "output.dense.bias"], M, D)
+            dz = T.gemm_nt(h, dx, T.transpose(P[l + "output.dense.weight"]), None, M, 4 * D, D, epi=T.TE_GELU_GRAD, r=L["z"])
+            T.gemm_tn(h, dz, L["y2"], G[l + "intermediate.dense.weight"], M, 4 * D, D)
+            T.colsum(dz, G[l + "intermediate.dense.bias"], M, 4 * D)
+            dy2 = T.gemm_nt(h, dz, T.transpose(P[l + "intermediate.dense.weight"]), None, M, D, 4 * D, epi=T.TE_NONE)
+            del dz
+            dxm = T.layernorm_bwd(L["xm"], dy2, P[l + "layernorm_after.weight"], L["m2"], L["r2"], G[l + "layernorm_after.weight"],
+                                  G[l + "layernorm_after.bias"], dres=dx)
+            # attention
+            T.gemm_tn(h, dxm, L["ctx"], G[l + "attention.output.dense.weight"], M, D, D)
+            T.colsum(dxm, G[l + "attention.output.dense.bias"], M, D)
+            dctx = T.gemm_nt(h, dxm, T.transpose(P[l + "attention.output.dense.weight"]), None, M, D, D, epi=T.TE_NONE)
+            dqkv = T.attention_bwd(L["qkv"], L["ctx"], dctx, L["lse"], B, seq, heads)
+            del dctx
+            wt = torch.empty((D, 3 * D), dtype=torch.float32, device=dev)      # [Wq^T | Wk^T | Wv^T]
+            for s, nme in enumerate(("query", "key", "value")):
+                T.gemm_tn(h, dqkv[:, s * D:], L["y1"], G[a + nme + ".weight"], M, D, D, ldy=3 * D)
+                T.colsum(dqkv[:, s * D:], G[a + nme + ".bias"], M, D, ldy=3 * D)
+                T.transpose(P[a + nme + ".weight"], out=wt[:, s * D:], ldo=3 * D)
+            dy1 = T.gemm_nt(h, dqkv, wt, None, M, D, 3 * D, epi=T.TE_NONE)
+            del dqkv
+            dx = T.layernorm_bwd(L["x"], dy1, P[l + "layernorm_before.weight"], L["m1"], L["r1"], G[l + "layernorm_before.weight"],
+                                 G[l + "layernorm_before.bias"], dres=dxm)
+        # patch embedding: weight, position embeddings, bias / mask token
+        T.gemm_tn(h, dx, S["hm"], G[v + "embeddings.patch_embeddings.projection.weight"], M, D, 256, loader=T.LD_PATCH)
+        dpos = G[v + "embeddings.position_embeddings"]
+        T.colsum(dx, dpos, B, seq * D)                                    # sum over the batch: dx viewed as [B, seq*D]
+        _lib.check(lib.egotap_train_patch_split(h, T._p(dpos), T._p(G[v + "embeddings.patch_embeddings.projection.bias"]),
+                                                T._p(G[v + "embeddings.mask_token"]), 0, st()))
+        ctx.egotap = None
+        return (None, None) + tuple(G[k] for k in keys)
+
+
+class PoseLossFn(torch.autograd.Function):
+    """returns a tensor [2] = (loss_pose, loss_cos_sim) exactly as backward_AutoEncoder weighs them"""
+
+    @staticmethod
+    def forward(ctx, net, pred, gt, lambda_mpjpe, lambda_cos_sim):
+        out, dpred = T.pose_loss(net._ensure_handle(), pred.detach().contiguous(), gt.detach().float().contiguous(), lambda_mpjpe, lambda_cos_sim)
+        ctx.save_for_backward(dpred)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (dpred,) = ctx.saved_tensors
+        # d(out[0] + out[1]) / d pred is what the kernel produced; both weights are 1 in loss_total = sum(losses)
+        scale = dout[0] if dout is not None else 1.0
+        return None, dpred * scale, None, None, None
+
+
+def lift_train_forward(net, hm):
+    """training-mode forward of EgoTAPAutoEncoder through the HIP operators, differentiable w.r.t. net.parameters()"""
+    params = dict(net.named_parameters())
+    return LiftTrainFn.apply(net, hm, *[params[k] for k in _param_order(net.preset)])
+
+
+class EgotapAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction) with the update done by the HIP kernel."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue                        # cls_token / pooler: never receive a gradient, never move
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                T.adamw(p, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], group["lr"], st["step"], b1, b2, group["eps"],
+                        group["weight_decay"])
+        return None

@@ -137,6 +137,8 @@ int egotap_train_bn_lrelu_fwd(const float* z, float* y, const float* gamma, cons
 int egotap_train_bn_lrelu_bwd(const float* z, const float* y, const float* dy, const float* gamma, const float* mean,
                               const float* rstd, float* dz, float* dgamma, float* dbeta, int R, int C, int accumulate,
                               void* ws, size_t ws_bytes, void* stream);
+int egotap_train_qkv_fwd(const float* y, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
+                         const float* bv, float* qkv, int M, int D, void* stream);
 int egotap_train_attention_fwd(const float* qkv, float* ctx, float* lse, int B, int N, int heads, void* stream);
 int egotap_train_attention_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* delta,
                                float* dqkv, int B, int N, int heads, void* stream);

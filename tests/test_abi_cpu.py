@@ -101,5 +101,5 @@ def test_module_mirror_has_reference_state_dict():
     with pytest.raises(L.EgotapError):
         net(torch.zeros(1, 90, 64, 64))          # CPU tensor: no fallback, must raise
     net.train()
-    with pytest.raises(NotImplementedError):
-        net(torch.zeros(1, 90, 64, 64))
+    with pytest.raises(L.EgotapError):
+        net(torch.zeros(1, 90, 64, 64))          # training mode: same rule, no CPU path

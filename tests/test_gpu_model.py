@@ -55,8 +55,8 @@ def test_wrapper_evaluate_matches_oracle_chain():
     # attributes the reference's callers read
     assert m.pred_heatmap_left.shape == (B, 15, 64, 64) and m.pred_limb_heatmap_right.shape == (B, 30, 64, 64)
     assert float(m.pred_heatmap_rec_cat.abs().max()) == 0.0 and m.eval_key == "mpjpe"
-    with pytest.raises(NotImplementedError):
-        m.optimize_parameters()
+    with pytest.raises(RuntimeError):
+        m.optimize_parameters()              # created with isTrain = False
 
 
 def test_wrapper_gt_heatmap_path():

@@ -69,9 +69,11 @@ def test_gemm_nt_training_epilogues():
     z_ref = xd @ wd.T + b.double()
     _close(T.gemm_nt(h, x.cuda(), w.cuda(), None, M, N, K, epi=T.TE_NONE), xd @ wd.T, 2e-5)
     _close(T.gemm_nt(h, x.cuda(), w.cuda(), None, M, N, K, epi=T.TE_ACCUM, r=r.cuda()), xd @ wd.T + r.double(), 2e-5)
-    z = torch.empty((M, N), device="cuda")
+    zbuf = torch.full((M + 300, N), 7.0, device="cuda")        # canary rows behind z: the ragged last tile must not touch them
+    z = zbuf[:M]
     hcu = T.gemm_nt(h, x.cuda(), w.cuda(), b.cuda(), M, N, K, epi=T.TE_BIAS_GELU_SAVE, z=z)
     _close(z, z_ref, 2e-5)
+    assert float((zbuf[M:] - 7.0).abs().max()) == 0.0
     _close(hcu, 0.5 * z_ref * (1 + torch.erf(z_ref / math.sqrt(2))), 2e-5)
     dg = 0.5 * (1 + torch.erf(r.double() / math.sqrt(2))) + r.double() * torch.exp(-0.5 * r.double() ** 2) / math.sqrt(2 * math.pi)
     _close(T.gemm_nt(h, x.cuda(), w.cuda(), None, M, N, K, epi=T.TE_GELU_GRAD, r=r.cuda()), (xd @ wd.T) * dg, 3e-5)

@@ -1,0 +1,114 @@
+"""GPU parity of one whole training step of the lifting head (forward in train mode, loss, backward, AdamW -- all
+HIP, PyTorch only as autograd glue) against golden vectors captured from ONE optimisation step of the reference's own
+modules (tools/make_golden.py gen_train) and against the reference wrapper's optimize_parameters() semantics."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from egotap_amd.synthetic import synth_input, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _fresh_net():
+    from egotap_amd import networks, spec
+    from egotap_amd.options import preset_defaults
+    p = spec.lift_preset("UnrealEgo")
+    net = networks.EgoTAPAutoEncoder(preset_defaults("UnrealEgo"), input_channel_scale=2)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
+    return net.cuda(), p
+
+
+def _check_against_golden(net, g, losses):
+    norms = dict(zip(g["grad_keys"], g["grad_norms"]))
+    params = dict(net.named_parameters())
+    assert sorted(k for k, v in params.items() if v.grad is not None) == sorted(g["grad_keys"])
+    assert sorted(k for k, v in params.items() if v.grad is None) == sorted(g["no_grad_keys"])
+    np.testing.assert_allclose(losses[0], g["loss_pose"], rtol=1e-4)
+    np.testing.assert_allclose(losses[1], g["loss_cos_sim"], rtol=2e-3, atol=1e-7)
+    worst = 0.0
+    for k in g["grad_keys"]:
+        gr = params[k].grad
+        got = gr.reshape(-1)[:: max(1, gr.numel() // 257)].cpu().numpy()
+        scale = max(norms[k] / np.sqrt(gr.numel()), 1e-12)
+        err = np.abs(got - g["g:" + k]).max()
+        assert err <= 5e-3 * scale + 5e-9, f"{k}: sample err {err:.3e} vs typical magnitude {scale:.3e}"
+        np.testing.assert_allclose(float(gr.double().norm()), norms[k], rtol=1e-3, atol=5e-9 * np.sqrt(gr.numel()) + 1e-8, err_msg=k)  # zero-by-symmetry gradients are noise
+        worst = max(worst, err / scale)
+    return worst
+
+
+def test_train_forward_backward_adamw_match_reference():
+    from egotap_amd.training import EgotapAdamW, PoseLossFn
+    g = np.load(os.path.join(GOLD, "train_step_ue_b2.npz"))
+    net, p = _fresh_net()
+    net.train()
+    hm = torch.from_numpy(synth_input("hm_train", (2, 90, 64, 64))).cuda()
+    gt = torch.from_numpy(synth_input("gt_train", (2, 16, 3), -1.0, 1.0)).cuda()
+    opt = EgotapAdamW(net.parameters(), lr=1e-3, eps=1e-4, weight_decay=0.0)
+    opt.zero_grad()
+    pose = net(hm)[0]
+    assert pose.requires_grad
+    np.testing.assert_allclose(pose.detach().cpu().numpy(), g["pose"], atol=1e-4)
+    both = PoseLossFn.apply(net, pose, gt, 0.1, -0.01)
+    both.sum().backward()
+    torch.cuda.synchronize()
+    _check_against_golden(net, g, both.detach().cpu().numpy())
+    sd = net.state_dict()
+    for k in g.files:
+        if k.startswith("buf:"):
+            np.testing.assert_allclose(sd[k[4:]].cpu().numpy(), g[k], atol=2e-6, err_msg=k)
+    opt.step()
+    torch.cuda.synchronize()
+    params = dict(net.named_parameters())
+    for k in g["grad_keys"]:
+        got = params[k].detach().reshape(-1)[:: max(1, params[k].numel() // 257)].cpu().numpy()
+        np.testing.assert_allclose(got, g["p:" + k], atol=3e-5, err_msg=k)
+    for k in g["no_grad_keys"]:        # cls_token / pooler never move
+        assert params[k].grad is None
+
+
+def test_training_step_is_deterministic_and_eval_unchanged():
+    net, p = _fresh_net()
+    hm = torch.from_numpy(synth_input("hm_train", (3, 90, 64, 64))).cuda()
+    gt = torch.from_numpy(synth_input("gt_train3", (3, 16, 3), -1.0, 1.0)).cuda()
+    from egotap_amd.training import PoseLossFn
+    grads = []
+    for _ in range(2):
+        net.train()
+        net.zero_grad()
+        PoseLossFn.apply(net, net(hm)[0], gt, 0.1, -0.01).sum().backward()
+        grads.append({k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None})
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k        # fixed-order reductions: bitwise reproducible
+    net.eval()
+    with torch.no_grad():
+        assert net(hm)[0].requires_grad is False
+
+
+def test_wrapper_optimize_parameters():
+    """create_model(opt) with isTrain: set_input -> optimize_parameters -> get_current_errors, as train.py drives it"""
+    from egotap_amd import models, spec
+    from egotap_amd.options import preset_defaults
+    g = np.load(os.path.join(GOLD, "train_step_ue_b2.npz"))
+    opt = preset_defaults("UnrealEgo")
+    opt.isTrain, opt.use_gt_heatmap, opt.lr, opt.opt_eps, opt.weight_decay = True, True, 1e-3, 1e-4, 0.0
+    m = models.create_model(opt)
+    p = spec.lift_preset("UnrealEgo")
+    m.net_AutoEncoder.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
+    hm = torch.from_numpy(synth_input("hm_train", (2, 90, 64, 64)))
+    data = {"input_rgb_left": torch.zeros(2, 3, 256, 256), "input_rgb_right": torch.zeros(2, 3, 256, 256),
+            "gt_heatmap_left": hm[:, :15], "gt_heatmap_right": hm[:, 15:30], "gt_limb_heatmap_left": hm[:, 30:60],
+            "gt_limb_heatmap_right": hm[:, 60:], "gt_local_pose": torch.from_numpy(synth_input("gt_train", (2, 16, 3), -1.0, 1.0))}
+    m.set_input(data)
+    m.optimize_parameters()
+    errs = m.get_current_errors()
+    np.testing.assert_allclose(errs["pose"], g["loss_pose"], rtol=1e-4)
+    np.testing.assert_allclose(errs["cos_sim"], g["loss_cos_sim"], rtol=2e-3, atol=1e-7)
+    params = dict(m.net_AutoEncoder.named_parameters())
+    for k in list(g["grad_keys"])[::7]:
+        got = params[k].detach().reshape(-1)[:: max(1, params[k].numel() // 257)].cpu().numpy()
+        np.testing.assert_allclose(got, g["p:" + k], atol=3e-5, err_msg=k)
