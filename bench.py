@@ -173,6 +173,47 @@ def bench_full(args, p, dev, rank, world, barrier, lib, L):
     }
 
 
+def bench_train(args, p, dev, rank, world, barrier):
+    """Secondary measurement: one optimisation step of the lifting head (train-mode forward from resident heatmaps,
+    loss, backward, gradient all-reduce when world > 1, AdamW), fp32, same per-GPU batch as the headline."""
+    import torch
+    from egotap_amd import models, parallel, spec
+    from egotap_amd.options import preset_defaults
+    from egotap_amd.synthetic import synth_input, synth_state_dict
+    opt = preset_defaults(args.preset)
+    opt.gpu_ids, opt.isTrain, opt.use_gt_heatmap = [dev.index], True, True
+    opt.lr, opt.opt_eps, opt.weight_decay = 1e-3, 1e-4, 0.0
+    m = models.create_model(opt)
+    m.net_AutoEncoder.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
+    B, J = args.train_batch, p.n_joints_hm
+    hm = torch.from_numpy(synth_input(f"hm_train_rank{rank}", (min(B, 16), p.in_channels, p.hm_size, p.hm_size))).to(dev)
+    hm = hm.repeat((B + hm.shape[0] - 1) // hm.shape[0], 1, 1, 1)[:B].contiguous()
+    gt = torch.from_numpy(synth_input(f"gt_train_rank{rank}", (B, p.out_joints, 3), -20.0, 20.0)).to(dev)
+    data = {"input_rgb_left": torch.zeros(1, 3, 4, 4), "input_rgb_right": torch.zeros(1, 3, 4, 4), "gt_heatmap_left": hm[:, :J],
+            "gt_heatmap_right": hm[:, J:2 * J], "gt_limb_heatmap_left": hm[:, 2 * J:4 * J], "gt_limb_heatmap_right": hm[:, 4 * J:],
+            "gt_local_pose": gt}
+    m.set_input(data)
+    m.optimize_parameters()                      # warm-up (allocator, BN buffers, optimizer state)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        m.optimize_parameters()
+    torch.cuda.synchronize(dev)
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    barrier()
+    errs = m.get_current_errors()
+    fps = world * B * args.train_steps / elapsed
+    flops = 3.0 * lift_flops_per_frame(p)        # algorithmic: backward = 2 x forward (dgrad + wgrad)
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    return {"value": round(fps, 1), "unit": "stereo frames/s (training step)", "ms_per_step": round(1e3 * elapsed / args.train_steps, 2),
+            "steps": args.train_steps, "batch_per_gpu": B, "dtype": "f32", "flops_per_frame": flops,
+            "end_to_end_tflops_per_gpu": round(fps * flops / world / 1e12, 2),
+            "end_to_end_frac_of_f32_mfma_peak": round(fps * flops / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "loss_pose": errs.get("pose"), "loss_cos_sim": errs.get("cos_sim"), "peak_hbm_gib": round(peak_gb, 1),
+            "note": "heatmap estimators frozen and fed from resident heatmaps (use_gt_heatmap); attention backward recomputes "
+                    "S three times (8 MFMA products instead of 5), not counted in flops_per_frame"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +226,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--lift-only", action="store_true", help="skip the secondary full-pipeline (RGB -> joints) measurement")
     ap.add_argument("--full-steps", type=int, default=3)
+    ap.add_argument("--train-steps", type=int, default=2, help="timed optimisation steps of the secondary training measurement (0 = skip)")
+    ap.add_argument("--train-batch", type=int, default=256)
     args = ap.parse_args()
 
     import torch
@@ -262,6 +305,10 @@ def main():
     if not args.lift_only:
         full = bench_full(args, p, dev, rank, world, barrier, lib, L)
 
+    train = None
+    if not args.lift_only and args.train_steps > 0:
+        train = bench_train(args, p, dev, rank, world, barrier)
+
     cpu = None
     gpu_vs_oracle = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -287,7 +334,7 @@ def main():
             "end_to_end_tflops_per_gpu": round(fps * flops_frame / world / 1e12, 2),
             "end_to_end_frac_of_f32_mfma_peak": round(fps * flops_frame / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roof, "cpu_baseline": cpu, "max_abs_diff_vs_oracle": gpu_vs_oracle,
-            "full_pipeline_from_rgb": full,
+            "full_pipeline_from_rgb": full, "train_step_lifting_head": train,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

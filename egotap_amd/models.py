@@ -159,6 +159,8 @@ class EgoTAPAutoEncoderModel(nn.Module):
         self.loss_total = 0.0
         self.backward_AutoEncoder()
         self.loss_total.backward()
+        from . import parallel                              # data parallel: average gradients over the ranks (RCCL); no-op for one rank
+        parallel.allreduce_gradients(list(self.net_AutoEncoder.parameters()))
         for o in self.optimizers:
             o.step()
 

@@ -53,3 +53,35 @@ def test_two_rank_gloo(tmp_path):
         got = np.load(tmp_path / f"r{rank}.npy")
         assert got[0] == 1.5                                    # max over ranks
         np.testing.assert_array_equal(got[1:], ref)             # same gathered batch on every rank, rank order
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    P.init_from_env("gloo")
+    g = torch.Generator().manual_seed(7)
+    shapes = [(300, 200), (17,), (64, 3, 3), (5,), (1000,)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    for i, prm in enumerate(params):
+        base = torch.rand(prm.shape, generator=g)
+        prm.grad = None if i == 3 else base * (rank + 1)      # parameter 3 never gets a gradient (like cls_token / pooler)
+    n = P.allreduce_gradients(params, bucket_bytes=100_000)   # small buckets: several collectives in flight
+    assert n >= 2 and params[3].grad is None
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), torch.cat([q.grad.reshape(-1) for q in params if q.grad is not None]).numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_gradient_allreduce_two_ranks(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(7)
+    ref = []
+    for i, shp in enumerate([(300, 200), (17,), (64, 3, 3), (5,), (1000,)]):
+        base = torch.rand(shp, generator=g)
+        if i != 3:
+            ref.append((base * 1.5).reshape(-1))               # mean of 1x and 2x
+    ref = torch.cat(ref).numpy()
+    for rank in range(2):
+        np.testing.assert_allclose(np.load(tmp_path / f"g{rank}.npy"), ref, rtol=1e-6)
