@@ -24,6 +24,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 256 CUs @ 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 
 
 def lift_flops_per_frame(p) -> float:
@@ -108,6 +109,60 @@ def cpu_baseline(p, sd_np, batch: int, reps: int):
     med = ts[len(ts) // 2]
     return {"value": batch / med, "unit": "stereo frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle/lift_ref.lift_forward, B={batch}, fp32, {reps} timed passes (median), torch CPU threads={cores}"}, out
+
+
+def measured_traffic(by_kernel, batch):
+    """HBM bytes per launch of the GEMM kernels from the PMC counters of the committed rocprofv3 run
+    (profiles/rNN_traffic.json, written by tools/summarize_prof.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes over
+    this same command at B = 256), weighted by this run's launch counts.  None when no profile matches."""
+    import glob
+    import re
+    if batch != 256:
+        return None, None
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    prof = json.load(open(files[-1]))["kernels"]
+
+    def key(name):
+        base = name.split("<", 1)[0]
+        ids = re.findall(r"(ALoad\w+|Epi\w+|bf16x3)", name)
+        return (base,) + tuple(ids)
+    table = {key(k): v for k, v in prof.items()}
+    tot, n = 0.0, 0
+    for name, v in by_kernel.items():
+        t = table.get(key(name))
+        if t is None:
+            continue
+        tot += v["launches"] * (t["read_bytes"] + t["write_bytes"])
+        n += v["launches"]
+    if n == 0:
+        return None, None
+    return tot / n, os.path.basename(files[-1])
+
+
+def timed_lift(net, hm, steps, warmup, lib, L, h, barrier, dev, timing, world):
+    """W warm-up + K timed forwards bracketed by barrier + synchronize; returns (elapsed max over ranks, pose, timing detail)"""
+    import torch
+    from egotap_amd import parallel
+    for _ in range(max(warmup, 1)):
+        pose = net.predict_pose(hm)
+    barrier()
+    lib.check(L.egotap_timing_enable(h, int(timing)))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pose = net.predict_pose(hm)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    barrier()
+    elapsed = parallel.max_over_ranks(elapsed, dev)
+    out = None
+    if timing:
+        n, ms, fl = C.c_int(), C.c_double(), C.c_double()
+        lib.check(L.egotap_timing_read(h, C.byref(n), C.byref(ms), C.byref(fl)))
+        out = (n.value, ms.value, fl.value, json.loads(L.egotap_timing_detail(h).decode()))
+        lib.check(L.egotap_timing_enable(h, 0))
+    return elapsed, pose, out
 
 
 def bench_full(args, p, dev, rank, world, barrier, lib, L):
@@ -226,6 +281,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--lift-only", action="store_true", help="skip the secondary full-pipeline (RGB -> joints) measurement")
     ap.add_argument("--full-steps", type=int, default=3)
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary bf16x3 fast-mode measurement")
     ap.add_argument("--train-steps", type=int, default=2, help="timed optimisation steps of the secondary training measurement (0 = skip)")
     ap.add_argument("--train-batch", type=int, default=256)
     args = ap.parse_args()
@@ -265,41 +321,59 @@ def main():
     def barrier():
         parallel.barrier(dev)
 
-    for _ in range(max(args.warmup, 1)):
-        pose = net.predict_pose(hm)
-    barrier()
     timing = not args.no_kernel_timing
-    lib.check(L.egotap_timing_enable(h, int(timing)))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pose = net.predict_pose(hm)
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    barrier()
-    elapsed = parallel.max_over_ranks(elapsed, dev)
+    elapsed, pose, t1 = timed_lift(net, hm, args.steps, args.warmup, lib, L, h, barrier, dev, timing, world)
 
     roof = None
     if timing:
-        n, ms, fl = C.c_int(), C.c_double(), C.c_double()
-        lib.check(L.egotap_timing_read(h, C.byref(n), C.byref(ms), C.byref(fl)))
-        detail = json.loads(L.egotap_timing_detail(h).decode())
-        lib.check(L.egotap_timing_enable(h, 0))
+        n_launch, ms_total, fl_total, detail = t1
         by_kernel = {}
         for d in detail:
             k = by_kernel.setdefault(d["kernel"], {"launches": 0, "ms": 0.0, "flops": 0.0})
             k["launches"] += d["launches"]; k["ms"] += d["ms"]; k["flops"] += d["flops"]
-        achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        achieved = fl_total / (ms_total * 1e-3) / 1e12 if ms_total > 0 else 0.0
         roof = {
             "bound": "mfma", "kernel": "gemm_f32_kernel (all instantiations, v_mfma_f32_32x32x2_f32)",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "launches": n.value, "avg_launch_ms": round(ms.value / max(n.value, 1), 4),
-            "gemm_share_of_step_time": round(ms.value * 1e-3 / (elapsed if world == 1 else elapsed), 4),
+            "algorithmic_bytes": None, "traffic_source": None,
+            "launches": n_launch, "avg_launch_ms": round(ms_total / max(n_launch, 1), 4),
+            "gemm_share_of_step_time": round(ms_total * 1e-3 / elapsed, 4),
             "by_kernel": {k: {"launches": v["launches"], "avg_ms": round(v["ms"] / v["launches"], 4),
                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in by_kernel.items()},
             "by_role": {d["role"]: {"avg_ms": round(d["ms"] / d["launches"], 4),
                                     "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)} for d in detail},
         }
+
+        traffic, src = measured_traffic(by_kernel, B)
+        if traffic is not None:
+            roof["traffic"] = round(traffic)
+            roof["traffic_source"] = f"profiles/{src}: rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE per launch, launch-weighted over the GEMM kernels"
+        # compulsory fp32 bytes of the same launches: A (M*K, or the gathered heatmap bytes) + W (N*K) + C (M*N), launch-weighted
+        M_, D_ = B * p.seq, p.vit_dim
+        per_layer = [(M_, 3 * D_, D_), (M_, D_, D_), (M_, 4 * D_, D_), (M_, D_, 4 * D_)]
+        shapes = [(M_, D_, 256)] + per_layer * p.vit_layers + [(B * p.tokens, 2048, p.ppd * p.ppd * D_), (B * p.tokens, 2048, 2 * p.hm_size ** 2)]
+        roof["algorithmic_bytes"] = round(sum(4.0 * (m * k + n_ * k + m * n_) for m, n_, k in shapes) / len(shapes))
+
+    # opt-in fast mode: same path with the large GEMMs on the bf16 matrix cores as hi+lo splits (egotap_set_precision)
+    fast = None
+    if not args.no_fast_mode:
+        net.set_precision("bf16x3")
+        try:
+            el3, pose3, t3 = timed_lift(net, hm, args.steps, args.warmup, lib, L, h, barrier, dev, timing, world)
+        finally:
+            net.set_precision("f32")
+        fps3 = world * B * args.steps / el3
+        fast = {"value": round(fps3, 1), "unit": "stereo frames/s", "ms_per_step": round(1e3 * el3 / args.steps, 3),
+                "dtype": "bf16x3 (fp32 operands split hi+lo in registers, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; "
+                         "fp32 tensors in HBM; attention, LayerNorm, PU chain, pose head stay exact fp32)",
+                "max_abs_diff_vs_f32_mode": float((pose3 - pose).abs().max()),
+                "speedup_vs_f32_mode": round(fps3 / (world * B * args.steps / elapsed), 3)}
+        if t3 is not None and t3[1] > 0:
+            fast["gemm_algorithmic_tflops"] = round(t3[2] / (t3[1] * 1e-3) / 1e12, 2)
+            fast["gemm_executed_bf16_tflops"] = round(3 * t3[2] / (t3[1] * 1e-3) / 1e12, 2)
+            fast["gemm_frac_of_bf16_mfma_peak"] = round(3 * t3[2] / (t3[1] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
+            fast["gemm_share_of_step_time"] = round(t3[1] * 1e-3 / el3, 4)
 
     full = None
     if not args.lift_only:
@@ -317,6 +391,10 @@ def main():
         hm_c = torch.from_numpy(synth_input("hm_cpu_baseline", (args.cpu_batch, p.in_channels, p.hm_size, p.hm_size))).to(dev)
         got = net.predict_pose(hm_c).cpu()
         gpu_vs_oracle = float((got - ref).abs().max())
+        if fast is not None:
+            net.set_precision("bf16x3")
+            fast["max_abs_diff_vs_oracle"] = float((net.predict_pose(hm_c).cpu() - ref).abs().max())
+            net.set_precision("f32")
 
     if rank == 0:
         frames = world * B * args.steps
@@ -334,7 +412,7 @@ def main():
             "end_to_end_tflops_per_gpu": round(fps * flops_frame / world / 1e12, 2),
             "end_to_end_frac_of_f32_mfma_peak": round(fps * flops_frame / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roof, "cpu_baseline": cpu, "max_abs_diff_vs_oracle": gpu_vs_oracle,
-            "full_pipeline_from_rgb": full, "train_step_lifting_head": train,
+            "fast_mode_bf16x3": fast, "full_pipeline_from_rgb": full, "train_step_lifting_head": train,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "conv_f32.h"
 #include "gemm_f32.h"
+#include "gemm_bf16.h"
 #include "layernorm.h"
 #include "pu_chain.h"
 
@@ -54,6 +55,8 @@ extern "C" const char* egotap_gemm_tile_name(int tile) {
         case 10: return "pipe256x128x16/8w";
         case 11: return "pipe256x256x16/8w";
         case 12: return "persist256x256x16/8w";
+        case 13: return "persist256x256x16/8w/bf16x3";
+        case 14: return "persist256x256x32/8w/bf16";
         default: return nullptr;
     }
 }
@@ -97,6 +100,7 @@ struct egotap_handle_s {
     bool hm_resolved[EGOTAP_NET_COUNT] = {false, false, false};
     HmParams hp[EGOTAP_NET_COUNT];
     int debug_stop = 0;
+    int precision = EGOTAP_PREC_F32;   // arithmetic of the large GEMMs (egotap_set_precision)
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;   // start/stop pairs
@@ -415,6 +419,11 @@ template <class AL, class Epi>
 static hipError_t gemm_big(Handle* h, const char* role, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc,
                            int M, int N, int K, hipStream_t s) {
     using Cfg = PipeD;
+    if (h && h->precision == EGOTAP_PREC_BF16X3) {
+        static const std::string kname3 = std::string("gemm_bf16_persist_kernel<256x256x16,bf16x3,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
+        GemmTimer t(h, s, role, kname3.c_str(), 2.0 * M * N * K);
+        return gemm_bf16_persist_launch<BfCfg<3>, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
+    }
     static const std::string kname = std::string("gemm_f32_persist_kernel<256x256x16,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
     GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
     return gemm_f32_persist_launch<Cfg, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
@@ -456,6 +465,13 @@ extern "C" int egotap_lift_intermediate(egotap_handle h, int B, const char* name
     else if (!strcmp(name, "rot_embed")) { *offset = w.ROTZ; *numel = (int64_t)B * h->T * h->hid; }
     else if (!strcmp(name, "skel_embed")) { *offset = w.HS1; *numel = (int64_t)h->J * B * h->H; }
     else { egotap_set_error("unknown intermediate '%s'", name); return EGOTAP_ERR_INVALID; }
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_set_precision(egotap_handle h, int mode) {
+    EGO_CHECK(h, "null handle");
+    EGO_CHECK(mode == EGOTAP_PREC_F32 || mode == EGOTAP_PREC_BF16X3, "egotap_set_precision: unknown mode %d", mode);
+    h->precision = mode;
     return EGOTAP_OK;
 }
 
@@ -842,6 +858,8 @@ extern "C" int egotap_linear_f32(const float* x, const float* w, const float* b,
         case 10: e = gemm_f32_pipe_launch<PipeC>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
         case 11: e = gemm_f32_pipe_launch<PipeD>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, s); break;
         case 12: e = gemm_f32_persist_launch<PipeD>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
+        case 13: e = gemm_bf16_persist_launch<BfCfg<3>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
+        case 14: e = gemm_bf16_persist_launch<BfCfg<1>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
         default: egotap_set_error("unknown tile id %d", tile); return EGOTAP_ERR_INVALID;
     }
     if (e == hipErrorInvalidValue) {

@@ -10,6 +10,7 @@ from . import build as _build
 ERR_NAMES = {1: "EGOTAP_ERR_INVALID", 2: "EGOTAP_ERR_HIP", 3: "EGOTAP_ERR_UNBOUND", 4: "EGOTAP_ERR_WORKSPACE"}
 NET_LIFT, NET_HM_POS, NET_HM_ROT = 0, 1, 2
 F32, I64 = 0, 1
+PRECISIONS = {"f32": 0, "bf16x3": 1}      # egotap.h EGOTAP_PREC_*
 
 
 class EgotapConfig(C.Structure):
@@ -35,6 +36,7 @@ _PROTOS = {
     "egotap_lift_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egotap_lift_intermediate": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "egotap_lift_debug_stop": (C.c_int, [C.c_void_p, C.c_int]),
+    "egotap_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "egotap_hm_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "egotap_hm_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),

@@ -140,6 +140,15 @@ class EgoTAPAutoEncoder(nn.Module):
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
         return self._ws
 
+    def set_precision(self, mode: str = "f32"):
+        """Arithmetic of the large GEMMs (egotap.h egotap_set_precision): "f32" = exact fp32 MFMA (default),
+        "bf16x3" = fp32 operands split into hi + lo bf16, three bf16 MFMAs per product, fp32 accumulate (opt-in fast mode)."""
+        if mode not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
+        _lib.check(_lib.load().egotap_set_precision(self._ensure_handle(), _lib.PRECISIONS[mode]))
+        self.precision = mode
+        return self
+
     def intermediate(self, name: str, B: int):
         """View of an intermediate of the LAST forward inside the workspace (parity tests)."""
         off, n = C.c_size_t(), C.c_int64()

@@ -91,6 +91,15 @@ int egotap_hm_forward(egotap_handle h, int net, const float* left, const float* 
 /* name in {"layer0".."layer4" (backbone pyramid, images interleaved n = 2b + eye), "conv_up3","conv_up2","conv_up1"} */
 int egotap_hm_intermediate(egotap_handle h, int B, const char* name, size_t* offset, int64_t* numel);
 
+/* Arithmetic of the large GEMMs of the lifting head (nn.Linear layers of the ViT and fc1; everything else is always fp32).
+ *   EGOTAP_PREC_F32     v_mfma_f32_32x32x2_f32: exact fp32 products (default; what the headline benchmark measures)
+ *   EGOTAP_PREC_BF16X3  each fp32 operand split in registers into hi + lo bf16 (16 significant bits), a*b taken as
+ *                       a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; operands and
+ *                       results stay fp32 in HBM.  Error ~2^-16 per product against 2^-24: opt-in fast mode, the reference
+ *                       offers the analogous knob as --use_amp (egotap_autoencoder_model.py:177-183). */
+enum { EGOTAP_PREC_F32 = 0, EGOTAP_PREC_BF16X3 = 1 };
+int egotap_set_precision(egotap_handle h, int mode);
+
 /* debugging aid for parity tests: 0 = full forward (default); 1 = return after the embeddings;
  * 2+i = return after ViT layer i.  The state is then readable as intermediate "x". */
 int egotap_lift_debug_stop(egotap_handle h, int stage);

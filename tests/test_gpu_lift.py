@@ -103,3 +103,28 @@ def test_empty_batch_and_bad_input():
         net.predict_pose(torch.zeros(1, p.in_channels - 1, 64, 64, device="cuda"))
     with pytest.raises(lib.EgotapError):
         net.predict_pose(torch.zeros(1, p.in_channels, 64, 64))
+
+
+@pytest.mark.parametrize("tag,preset", [("ue", "UnrealEgo"), ("ec", "EgoCap")])
+def test_lift_forward_bf16x3_mode_within_north_star_tolerance(tag, preset):
+    """Opt-in fast mode (egotap_set_precision BF16X3): same gate as fp32 (1e-4 on the joints vs the reference golden);
+    observed ~5e-6.  Also: deterministic, and switching back restores the exact-fp32 result bit for bit."""
+    from gpu_util import lift_net
+    g = np.load(os.path.join(GOLD, f"lift_fwd_{tag}_b2.npz"))
+    net, _, p = lift_net(preset)
+    hm = torch.from_numpy(synth_input(f"hm_{tag}", (2, p.in_channels, 64, 64))).cuda()
+    exact = net.predict_pose(hm).clone()
+    try:
+        net.set_precision("bf16x3")
+        fast = net.predict_pose(hm).clone()
+        again = net.predict_pose(hm).clone()
+    finally:
+        net.set_precision("f32")
+    back = net.predict_pose(hm).clone()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(fast.cpu().numpy(), g["pose"], atol=TOL, rtol=0)
+    assert np.abs(fast.cpu().numpy() - g["pose"]).max() < 3e-5
+    assert torch.equal(fast, again) and torch.equal(back, exact)
+    assert not torch.equal(fast, exact)           # the mode really switched kernels
+    with pytest.raises(ValueError):
+        net.set_precision("fp8")

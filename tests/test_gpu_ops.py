@@ -128,3 +128,45 @@ def test_linear_persistent_tile_many_shapes(M, N, K):
     _close(y, ref, atol=2e-6 * math.sqrt(K) + 1e-6)
     y1 = lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=8)
     assert torch.equal(y, y1)            # same k order as the 128x128 pipelined kernel: bit-identical
+
+
+# ---- bf16 matrix-core GEMMs with fp32 operands in HBM (gemm_bf16.h): tile 13 = bf16x3 split, tile 14 = plain bf16
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 1024), (300, 256, 16), (257, 256, 48), (2048, 1024, 4096)])
+def test_linear_bf16x3_error_model(M, N, K):
+    """hi+lo split keeps 16 significant bits per operand and drops a_lo*b_lo: error <= ~2^-16 per product, random signs.
+    Checked against float64: rms error within 8x of the exact-fp32 kernel's and far below plain bf16's."""
+    from egotap_amd import lib
+    x, w, b = _rand((M, K), 31), _rand((N, K), 32, -1.0, 1.0) / math.sqrt(K), _rand((N,), 33)
+    ref = x.double() @ w.double().T + b.double()
+    scale = float((x.double().abs() @ w.double().abs().T).mean())       # sum |a||b| per output
+    y3 = lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=13).cpu().double()
+    err3 = (y3 - ref).abs()
+    assert float(err3.max()) < 2.0 ** -15 * scale, (float(err3.max()), scale)
+    assert float(err3.pow(2).mean().sqrt()) < 2.0 ** -17 * scale
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 1024), (300, 256, 32), (257, 256, 96)])
+def test_linear_bf16_plain(M, N, K):
+    """plain bf16 operands (RNE), fp32 accumulate: equals the float64 product of the bf16-rounded operands to fp32 rounding"""
+    from egotap_amd import lib
+    x, w, b = _rand((M, K), 41), _rand((N, K), 42, -1.0, 1.0) / math.sqrt(K), _rand((N,), 43)
+    xr, wr = x.bfloat16().double(), w.bfloat16().double()
+    ref = xr @ wr.T + b.double()
+    y = lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=14)
+    _close(y, ref, atol=2e-6 * math.sqrt(K))
+
+
+def test_linear_bf16x3_identity_asymmetric_and_ragged_rows():
+    """A = I: hi+lo of 1.0 is exact, so the result is W^T rounded to 16 bits of mantissa; rows past M are never written."""
+    from egotap_amd import lib
+    K = 128
+    x = torch.eye(K)
+    w = (torch.arange(256 * K, dtype=torch.float32).reshape(256, K) * 0.5)
+    y = lib.linear(x.cuda(), w.cuda(), torch.zeros(256).cuda(), tile=13).cpu()
+    assert float((y - w.T).abs().max()) <= float(w.abs().max()) * 2.0 ** -16
+    M, N = 300, 512
+    xb = _rand((M, K), 51).cuda()
+    wb, bb = _rand((N, K), 52).cuda(), _rand((N,), 53).cuda()
+    full = lib.linear(xb, wb, bb, tile=13)
+    part = lib.linear(xb[:37].contiguous(), wb, bb, tile=13)
+    assert torch.equal(full[:37], part)          # per-row result independent of M (fixed k order)

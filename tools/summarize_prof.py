@@ -71,6 +71,15 @@ def main():
         clk = v["GRBM_GUI_ACTIVE"] / 8 / v["ns"] if v and v["ns"] else float("nan")
         busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8 * 1024) if v and v["GRBM_GUI_ACTIVE"] else float("nan")
         lines.append(f"| `{k}` | {s['Calls']} | {avg:.4f} | {float(s['Percentage']):.2f} | {fr:.1f} | {wr:.1f} | {clk:.2f} | {busy:.3f} |")
+    import json
+    traffic = {}
+    for s in stats:
+        k = short(s["Name"])
+        if fetch[k] and write[k]:
+            traffic[k] = {"read_bytes": 2 * sum(fetch[k]) / len(fetch[k]) * 1024, "write_bytes": sum(write[k]) / len(write[k]) * 1024,
+                          "launches_profiled": len(fetch[k]), "avg_ms": float(s["AverageNs"]) / 1e6}
+    json.dump({"tag": tag, "note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE, separate passes; "
+               "B = 256 per GPU", "kernels": traffic}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
     open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
