@@ -57,6 +57,8 @@ extern "C" const char* egotap_gemm_tile_name(int tile) {
         case 12: return "persist256x256x16/8w";
         case 13: return "persist256x256x16/8w/bf16x3";
         case 14: return "persist256x256x32/8w/bf16";
+        case 15: return "persist256x256x16/8w/bf16x3/interleaved";
+        case 16: return "persist256x256x32/8w/bf16/interleaved";
         default: return nullptr;
     }
 }
@@ -422,7 +424,7 @@ static hipError_t gemm_big(Handle* h, const char* role, const AL& al, const SegM
     if (h && h->precision == EGOTAP_PREC_BF16X3) {
         static const std::string kname3 = std::string("gemm_bf16_persist_kernel<256x256x16,bf16x3,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
         GemmTimer t(h, s, role, kname3.c_str(), 2.0 * M * N * K);
-        return gemm_bf16_persist_launch<BfCfg<3>, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
+        return gemm_bf16_persist_launch<BfCfg<3, 1>, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
     }
     static const std::string kname = std::string("gemm_f32_persist_kernel<256x256x16,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
     GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
@@ -860,6 +862,8 @@ extern "C" int egotap_linear_f32(const float* x, const float* w, const float* b,
         case 12: e = gemm_f32_persist_launch<PipeD>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
         case 13: e = gemm_bf16_persist_launch<BfCfg<3>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
         case 14: e = gemm_bf16_persist_launch<BfCfg<1>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
+        case 15: e = gemm_bf16_persist_launch<BfCfg<3, 1>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
+        case 16: e = gemm_bf16_persist_launch<BfCfg<1, 1>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
         default: egotap_set_error("unknown tile id %d", tile); return EGOTAP_ERR_INVALID;
     }
     if (e == hipErrorInvalidValue) {

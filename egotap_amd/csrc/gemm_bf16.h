@@ -17,18 +17,20 @@
 //                        NP = 1: group 0 = k0..15,     group 1 = k16..31,    slab depth 32.
 // A lane's fragment of one 32x32x16 MFMA is the 16 bytes (8 bf16) at  row*80 + group*32 + (lane>>5)*16.
 //
-// Pipeline per slab and wave (64 x 128 sub-tile = 2 x 4 MFMA tiles): the A fragments of a slab live in registers
-// (double buffered across slabs), the B fragments of tile column j+1 are read while column j multiplies; global loads
-// run FOUR slabs ahead in two register sets (a slab lasts ~0.6 us here, a fifth of the fp32 kernel's, so one set in
-// flight no longer covers the L2 latency); one barrier per slab.
+// Pipeline per slab and wave (64 x 128 sub-tile = 2 x 4 MFMA tiles): the A fragments of a slab live in registers, the B
+// fragments of tile column j+1 are read while column j multiplies; global loads run FOUR slabs ahead in two register
+// sets (a slab lasts ~0.6 us here, a fifth of the fp32 kernel's, so one set in flight no longer covers the L2 latency);
+// one barrier per slab.  Register budget is the constraint (8 waves = 256 VGPRs each: 128 accumulators, 32 staging,
+// 32 fragments): a spill reload inside the slab loop is a vector-memory operation that the in-order vmcnt makes wait
+// for every older global load.
 #pragma once
 #include "gemm_f32.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int NP_>
+template <int NP_, int SCHED_ = 0>
 struct BfCfg {
-    static constexpr int NP = NP_;
+    static constexpr int NP = NP_, SCHED = SCHED_;
     static constexpr int BM = 256, BN = 256, WM = 4, WN = 2, MINW = 2;
     static constexpr int BK = NP_ == 1 ? 32 : 16;          // floats of k per slab
     static constexpr int THREADS = 64 * WM * WN;
@@ -110,8 +112,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_ker
     set_rows(0);
 
     f32x4 ga[2][V4], gb[2][V4];         // two global-load register sets (slab s uses set s & 1)
-    bf16x8 fa[2][2][TM];                // [slab parity][group][i]
+    bf16x8 fa[2][TM];                   // [group][i]   A fragments of the current slab
     bf16x8 fb[2][2];                    // [j parity][group]
+    bf16x8 cv0_, cv1_;                  // converted staging data on its way to LDS
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -133,34 +136,44 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_ker
             if (++l_tile < my_n) set_rows(l_tile);                                                   \
         }                                                                                            \
     }
-    // registers -> bf16 -> LDS slab BUF.  NP = 3: this thread's 8 floats give hi -> group 0, lo -> group 1, each at
-    // half sg; NP = 1: its 16 floats give the two halves of group sg.
-#define LSTORE(SET, BUF)                                                                             \
+    // registers -> bf16, half H (0 / 1) of this thread's floats of one operand.  NP = 3: floats 4H..4H+3 of its 8 give
+    // elements 4H.. of hi (cv0_) and lo (cv1_); NP = 1: float4 pair H of its 16 floats gives cv0_ (H = 0) or cv1_ (H = 1).
+#define CONV_HALF(G, H)                                                                              \
     {                                                                                                \
-        float* ap_ = As + (BUF) * BM * LDR + s_off;                                                  \
-        float* bp_ = Bs + (BUF) * BN * LDR + s_off;                                                  \
         if (NP == 3) {                                                                               \
-            bf16x8 h_, l_;                                                                           \
-            bf16_split8(ga[SET][0], ga[SET][1], h_, l_);                                             \
-            *(bf16x8*)(ap_ + 4 * sg) = h_;                                                           \
-            *(bf16x8*)(ap_ + 8 + 4 * sg) = l_;                                                       \
-            bf16_split8(gb[SET][0], gb[SET][1], h_, l_);                                             \
-            *(bf16x8*)(bp_ + 4 * sg) = h_;                                                           \
-            *(bf16x8*)(bp_ + 8 + 4 * sg) = l_;                                                       \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                          \
+                const __bf16 h_ = (__bf16)G[H][e];                                                   \
+                cv0_[4 * (H) + e] = h_;                                                              \
+                cv1_[4 * (H) + e] = (__bf16)(G[H][e] - (float)h_);                                   \
+            }                                                                                        \
+        } else if ((H) == 0) {                                                                       \
+            cv0_ = bf16_round8(G[0], G[1]);                                                          \
         } else {                                                                                     \
-            *(bf16x8*)(ap_ + 8 * sg) = bf16_round8(ga[SET][0], ga[SET][1]);                          \
-            *(bf16x8*)(ap_ + 8 * sg + 4) = bf16_round8(ga[SET][V4 - 2], ga[SET][V4 - 1]);            \
-            *(bf16x8*)(bp_ + 8 * sg) = bf16_round8(gb[SET][0], gb[SET][1]);                          \
-            *(bf16x8*)(bp_ + 8 * sg + 4) = bf16_round8(gb[SET][V4 - 2], gb[SET][V4 - 1]);            \
+            cv1_ = bf16_round8(G[V4 - 2], G[V4 - 1]);                                                \
         }                                                                                            \
     }
-#define AFRAGS(PAR, BUF)                                                                             \
+    // ... and into LDS: NP = 3: hi -> group 0, lo -> group 1, each at half sg; NP = 1: the two halves of group sg
+#define CWRITE(BASE)                                                                                 \
     {                                                                                                \
-        const float* p_ = As + (BUF) * BM * LDR + a_off;                                             \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                             \
-            fa[PAR][0][i] = *(const bf16x8*)(p_ + i * 32 * LDR);                                     \
-            fa[PAR][1][i] = *(const bf16x8*)(p_ + i * 32 * LDR + 8);                                 \
+        float* p_ = (BASE) + s_off;                                                                  \
+        if (NP == 3) {                                                                               \
+            *(bf16x8*)(p_ + 4 * sg) = cv0_;                                                          \
+            *(bf16x8*)(p_ + 8 + 4 * sg) = cv1_;                                                      \
+        } else {                                                                                     \
+            *(bf16x8*)(p_ + 8 * sg) = cv0_;                                                          \
+            *(bf16x8*)(p_ + 8 * sg + 4) = cv1_;                                                      \
         }                                                                                            \
+    }
+#define LSTORE(SET, BUF)                                                                             \
+    {                                                                                                \
+        CONV_HALF(ga[SET], 0) CONV_HALF(ga[SET], 1) CWRITE(As + (BUF) * BM * LDR)                    \
+        CONV_HALF(gb[SET], 0) CONV_HALF(gb[SET], 1) CWRITE(Bs + (BUF) * BN * LDR)                    \
+    }
+#define AFRAG(BUF, I)                                                                                \
+    {                                                                                                \
+        const float* p_ = As + (BUF) * BM * LDR + a_off + (I) * 32 * LDR;                            \
+        fa[0][I] = *(const bf16x8*)(p_);                                                             \
+        fa[1][I] = *(const bf16x8*)(p_ + 8);                                                         \
     }
 #define BFRAGS(PAR, BUF, J)                                                                          \
     {                                                                                                \
@@ -168,28 +181,37 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_ker
         fb[PAR][0] = *(const bf16x8*)(p_);                                                           \
         fb[PAR][1] = *(const bf16x8*)(p_ + 8);                                                       \
     }
-#define MFMAS(APAR, BPAR, J)                                                                         \
+#define MFMAS_I(I, BPAR, J)                                                                          \
     {                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                             \
-            acc[i][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[APAR][0][i], fb[BPAR][0], acc[i][J], 0, 0, 0); \
-            if (NP == 3) {                                                                           \
-                acc[i][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[APAR][0][i], fb[BPAR][1], acc[i][J], 0, 0, 0); \
-                acc[i][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[APAR][1][i], fb[BPAR][0], acc[i][J], 0, 0, 0); \
-            } else {                                                                                 \
-                acc[i][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[APAR][1][i], fb[BPAR][1], acc[i][J], 0, 0, 0); \
-            }                                                                                        \
+        acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][I], fb[BPAR][0], acc[I][J], 0, 0, 0); \
+        if (NP == 3) {                                                                               \
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][I], fb[BPAR][1], acc[I][J], 0, 0, 0); \
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][I], fb[BPAR][0], acc[I][J], 0, 0, 0); \
+        } else {                                                                                     \
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][I], fb[BPAR][1], acc[I][J], 0, 0, 0); \
         }                                                                                            \
     }
+    // pattern for the scheduler inside one fenced region: NM times (1 MFMA, NV VALU)
+#define INTERLEAVE(NM, NV)                                                                           \
+    _Pragma("unroll") for (int q_ = 0; q_ < (NM); ++q_) {                                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                           \
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                                          \
+    }
 
-    // prologue: slabs 0 and 1 staged, slabs 2 and 3 in flight, first fragments of slab 0 in registers
+    // prologue: slabs 0 and 1 staged, slabs 2 and 3 in flight, first fragments of slab 0 in registers.
+    // GLOAD / LSTORE are UNCONDITIONAL everywhere: past the end of this block's slab stream the loader re-reads slabs of
+    // its last tile (valid memory) and the LDS write lands in a slab nobody reads.  With `if (gs + 2 < total)` guards the
+    // compiler's waitcnt pass loses count at the control-flow joins and drains EVERY outstanding load (s_waitcnt
+    // vmcnt(0)) before each LDS write.
     GLOAD(0)
-    if (total > 1) GLOAD(1)
+    GLOAD(1)
     LSTORE(0, 0)
-    if (total > 1) LSTORE(1, 1)
-    if (total > 2) GLOAD(0)
-    if (total > 3) GLOAD(1)
+    LSTORE(1, 1)
+    GLOAD(0)
+    GLOAD(1)
     __syncthreads();
-    AFRAGS(0, 0)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) AFRAG(0, i)
     BFRAGS(0, 0, 0)
 
     int buf = 0, c_tile = 0, c_kt = 0;
@@ -229,24 +251,45 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_ker
         }
     };
 
+    // One slab.  The A fragments are single buffered: row block i of the NEXT slab is re-read into the same registers right
+    // after the last MFMAs that use them have issued (tile column TN-1), under the MFMAs of the other row block / the
+    // first ones of the next slab.  SCHED = 1: the staged slab gs+2 is converted under the MFMAs of the last two tile
+    // columns (A operand under column TN-2, W operand under TN-1), ~4 VALU per MFMA -- an MFMA holds the issue port 8 of
+    // its 32 cycles.  Done as one block mid-slab (SCHED = 0) the two co-resident waves of a SIMD convert at the same time
+    // and the matrix pipe idles (bf16x3: 303 -> 355 TFLOP/s); plain bf16 is load-bound and prefers the early request.
     auto body = [&](auto PT, int gs) __attribute__((always_inline)) {
-        constexpr int P = decltype(PT)::value;          // parity of gs: A-fragment set and global-load set of this slab
+        constexpr int P = decltype(PT)::value;          // parity of gs: global-load register set of slabs gs+2 / gs+4
+        constexpr int NMI = NP == 3 ? 3 : 2, NV = NP == 3 ? 4 : 2;
         const int b1 = buf + 1 >= NS ? buf + 1 - NS : buf + 1;
         const int b2 = b1 + 1 >= NS ? b1 + 1 - NS : b1 + 1;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            if (j + 1 < TN) {
-                BFRAGS((j + 1) & 1, buf, j + 1)
-            } else if (gs + 1 < total) {                // next slab (published by the previous barrier)
-                AFRAGS(P ^ 1, b1)
-                BFRAGS(0, b1, 0)
+            if (j + 1 < TN) BFRAGS((j + 1) & 1, buf, j + 1) else BFRAGS(0, b1, 0)   // next column / next slab (published)
+            __builtin_amdgcn_sched_barrier(0);
+            const bool conv = Cfg::SCHED == 1 && j >= TN - 2;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                MFMAS_I(i, j & 1, j)
+                if (conv) {
+                    if (j == TN - 2) CONV_HALF(ga[P], i) else CONV_HALF(gb[P], i)
+                    INTERLEAVE(NMI, NV)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == TN - 1) {
+                    AFRAG(b1, i)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            MFMAS(P, j & 1, j)
-            __builtin_amdgcn_sched_barrier(0);
-            if (j == TN / 2 - 1) {
-                if (gs + 2 < total) LSTORE(P, b2)       // slab gs+2 (requested two slabs ago) -> the free LDS slab
-                if (gs + 4 < total) GLOAD(P)            // request slab gs+4 into the registers just freed
+            if (Cfg::SCHED == 1) {
+                if (j == TN - 2) CWRITE(As + b2 * BM * LDR)
+                if (j == TN - 1) {
+                    CWRITE(Bs + b2 * BN * LDR)
+                    GLOAD(P)                            // request slab gs+4 into the registers just freed
+                }
+                if (j >= TN - 2) __builtin_amdgcn_sched_barrier(0);
+            } else if (j == TN / 2 - 1) {
+                LSTORE(P, b2)                           // slab gs+2 (requested two slabs ago) -> the free LDS slab
+                GLOAD(P)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -265,10 +308,13 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_ker
     }
     if (gs < total) body(std::integral_constant<int, 0>{}, gs);
 #undef GLOAD
+#undef CONV_HALF
+#undef CWRITE
 #undef LSTORE
-#undef AFRAGS
+#undef AFRAG
 #undef BFRAGS
-#undef MFMAS
+#undef MFMAS_I
+#undef INTERLEAVE
 }
 
 template <class Cfg, class ALoad, class Epi>
