@@ -626,6 +626,11 @@ static int hm_resolve(Handle* h, int net) {
 }
 
 //                      taps stride log2W CO_T WCO WPX CI_S
+using C3s1_128_co64 = ConvCfg<9, 1, 7,  64, 2, 4, 8>;    // 128-wide maps: 512x512 RGB (BASELINE config 5)
+using C3s1_128      = ConvCfg<9, 1, 7, 128, 2, 4, 8>;
+using C3s2_64       = ConvCfg<9, 2, 6,  64, 2, 4, 8>;
+using C1s1_128      = ConvCfg<1, 1, 7,  64, 2, 4, 32>;
+using C1s2_64       = ConvCfg<1, 2, 6,  64, 2, 4, 8>;
 using C3s1_64_co64  = ConvCfg<9, 1, 6,  64, 2, 4, 8>;
 using C3s1_64       = ConvCfg<9, 1, 6, 128, 2, 4, 8>;
 using C3s1_32       = ConvCfg<9, 1, 5, 128, 2, 4, 8>;
@@ -651,23 +656,27 @@ static hipError_t conv(Handle* h, const char* role, const ConvArgs& a, hipStream
     return conv_f32_launch<Cfg>(a, s);
 }
 
-// dispatch on (taps, stride, output width); wout in {64, 32, 16, 8}
+// dispatch on (taps, stride, output width); wout in {128, 64, 32, 16, 8}
 static hipError_t conv_any(Handle* h, const char* role, int taps, int stride, int wout, const ConvArgs& a, hipStream_t s) {
     if (taps == 9 && stride == 1) {
+        if (wout == 128) return a.Cout <= 64 ? conv<C3s1_128_co64>(h, role, a, s) : conv<C3s1_128>(h, role, a, s);
         if (wout == 64) return a.Cout <= 64 ? conv<C3s1_64_co64>(h, role, a, s) : conv<C3s1_64>(h, role, a, s);
         if (wout == 32) return conv<C3s1_32>(h, role, a, s);
         if (wout == 16) return conv<C3s1_16>(h, role, a, s);
         if (wout == 8) return conv<C3s1_8>(h, role, a, s);
     } else if (taps == 9 && stride == 2) {
+        if (wout == 64) return conv<C3s2_64>(h, role, a, s);
         if (wout == 32) return conv<C3s2_32>(h, role, a, s);
         if (wout == 16) return conv<C3s2_16>(h, role, a, s);
         if (wout == 8) return conv<C3s2_8>(h, role, a, s);
     } else if (taps == 1 && stride == 1) {
+        if (wout == 128) return conv<C1s1_128>(h, role, a, s);
         if (wout == 64) return conv<C1s1_64>(h, role, a, s);
         if (wout == 32) return conv<C1s1_32>(h, role, a, s);
         if (wout == 16) return conv<C1s1_16>(h, role, a, s);
         if (wout == 8) return conv<C1s1_8>(h, role, a, s);
     } else if (taps == 1 && stride == 2) {
+        if (wout == 64) return conv<C1s2_64>(h, role, a, s);
         if (wout == 32) return conv<C1s2_32>(h, role, a, s);
         if (wout == 16) return conv<C1s2_16>(h, role, a, s);
         if (wout == 8) return conv<C1s2_8>(h, role, a, s);
@@ -735,7 +744,7 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
     EGO_CHECK(B > 0 && left && right && out && ws, "egotap_hm_forward: null argument or negative batch");
     EGO_CHECK((((uintptr_t)left | (uintptr_t)right | (uintptr_t)out) & 15) == 0 && ((uintptr_t)ws & 255) == 0, "pointers must be 16-byte (ws: 256-byte) aligned");
     const int S0 = h->cfg.hm_size * 4, s64 = S0 / 4, s32 = S0 / 8, s16 = S0 / 16, s8 = S0 / 32;
-    EGO_CHECK(s64 == 64, "this build instantiates the conv kernels for 256x256 RGB (64x64 heatmaps) only");
+    EGO_CHECK(s64 == 64 || s64 == 128, "this build instantiates the conv kernels for 256x256 and 512x512 RGB (64x64 / 128x128 heatmaps)");
     int rc = hm_resolve(h, net);
     if (rc != EGOTAP_OK) return rc;
     const HmWs w = hm_ws(h, B);

@@ -28,12 +28,12 @@ def lift_net(preset="UnrealEgo", hm=64, device="cuda"):
     return _cache[key]
 
 
-def hm_net(which="pos", device="cuda"):
+def hm_net(which="pos", device="cuda", preset="UnrealEgo", hm=64):
     """HeatMap_UnrealEgo_Shared (position or sin/cos net) with hash-RNG weights on the GPU, eval mode."""
     from egotap_amd.synthetic import synth_hm_state_dict
-    key = ("hm", which, device)
+    key = ("hm", which, device, preset, hm)
     if key not in _cache:
-        opt = make_opt("UnrealEgo")
+        opt = make_opt(preset, hm)
         if which == "pos":
             opt.num_rot_heatmap = 0
         else:

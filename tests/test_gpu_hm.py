@@ -64,3 +64,21 @@ def test_hm_writes_into_channel_slice_and_batch_independent():
     torch.cuda.synchronize()
     assert torch.equal(cat[:, :30], alone.expand(5, -1, -1, -1))      # bit-identical per sample, any batch
     assert float((cat[:, 30:] - 7.0).abs().max()) == 0.0              # nothing outside the slice is touched
+
+
+def test_hm_forward_512_rgb_egocap_matches_oracle():
+    """BASELINE config 5 geometry: EgoCap preset, 512x512 RGB -> 128x128 heatmaps (128-wide conv instantiations,
+    stride-2 convs from 128 to 64)."""
+    from gpu_util import hm_net
+    from oracle import hm_ref as H
+    net, sd_np = hm_net("pos", preset="EgoCap", hm=128)
+    left = torch.from_numpy(synth_input("rgbL_ec512", (1, 3, 512, 512), -2.0, 2.0))
+    right = torch.from_numpy(synth_input("rgbR_ec512", (1, 3, 512, 512), -2.0, 2.0))
+    sd = H.to_torch_sd(sd_np, torch.float64)
+    with torch.no_grad():
+        ref = H.hm_forward(left.double(), right.double(), sd)
+    y = net(left.cuda(), right.cuda())
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (1, 34, 128, 128)
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err < 1e-4 * max(1.0, ref.abs().max().item()), f"max err {err:.3e} (max |ref| {ref.abs().max().item():.3e})"

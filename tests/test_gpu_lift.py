@@ -128,3 +128,25 @@ def test_lift_forward_bf16x3_mode_within_north_star_tolerance(tag, preset):
     assert not torch.equal(fast, exact)           # the mode really switched kernels
     with pytest.raises(ValueError):
         net.set_precision("fp8")
+
+
+def test_lift_forward_hm128_egocap_matches_oracle():
+    """BASELINE config 5 geometry: EgoCap preset on 128x128 heatmaps (512x512 RGB): 768^2 ViT image, 2304 tokens,
+    fc1 K = 65536 / 32768.  fp32 and the bf16x3 fast mode against the float64 oracle."""
+    from gpu_util import lift_net
+    from oracle import lift_ref as O
+    net, sd_np, p = lift_net("EgoCap", hm=128)
+    assert p.seq == 2304 and p.in_channels == 102
+    hm = torch.from_numpy(synth_input("hm_ec128", (1, p.in_channels, 128, 128)))
+    sd = O.to_torch_sd(sd_np, torch.float64)
+    with torch.no_grad():
+        ref = O.lift_forward(hm.double(), sd, p).numpy()
+    pose = net.predict_pose(hm.cuda())
+    try:
+        net.set_precision("bf16x3")
+        fast = net.predict_pose(hm.cuda())
+    finally:
+        net.set_precision("f32")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pose.cpu().numpy(), ref, atol=TOL, rtol=0)
+    np.testing.assert_allclose(fast.cpu().numpy(), ref, atol=TOL, rtol=0)
