@@ -228,9 +228,10 @@ def bench_full(args, p, dev, rank, world, barrier, lib, L):
     }
 
 
-def bench_train(args, p, dev, rank, world, barrier):
+def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None):
     """Secondary measurement: one optimisation step of the lifting head (train-mode forward from resident heatmaps,
-    loss, backward, gradient all-reduce when world > 1, AdamW), fp32, same per-GPU batch as the headline."""
+    loss, backward, gradient all-reduce when world > 1, AdamW).  mode = arithmetic of the GEMMs (egotap_set_precision):
+    f32 exact, bf16x3 split (fp32-grade gradients), bf16 (BASELINE config 3: bf16 MFMA, fp32 accumulate and master weights)."""
     import torch
     from egotap_amd import models, parallel, spec
     from egotap_amd.options import preset_defaults
@@ -240,7 +241,9 @@ def bench_train(args, p, dev, rank, world, barrier):
     opt.lr, opt.opt_eps, opt.weight_decay = 1e-3, 1e-4, 0.0
     m = models.create_model(opt)
     m.net_AutoEncoder.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
-    B, J = args.train_batch, p.n_joints_hm
+    m.net_AutoEncoder.set_precision(mode)
+    torch.cuda.reset_peak_memory_stats(dev)
+    B, J = batch or args.train_batch, p.n_joints_hm
     hm = torch.from_numpy(synth_input(f"hm_train_rank{rank}", (min(B, 16), p.in_channels, p.hm_size, p.hm_size))).to(dev)
     hm = hm.repeat((B + hm.shape[0] - 1) // hm.shape[0], 1, 1, 1)[:B].contiguous()
     gt = torch.from_numpy(synth_input(f"gt_train_rank{rank}", (B, p.out_joints, 3), -20.0, 20.0)).to(dev)
@@ -260,8 +263,10 @@ def bench_train(args, p, dev, rank, world, barrier):
     fps = world * B * args.train_steps / elapsed
     flops = 3.0 * lift_flops_per_frame(p)        # algorithmic: backward = 2 x forward (dgrad + wgrad)
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    del m, hm, gt, data
+    torch.cuda.empty_cache()
     return {"value": round(fps, 1), "unit": "stereo frames/s (training step)", "ms_per_step": round(1e3 * elapsed / args.train_steps, 2),
-            "steps": args.train_steps, "batch_per_gpu": B, "dtype": "f32", "flops_per_frame": flops,
+            "steps": args.train_steps, "batch_per_gpu": B, "dtype": mode, "flops_per_frame": flops,
             "end_to_end_tflops_per_gpu": round(fps * flops / world / 1e12, 2),
             "end_to_end_frac_of_f32_mfma_peak": round(fps * flops / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "loss_pose": errs.get("pose"), "loss_cos_sim": errs.get("cos_sim"), "peak_hbm_gib": round(peak_gb, 1),
@@ -284,6 +289,7 @@ def main():
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary bf16x3 fast-mode measurement")
     ap.add_argument("--train-steps", type=int, default=2, help="timed optimisation steps of the secondary training measurement (0 = skip)")
     ap.add_argument("--train-batch", type=int, default=256)
+    ap.add_argument("--train-batch-bf16", type=int, default=1024, help="per-GPU batch of the bf16 training measurement (BASELINE config 3)")
     args = ap.parse_args()
 
     import torch
@@ -382,6 +388,9 @@ def main():
     train = None
     if not args.lift_only and args.train_steps > 0:
         train = bench_train(args, p, dev, rank, world, barrier)
+        train["bf16x3"] = bench_train(args, p, dev, rank, world, barrier, mode="bf16x3")
+        # BASELINE configs[2]: UnrealEgo training step (fwd+bwd+AdamW), bf16, batch 1024 per GPU
+        train["config3_bf16_b1024"] = bench_train(args, p, dev, rank, world, barrier, mode="bf16", batch=args.train_batch_bf16)
 
     cpu = None
     gpu_vs_oracle = None

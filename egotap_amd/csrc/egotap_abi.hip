@@ -426,6 +426,11 @@ static hipError_t gemm_big(Handle* h, const char* role, const AL& al, const SegM
         GemmTimer t(h, s, role, kname3.c_str(), 2.0 * M * N * K);
         return gemm_bf16_persist_launch<BfCfg<3, 1>, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
     }
+    if (h && h->precision == EGOTAP_PREC_BF16) {
+        static const std::string kname1 = std::string("gemm_bf16_persist_kernel<256x256x32,bf16,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
+        GemmTimer t(h, s, role, kname1.c_str(), 2.0 * M * N * K);
+        return gemm_bf16_persist_launch<BfCfg<1, 1>, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
+    }
     static const std::string kname = std::string("gemm_f32_persist_kernel<256x256x16,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
     GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
     return gemm_f32_persist_launch<Cfg, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
@@ -472,7 +477,7 @@ extern "C" int egotap_lift_intermediate(egotap_handle h, int B, const char* name
 
 extern "C" int egotap_set_precision(egotap_handle h, int mode) {
     EGO_CHECK(h, "null handle");
-    EGO_CHECK(mode == EGOTAP_PREC_F32 || mode == EGOTAP_PREC_BF16X3, "egotap_set_precision: unknown mode %d", mode);
+    EGO_CHECK(mode == EGOTAP_PREC_F32 || mode == EGOTAP_PREC_BF16X3 || mode == EGOTAP_PREC_BF16, "egotap_set_precision: unknown mode %d", mode);
     h->precision = mode;
     return EGOTAP_OK;
 }
@@ -904,6 +909,7 @@ extern "C" int egotap_attention_f32(const float* qkv, float* ctx, int B, int N, 
 // egotap_amd/autograd.py.  Each takes caller-owned device buffers and the caller's stream.
 #include "attention_bwd_f32.h"
 #include "gemm_tn_f32.h"
+#include "gemm_tn_bf16.h"
 #include "train_ops.h"
 
 using TnBig = TnCfg<256, 256, 16, 4, 2>;     // 8 waves, 64x128 per wave
@@ -913,7 +919,11 @@ enum { LD_PLAIN = 0, LD_PATCH = 1, LD_TOKENS = 2, LD_ROT = 3, LD_STEREO = 4, LD_
 enum { TE_NONE = 0, TE_BIAS = 1, TE_BIAS_RES = 2, TE_BIAS_GELU_SAVE = 3, TE_ACCUM = 4, TE_GELU_GRAD = 5, TE_PATCH = 6 };
 
 template <class AL, class Epi>
-static hipError_t nt_any(const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K, hipStream_t s) {
+static hipError_t nt_any(Handle* h, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K, hipStream_t s) {
+    if (N % 256 == 0 && K % 32 == 0 && M >= 1024 && h->precision == EGOTAP_PREC_BF16X3)
+        return gemm_bf16_persist_launch<BfCfg<3, 1>, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
+    if (N % 256 == 0 && K % 32 == 0 && M >= 1024 && h->precision == EGOTAP_PREC_BF16)
+        return gemm_bf16_persist_launch<BfCfg<1, 1>, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
     if (N % 256 == 0 && K % 16 == 0 && M >= 1024) return gemm_f32_persist_launch<PipeD, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
     if (N % 128 == 0 && K % 32 == 0) return gemm_f32_launch<TileA, AL, Epi>(al, W, epi, C, ldc, M, N, K, s);
     return hipErrorInvalidValue;
@@ -924,12 +934,12 @@ static hipError_t nt_epi(const AL& al, const float* w, const float* b, float* y,
                          float* z, const LiftParams* lp, Handle* h, hipStream_t s) {
     const SegMat W = segmat1(w, N, K);
     switch (epi) {
-        case TE_NONE: return nt_any(al, W, EpiNone{}, y, N, M, N, K, s);
-        case TE_BIAS: return nt_any(al, W, EpiBias{segvec1(b, N)}, y, N, M, N, K, s);
-        case TE_BIAS_RES: return nt_any(al, W, EpiBiasRes{segvec1(b, N), r, N}, y, N, M, N, K, s);
-        case TE_BIAS_GELU_SAVE: return nt_any(al, W, EpiBiasGeluSave{segvec1(b, N), z, N}, y, N, M, N, K, s);
-        case TE_ACCUM: return nt_any(al, W, EpiAccum{r, N}, y, N, M, N, K, s);
-        case TE_GELU_GRAD: return nt_any(al, W, EpiGeluGrad{r, N}, y, N, M, N, K, s);
+        case TE_NONE: return nt_any(h, al, W, EpiNone{}, y, N, M, N, K, s);
+        case TE_BIAS: return nt_any(h, al, W, EpiBias{segvec1(b, N)}, y, N, M, N, K, s);
+        case TE_BIAS_RES: return nt_any(h, al, W, EpiBiasRes{segvec1(b, N), r, N}, y, N, M, N, K, s);
+        case TE_BIAS_GELU_SAVE: return nt_any(h, al, W, EpiBiasGeluSave{segvec1(b, N), z, N}, y, N, M, N, K, s);
+        case TE_ACCUM: return nt_any(h, al, W, EpiAccum{r, N}, y, N, M, N, K, s);
+        case TE_GELU_GRAD: return nt_any(h, al, W, EpiGeluGrad{r, N}, y, N, M, N, K, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -965,14 +975,18 @@ extern "C" int egotap_train_patch_fwd(egotap_handle h, const float* hm, int B, c
     const int S = h->cfg.hm_size, D = h->D, M = B * h->seq;
     ALoadPatch al{hm, h->C, S, h->seq, h->side, h->ppd, h->grid, h->T};
     EpiPatch ep{b, mask_tok, pos, D, h->seq, h->side, h->ppd, h->grid, h->T};
-    EGO_HIP((gemm_f32_persist_launch<PipeD, ALoadPatch, EpiPatch>(al, segmat1(w, D, 256), ep, x, D, M, D, 256, device_cu_count(), (hipStream_t)stream)));
+    EGO_HIP((gemm_big(h, "patch_embed", al, segmat1(w, D, 256), ep, x, D, M, D, 256, (hipStream_t)stream)));
     return EGOTAP_OK;
 }
 
 template <class XL>
-static hipError_t tn_any(const float* dy, const XL& xl, float* dw, float* ws, size_t ws_bytes, int M, int N, int K, int acc, hipStream_t s,
+static hipError_t tn_any(Handle* h, const float* dy, const XL& xl, float* dw, float* ws, size_t ws_bytes, int M, int N, int K, int acc, hipStream_t s,
                          long ldy = 0) {
     if (ldy <= 0) ldy = N;
+    if (N % 256 == 0 && K % 256 == 0 && M >= 1024 && h->precision == EGOTAP_PREC_BF16X3)
+        return gemm_tn_bf16_launch<TnBfCfg<3>, XL>(dy, ldy, xl, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
+    if (N % 256 == 0 && K % 256 == 0 && M >= 1024 && h->precision == EGOTAP_PREC_BF16)
+        return gemm_tn_bf16_launch<TnBfCfg<1>, XL>(dy, ldy, xl, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
     if (N % 256 == 0 && K % 256 == 0) return gemm_tn_f32_launch<TnBig, XL>(dy, ldy, xl, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
     if (N % 128 == 0 && K % 128 == 0) return gemm_tn_f32_launch<TnSmall, XL>(dy, ldy, xl, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
     return hipErrorInvalidValue;
@@ -987,13 +1001,13 @@ extern "C" int egotap_train_gemm_tn(egotap_handle h, int loader, const float* dy
     float* w = (float*)ws;
     hipError_t e;
     switch (loader) {
-        case LD_PLAIN: e = tn_any(dy, ALoadPlain{x, K}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
-        case LD_PATCH: e = tn_any(dy, ALoadPatch{x, h->C, S, h->seq, h->side, h->ppd, h->grid, h->T}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
-        case LD_TOKENS: e = tn_any(dy, ALoadTokens{x, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
-        case LD_ROT: e = tn_any(dy, ALoadRot{x, h->C, h->J, S * S}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
-        case LD_STEREO: e = tn_any(dy, ALoadStereo{x, Bsz, h->J, h->hid}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
+        case LD_PLAIN: e = tn_any(h, dy, ALoadPlain{x, K}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
+        case LD_PATCH: e = tn_any(h, dy, ALoadPatch{x, h->C, S, h->seq, h->side, h->ppd, h->grid, h->T}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
+        case LD_TOKENS: e = tn_any(h, dy, ALoadTokens{x, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
+        case LD_ROT: e = tn_any(h, dy, ALoadRot{x, h->C, h->J, S * S}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
+        case LD_STEREO: e = tn_any(h, dy, ALoadStereo{x, Bsz, h->J, h->hid}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy); break;
         case LD_STEREO_GATED:
-            e = tn_any(dy, ALoadStereoGated{ALoadStereo{x, Bsz, h->J, h->hid}, aux, h->H + 2 * h->hid, h->H}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy);
+            e = tn_any(h, dy, ALoadStereoGated{ALoadStereo{x, Bsz, h->J, h->hid}, aux, h->H + 2 * h->hid, h->H}, dw, w, ws_bytes, M, N, K, accumulate, s, ldy);
             break;
         default: egotap_set_error("egotap_train_gemm_tn: bad loader %d", loader); return EGOTAP_ERR_INVALID;
     }
@@ -1283,7 +1297,7 @@ extern "C" int egotap_train_pu_bwd(egotap_handle h, const float* posz, const flo
         return EGOTAP_OK;
     };
     auto wgrad = [&](const float* dy, int N, int loader_plain_K, const float* xin, float* dwp) -> hipError_t {   // plain X [JB, K]
-        return tn_any(dy, ALoadPlain{xin, loader_plain_K}, dwp, part, part_bytes, JB, N, loader_plain_K, accumulate, s);
+        return tn_any(h, dy, ALoadPlain{xin, loader_plain_K}, dwp, part, part_bytes, JB, N, loader_plain_K, accumulate, s);
     };
     auto bias = [&](const float* dy, int N, float* dbp) -> hipError_t { return colsum_f32_launch(dy, N, dbp, part, part_bytes, JB, N, accumulate, s); };
 
@@ -1306,7 +1320,7 @@ extern "C" int egotap_train_pu_bwd(egotap_handle h, const float* posz, const flo
     EGO_HIP(wgrad(dG, 4 * H, H, HP, grads[H2H0_W]));
     EGO_HIP(bias(dG, 4 * H, grads[H2H0_B]));
     // bridge branch: gates += b2h(sigmoid(fb) * bridge)
-    EGO_HIP(tn_any(dG, ALoadStereoGated{ALoadStereo{rotz, B, J, hid}, F0, NF0, H}, grads[B2H0_W], part, part_bytes, JB, 4 * H, x, accumulate, s));
+    EGO_HIP(tn_any(h, dG, ALoadStereoGated{ALoadStereo{rotz, B, J, hid}, F0, NF0, H}, grads[B2H0_W], part, part_bytes, JB, 4 * H, x, accumulate, s));
     EGO_HIP(bias(dG, 4 * H, grads[B2H0_B]));
     transpose(p.b2h0_w, 4 * H, x);
     EGO_HIP(nt(dG, JB, x, 4 * H, dBp, nullptr));
@@ -1315,9 +1329,9 @@ extern "C" int egotap_train_pu_bwd(egotap_handle h, const float* posz, const flo
         hipLaunchKernelGGL(pu_bridge_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dBp, F0, NF0, H, rotz, dF, drotz, B, J, hid);
     }
     // input branch: gates += x2h(x), F = x2f(x)
-    EGO_HIP(tn_any(dG, ALoadStereo{posz, B, J, hid}, grads[X2H0_W], part, part_bytes, JB, 4 * H, x, accumulate, s));
+    EGO_HIP(tn_any(h, dG, ALoadStereo{posz, B, J, hid}, grads[X2H0_W], part, part_bytes, JB, 4 * H, x, accumulate, s));
     EGO_HIP(bias(dG, 4 * H, grads[X2H0_B]));
-    EGO_HIP(tn_any(dF, ALoadStereo{posz, B, J, hid}, grads[X2F0_W], part, part_bytes, JB, NF0, x, accumulate, s));
+    EGO_HIP(tn_any(h, dF, ALoadStereo{posz, B, J, hid}, grads[X2F0_W], part, part_bytes, JB, NF0, x, accumulate, s));
     EGO_HIP(bias(dF, NF0, grads[X2F0_B]));
     transpose(p.x2h0_w, 4 * H, x);
     EGO_HIP(nt(dG, JB, x, 4 * H, dXs, nullptr));
@@ -1411,13 +1425,12 @@ extern "C" int egotap_train_tokens_scatter(egotap_handle h, const float* dA, flo
 
 
 // fused Q|K|V projection (three nn.Linear of ViTSelfAttention, modeling_vit.py:212-214) into one [M, 3D] buffer
-extern "C" int egotap_train_qkv_fwd(const float* y, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
+extern "C" int egotap_train_qkv_fwd(egotap_handle h, const float* y, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
                                     const float* bv, float* qkv, int M, int D, void* stream) {
-    EGO_CHECK(y && wq && bq && wk && bk && wv && bv && qkv, "egotap_train_qkv_fwd: null argument");
+    EGO_CHECK(h && y && wq && bq && wk && bk && wv && bv && qkv, "egotap_train_qkv_fwd: null argument");
     EGO_CHECK(D % 256 == 0, "egotap_train_qkv_fwd: hidden size must be a multiple of 256");
     SegMat W; W.p[0] = wq; W.p[1] = wk; W.p[2] = wv; W.seg = D; W.ld = D;
     SegVec b; b.p[0] = bq; b.p[1] = bk; b.p[2] = bv; b.seg = D;
-    EGO_HIP((gemm_f32_persist_launch<PipeD, ALoadPlain, EpiBias>(ALoadPlain{y, D}, W, EpiBias{b}, qkv, 3L * D, M, 3 * D, D, device_cu_count(),
-                                                                 (hipStream_t)stream)));
+    EGO_HIP((gemm_big(h, "qkv", ALoadPlain{y, D}, W, EpiBias{b}, qkv, 3L * D, M, 3 * D, D, (hipStream_t)stream)));
     return EGOTAP_OK;
 }

@@ -10,7 +10,7 @@ from . import build as _build
 ERR_NAMES = {1: "EGOTAP_ERR_INVALID", 2: "EGOTAP_ERR_HIP", 3: "EGOTAP_ERR_UNBOUND", 4: "EGOTAP_ERR_WORKSPACE"}
 NET_LIFT, NET_HM_POS, NET_HM_ROT = 0, 1, 2
 F32, I64 = 0, 1
-PRECISIONS = {"f32": 0, "bf16x3": 1}      # egotap.h EGOTAP_PREC_*
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}      # egotap.h EGOTAP_PREC_*
 
 
 class EgotapConfig(C.Structure):
@@ -63,7 +63,7 @@ _PROTOS = {
     "egotap_train_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egotap_train_bn_lrelu_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egotap_train_bn_lrelu_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "egotap_train_qkv_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p]),
+    "egotap_train_qkv_fwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]),
     "egotap_train_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "egotap_train_attention_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "egotap_train_pu_saved_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -49,7 +49,7 @@ class LiftTrainFn(torch.autograd.Function):
             a = l + "attention.attention."
             y1, m1, r1 = T.layernorm_fwd(x, P[l + "layernorm_before.weight"], P[l + "layernorm_before.bias"])
             qkv = torch.empty((M, 3 * D), dtype=torch.float32, device=dev)
-            _lib.check(lib.egotap_train_qkv_fwd(T._p(y1), T._p(P[a + "query.weight"]), T._p(P[a + "query.bias"]), T._p(P[a + "key.weight"]),
+            _lib.check(lib.egotap_train_qkv_fwd(h, T._p(y1), T._p(P[a + "query.weight"]), T._p(P[a + "query.bias"]), T._p(P[a + "key.weight"]),
                                                 T._p(P[a + "key.bias"]), T._p(P[a + "value.weight"]), T._p(P[a + "value.bias"]), T._p(qkv), M, D, st()))
             ctx_, lse = T.attention_fwd(qkv, B, seq, heads)
             xm = T.gemm_nt(h, ctx_, P[l + "attention.output.dense.weight"], P[l + "attention.output.dense.bias"], M, D, D, epi=T.TE_BIAS_RES, r=x)

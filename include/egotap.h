@@ -96,8 +96,13 @@ int egotap_hm_intermediate(egotap_handle h, int B, const char* name, size_t* off
  *   EGOTAP_PREC_BF16X3  each fp32 operand split in registers into hi + lo bf16 (16 significant bits), a*b taken as
  *                       a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; operands and
  *                       results stay fp32 in HBM.  Error ~2^-16 per product against 2^-24: opt-in fast mode, the reference
- *                       offers the analogous knob as --use_amp (egotap_autoencoder_model.py:177-183). */
-enum { EGOTAP_PREC_F32 = 0, EGOTAP_PREC_BF16X3 = 1 };
+ *                       offers the analogous knob as --use_amp (egotap_autoencoder_model.py:177-183).
+ *   EGOTAP_PREC_BF16    operands rounded to bf16 in registers (round to nearest even), one MFMA per product, fp32 accumulate,
+ *                       fp32 master weights / activations / gradients in HBM: the reduced-precision training configurations
+ *                       (the reference trains under fp16 autocast, egotap_autoencoder_model.py:299-323 + --use_amp).
+ * The mode also selects the kernels of egotap_train_gemm_nt / egotap_train_gemm_tn (forward, input-gradient and
+ * weight-gradient GEMMs of the training step) for shapes the bf16 kernels cover (N, K multiples of 256, M >= 1024). */
+enum { EGOTAP_PREC_F32 = 0, EGOTAP_PREC_BF16X3 = 1, EGOTAP_PREC_BF16 = 2 };
 int egotap_set_precision(egotap_handle h, int mode);
 
 /* debugging aid for parity tests: 0 = full forward (default); 1 = return after the embeddings;
@@ -146,7 +151,7 @@ int egotap_train_bn_lrelu_fwd(const float* z, float* y, const float* gamma, cons
 int egotap_train_bn_lrelu_bwd(const float* z, const float* y, const float* dy, const float* gamma, const float* mean,
                               const float* rstd, float* dz, float* dgamma, float* dbeta, int R, int C, int accumulate,
                               void* ws, size_t ws_bytes, void* stream);
-int egotap_train_qkv_fwd(const float* y, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
+int egotap_train_qkv_fwd(egotap_handle h, const float* y, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
                          const float* bv, float* qkv, int M, int D, void* stream);
 int egotap_train_attention_fwd(const float* qkv, float* ctx, float* lse, int B, int N, int heads, void* stream);
 int egotap_train_attention_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* delta,

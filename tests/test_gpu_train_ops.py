@@ -215,3 +215,58 @@ def test_pu_chain_and_pose_head_backward():
     _close(drotz, rz.grad, 2e-6, rtol=1e-3, msg="drotz")
     for k in keys:
         _close(g[k], leaves[k].grad, 3e-6, rtol=2e-3, msg=k)
+
+
+# ---- weight-gradient / training GEMMs on the bf16 matrix cores (gemm_tn_bf16.h, gemm_bf16.h) selected by the handle's precision
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(1024, 256, 256), (5000, 512, 1024), (9001, 1024, 256)])
+def test_gemm_tn_bf16_modes(mode, M, N, K):
+    """transposed LDS reads (ds_read_b64_tr_b16): asymmetric random operands, ragged M (zero-filled tail rows), split-M slabs.
+    bf16x3 against float64 with the 2^-16-per-product error model; bf16 against the float64 product of the rounded operands."""
+    from egotap_amd import train_ops as T
+    h, net, _ = _handle()
+    dy, x = _rand((M, N), 61), _rand((M, K), 62)
+    dw = torch.full((N, K), 3.0, device="cuda")
+    try:
+        net.set_precision(mode)
+        T.gemm_tn(h, dy.cuda(), x.cuda(), dw, M, N, K)
+        first = dw.clone()
+        T.gemm_tn(h, dy.cuda(), x.cuda(), dw, M, N, K, accumulate=True)
+        again = torch.empty_like(dw)
+        T.gemm_tn(h, dy.cuda(), x.cuda(), again, M, N, K)
+    finally:
+        net.set_precision("f32")
+    assert torch.equal(first, again)                       # fixed summation order
+    if mode == "bf16x3":
+        ref = dy.double().T @ x.double()
+        scale = float((dy.double().abs().T @ x.double().abs()).mean())
+        err = (first.cpu().double() - ref).abs()
+        assert float(err.max()) < 2.0 ** -15 * scale and float(err.pow(2).mean().sqrt()) < 2.0 ** -17 * scale
+        _close(dw, 2 * ref, atol=2.0 ** -14 * scale)
+    else:
+        ref = dy.bfloat16().double().T @ x.bfloat16().double()
+        _close(first, ref, atol=4e-5 * math.sqrt(M))
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_gemm_nt_training_epilogues_bf16_modes(mode):
+    """forward / input-gradient GEMMs of the training step follow the handle's precision (GELU-save and GELU-grad epilogues)"""
+    from egotap_amd import train_ops as T
+    h, net, _ = _handle()
+    M, N, K = 1100, 512, 256
+    x, w, b = _rand((M, K), 71), _rand((N, K), 72, -0.1, 0.1), _rand((N,), 73)
+    xr, wr = (x, w) if mode == "bf16x3" else (x.bfloat16().float(), w.bfloat16().float())
+    zref = xr.double() @ wr.double().T + b.double()
+    tol = 1e-4 if mode == "bf16x3" else 2e-5
+    try:
+        net.set_precision(mode)
+        z = torch.empty((M, N), device="cuda")
+        y = T.gemm_nt(h, x.cuda(), w.cuda(), b.cuda(), M, N, K, epi=T.TE_BIAS_GELU_SAVE, z=z)
+        d = T.gemm_nt(h, x.cuda(), w.cuda(), None, M, N, K, epi=T.TE_GELU_GRAD, r=z)
+    finally:
+        net.set_precision("f32")
+    _close(z, zref, atol=tol)
+    _close(y, 0.5 * zref * (1.0 + torch.erf(zref / math.sqrt(2.0))), atol=tol)
+    zz = z.cpu().double()
+    dg = 0.5 * (1.0 + torch.erf(zz / math.sqrt(2.0))) + zz * torch.exp(-0.5 * zz * zz) / math.sqrt(2.0 * math.pi)
+    _close(d, (xr.double() @ wr.double().T) * dg, atol=tol)
