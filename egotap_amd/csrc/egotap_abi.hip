@@ -15,6 +15,7 @@
 #include "gemm_f32.h"
 #include "gemm_bf16.h"
 #include "layernorm.h"
+#include "metrics.h"
 #include "pu_chain.h"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -901,6 +902,17 @@ extern "C" int egotap_attention_f32(const float* qkv, float* ctx, int B, int N, 
     EGO_CHECK(N > 0 && N % 32 == 0, "egotap_attention_f32: sequence length must be a multiple of 32");
     EGO_CHECK(heads > 0, "egotap_attention_f32: heads must be positive");
     EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, (hipStream_t)stream));
+    return EGOTAP_OK;
+}
+
+// per-sample MPJPE / PA-MPJPE of a batch of poses (egotap_autoencoder_model.py:329-350, utils/util.py:328-379)
+extern "C" int egotap_pose_metrics(const float* pred, const float* gt, int B, int J, float* mpjpe, float* pa_mpjpe, float* aligned,
+                                   void* stream) {
+    if (B == 0) return EGOTAP_OK;
+    EGO_CHECK(pred && gt && mpjpe && pa_mpjpe, "egotap_pose_metrics: null argument");
+    EGO_CHECK(B > 0 && J >= 1 && J <= EGOTAP_MAX_JOINTS, "egotap_pose_metrics: bad shape B=%d J=%d", B, J);
+    hipLaunchKernelGGL(pose_metrics_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, pred, gt, B, J, mpjpe, pa_mpjpe, aligned);
+    EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
 

@@ -45,6 +45,7 @@ _PROTOS = {
     "egotap_gemm_tile_name": (C.c_char_p, [C.c_int]),
     "egotap_layernorm_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "egotap_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "egotap_pose_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egotap_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "egotap_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egotap_timing_detail": (C.c_char_p, [C.c_void_p]),
@@ -145,6 +146,20 @@ def linear(x, w, b, epi: str = "bias", residual=None, bn=None, tile: int = 0):
     check(load().egotap_linear_f32(_ptr(x), _ptr(w), _ptr(b), _ptr(y), M, N, K, code, _ptr(residual), _ptr(g), _ptr(beta),
                                    _ptr(mean), _ptr(var), tile, _stream()))
     return y
+
+
+def pose_metrics(pred, gt, want_aligned: bool = False):
+    """per-sample (mpjpe [B], pa_mpjpe [B][, aligned [B,J,3]]) of poses [B,J,3] in the input units (egotap_pose_metrics)"""
+    import torch
+    pred, gt = pred.detach().float().contiguous(), gt.detach().float().contiguous()
+    _need_cuda_f32(pred, gt)
+    if pred.shape != gt.shape or pred.dim() != 3 or pred.shape[2] != 3:
+        raise ValueError(f"expected pred, gt [B, J, 3]; got {tuple(pred.shape)}, {tuple(gt.shape)}")
+    B, J = pred.shape[0], pred.shape[1]
+    e, pa = torch.empty(B, device=pred.device), torch.empty(B, device=pred.device)
+    al = torch.empty_like(pred) if want_aligned else None
+    check(load().egotap_pose_metrics(_ptr(pred), _ptr(gt), B, J, _ptr(e), _ptr(pa), _ptr(al), _stream()))
+    return (e, pa, al) if want_aligned else (e, pa)
 
 
 def layernorm(x, gamma, beta, eps: float = 1e-12):

@@ -123,6 +123,12 @@ int egotap_layernorm_f32(const float* x, float* y, const float* gamma, const flo
 /* ViTSelfAttention core (modeling_vit.py:233-252) on a fused [B*N, 3*heads*128] q|k|v buffer -> ctx [B*N, heads*128] */
 int egotap_attention_f32(const float* qkv, float* ctx, int B, int N, int heads, void* stream);
 
+/* Evaluation metrics of EgoTAPAutoEncoderModel.evaluate (model/egotap_autoencoder_model.py:329-350): per-sample MPJPE and
+ * Procrustes-aligned MPJPE (utils/util.py:328-379 batch_compute_similarity_transform_torch: 3x3 SVD, reflection fix,
+ * scale, translation), one launch for the batch instead of the reference's two Python loops.
+ *   pred, gt  device f32 [B, J, 3];  mpjpe, pa_mpjpe  device f32 [B] (input units);  aligned  device f32 [B, J, 3] or NULL */
+int egotap_pose_metrics(const float* pred, const float* gt, int B, int J, float* mpjpe, float* pa_mpjpe, float* aligned, void* stream);
+
 /* ---- training-step operators (fp32), called by the autograd glue (egotap_amd/training.py) ------------------------------
  * They implement the backward of the modules above plus loss / optimizer (egotap_autoencoder_model.py:284-323,
  * utils/loss.py:54-85, network.py:72-78 AdamW).  All buffers are caller-owned device memory; reductions have a fixed order.

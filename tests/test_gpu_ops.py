@@ -170,3 +170,41 @@ def test_linear_bf16x3_identity_asymmetric_and_ragged_rows():
     full = lib.linear(xb, wb, bb, tile=13)
     part = lib.linear(xb[:37].contiguous(), wb, bb, tile=13)
     assert torch.equal(full[:37], part)          # per-row result independent of M (fixed k order)
+
+
+# ---- fused evaluation metrics (metrics.h): MPJPE + Procrustes-aligned MPJPE per sample
+@pytest.mark.parametrize("B,J", [(6, 16), (37, 17), (1, 16), (300, 16)])
+def test_pose_metrics_matches_reference_golden_and_oracle(B, J):
+    import os
+    from egotap_amd import lib
+    from egotap_amd.synthetic import synth_input
+    from oracle import lift_ref as O
+    s1 = torch.from_numpy(synth_input("procrustes_s1", (B, J, 3), -30.0, 30.0))
+    s2 = torch.from_numpy(synth_input("procrustes_s2", (B, J, 3), -30.0, 30.0))
+    s2[:3] = s1[:3] * 1.7 + 0.3 * s2[:3]          # as tools/make_golden.py gen_procrustes: partly correlated pairs
+    e, pa, al = lib.pose_metrics(s1.cuda(), s2.cuda(), want_aligned=True)
+    ref_al = O.procrustes_align(s1.double(), s2.double())
+    _close(al, ref_al, atol=2e-4, rtol=1e-5)
+    _close(e, torch.linalg.norm(s2.double() - s1.double(), dim=-1).mean(-1), atol=1e-4)
+    _close(pa, torch.linalg.norm(s2.double() - ref_al, dim=-1).mean(-1), atol=1e-4)
+    if (B, J) == (6, 16):        # the reference's own batch_compute_similarity_transform_torch on these inputs
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "procrustes.npz"))
+        np.testing.assert_allclose(al.cpu().numpy(), g["s1_hat"], atol=2e-4, rtol=1e-4)
+
+
+def test_pose_metrics_reflection_and_identity():
+    """gt = mirrored pred needs the det-sign fix (a reflection is not allowed); gt = similarity(pred) aligns to zero error"""
+    from egotap_amd import lib
+    from oracle import lift_ref as O
+    s1 = _rand((8, 16, 3), 81, -20, 20)
+    mirrored = s1.clone(); mirrored[..., 0] *= -1
+    e, pa, al = lib.pose_metrics(s1.cuda(), mirrored.cuda(), want_aligned=True)
+    _close(al, O.procrustes_align(s1.double(), mirrored.double()), atol=5e-4)
+    assert float(pa.min()) > 0.5                       # cannot be aligned by a proper rotation
+    c, s_ = math.cos(0.7), math.sin(0.7)
+    R = torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
+    moved = 1.7 * s1 @ R.T + torch.tensor([3.0, -2.0, 5.0])
+    e, pa = lib.pose_metrics(s1.cuda(), moved.cuda())
+    assert float(pa.max()) < 1e-4 and float(e.min()) > 1.0
+    with pytest.raises(ValueError):
+        lib.pose_metrics(s1.cuda(), moved[:, :15].cuda())
