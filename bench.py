@@ -381,16 +381,24 @@ def main():
             fast["gemm_frac_of_bf16_mfma_peak"] = round(3 * t3[2] / (t3[1] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
             fast["gemm_share_of_step_time"] = round(t3[1] * 1e-3 / el3, 4)
 
+    def leg(fn, *a, **k):
+        """secondary measurements never take the headline line down with them"""
+        try:
+            return fn(*a, **k)
+        except Exception as exc:      # noqa: BLE001 - reported in the JSON line
+            torch.cuda.empty_cache()
+            return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
     full = None
     if not args.lift_only:
-        full = bench_full(args, p, dev, rank, world, barrier, lib, L)
+        full = leg(bench_full, args, p, dev, rank, world, barrier, lib, L)
 
     train = None
     if not args.lift_only and args.train_steps > 0:
-        train = bench_train(args, p, dev, rank, world, barrier)
-        train["bf16x3"] = bench_train(args, p, dev, rank, world, barrier, mode="bf16x3")
-        # BASELINE configs[2]: UnrealEgo training step (fwd+bwd+AdamW), bf16, batch 1024 per GPU
-        train["config3_bf16_b1024"] = bench_train(args, p, dev, rank, world, barrier, mode="bf16", batch=args.train_batch_bf16)
+        train = leg(bench_train, args, p, dev, rank, world, barrier)
+        train["bf16x3"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16x3")
+        # BASELINE configs[2] / [3]: UnrealEgo training step (fwd+bwd+AdamW), bf16, batch 1024 per GPU (x N GPUs, gradient all-reduce)
+        train["config3_bf16_b1024"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16", batch=args.train_batch_bf16)
 
     cpu = None
     gpu_vs_oracle = None
