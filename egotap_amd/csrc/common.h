@@ -32,6 +32,34 @@ void egotap_set_error(const char* fmt, ...);
     } while (0)
 
 
+// erf for the GELU epilogues (modeling_vit.py:320-327 ACT2FN["gelu"], exact-erf GELU): Abramowitz-Stegun 7.1.26,
+// erf|x| = 1 - (a1 t + .. + a5 t^5) exp(-x^2), t = 1/(1 + p|x|): 13 VALU instructions (one v_rcp_f32, one v_exp_f32)
+// against ~45 for ocml's erff.  In fp32 arithmetic: max |error| 5.5e-7 on erf; GELU(x) = x/2 (1 + erf(x/sqrt 2)) is
+// within 4.7e-7 of float64 over [-8, 8], the same as the fp32 rounding of the final product with an exact erf (4.5e-7).
+// The epilogue runs with the matrix pipe idle (all waves of a block reach it together): on the bf16x3 GEMM the erff
+// GELU was a quarter of the MLP-up launch.  exp(-x^2) is returned too: the GELU derivative needs exp(-z^2/2) = exp(-(z/sqrt 2)^2).
+__device__ __forceinline__ float fast_erf_exp(float x, float& e) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = 1.061405429f;
+    p = fmaf(p, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    e = __builtin_amdgcn_exp2f(-(ax * ax) * 1.4426950408889634f);
+    return copysignf(fmaf(-p, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    float e;
+    return 0.5f * x * (1.0f + fast_erf_exp(x * 0.70710678118654752440f, e));
+}
+__device__ __forceinline__ float dgelu_erf(float z) {      // d/dz GELU(z) = Phi(z) + z phi(z)
+    float e;
+    const float er = fast_erf_exp(z * 0.70710678118654752440f, e);
+    return fmaf(z * e, 0.39894228040143267794f, 0.5f * (1.0f + er));
+}
+
 // A vector of N floats that may be split over up to three equally long
 // segments (the ViT keeps query/key/value as three nn.Linear; we run them as
 // one GEMM without packing, so weights stay the caller's live tensors).

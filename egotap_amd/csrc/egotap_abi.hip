@@ -14,6 +14,7 @@
 #include "conv_f32.h"
 #include "gemm_f32.h"
 #include "gemm_bf16.h"
+#include "attention_bf16.h"
 #include "layernorm.h"
 #include "metrics.h"
 #include "pu_chain.h"
@@ -538,7 +539,9 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
             SegVec bqkv; bqkv.p[0] = L.q_b; bqkv.p[1] = L.k_b; bqkv.p[2] = L.v_b; bqkv.seg = D;
             EGO_HIP((gemm_big(h, "qkv", ALoadPlain{Y, D}, Wqkv, EpiBias{bqkv}, QKV, 3L * D, M, 3 * D, D, s)));
         }
-        EGO_HIP(attention_f32_launch(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
+        if (h->precision == EGOTAP_PREC_BF16X3) EGO_HIP(attention_bf16_launch<3>(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
+        else if (h->precision == EGOTAP_PREC_BF16) EGO_HIP(attention_bf16_launch<1>(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
+        else EGO_HIP(attention_f32_launch(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
         EGO_HIP((gemm_big(h, "attn_out", ALoadPlain{CTX, D}, segmat1(L.o_w, D, D), EpiBiasRes{segvec1(L.o_b, D), X, D}, X, D, M, D, D, s)));
         EGO_HIP(launch_ln(X, Y, L.ln2_g, L.ln2_b, M, 1e-12f, s));
         EGO_HIP((gemm_big(h, "mlp_up", ALoadPlain{Y, D}, segmat1(L.up_w, 4 * D, D), EpiBiasGelu{segvec1(L.up_b, 4 * D)}, HID, 4L * D, M, 4 * D, D, s)));
@@ -913,6 +916,18 @@ extern "C" int egotap_pose_metrics(const float* pred, const float* gt, int B, in
     EGO_CHECK(B > 0 && J >= 1 && J <= EGOTAP_MAX_JOINTS, "egotap_pose_metrics: bad shape B=%d J=%d", B, J);
     hipLaunchKernelGGL(pose_metrics_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, pred, gt, B, J, mpjpe, pa_mpjpe, aligned);
     EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+// same operator with the arithmetic of egotap_set_precision (EGOTAP_PREC_*): fp32 MFMA, bf16x3 split or plain bf16
+extern "C" int egotap_attention(const float* qkv, float* ctx, int B, int N, int heads, int precision, void* stream) {
+    EGO_CHECK(qkv && ctx, "egotap_attention: null argument");
+    EGO_CHECK(N > 0 && N % 32 == 0, "egotap_attention: sequence length must be a multiple of 32");
+    EGO_CHECK(heads > 0, "egotap_attention: heads must be positive");
+    if (precision == EGOTAP_PREC_F32) EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, (hipStream_t)stream));
+    else if (precision == EGOTAP_PREC_BF16X3) EGO_HIP(attention_bf16_launch<3>(qkv, ctx, B, N, heads, (hipStream_t)stream));
+    else if (precision == EGOTAP_PREC_BF16) EGO_HIP(attention_bf16_launch<1>(qkv, ctx, B, N, heads, (hipStream_t)stream));
+    else { egotap_set_error("egotap_attention: unknown precision %d", precision); return EGOTAP_ERR_INVALID; }
     return EGOTAP_OK;
 }
 

@@ -148,7 +148,7 @@ struct EpiBiasGelu {      // exact erf GELU (modeling_vit.py:320-327, hidden_act
     __device__ __forceinline__ Col col(int n) const { return Col{bias.at(n)}; }
     __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const {
         const float x = acc + c.b;
-        return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        return gelu_erf(x);
     }
     struct Col4 { f32x4 b; };
     __device__ __forceinline__ Col4 col4(int n0) const { return Col4{f32x4{bias.at(n0), bias.at(n0 + 1), bias.at(n0 + 2), bias.at(n0 + 3)}}; }
@@ -159,7 +159,7 @@ struct EpiBiasGelu {      // exact erf GELU (modeling_vit.py:320-327, hidden_act
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float x = acc[i] + c.b[i];
-            o[i] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+            o[i] = gelu_erf(x);
         }
         return o;
     }
@@ -241,7 +241,7 @@ struct EpiBiasGeluSave {  // z = acc + bias is stored to Z (kept for the backwar
     __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const {
         const float x = acc + c.b;
         Z[(long)m * ldz + n] = x;
-        return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        return gelu_erf(x);
     }
     struct Col4 { f32x4 b; };
     __device__ __forceinline__ Col4 col4(int n0) const { return Col4{f32x4{bias.at(n0), bias.at(n0 + 1), bias.at(n0 + 2), bias.at(n0 + 3)}}; }
@@ -252,7 +252,7 @@ struct EpiBiasGeluSave {  // z = acc + bias is stored to Z (kept for the backwar
         *(f32x4*)(Z + (long)m * ldz + n0) = x;
         f32x4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = 0.5f * x[i] * (1.0f + erff(x[i] * 0.70710678118654752440f));
+        for (int i = 0; i < 4; ++i) o[i] = gelu_erf(x[i]);
         return o;
     }
 };
@@ -260,7 +260,7 @@ struct EpiGeluGrad {      // C = acc * gelu'(Z[m, n])   (input gradient of the M
     const float* Z;
     long ldz;
     __device__ __forceinline__ static float dgelu(float z) {
-        return 0.5f * (1.0f + erff(z * 0.70710678118654752440f)) + z * expf(-0.5f * z * z) * 0.39894228040143267794f;
+        return dgelu_erf(z);
     }
     struct Col {};
     __device__ __forceinline__ Col col(int n) const { return Col{}; }

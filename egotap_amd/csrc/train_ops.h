@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        o[k] = d[k] * (0.5f * (1.0f + erff(z[k] * 0.70710678118654752440f)) + z[k] * expf(-0.5f * z[k] * z[k]) * 0.39894228040143267794f);
+        o[k] = d[k] * dgelu_erf(z[k]);
     *(f32x4*)(dZ + i * 4) = o;
 }
 

@@ -46,6 +46,7 @@ _PROTOS = {
     "egotap_layernorm_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "egotap_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "egotap_pose_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "egotap_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "egotap_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "egotap_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egotap_timing_detail": (C.c_char_p, [C.c_void_p]),
@@ -171,10 +172,10 @@ def layernorm(x, gamma, beta, eps: float = 1e-12):
     return y
 
 
-def attention(qkv, B: int, N: int, heads: int):
+def attention(qkv, B: int, N: int, heads: int, precision: str = "f32"):
     """qkv [B*N, 3*heads*128] (q|k|v) -> ctx [B*N, heads*128]"""
     import torch
     _need_cuda_f32(qkv)
     ctx = torch.empty((B * N, heads * 128), device=qkv.device, dtype=torch.float32)
-    check(load().egotap_attention_f32(_ptr(qkv), _ptr(ctx), B, N, heads, _stream()))
+    check(load().egotap_attention(_ptr(qkv), _ptr(ctx), B, N, heads, PRECISIONS[precision], _stream()))
     return ctx

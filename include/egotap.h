@@ -122,6 +122,8 @@ int egotap_layernorm_f32(const float* x, float* y, const float* gamma, const flo
                          void* stream);
 /* ViTSelfAttention core (modeling_vit.py:233-252) on a fused [B*N, 3*heads*128] q|k|v buffer -> ctx [B*N, heads*128] */
 int egotap_attention_f32(const float* qkv, float* ctx, int B, int N, int heads, void* stream);
+/* the same operator with the arithmetic of egotap_set_precision (EGOTAP_PREC_F32 / _BF16X3 / _BF16) */
+int egotap_attention(const float* qkv, float* ctx, int B, int N, int heads, int precision, void* stream);
 
 /* Evaluation metrics of EgoTAPAutoEncoderModel.evaluate (model/egotap_autoencoder_model.py:329-350): per-sample MPJPE and
  * Procrustes-aligned MPJPE (utils/util.py:328-379 batch_compute_similarity_transform_torch: 3x3 SVD, reflection fix,

@@ -208,3 +208,42 @@ def test_pose_metrics_reflection_and_identity():
     assert float(pa.max()) < 1e-4 and float(e.min()) > 1.0
     with pytest.raises(ValueError):
         lib.pose_metrics(s1.cuda(), moved[:, :15].cuda())
+
+
+# ---- attention on the bf16 matrix cores (attention_bf16.h): transposed V reads, probability accumulators as operands
+def _attn_ref(qkv, B, N, heads, rounded=False):
+    D = heads * 128
+    src = qkv.bfloat16().float() if rounded else qkv
+    q, k, v = [t.reshape(B, N, heads, 128).transpose(1, 2).double() for t in src.split(D, dim=1)]
+    s = q @ k.transpose(-1, -2) / math.sqrt(128.0)
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * N, D)
+
+
+@pytest.mark.parametrize("B,N,heads", [(1, 32, 1), (2, 576, 8), (1, 64, 2), (3, 96, 8), (1, 2304, 2)])
+def test_attention_bf16x3(B, N, heads):
+    """hi+lo split of Q, K, V and of the probabilities: asymmetric random data (a transposed or permuted V fragment, a
+    wrong key order of the probability operand or a bad lane map all show up as O(1) errors), partial last query group."""
+    from egotap_amd import lib
+    qkv = _rand((B * N, 3 * heads * 128), 41, -2, 2)
+    got = lib.attention(qkv.cuda(), B, N, heads, precision="bf16x3")
+    _close(got, _attn_ref(qkv, B, N, heads), 4e-5)
+    assert torch.equal(got, lib.attention(qkv.cuda(), B, N, heads, precision="bf16x3"))
+
+
+@pytest.mark.parametrize("B,N,heads", [(2, 576, 8), (1, 96, 1)])
+def test_attention_bf16_plain(B, N, heads):
+    from egotap_amd import lib
+    qkv = _rand((B * N, 3 * heads * 128), 43, -2, 2)
+    got = lib.attention(qkv.cuda(), B, N, heads, precision="bf16")
+    _close(got, _attn_ref(qkv, B, N, heads, rounded=True), 2e-2)      # probabilities are rounded to bf16 too
+
+
+def test_attention_bf16x3_rescale_branch_and_structured_v():
+    from egotap_amd import lib
+    B, N, heads, D = 1, 128, 1, 128
+    qkv = _rand((N, 3 * D), 51, -0.5, 0.5)
+    qkv[7, :128] = 3.0
+    qkv[100, 128:256] = 3.0
+    # V[key][d] = key + d/1000: every (key, d) pair is distinguishable in the output
+    qkv[:, 256:] = torch.arange(N, dtype=torch.float32)[:, None] + torch.arange(128, dtype=torch.float32)[None, :] / 1000.0
+    _close(lib.attention(qkv.cuda(), B, N, heads, precision="bf16x3"), _attn_ref(qkv, B, N, heads), 2e-3, rtol=2e-5)

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --steps 2 --warmup 1 --full-steps 1 --no-cpu-baseline"
+ARGS="bench.py --steps 2 --warmup 1 --full-steps 1 --train-steps 1 --train-batch-bf16 256 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 echo "trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS --no-kernel-timing > $OUT/pmc_fetch.log 2>&1
