@@ -371,8 +371,8 @@ def main():
             net.set_precision("f32")
         fps3 = world * B * args.steps / el3
         fast = {"value": round(fps3, 1), "unit": "stereo frames/s", "ms_per_step": round(1e3 * el3 / args.steps, 3),
-                "dtype": "bf16x3 (fp32 operands split hi+lo in registers, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; "
-                         "fp32 tensors in HBM; attention, LayerNorm, PU chain, pose head stay exact fp32)",
+                "dtype": "bf16x3 (large GEMMs and attention: fp32 operands split hi+lo in registers, 3 x v_mfma_f32_32x32x16_bf16 per product, "
+                         "fp32 accumulate; fp32 tensors in HBM; LayerNorm, small GEMMs, PU chain, pose head stay exact fp32)",
                 "max_abs_diff_vs_f32_mode": float((pose3 - pose).abs().max()),
                 "speedup_vs_f32_mode": round(fps3 / (world * B * args.steps / elapsed), 3)}
         if t3 is not None and t3[1] > 0:
