@@ -12,6 +12,7 @@
 #include "attention_f32.h"
 #include "common.h"
 #include "conv_f32.h"
+#include "conv_bf16.h"
 #include "gemm_f32.h"
 #include "gemm_bf16.h"
 #include "attention_bf16.h"
@@ -105,6 +106,7 @@ struct egotap_handle_s {
     HmParams hp[EGOTAP_NET_COUNT];
     int debug_stop = 0;
     int precision = EGOTAP_PREC_F32;   // arithmetic of the large GEMMs (egotap_set_precision)
+    __bf16* conv_pack = nullptr;       // scratch for repacked conv weights (set per egotap_hm_forward call from the workspace)
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;   // start/stop pairs
@@ -665,8 +667,22 @@ static hipError_t conv(Handle* h, const char* role, const ConvArgs& a, hipStream
     return conv_f32_launch<Cfg>(a, s);
 }
 
+template <class Cfg>
+static hipError_t conv_bf(Handle* h, const char* role, const ConvArgs& a, hipStream_t s) {
+    static const std::string kname = std::string("conv_bf16_kernel<3x3,s1,W") + std::to_string(Cfg::W) + (Cfg::NP == 3 ? ",bf16x3>" : ",bf16>");
+    GemmTimer t(h, s, role, kname.c_str(), 2.0 * a.Cout * a.Cin * 9 * (double)a.Nimg * Cfg::W * Cfg::W);
+    return conv_bf16_launch<Cfg>(a, h->conv_pack, s);
+}
+
 // dispatch on (taps, stride, output width); wout in {128, 64, 32, 16, 8}
 static hipError_t conv_any(Handle* h, const char* role, int taps, int stride, int wout, const ConvArgs& a, hipStream_t s) {
+    // opt-in modes: 3x3 stride-1 convs with a multiple of 128 output channels at widths 64 / 32 / 16 run on the bf16 matrix cores
+    if (h->precision != EGOTAP_PREC_F32 && h->conv_pack && taps == 9 && stride == 1 && a.Cout % 128 == 0) {
+        const bool x3 = h->precision == EGOTAP_PREC_BF16X3;
+        if (wout == 64) return x3 ? conv_bf<ConvBfCfg<6, 3>>(h, role, a, s) : conv_bf<ConvBfCfg<6, 1>>(h, role, a, s);
+        if (wout == 32) return x3 ? conv_bf<ConvBfCfg<5, 3>>(h, role, a, s) : conv_bf<ConvBfCfg<5, 1>>(h, role, a, s);
+        if (wout == 16) return x3 ? conv_bf<ConvBfCfg<4, 3>>(h, role, a, s) : conv_bf<ConvBfCfg<4, 1>>(h, role, a, s);
+    }
     if (taps == 9 && stride == 1) {
         if (wout == 128) return a.Cout <= 64 ? conv<C3s1_128_co64>(h, role, a, s) : conv<C3s1_128>(h, role, a, s);
         if (wout == 64) return a.Cout <= 64 ? conv<C3s1_64_co64>(h, role, a, s) : conv<C3s1_64>(h, role, a, s);
@@ -694,7 +710,7 @@ static hipError_t conv_any(Handle* h, const char* role, int taps, int stride, in
 }
 
 struct HmWs {
-    size_t L0, P0, S[4][4] /* per stage: Ta, Tb, Td, L */, U4, CAT3, X3, CAT2, X2, CAT1, X1, total;
+    size_t L0, P0, S[4][4] /* per stage: Ta, Tb, Td, L */, U4, CAT3, X3, CAT2, X2, CAT1, X1, WPACK, total;
 };
 static HmWs hm_ws(const Handle* h, int B) {
     HmWs w;
@@ -712,6 +728,7 @@ static HmWs hm_ws(const Handle* h, int B) {
     w.CAT3 = take((size_t)B * 1540 * s16 * s16); w.X3 = take((size_t)B * 1024 * s16 * s16);
     w.CAT2 = take((size_t)B * 1280 * s32 * s32); w.X2 = take((size_t)B * 512 * s32 * s32);
     w.CAT1 = take((size_t)B * 640 * s64 * s64);  w.X1 = take((size_t)B * 512 * s64 * s64);
+    w.WPACK = take(conv_bf16_pack_bytes(1024, 1540) / 4);      // largest conv (conv_up3) repacked for the bf16 kernels
     w.total = o;
     return w;
 }
@@ -763,6 +780,7 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
     }
     const HmParams& p = h->hp[net];
     EGO_CHECK(out_image_stride >= (int64_t)p.n_out * s64 * s64, "out_image_stride smaller than the output image");
+    h->conv_pack = (__bf16*)((char*)ws + w.WPACK);
     hipStream_t s = (hipStream_t)stream;
     char* base = (char*)ws;
     auto F = [&](size_t off) { return (float*)(base + off); };

@@ -164,6 +164,12 @@ class EgoTAPAutoEncoderModel(nn.Module):
         for o in self.optimizers:
             o.step()
 
+    def set_precision(self, mode: str = "f32"):
+        """f32 (default) | bf16x3 | bf16 for the three networks (the reference's analogous switch is --use_amp)"""
+        for n in (self.net_HeatMap, self.net_RotHeatMap, self.net_AutoEncoder):
+            n.set_precision(mode)
+        return self
+
     def set_eval_mode(self):
         self.net_AutoEncoder.eval()
         self.net_HeatMap.eval()

@@ -255,6 +255,15 @@ class HeatMap_UnrealEgo_Shared(nn.Module):
         self._bound_sig = None
         self._ws = None
 
+    def set_precision(self, mode: str = "f32"):
+        """Arithmetic of the 3x3 stride-1 convolutions with >= 128 output channels (88 % of the FLOPs): "f32" exact (default),
+        "bf16x3" split operands, "bf16" rounded operands; everything else stays fp32 (egotap.h egotap_set_precision)."""
+        if mode not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
+        _lib.check(_lib.load().egotap_set_precision(self._ensure_handle(), _lib.PRECISIONS[mode]))
+        self.precision = mode
+        return self
+
     def _locate(self, key):
         parts = key.split(".")
         mod = self

@@ -82,3 +82,42 @@ def test_hm_forward_512_rgb_egocap_matches_oracle():
     assert tuple(y.shape) == (1, 34, 128, 128)
     err = (y.cpu().double() - ref).abs().max().item()
     assert err < 1e-4 * max(1.0, ref.abs().max().item()), f"max err {err:.3e} (max |ref| {ref.abs().max().item():.3e})"
+
+
+@pytest.mark.parametrize("which,B", [("pos", 3), ("rot", 1)])
+def test_hm_forward_bf16x3_mode_matches_oracle(which, B):
+    """opt-in mode: 3x3 stride-1 convs with >= 128 output channels on the bf16 matrix cores as hi+lo splits (channels-last LDS
+    image, repacked weights, Cin = 1540 tail slab); same gate as fp32.  Switching back restores the exact result bit for bit."""
+    from gpu_util import hm_net
+    from oracle import hm_ref as H
+    net, sd_np = hm_net(which)
+    left, right = _rgb(f"rgbL_{which}_{B}", B), _rgb(f"rgbR_{which}_{B}", B)
+    sd = H.to_torch_sd(sd_np, torch.float64)
+    with torch.no_grad():
+        ref = H.hm_forward(left.double(), right.double(), sd)
+    exact = net(left.cuda(), right.cuda()).clone()
+    try:
+        net.set_precision("bf16x3")
+        fast = net(left.cuda(), right.cuda()).clone()
+        again = net(left.cuda(), right.cuda()).clone()
+    finally:
+        net.set_precision("f32")
+    back = net(left.cuda(), right.cuda()).clone()
+    torch.cuda.synchronize()
+    err = (fast.cpu().double() - ref).abs().max().item()
+    assert err < 1e-4 * max(1.0, ref.abs().max().item()), f"max err {err:.3e} (max |ref| {ref.abs().max().item():.3e})"
+    assert torch.equal(fast, again) and torch.equal(back, exact) and not torch.equal(fast, exact)
+
+
+def test_hm_forward_bf16_mode_tracks_fp32():
+    from gpu_util import hm_net
+    net, _ = hm_net("pos")
+    left, right = _rgb("rgb_left", 1).cuda(), _rgb("rgb_right", 1).cuda()
+    exact = net(left, right).clone()
+    try:
+        net.set_precision("bf16")
+        low = net(left, right).clone()
+    finally:
+        net.set_precision("f32")
+    rel = float((low - exact).norm() / exact.norm())
+    assert 1e-5 < rel < 3e-2, rel
