@@ -165,7 +165,7 @@ def timed_lift(net, hm, steps, warmup, lib, L, h, barrier, dev, timing, world):
     return elapsed, pose, out
 
 
-def bench_full(args, p, dev, rank, world, barrier, lib, L):
+def bench_full(args, p, dev, rank, world, barrier, lib, L, mode="f32"):
     """Secondary measurement: the whole path from RGB (two heatmap estimators + lifting head), same batch."""
     import torch
     import torch.distributed as dist
@@ -187,6 +187,7 @@ def bench_full(args, p, dev, rank, world, barrier, lib, L):
     r = torch.from_numpy(synth_input(f"rgb_r_rank{rank}", (blk, 3, S, S), -2.0, 2.0)).to(dev).repeat((B + blk - 1) // blk, 1, 1, 1)[:B].contiguous()
     m.set_input({"input_rgb_left": l, "input_rgb_right": r})
     m.set_eval_mode()
+    m.set_precision(mode)
     h = m.net_HeatMap._ensure_handle()
     with torch.no_grad():
         m.forward(evaluate=True)
@@ -215,12 +216,16 @@ def bench_full(args, p, dev, rank, world, barrier, lib, L):
     flops_frame = lift_flops_per_frame(p) + hm_flops_per_frame(2 * J, S) + hm_flops_per_frame(4 * J, S)
     fps = world * B * args.full_steps / elapsed
     conv_tf = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    pose = m.pred_pose.detach().clone()
+    del m, l, r
+    torch.cuda.empty_cache()
     return {
+        "_pose": pose, "dtype": mode,
         "value": round(fps, 1), "unit": "stereo frames/s", "ms_per_step": round(1e3 * elapsed / args.full_steps, 2),
         "steps": args.full_steps, "flops_per_frame": flops_frame,
         "end_to_end_tflops_per_gpu": round(fps * flops_frame / world / 1e12, 2),
         "end_to_end_frac_of_f32_mfma_peak": round(fps * flops_frame / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-        "conv_roofline": {"bound": "mfma", "kernel": "conv_f32_kernel (all instantiations)", "achieved": round(conv_tf, 2),
+        "conv_roofline": {"bound": "mfma", "kernel": "conv kernels (all instantiations, algorithmic FLOPs)", "achieved": round(conv_tf, 2),
                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(conv_tf / PEAK_F32_MFMA_TFLOPS, 4),
                           "conv_share_of_step_time": round(tot_ms * 1e-3 / elapsed, 4)},
         "by_role": {k: {"kernel": v["kernel"], "avg_ms": round(v["ms"] / v["launches"], 4),
@@ -392,6 +397,15 @@ def main():
     full = None
     if not args.lift_only:
         full = leg(bench_full, args, p, dev, rank, world, barrier, lib, L)
+        if not args.no_fast_mode:
+            ff = leg(bench_full, args, p, dev, rank, world, barrier, lib, L, mode="bf16x3")
+            if "_pose" in ff and "_pose" in full:
+                ff["max_abs_pose_diff_vs_f32_mode"] = float((ff["_pose"] - full["_pose"]).abs().max())
+                ff["speedup_vs_f32_mode"] = round(ff["value"] / full["value"], 3)
+            ff.pop("_pose", None)
+            ff.pop("by_role", None)
+            full["fast_mode_bf16x3"] = ff
+        full.pop("_pose", None)
 
     train = None
     if not args.lift_only and args.train_steps > 0:

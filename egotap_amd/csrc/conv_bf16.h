@@ -1,6 +1,6 @@
 // 3x3 stride-1 NCHW convolution on the bf16 matrix cores with fp32 tensors in HBM (opt-in modes of egotap_set_precision):
 // the U-Net decoder convs and the stride-1 BasicBlock convs of HeatMap_UnrealEgo_Shared (model/net_architecture.py:53-173,
-// model/network_utils.py:144-148) at map widths 64 / 32 / 16 -- 88 % of the estimators' FLOPs.  Arithmetic as gemm_bf16.h:
+// model/network_utils.py:144-148) at map widths 64 / 32 / 16 / 8 -- 97 % of the estimators' FLOPs.  Arithmetic as gemm_bf16.h:
 // NP = 3 takes every product as hi*hi + hi*lo + lo*hi of operands split into hi + lo bf16, NP = 1 rounds to bf16.
 //
 //   D[co][pixel] = sum_{tap, ci} W[co][ci][tap] * X[ci][pixel + tap]        (implicit GEMM, never im2col'ed)
@@ -11,7 +11,7 @@
 // * weights: PyTorch's [Cout][Cin][3][3] has the tap innermost; conv_pack_w_kernel rewrites them per launch (the tensors stay
 //   the caller's live parameters; 57 MB for the largest conv = ~25 us) into [co][ci/16][tap][hi 16 | lo 16], so a (slab, ky)
 //   sub-slab is 192 contiguous bytes per output channel and goes global -> LDS without touching the VALU.
-// * tile 128 co x 256 pixels, 8 waves as 2 x 4 (64 x 64 each); per 16-channel slab the input image is staged once and reused
+// * tile 128 (or 64) co x 256 pixels = whole rows of one image (whole 8x8 images at width 8), 8 waves, 64 co each; per 16-channel slab the input image is staged once and reused
 //   by three weight sub-slabs (ky = 0, 1, 2), both double buffered; one barrier per sub-slab (36 MFMAs per wave at NP = 3).
 // * epilogue = conv_f32.h's: BatchNorm(eval) or bias, residual, ReLU, 128-byte NCHW row segments with a caller-given image
 //   stride (concat-free).
@@ -40,25 +40,28 @@ __global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restric
     dst[0] = hi[0]; dst[1] = hi[1]; dst[2] = lo[0]; dst[3] = lo[1];
 }
 
-template <int LOG2W_, int NP_>
+template <int LOG2W_, int NP_, int CO_T_ = 128>
 struct ConvBfCfg {
-    static constexpr int LOG2W = LOG2W_, NP = NP_, W = 1 << LOG2W_;
-    static constexpr int PX_T = 256, R = PX_T / W, CO_T = 128, WCO = 2, WPX = 4, THREADS = 64 * WCO * WPX;
-    static constexpr int TCO = CO_T / WCO / 32, TPX = PX_T / WPX / 32;
-    static constexpr int XROW = W + 2, XROWS = R + 2, PXE = 40;            // staged pixels per row / rows; bf16 per pixel (80 B)
-    static constexpr int XBUF = XROWS * XROW * PXE;                        // bf16 per input buffer
+    static constexpr int LOG2W = LOG2W_, NP = NP_, W = 1 << LOG2W_, CO_T = CO_T_;
+    static constexpr int PX_T = 256, R = PX_T / W;                         // output rows per tile
+    static constexpr int G = R > W ? R / W : 1, RSEG = R > W ? W : R;      // whole images per tile when the map is small (W = 8)
+    static constexpr int WCO = CO_T / 64, WPX = 8 / WCO, THREADS = 512;    // every wave owns 64 output channels
+    static constexpr int TCO = 2, TPX = PX_T / WPX / 32;
+    static constexpr int XROW = W + 2, XROWS = RSEG + 2, PXE = 40;         // staged pixels per row / rows per image; bf16 per pixel (80 B)
+    static constexpr int XBUF = G * XROWS * XROW * PXE;                    // bf16 per input buffer
     static constexpr int WROW = 104, WBUF = CO_T * WROW;                   // 208-byte weight rows (3 taps x 64 B + pad)
     static constexpr int LDS_BYTES = 2 * (XBUF + WBUF) * 2;
-    static constexpr int NQ = 8 * XROWS * (W / 4);                         // (channel pair, row, float4 column) staging items
+    static constexpr int NQ = 8 * G * XROWS * (W / 4);                     // (channel pair, image, row, float4 column) staging items
     static constexpr int X_IT = (NQ + THREADS - 1) / THREADS;
-    static constexpr int W_IT = CO_T * 12 / THREADS;                       // 16-byte chunks of a weight sub-slab per thread
-    static_assert(R <= W && R >= 1, "tile = whole rows of one image");
-    static_assert(LDS_BYTES <= 160 * 1024 && (CO_T * 12) % THREADS == 0, "LDS budget / staging split");
+    static constexpr int W_IT = (CO_T * 12 + THREADS - 1) / THREADS;       // 16-byte chunks of a weight sub-slab per thread
+    static_assert(CO_T == 64 || CO_T == 128, "output-channel tile");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_bf16_kernel(ConvArgs a, const __bf16* __restrict__ wp, int S) {
     constexpr int W = Cfg::W, LOG2W = Cfg::LOG2W, R = Cfg::R, XROW = Cfg::XROW, XROWS = Cfg::XROWS, PXE = Cfg::PXE;
+    constexpr int G = Cfg::G, RSEG = Cfg::RSEG;
     constexpr int XBUF = Cfg::XBUF, WROW = Cfg::WROW, WBUF = Cfg::WBUF, THREADS = Cfg::THREADS, NP = Cfg::NP;
     constexpr int TCO = Cfg::TCO, TPX = Cfg::TPX, CO_T = Cfg::CO_T, X_IT = Cfg::X_IT, W_IT = Cfg::W_IT, NQ = Cfg::NQ;
     extern __shared__ __attribute__((aligned(16))) __bf16 csm[];
@@ -71,10 +74,16 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_bf16_kernel(ConvArgs a, 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wco = wid / Cfg::WPX, wpx = wid % Cfg::WPX;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int gr0 = tpx * R;
-    const int n0 = gr0 >> LOG2W, y0 = gr0 - (n0 << LOG2W);
+    int n0, y0;               // tile origin: image n0 (segment g -> image n0 + g), first output row y0
+    if (G == 1) {
+        const int gr0 = tpx * R;
+        n0 = gr0 >> LOG2W;
+        y0 = gr0 - (n0 << LOG2W);
+    } else {
+        n0 = tpx * G;
+        y0 = 0;
+    }
     const long ch_in = (long)W * W;
-    const float* in_img = a.in + (long)n0 * a.in_istride;
 
     // zero both input buffers once: x halos and rows outside the image are never written again
     for (int i = tid; i < 2 * XBUF / 8; i += THREADS) ((bf16x8*)Xs)[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_bf16_kernel(ConvArgs a, 
     auto wload = [&](int s, int ky) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
-            const int c = tid + it * THREADS, cr = c / 12, chk = c - cr * 12;
+            const int c = min(tid + it * THREADS, CO_T * 12 - 1), cr = c / 12, chk = c - cr * 12;
             const int co = min(co0 + cr, a.Cout - 1);
             wreg[it] = *(const f32x4*)(wp + (((long)co * S + s) * 9 + ky * 3) * 32 + chk * 8);
         }
@@ -93,17 +102,17 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_bf16_kernel(ConvArgs a, 
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int c = tid + it * THREADS, cr = c / 12, chk = c - cr * 12;
-            *(f32x4*)(Ws + buf * WBUF + cr * WROW + chk * 8) = wreg[it];
+            if (c < CO_T * 12) *(f32x4*)(Ws + buf * WBUF + cr * WROW + chk * 8) = wreg[it];
         }
     };
     auto xload = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
             const int q = tid + it * THREADS;
-            const int cp = q & 7, x4 = (q >> 3) % (W / 4), rr = (q >> 3) / (W / 4);
-            const int y = y0 - 1 + rr, ci = 16 * s + 2 * cp;
-            const bool ok = q < NQ && y >= 0 && y < W;
-            const float* p = in_img + (long)ci * ch_in + (long)y * W + x4 * 4;
+            const int cp = q & 7, x4 = (q >> 3) % (W / 4), gr = (q >> 3) / (W / 4), g = gr / XROWS, rr = gr - g * XROWS;
+            const int y = y0 - 1 + rr, ci = 16 * s + 2 * cp, n = n0 + g;
+            const bool ok = q < NQ && y >= 0 && y < W && n < a.Nimg;
+            const float* p = a.in + (long)n * a.in_istride + (long)ci * ch_in + (long)y * W + x4 * 4;
             xreg[it][0] = ok && ci < a.Cin ? *(const f32x4*)p : f32x4{0.f, 0.f, 0.f, 0.f};
             xreg[it][1] = ok && ci + 1 < a.Cin ? *(const f32x4*)(p + ch_in) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -112,10 +121,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_bf16_kernel(ConvArgs a, 
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
             const int q = tid + it * THREADS;
-            const int cp = q & 7, x4 = (q >> 3) % (W / 4), rr = (q >> 3) / (W / 4);
+            const int cp = q & 7, x4 = (q >> 3) % (W / 4), gr = (q >> 3) / (W / 4), g = gr / XROWS, rr = gr - g * XROWS;
             const int y = y0 - 1 + rr;
-            if (q < NQ && y >= 0 && y < W) {
-                __bf16* dst = Xs + buf * XBUF + (rr * XROW + 1 + 4 * x4) * PXE + 2 * cp;
+            if (q < NQ && y >= 0 && y < W) {            // images past Nimg are staged as zeros (xload)
+                __bf16* dst = Xs + buf * XBUF + (gr * XROW + 1 + 4 * x4) * PXE + 2 * cp;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -135,7 +144,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_bf16_kernel(ConvArgs a, 
 #pragma unroll
     for (int j = 0; j < TPX; ++j) {
         const int p = (wpx * TPX + j) * 32 + l31;
-        pixb[j] = (p >> LOG2W) * XROW + (p & (W - 1));
+        const int g = p / (RSEG * W), rem = p - g * (RSEG * W);
+        pixb[j] = (g * XROWS + (rem >> LOG2W)) * XROW + (rem & (W - 1));
     }
     const int a_off = (wco * TCO * 32 + l31) * WROW + 8 * lh;
 
@@ -217,11 +227,14 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_bf16_kernel(ConvArgs a, 
 #pragma unroll
             for (int j = 0; j < TPX; ++j) {
                 const int p = (wpx * TPX + j) * 32 + l31;
-                const long pix = (long)y0 * W + p;
+                const int g = p / (RSEG * W), rem = p - g * (RSEG * W);
+                const int n = n0 + g;
+                if (n >= a.Nimg) continue;
+                const long pix = (long)y0 * W + rem;
                 float v = acc[i][j][r] * sc + sh;
-                if (a.res) v += a.res[(long)n0 * a.res_istride + co * ch_out + pix];
+                if (a.res) v += a.res[(long)n * a.res_istride + co * ch_out + pix];
                 if (a.relu) v = fmaxf(v, 0.f);
-                a.out[(long)n0 * a.out_istride + co * ch_out + pix] = v;
+                a.out[(long)n * a.out_istride + co * ch_out + pix] = v;
             }
         }
     }
@@ -247,7 +260,7 @@ static hipError_t conv_bf16_launch(ConvArgs a, __bf16* wp, hipStream_t stream) {
         attr_done = true;
     }
     a.tiles_co = a.Cout / Cfg::CO_T;
-    a.tiles_px = (int)((long)a.Nimg * Cfg::W * Cfg::W / Cfg::PX_T);
+    a.tiles_px = Cfg::G == 1 ? (int)((long)a.Nimg * Cfg::W * Cfg::W / Cfg::PX_T) : (a.Nimg + Cfg::G - 1) / Cfg::G;
     hipLaunchKernelGGL(kern, dim3(a.tiles_co * a.tiles_px), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a, (const __bf16*)wp, S);
     return hipGetLastError();
 }

@@ -682,7 +682,10 @@ static hipError_t conv_any(Handle* h, const char* role, int taps, int stride, in
         if (wout == 64) return x3 ? conv_bf<ConvBfCfg<6, 3>>(h, role, a, s) : conv_bf<ConvBfCfg<6, 1>>(h, role, a, s);
         if (wout == 32) return x3 ? conv_bf<ConvBfCfg<5, 3>>(h, role, a, s) : conv_bf<ConvBfCfg<5, 1>>(h, role, a, s);
         if (wout == 16) return x3 ? conv_bf<ConvBfCfg<4, 3>>(h, role, a, s) : conv_bf<ConvBfCfg<4, 1>>(h, role, a, s);
+        if (wout == 8) return x3 ? conv_bf<ConvBfCfg<3, 3>>(h, role, a, s) : conv_bf<ConvBfCfg<3, 1>>(h, role, a, s);
     }
+    if (h->precision != EGOTAP_PREC_F32 && h->conv_pack && taps == 9 && stride == 1 && a.Cout == 64 && wout == 64)   // ResNet layer1
+        return h->precision == EGOTAP_PREC_BF16X3 ? conv_bf<ConvBfCfg<6, 3, 64>>(h, role, a, s) : conv_bf<ConvBfCfg<6, 1, 64>>(h, role, a, s);
     if (taps == 9 && stride == 1) {
         if (wout == 128) return a.Cout <= 64 ? conv<C3s1_128_co64>(h, role, a, s) : conv<C3s1_128>(h, role, a, s);
         if (wout == 64) return a.Cout <= 64 ? conv<C3s1_64_co64>(h, role, a, s) : conv<C3s1_64>(h, role, a, s);
