@@ -287,7 +287,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="stereo frames per GPU per step (BASELINE: 256)")
     ap.add_argument("--preset", default="UnrealEgo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-batch", type=int, default=32, help="frames per timed CPU pass (3 passes + warm-up: ~15 s of CPU work)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--lift-only", action="store_true", help="skip the secondary full-pipeline (RGB -> joints) measurement")
     ap.add_argument("--full-steps", type=int, default=3)

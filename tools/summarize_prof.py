@@ -17,9 +17,15 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "gpurun_out", "prof")
 
 
+def newest(pat):
+    """gpurun merges every call's files into gpurun_out/: keep only the newest file of a pass"""
+    fs = sorted(glob.glob(os.path.join(SRC, pat)), key=os.path.getmtime)
+    return fs[-1:] if fs else []
+
+
 def rows(pat):
     out = []
-    for f in glob.glob(os.path.join(SRC, pat)):
+    for f in newest(pat):
         out += list(csv.DictReader(open(f)))
     return out
 
@@ -40,7 +46,7 @@ def main():
     dst = os.path.join(REPO, "profiles")
     os.makedirs(dst, exist_ok=True)
     stats = rows("trace/*/*_kernel_stats.csv")
-    for f in glob.glob(os.path.join(SRC, "trace/*/*_kernel_stats.csv")):
+    for f in newest("trace/*/*_kernel_stats.csv"):
         shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
     pm = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
@@ -56,7 +62,7 @@ def main():
     for x in rows("pmc_write/*/*_counter_collection.csv"):
         write[short(x["Kernel_Name"])].append(float(x["Counter_Value"]))
     lines = [f"# rocprofv3 summary {tag}", "",
-             "Command: `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (B = 256, UnrealEgo lifting head, fp32) under",
+             "Command: `python3 bench.py --steps 2 --warmup 1 --full-steps 1 --train-steps 1 --train-batch-bf16 256 --no-cpu-baseline` (B = 256; every leg: fp32 headline, bf16x3 fast mode, full pipeline in both modes, training step in f32 / bf16x3 / bf16) under",
              "`rocprofv3 --kernel-trace --stats` (durations) and separate `--pmc` passes (FETCH_SIZE; WRITE_SIZE; "
              "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY).",
              "HBM read MB = FETCH_SIZE[KiB] x 2 / 1024 (gfx950 counts 64 B per 128-B request), write MB = WRITE_SIZE[KiB] / 1024.", "",
