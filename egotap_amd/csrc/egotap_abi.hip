@@ -956,6 +956,7 @@ extern "C" int egotap_attention(const float* qkv, float* ctx, int B, int N, int 
 // Building blocks of the training step (egotap_autoencoder_model.py:299-323), called by the autograd glue in
 // egotap_amd/autograd.py.  Each takes caller-owned device buffers and the caller's stream.
 #include "attention_bwd_f32.h"
+#include "attention_bwd_bf16.h"
 #include "gemm_tn_f32.h"
 #include "gemm_tn_bf16.h"
 #include "train_ops.h"
@@ -1155,22 +1156,27 @@ extern "C" int egotap_train_bn_lrelu_bwd(const float* z, const float* y, const f
     return EGOTAP_OK;
 }
 
-extern "C" int egotap_train_attention_fwd(const float* qkv, float* ctx, float* lse, int B, int N, int heads, void* stream) {
+extern "C" int egotap_train_attention_fwd(const float* qkv, float* ctx, float* lse, int B, int N, int heads, int precision, void* stream) {
     EGO_CHECK(qkv && ctx && lse, "egotap_train_attention_fwd: null argument");
     EGO_CHECK(N > 0 && N % 32 == 0 && heads > 0, "egotap_train_attention_fwd: bad shape");
-    EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, (hipStream_t)stream, lse));
+    hipStream_t s = (hipStream_t)stream;
+    if (precision == EGOTAP_PREC_BF16X3) EGO_HIP(attention_bf16_launch<3>(qkv, ctx, B, N, heads, s, lse));
+    else if (precision == EGOTAP_PREC_BF16) EGO_HIP(attention_bf16_launch<1>(qkv, ctx, B, N, heads, s, lse));
+    else EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, s, lse));
     return EGOTAP_OK;
 }
 
 extern "C" int egotap_train_attention_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* delta,
-                                          float* dqkv, int B, int N, int heads, void* stream) {
+                                          float* dqkv, int B, int N, int heads, int precision, void* stream) {
     EGO_CHECK(qkv && ctx && dctx && lse && delta && dqkv, "egotap_train_attention_bwd: null argument");
     EGO_CHECK(N > 0 && N % 32 == 0 && heads > 0, "egotap_train_attention_bwd: bad shape");
-    EGO_HIP(attention_bwd_f32_launch(qkv, ctx, dctx, lse, delta, dqkv, B, N, heads, (hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    if (precision == EGOTAP_PREC_BF16X3) EGO_HIP(attention_bwd_bf16_launch<3>(qkv, ctx, dctx, lse, delta, dqkv, B, N, heads, s));
+    else if (precision == EGOTAP_PREC_BF16) EGO_HIP(attention_bwd_bf16_launch<1>(qkv, ctx, dctx, lse, delta, dqkv, B, N, heads, s));
+    else EGO_HIP(attention_bwd_f32_launch(qkv, ctx, dctx, lse, delta, dqkv, B, N, heads, s));
     return EGOTAP_OK;
 }
 
-// loss_pose, loss_cos_sim -> out[2]; d(loss_pose + loss_cos_sim)/d pred -> dpred.  partial: [B, 2] scratch.
 extern "C" int egotap_train_pose_loss(egotap_handle h, const float* pred, const float* gt, float* dpred, float* out, float* partial,
                                       int B, float lambda_mpjpe, float lambda_cos_sim, void* stream) {
     EGO_CHECK(h && pred && gt && dpred && out && partial, "egotap_train_pose_loss: null argument");

@@ -111,17 +111,17 @@ def bn_lrelu_bwd(z, y, dy, gamma, mean, rstd, dgamma, dbeta, accumulate=False):
     return dz
 
 
-def attention_fwd(qkv, B, N, heads):
+def attention_fwd(qkv, B, N, heads, precision="f32"):
     ctx = torch.empty((B * N, heads * 128), dtype=torch.float32, device=qkv.device)
     lse = torch.empty((B * heads * N,), dtype=torch.float32, device=qkv.device)
-    _lib.check(_lib.load().egotap_train_attention_fwd(_p(qkv), _p(ctx), _p(lse), B, N, heads, _s()))
+    _lib.check(_lib.load().egotap_train_attention_fwd(_p(qkv), _p(ctx), _p(lse), B, N, heads, _lib.PRECISIONS[precision], _s()))
     return ctx, lse
 
 
-def attention_bwd(qkv, ctx, dctx, lse, B, N, heads):
+def attention_bwd(qkv, ctx, dctx, lse, B, N, heads, precision="f32"):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
-    _lib.check(_lib.load().egotap_train_attention_bwd(_p(qkv), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), B, N, heads, _s()))
+    _lib.check(_lib.load().egotap_train_attention_bwd(_p(qkv), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), B, N, heads, _lib.PRECISIONS[precision], _s()))
     return dqkv
 
 

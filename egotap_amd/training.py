@@ -31,6 +31,10 @@ class LiftTrainFn(torch.autograd.Function):
         P = dict(zip(keys, params))
         dev = hm.device
         h = net._ensure_handle()
+        # attention: exact fp32 unless the whole step is bf16.  Recomputing P = exp(S - lse) from split-bf16 scores (2^-16 per
+        # product) costs ~1e-4 relative in every probability, and gradients that are sums with heavy cancellation (mask_token)
+        # then miss the reference-golden gate (2.6 % of the tensor's typical magnitude against 0.5 %): bf16x3 stays fp32-grade.
+        prec = "bf16" if getattr(net, "precision", "f32") == "bf16" else "f32"
         net._bind(dev)
         B, D, seq, heads, J, T_, hid = hm.shape[0], p.vit_dim, p.seq, p.vit_heads, p.n_joints_hm, p.tokens, p.hidden
         M, BT = B * seq, B * T_
@@ -51,7 +55,7 @@ class LiftTrainFn(torch.autograd.Function):
             qkv = torch.empty((M, 3 * D), dtype=torch.float32, device=dev)
             _lib.check(lib.egotap_train_qkv_fwd(h, T._p(y1), T._p(P[a + "query.weight"]), T._p(P[a + "query.bias"]), T._p(P[a + "key.weight"]),
                                                 T._p(P[a + "key.bias"]), T._p(P[a + "value.weight"]), T._p(P[a + "value.bias"]), T._p(qkv), M, D, st()))
-            ctx_, lse = T.attention_fwd(qkv, B, seq, heads)
+            ctx_, lse = T.attention_fwd(qkv, B, seq, heads, prec)
             xm = T.gemm_nt(h, ctx_, P[l + "attention.output.dense.weight"], P[l + "attention.output.dense.bias"], M, D, D, epi=T.TE_BIAS_RES, r=x)
             y2, m2, r2 = T.layernorm_fwd(xm, P[l + "layernorm_after.weight"], P[l + "layernorm_after.bias"])
             z = torch.empty((M, 4 * D), dtype=torch.float32, device=dev)
@@ -95,6 +99,10 @@ class LiftTrainFn(torch.autograd.Function):
         net, P, keys, B = S["net"], S["P"], S["keys"], S["B"]
         p = net.preset
         h = net._ensure_handle()
+        # attention: exact fp32 unless the whole step is bf16.  Recomputing P = exp(S - lse) from split-bf16 scores (2^-16 per
+        # product) costs ~1e-4 relative in every probability, and gradients that are sums with heavy cancellation (mask_token)
+        # then miss the reference-golden gate (2.6 % of the tensor's typical magnitude against 0.5 %): bf16x3 stays fp32-grade.
+        prec = "bf16" if getattr(net, "precision", "f32") == "bf16" else "f32"
         dev = dpose.device
         D, seq, heads, J, T_, hid, H = p.vit_dim, p.seq, p.vit_heads, p.n_joints_hm, p.tokens, p.hidden, p.pu_hidden
         M, BT = B * seq, B * T_
@@ -162,7 +170,7 @@ class LiftTrainFn(torch.autograd.Function):
             T.gemm_tn(h, dxm, L["ctx"], G[l + "attention.output.dense.weight"], M, D, D)
             T.colsum(dxm, G[l + "attention.output.dense.bias"], M, D)
             dctx = T.gemm_nt(h, dxm, T.transpose(P[l + "attention.output.dense.weight"]), None, M, D, D, epi=T.TE_NONE)
-            dqkv = T.attention_bwd(L["qkv"], L["ctx"], dctx, L["lse"], B, seq, heads)
+            dqkv = T.attention_bwd(L["qkv"], L["ctx"], dctx, L["lse"], B, seq, heads, prec)
             del dctx
             wt = torch.empty((D, 3 * D), dtype=torch.float32, device=dev)      # [Wq^T | Wk^T | Wv^T]
             for s, nme in enumerate(("query", "key", "value")):

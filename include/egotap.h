@@ -161,9 +161,9 @@ int egotap_train_bn_lrelu_bwd(const float* z, const float* y, const float* dy, c
                               void* ws, size_t ws_bytes, void* stream);
 int egotap_train_qkv_fwd(egotap_handle h, const float* y, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
                          const float* bv, float* qkv, int M, int D, void* stream);
-int egotap_train_attention_fwd(const float* qkv, float* ctx, float* lse, int B, int N, int heads, void* stream);
+int egotap_train_attention_fwd(const float* qkv, float* ctx, float* lse, int B, int N, int heads, int precision, void* stream);
 int egotap_train_attention_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* delta,
-                               float* dqkv, int B, int N, int heads, void* stream);
+                               float* dqkv, int B, int N, int heads, int precision, void* stream);
 int egotap_train_pu_saved_bytes(egotap_handle h, int B, size_t* bytes, size_t* hs1_offset);
 int egotap_train_pu_fwd(egotap_handle h, const float* posz, const float* rotz, int B, void* saved, size_t saved_bytes, void* stream);
 int egotap_train_pu_bwd_ws_bytes(egotap_handle h, int B, size_t* bytes);

@@ -270,3 +270,24 @@ def test_gemm_nt_training_epilogues_bf16_modes(mode):
     zz = z.cpu().double()
     dg = 0.5 * (1.0 + torch.erf(zz / math.sqrt(2.0))) + zz * torch.exp(-0.5 * zz * zz) / math.sqrt(2.0 * math.pi)
     _close(d, (xr.double() @ wr.double().T) * dg, atol=tol)
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 5e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("B,N,heads", [(1, 64, 1), (2, 576, 8), (1, 96, 3)])
+def test_attention_fwd_bwd_bf16_modes(mode, tol, B, N, heads):
+    """attention forward (with log-sum-exp) and the three backward kernels on the bf16 matrix cores: row images, transposed
+    reads and split probability / dS accumulators against float64 autograd; asymmetric data, partial last group (N = 96)."""
+    from egotap_amd import train_ops as T
+    D = heads * 128
+    qkv, dctx = _rand((B * N, 3 * D), 31, -1.5, 1.5), _rand((B * N, D), 32)
+    qkvr = qkv.double().requires_grad_(True)
+    q, k, v = [t.reshape(B, N, heads, 128).transpose(1, 2) for t in qkvr.split(D, dim=1)]
+    s = q @ k.transpose(-1, -2) / math.sqrt(128.0)
+    ctx_ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * N, D)
+    ctx_ref.backward(dctx.double())
+    ctx, lse = T.attention_fwd(qkv.cuda(), B, N, heads, mode)
+    _close(ctx, ctx_ref.detach(), tol)
+    _close(lse.reshape(B, heads, N), torch.logsumexp(s.detach(), -1), tol)
+    dqkv = T.attention_bwd(qkv.cuda(), ctx, dctx.cuda(), lse, B, N, heads, mode)
+    _close(dqkv, qkvr.grad, tol, rtol=1e-3 if mode == "bf16x3" else 5e-2)
+    assert torch.equal(dqkv, T.attention_bwd(qkv.cuda(), ctx, dctx.cuda(), lse, B, N, heads, mode))
