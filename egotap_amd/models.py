@@ -88,6 +88,9 @@ class EgoTAPAutoEncoderModel(nn.Module):
             self.optimizer_AutoEncoder = EgotapAdamW(self.net_AutoEncoder.parameters(), lr=getattr(opt, "lr", 1e-3),
                                                      eps=getattr(opt, "opt_eps", 1e-4), weight_decay=getattr(opt, "weight_decay", 0.0))
             self.optimizers.append(self.optimizer_AutoEncoder)
+            if getattr(opt, "lr_policy", None):                      # egotap_autoencoder_model.py:151-152
+                from .training import get_scheduler
+                self.schedulers = [get_scheduler(o, opt) for o in self.optimizers]
 
     # ---- data --------------------------------------------------------------------------------------------------
     def set_input(self, data):
@@ -197,6 +200,27 @@ class EgoTAPAutoEncoderModel(nn.Module):
             net = getattr(self, "net_" + name)
             sd = OrderedDict((k, v.detach().cpu()) for k, v in net.state_dict().items())
             torch.save(sd, os.path.join(checkpoint_path, "%s_net_%s.pth" % (which_epoch, name)))
+        for i, o in enumerate(self.optimizers):                      # base_model.py:83-92
+            torch.save(o.state_dict(), os.path.join(checkpoint_path, "%s_optim_%s.pth" % (which_epoch, i)))
+        for i, sch in enumerate(self.schedulers):
+            torch.save(sch.state_dict(), os.path.join(checkpoint_path, "%s_scheduler_%s.pth" % (which_epoch, i)))
+        if isinstance(which_epoch, int) and which_epoch > 1 and which_epoch != getattr(self.opt, "epoch_count", None):
+            prev = which_epoch - 1                                   # base_model.py:94-114: keep only the latest numbered epoch
+            names = ["%s_net_%s.pth" % (prev, n) for n in self.model_names]
+            names += ["%s_optim_%s.pth" % (prev, i) for i in range(len(self.optimizers))]
+            names += ["%s_scheduler_%s.pth" % (prev, i) for i in range(len(self.schedulers))]
+            for fn in names:
+                fp = os.path.join(checkpoint_path, fn)
+                if os.path.exists(fp):
+                    os.remove(fp)
+
+    def load_optimizers(self, which_epoch="checkpoint", checkpoint_path=None):
+        """resume: optimizer / scheduler state written by save_networks (also accepts torch.optim.AdamW state files)"""
+        checkpoint_path = self.save_dir if checkpoint_path is None else checkpoint_path
+        for i, o in enumerate(self.optimizers):
+            o.load_state_dict(torch.load(os.path.join(checkpoint_path, "%s_optim_%s.pth" % (which_epoch, i)), map_location=self.device))
+        for i, sch in enumerate(self.schedulers):
+            sch.load_state_dict(torch.load(os.path.join(checkpoint_path, "%s_scheduler_%s.pth" % (which_epoch, i))))
 
     def load_networks(self, which_epoch=None, net=None, path_to_trained_weights=None, checkpoint_path=None):
         if path_to_trained_weights is not None:

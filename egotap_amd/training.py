@@ -232,7 +232,38 @@ class EgotapAdamW(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
-                st["step"] += 1
+                st["step"] = int(st["step"]) + 1        # torch.optim.AdamW checkpoints keep the step as a tensor
                 T.adamw(p, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], group["lr"], st["step"], b1, b2, group["eps"],
                         group["weight_decay"])
         return None
+
+
+def get_scheduler(optimizer, opt):
+    """Learning-rate policies of the reference (model/network.py:35-55), stepped once per iteration by
+    ``update_learning_rate`` (train.py:130).  ``cos_anneal_warmup`` restates transformers.optimization
+    .get_cosine_schedule_with_warmup (linear warm-up over niter epochs, then half a cosine to zero over niter_decay epochs):
+    the reference imports it; here it is a LambdaLR with the same multiplier, pinned by tests/golden/lr_schedules.npz."""
+    import math
+    from torch.optim import lr_scheduler
+    policy = getattr(opt, "lr_policy", "lambda")
+    niter, niter_decay = getattr(opt, "niter", 0), getattr(opt, "niter_decay", 0)
+    per_epoch = getattr(opt, "epoch_iter_cnt", 1)
+    if policy == "lambda":
+        epoch_count = getattr(opt, "epoch_count", 1)
+        return lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda e: 1.0 - max(0, e + epoch_count - niter) / float(niter_decay + 1))
+    if policy == "step":
+        return lr_scheduler.StepLR(optimizer, step_size=getattr(opt, "lr_decay_iters_step", 4), gamma=0.5)
+    if policy == "exponent":
+        return lr_scheduler.ExponentialLR(optimizer, gamma=0.95)
+    if policy == "cos_anneal":
+        return lr_scheduler.CosineAnnealingLR(optimizer, T_max=(niter + niter_decay) * per_epoch)
+    if policy == "cos_anneal_warmup":
+        warm, total = niter * per_epoch, (niter + niter_decay) * per_epoch
+
+        def mult(step):
+            if step < warm:
+                return float(step) / float(max(1, warm))
+            progress = float(step - warm) / float(max(1, total - warm))
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 2.0 * 0.5 * progress)))
+        return lr_scheduler.LambdaLR(optimizer, mult)
+    raise NotImplementedError("learning rate policy [%s] is not implemented" % policy)

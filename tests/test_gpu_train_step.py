@@ -159,3 +159,54 @@ def test_train_step_bf16_mode_tracks_fp32():
         rel = float((a - b).norm() / b.norm())
         worst_cos, worst_rel = min(worst_cos, cos), max(worst_rel, rel)
         assert cos > 0.98 and rel < 0.2, f"{k}: cos {cos:.5f} rel {rel:.3e}"
+
+
+def test_wrapper_checkpoint_roundtrip_and_scheduler(tmp_path):
+    """save_networks / load_networks / load_optimizers with the reference's file naming (base_model.py:64-148) and the
+    cos_anneal_warmup schedule driven by update_learning_rate (train.py:130): a resumed model continues bit for bit."""
+    from egotap_amd import models, spec
+    from egotap_amd.options import preset_defaults
+
+    def make():
+        opt = preset_defaults("UnrealEgo")
+        opt.isTrain, opt.use_gt_heatmap, opt.lr, opt.opt_eps, opt.weight_decay = True, True, 1e-3, 1e-4, 0.0
+        opt.lr_policy, opt.niter, opt.niter_decay, opt.epoch_iter_cnt, opt.epoch_count = "cos_anneal_warmup", 1, 3, 2, 1
+        opt.log_dir, opt.experiment_name = str(tmp_path), "exp"
+        return models.create_model(opt)
+    p = spec.lift_preset("UnrealEgo")
+    hm = torch.from_numpy(synth_input("hm_train", (2, 90, 64, 64)))
+    data = {"input_rgb_left": torch.zeros(2, 3, 256, 256), "input_rgb_right": torch.zeros(2, 3, 256, 256),
+            "gt_heatmap_left": hm[:, :15], "gt_heatmap_right": hm[:, 15:30], "gt_limb_heatmap_left": hm[:, 30:60],
+            "gt_limb_heatmap_right": hm[:, 60:], "gt_local_pose": torch.from_numpy(synth_input("gt_train", (2, 16, 3), -1.0, 1.0))}
+    a = make()
+    a.net_AutoEncoder.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
+    a.set_input(data)
+    lrs = []
+    for _ in range(3):
+        lrs.append(a.optimizers[0].param_groups[0]["lr"])
+        a.optimize_parameters()
+        a.update_learning_rate()
+    np.testing.assert_allclose(lrs, [0.0, 5e-4, 1e-3], rtol=1e-12)            # linear warm-up over niter * epoch_iter_cnt = 2 steps
+    a.save_networks(which_epoch=1)
+    a.save_networks(which_epoch=2)                                             # numbered epochs: the previous one is removed
+    names = sorted(os.listdir(a.save_dir))
+    assert names == sorted(["2_net_HeatMap.pth", "2_net_RotHeatMap.pth", "2_net_AutoEncoder.pth", "2_optim_0.pth", "2_scheduler_0.pth"]), names
+    sd = torch.load(os.path.join(a.save_dir, "2_net_AutoEncoder.pth"))
+    assert list(sd.keys()) == [k for k, _ in spec.lift_state_spec(p)]          # the reference's keys, in its order
+    b = make()
+    b.load_networks(which_epoch=2)
+    b.load_optimizers(which_epoch=2)
+    b.set_input(data)
+    for m in (a, b):
+        m.optimize_parameters()
+        m.update_learning_rate()
+    assert a.optimizers[0].param_groups[0]["lr"] == b.optimizers[0].param_groups[0]["lr"]
+    for (k, x), (_, y) in zip(a.net_AutoEncoder.state_dict().items(), b.net_AutoEncoder.state_dict().items()):
+        assert torch.equal(x, y), k
+    # a torch.optim.AdamW state file (step kept as a tensor) resumes too
+    ref_opt = torch.optim.AdamW([torch.nn.Parameter(v.detach().clone()) for v in a.net_AutoEncoder.parameters()], lr=1e-3, eps=1e-4, weight_decay=0.0)
+    for prm in ref_opt.param_groups[0]["params"]:
+        prm.grad = torch.zeros_like(prm)
+    ref_opt.step()
+    b.optimizers[0].load_state_dict(ref_opt.state_dict())
+    b.optimize_parameters()

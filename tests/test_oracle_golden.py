@@ -139,3 +139,25 @@ def test_train_step_matches_reference():
     for pre, (rm, rv) in out["bn"].items():
         np.testing.assert_allclose(rm.detach().numpy(), g["buf:" + pre + ".bn.running_mean"], atol=1e-6)
         np.testing.assert_allclose(rv.detach().numpy(), g["buf:" + pre + ".bn.running_var"], atol=1e-6)
+
+
+def test_lr_schedules_match_reference():
+    """get_scheduler (host logic of the training wrapper) against tables produced by the reference's own get_scheduler
+    (model/network.py:35-55; cos_anneal_warmup = transformers' cosine schedule with warm-up) on a dummy optimizer."""
+    import types
+    from egotap_amd.training import get_scheduler
+    g = _load("lr_schedules.npz")
+    for tag in g.files:
+        policy, niter, niter_decay, per = tag.rsplit("_", 3)
+        opt = types.SimpleNamespace(lr_policy=policy, epoch_count=1, lr_decay_iters_step=4, niter=int(niter),
+                                    niter_decay=int(niter_decay), epoch_iter_cnt=int(per))
+        optim = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+        sch = get_scheduler(optim, opt)
+        lrs = []
+        for _ in range(len(g[tag])):
+            lrs.append(optim.param_groups[0]["lr"])
+            optim.step()
+            sch.step()
+        np.testing.assert_allclose(lrs, g[tag], rtol=1e-12, atol=1e-18, err_msg=tag)
+    with pytest.raises(NotImplementedError):
+        get_scheduler(optim, types.SimpleNamespace(lr_policy="plateau"))

@@ -312,9 +312,37 @@ def gen_hm():
         print(f"hm_full_{tag}:", tuple(y.shape), float(y.abs().mean()))
 
 
+def gen_sched():
+    """learning-rate tables of the reference's own get_scheduler (model/network.py:35-55) on a dummy optimizer"""
+    import types
+    from model import network as N
+
+    out = {}
+    for policy, kw in (("cos_anneal_warmup", dict(niter=1, niter_decay=15, epoch_iter_cnt=7)),
+                       ("cos_anneal_warmup", dict(niter=2, niter_decay=3, epoch_iter_cnt=5)),
+                       ("cos_anneal", dict(niter=1, niter_decay=4, epoch_iter_cnt=6)),
+                       ("lambda", dict(niter=3, niter_decay=5, epoch_iter_cnt=1)),
+                       ("step", dict(niter=1, niter_decay=1, epoch_iter_cnt=1)),
+                       ("exponent", dict(niter=1, niter_decay=1, epoch_iter_cnt=1))):
+        opt = types.SimpleNamespace(lr_policy=policy, epoch_count=1, lr_decay_iters_step=4, **kw)
+        prm = torch.nn.Parameter(torch.zeros(1))
+        optim = torch.optim.AdamW([prm], lr=1e-3)
+        sch = N.get_scheduler(optim, opt)
+        steps = (kw["niter"] + kw["niter_decay"]) * kw["epoch_iter_cnt"] + 3
+        lrs = []
+        for _ in range(steps):
+            lrs.append(optim.param_groups[0]["lr"])
+            optim.step()
+            sch.step()
+        tag = f"{policy}_{kw['niter']}_{kw['niter_decay']}_{kw['epoch_iter_cnt']}"
+        out[tag] = np.array(lrs, dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, "lr_schedules.npz"), **out)
+    print("lr_schedules ok", {k: len(v) for k, v in out.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="lift,pu,fc,loss,hm,procrustes,train")
+    ap.add_argument("--only", default="lift,pu,fc,loss,hm,procrustes,train,sched")
     args = ap.parse_args()
     which = set(args.only.split(","))
     os.makedirs(GOLD, exist_ok=True)
@@ -335,6 +363,8 @@ def main():
         gen_procrustes()
     if "train" in which:
         gen_train()
+    if "sched" in which:
+        gen_sched()
 
 
 if __name__ == "__main__":
