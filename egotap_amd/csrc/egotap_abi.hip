@@ -18,6 +18,7 @@
 #include "attention_bf16.h"
 #include "layernorm.h"
 #include "metrics.h"
+#include "heatmap_synth.h"
 #include "pu_chain.h"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -936,6 +937,28 @@ extern "C" int egotap_pose_metrics(const float* pred, const float* gt, int B, in
     EGO_CHECK(pred && gt && mpjpe && pa_mpjpe, "egotap_pose_metrics: null argument");
     EGO_CHECK(B > 0 && J >= 1 && J <= EGOTAP_MAX_JOINTS, "egotap_pose_metrics: bad shape B=%d J=%d", B, J);
     hipLaunchKernelGGL(pose_metrics_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, pred, gt, B, J, mpjpe, pa_mpjpe, aligned);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+// joints -> ground-truth heatmaps in the lifting head's input layout (dataloader/data_loader.py:76-215 with --use_gt_heatmap)
+extern "C" int egotap_synth_heatmaps(const float* pts2d_left, const float* pts2d_right, const float* pose3d, const int* parents, int B,
+                                     int J, int res, float* hm, float* plength, float* theta, void* stream) {
+    if (B == 0) return EGOTAP_OK;
+    EGO_CHECK(pts2d_left && pts2d_right && pose3d && parents && hm, "egotap_synth_heatmaps: null argument");
+    EGO_CHECK(B > 0 && J >= 1 && J <= 64 && res >= 16 && res <= 128, "egotap_synth_heatmaps: bad shape B=%d J=%d res=%d", B, J, res);
+    GaussTaps g;                                   // scipy.ndimage._gaussian_kernel1d(sigma = 1, order 0, radius 4)
+    double sum = 0.0;
+    for (int k = -4; k <= 4; ++k) { g.w[k + 4] = exp(-0.5 * k * k); sum += g.w[k + 4]; }
+    for (int k = 0; k < 9; ++k) g.w[k] /= sum;
+    const size_t lds = (size_t)2 * res * res * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        EGO_HIP(hipFuncSetAttribute((const void*)heatmap_synth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128 * 4));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(heatmap_synth_kernel, dim3(B * 2 * J), dim3(256), lds, (hipStream_t)stream, pts2d_left, pts2d_right, pose3d, parents,
+                       B, J, res, g, hm, plength, theta);
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }

@@ -47,6 +47,7 @@ _PROTOS = {
     "egotap_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "egotap_pose_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egotap_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "egotap_synth_heatmaps": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egotap_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "egotap_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egotap_timing_detail": (C.c_char_p, [C.c_void_p]),
@@ -161,6 +162,35 @@ def pose_metrics(pred, gt, want_aligned: bool = False):
     al = torch.empty_like(pred) if want_aligned else None
     check(load().egotap_pose_metrics(_ptr(pred), _ptr(gt), B, J, _ptr(e), _ptr(pa), _ptr(al), _stream()))
     return (e, pa, al) if want_aligned else (e, pa)
+
+
+KINEMATIC_PARENTS = {          # utils/util.py:51-52
+    "UnrealEgo": [0, 0, 1, 1, 2, 3, 4, 5, 2, 3, 8, 9, 10, 11, 12, 13],
+    "EgoCap": [0, 0, 1, 2, 3, 4, 1, 6, 7, 8, 2, 10, 11, 12, 6, 14, 15, 16],
+}
+
+
+def synth_heatmaps(pts2d_left, pts2d_right, pose3d, joint_preset: str = "UnrealEgo", res: int = 64):
+    """Ground-truth heatmaps on the device (egotap_synth_heatmaps): joints [B, J+1, 2] x 2 eyes in the 1024-pixel frame and
+    gt_local_pose [B, J+1, 3] -> dict with the data loader's keys plus ``cat`` [B, 6J, res, res], the lifting head's input."""
+    import torch
+    parents = KINEMATIC_PARENTS[joint_preset]
+    J1 = len(parents)
+    J = J1 - 1
+    pl, pr, p3 = (t.detach().float().contiguous() for t in (pts2d_left, pts2d_right, pose3d))
+    _need_cuda_f32(pl, pr, p3)
+    B = pl.shape[0]
+    if tuple(pl.shape) != (B, J1, 2) or tuple(pr.shape) != (B, J1, 2) or tuple(p3.shape) != (B, J1, 3):
+        raise ValueError(f"expected [B, {J1}, 2] x 2 and [B, {J1}, 3] for {joint_preset}")
+    dev = pl.device
+    par = torch.tensor(parents, dtype=torch.int32, device=dev)
+    cat = torch.empty((B, 6 * J, res, res), device=dev)
+    plen = torch.empty((B, 2, J), device=dev)
+    theta = torch.empty((B, J), device=dev)
+    check(load().egotap_synth_heatmaps(_ptr(pl), _ptr(pr), _ptr(p3), _ptr(par), B, J, res, _ptr(cat), _ptr(plen), _ptr(theta), _stream()))
+    return {"cat": cat, "gt_heatmap_left": cat[:, :J], "gt_heatmap_right": cat[:, J:2 * J],
+            "gt_limb_heatmap_left": cat[:, 2 * J:4 * J], "gt_limb_heatmap_right": cat[:, 4 * J:],
+            "gt_plength_left": plen[:, 0].repeat(1, 2), "gt_plength_right": plen[:, 1].repeat(1, 2), "gt_limb_theta": theta}
 
 
 def layernorm(x, gamma, beta, eps: float = 1e-12):

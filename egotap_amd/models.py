@@ -102,14 +102,27 @@ class EgoTAPAutoEncoderModel(nn.Module):
         for k in ("gt_heatmap_left", "gt_heatmap_right", "gt_limb_heatmap_left", "gt_limb_heatmap_right"):
             setattr(self, k, data[k].to(dev, non_blocking=True) if k in data else None)
         self.gt_pose = data["gt_local_pose"].to(dev, non_blocking=True) if "gt_local_pose" in data else None
+        if self.gt_heatmap_left is None and "gt_camera_2d_left" in data and getattr(self.opt, "use_gt_heatmap", False):
+            # joints instead of rendered heatmaps: synthesise them on the device (the data loader's per-frame CPU work,
+            # dataloader/data_loader.py:76-215); gt_local_pose_full = all J+1 joints incl. the root, for the limb directions
+            from . import lib as _lib
+            full = data.get("gt_local_pose_full", data["gt_local_pose"]).to(dev)
+            syn = _lib.synth_heatmaps(data["gt_camera_2d_left"].to(dev), data["gt_camera_2d_right"].to(dev), full,
+                                      self.opt.joint_preset, self.net_AutoEncoder.preset.hm_size)
+            for k in ("gt_heatmap_left", "gt_heatmap_right", "gt_limb_heatmap_left", "gt_limb_heatmap_right"):
+                setattr(self, k, syn[k])
+            self._gt_cat = syn["cat"]
 
     # ---- forward -----------------------------------------------------------------------------------------------
     def forward_heatmap(self):
         p = self.net_AutoEncoder.preset
         J = p.n_joints_hm
         if getattr(self.opt, "use_gt_heatmap", False):
-            cat = torch.cat((self.gt_heatmap_left, self.gt_heatmap_right, self.gt_limb_heatmap_left,
-                             self.gt_limb_heatmap_right), dim=1).float().contiguous()
+            if getattr(self, "_gt_cat", None) is not None and self.gt_heatmap_left.data_ptr() == self._gt_cat.data_ptr():
+                cat = self._gt_cat                     # synthesised in place in the head's layout: no torch.cat
+            else:
+                cat = torch.cat((self.gt_heatmap_left, self.gt_heatmap_right, self.gt_limb_heatmap_left,
+                                 self.gt_limb_heatmap_right), dim=1).float().contiguous()
         else:
             left = self.input_rgb_left.float().contiguous()
             right = self.input_rgb_right.float().contiguous()

@@ -131,6 +131,17 @@ int egotap_attention(const float* qkv, float* ctx, int B, int N, int heads, int 
  *   pred, gt  device f32 [B, J, 3];  mpjpe, pa_mpjpe  device f32 [B] (input units);  aligned  device f32 [B, J, 3] or NULL */
 int egotap_pose_metrics(const float* pred, const float* gt, int B, int J, float* mpjpe, float* pa_mpjpe, float* aligned, void* stream);
 
+/* Ground-truth heatmaps from joints, written in the lifting head's input layout (the data loader's per-frame CPU work when
+ * training with --use_gt_heatmap: dataloader/data_loader.py:76-215, utils/projection.py:263-279 coord2d_to_heatmap,
+ * utils/data.py:175-262 get_limb_data / overwrite_limb_data).
+ *   pts2d_left/right  device f32 [B, J+1, 2]  joints in the 1024-pixel image frame (gt_camera_2d_*), joint 0 = root
+ *   pose3d            device f32 [B, J+1, 3]  gt_local_pose (the pelvis offset cancels in the limb direction)
+ *   parents           device i32 [J+1]        kinematic parents (utils/util.py:51-52)
+ *   hm                device f32 [B, 6J, res, res]: L pos, R pos, L cos, L sin, R cos, R sin
+ *   plength           device f32 [B, 2, J] or NULL (gt_pixel_length_left/right);  theta  device f32 [B, J] or NULL */
+int egotap_synth_heatmaps(const float* pts2d_left, const float* pts2d_right, const float* pose3d, const int* parents, int B, int J,
+                          int res, float* hm, float* plength, float* theta, void* stream);
+
 /* ---- training-step operators (fp32), called by the autograd glue (egotap_amd/training.py) ------------------------------
  * They implement the backward of the modules above plus loss / optimizer (egotap_autoencoder_model.py:284-323,
  * utils/loss.py:54-85, network.py:72-78 AdamW).  All buffers are caller-owned device memory; reductions have a fixed order.

@@ -74,3 +74,36 @@ def test_wrapper_gt_heatmap_path():
     direct = m.net_AutoEncoder.predict_pose(hm.cuda())
     torch.cuda.synchronize()
     assert torch.equal(m.pred_pose, direct)
+
+
+def test_wrapper_synthesises_gt_heatmaps_from_joints():
+    """--use_gt_heatmap with joints in the batch instead of rendered heatmaps: the wrapper renders them on the device, in the
+    head's layout, and the pose equals the one from CPU-rendered heatmaps (oracle/heatmap_synth_ref.py) fed the usual way."""
+    import numpy as np
+    from egotap_amd import models, spec
+    from egotap_amd.options import preset_defaults
+    from egotap_amd.synthetic import synth_input, synth_state_dict
+    from oracle import heatmap_synth_ref as R
+    opt = preset_defaults("UnrealEgo")
+    opt.gpu_ids, opt.use_gt_heatmap = [0], True
+    m = models.create_model(opt)
+    p = spec.lift_preset("UnrealEgo")
+    m.net_AutoEncoder.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
+    m.set_eval_mode()
+    B = 2
+    p2l, p2r = synth_input("wr_p2l", (B, 16, 2), 0.0, 1024.0), synth_input("wr_p2r", (B, 16, 2), 0.0, 1024.0)
+    p3 = synth_input("wr_p3", (B, 16, 3), -40.0, 40.0)
+    rgb = torch.zeros(B, 3, 256, 256)
+    m.set_input({"input_rgb_left": rgb, "input_rgb_right": rgb, "gt_camera_2d_left": torch.from_numpy(p2l),
+                 "gt_camera_2d_right": torch.from_numpy(p2r), "gt_local_pose": torch.from_numpy(p3)})
+    with torch.no_grad():
+        m.forward(evaluate=True)
+    pose_dev = m.pred_pose.clone()
+    cats = np.stack([R.process_frame(p2l[b].astype(np.float64), p2r[b].astype(np.float64), p3[b].astype(np.float64))[0] for b in range(B)])
+    cat = torch.from_numpy(cats)
+    m.set_input({"input_rgb_left": rgb, "input_rgb_right": rgb, "gt_heatmap_left": cat[:, :15], "gt_heatmap_right": cat[:, 15:30],
+                 "gt_limb_heatmap_left": cat[:, 30:60], "gt_limb_heatmap_right": cat[:, 60:], "gt_local_pose": torch.from_numpy(p3)})
+    m._gt_cat = None
+    with torch.no_grad():
+        m.forward(evaluate=True)
+    assert float((m.pred_pose - pose_dev).abs().max()) < 1e-4

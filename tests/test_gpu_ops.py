@@ -247,3 +247,31 @@ def test_attention_bf16x3_rescale_branch_and_structured_v():
     # V[key][d] = key + d/1000: every (key, d) pair is distinguishable in the output
     qkv[:, 256:] = torch.arange(N, dtype=torch.float32)[:, None] + torch.arange(128, dtype=torch.float32)[None, :] / 1000.0
     _close(lib.attention(qkv.cuda(), B, N, heads, precision="bf16x3"), _attn_ref(qkv, B, N, heads), 2e-3, rtol=2e-5)
+
+
+# ---- ground-truth heatmap synthesis on the device (heatmap_synth.h)
+@pytest.mark.parametrize("preset,n", [("UnrealEgo", 16), ("EgoCap", 18)])
+@pytest.mark.parametrize("res", [64, 128])
+def test_synth_heatmaps_matches_oracle_and_reference_fixture(preset, n, res):
+    import os
+    from egotap_amd import lib
+    from egotap_amd.synthetic import synth_input
+    from oracle import heatmap_synth_ref as R
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "heatmap_synth.npz"))
+    p2l = synth_input(f"synth_p2l_{preset}", (3, n, 2), -60.0, 1080.0)
+    p2r = synth_input(f"synth_p2r_{preset}", (3, n, 2), -60.0, 1080.0)
+    p2l[0, 1] = [512.0, 256.0]
+    p2l[0, 2] = [-100.0, 500.0]
+    p3 = synth_input(f"synth_p3_{preset}", (3, n, 3), -40.0, 40.0)
+    out = lib.synth_heatmaps(torch.from_numpy(p2l).cuda(), torch.from_numpy(p2r).cuda(), torch.from_numpy(p3).cuda(), preset, res)
+    J = n - 1
+    cat = out["cat"].cpu().numpy()
+    assert cat.shape == (3, 6 * J, res, res)
+    for b in range(3):
+        ref, plen, theta = R.process_frame(p2l[b].astype(np.float64), p2r[b].astype(np.float64), p3[b].astype(np.float64), preset, res)
+        np.testing.assert_allclose(cat[b], ref, atol=2e-6, rtol=0)
+        np.testing.assert_allclose(out["gt_limb_theta"][b].cpu().numpy(), theta, atol=1e-6)
+        np.testing.assert_allclose(out["gt_plength_left"][b, :J].cpu().numpy(), plen[0], rtol=1e-5)
+        np.testing.assert_allclose(out["gt_plength_right"][b, J:].cpu().numpy(), plen[1], rtol=1e-5)
+        np.testing.assert_allclose(cat[b, :2 * J], g[f"{preset}_{res}_{b}_pos"], atol=2e-6, rtol=0)      # the reference's own output
+    assert float(cat[0, 1].max()) == 0.0 or p2l[0, 2, 0] >= 0        # the off-frame joint leaves an empty position map

@@ -340,9 +340,41 @@ def gen_sched():
     print("lr_schedules ok", {k: len(v) for k, v in out.items()})
 
 
+def gen_synth():
+    """ground-truth heatmap synthesis by the reference's own coord2d_to_heatmap / get_limb_data; skimage.draw.line_aa (not
+    installed) is supplied by oracle/heatmap_synth_ref.line_aa, so that one step is NOT pinned by this fixture"""
+    from oracle import heatmap_synth_ref as R
+    sys.modules["skimage.draw"].line_aa = R.line_aa
+    import importlib
+    import utils.data as UD
+    import utils.projection as UP
+    importlib.reload(UD)                       # rebinds `from skimage.draw import line_aa`
+    out = {}
+    for preset, n in (("UnrealEgo", 16), ("EgoCap", 18)):
+        for res in (64, 128):
+            # joints spread over (and slightly beyond) the 1024-pixel frame, one exactly on a pixel centre, one off-frame
+            p2l = synth_input(f"synth_p2l_{preset}", (3, n, 2), -60.0, 1080.0).astype(np.float64)
+            p2r = synth_input(f"synth_p2r_{preset}", (3, n, 2), -60.0, 1080.0).astype(np.float64)
+            p2l[0, 1] = [512.0, 256.0]
+            p2l[0, 2] = [-100.0, 500.0]
+            p3 = synth_input(f"synth_p3_{preset}", (3, n, 3), -40.0, 40.0).astype(np.float64)
+            for b in range(3):
+                hl = UP.coord2d_to_heatmap(p2l[b][1:], res=res, sigma=1.0)
+                hr = UP.coord2d_to_heatmap(p2r[b][1:], res=res, sigma=1.0)
+                ll, len_l, th = UD.get_limb_data(p2l[b].copy(), p3[b], res=res, area=res, htype="line", sigma=1, joint_preset=preset)
+                lr, len_r, _ = UD.get_limb_data(p2r[b].copy(), p3[b], res=res, area=res, htype="line", sigma=1, joint_preset=preset)
+                tag = f"{preset}_{res}_{b}"
+                out[tag + "_pos"] = np.concatenate([hl, hr]).astype(np.float32)
+                out[tag + "_limb"] = np.concatenate([ll, lr]).astype(np.float32)
+                out[tag + "_len"] = np.stack([len_l, len_r]).astype(np.float32)
+                out[tag + "_theta"] = th.astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "heatmap_synth.npz"), **out)
+    print("heatmap_synth ok", len(out), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="lift,pu,fc,loss,hm,procrustes,train,sched")
+    ap.add_argument("--only", default="lift,pu,fc,loss,hm,procrustes,train,sched,synth")
     args = ap.parse_args()
     which = set(args.only.split(","))
     os.makedirs(GOLD, exist_ok=True)
@@ -365,6 +397,8 @@ def main():
         gen_train()
     if "sched" in which:
         gen_sched()
+    if "synth" in which:
+        gen_synth()
 
 
 if __name__ == "__main__":
