@@ -291,6 +291,10 @@ __global__ __launch_bounds__(256) void stem_conv7_kernel(const float* __restrict
     float* dst = out + (long)n * 64 * HO * HO + (long)y * HO + x;
 #pragma unroll
     for (int co = 0; co < 64; ++co) {
+        if (gamma == nullptr) {            // training: raw convolution output, BatchNorm (batch statistics) follows
+            dst[(long)co * HO * HO] = acc[co];
+            continue;
+        }
         const float sc = gamma[co] / sqrtf(var[co] + 1e-5f);
         const float v = acc[co] * sc + (beta[co] - mean[co] * sc);
         dst[(long)co * HO * HO] = fmaxf(v, 0.f);

@@ -1511,3 +1511,183 @@ extern "C" int egotap_train_qkv_fwd(egotap_handle h, const float* y, const float
     EGO_HIP((gemm_big(h, "qkv", ALoadPlain{y, D}, W, EpiBias{b}, qkv, 3L * D, M, 3 * D, D, (hipStream_t)stream)));
     return EGOTAP_OK;
 }
+
+
+// ================================================================================================ heatmap-estimator training
+// Building blocks of one optimisation step of the stage-1 model (model/heatmap_shared_model.py:98-172: HeatMap_UnrealEgo_Shared
+// in train mode, MSE losses, Adam), called by the autograd glue in egotap_amd/hm_training.py.  All tensors are caller-owned
+// NCHW fp32 device buffers with explicit image strides (so concat slices are read and written in place).
+#include "hm_train.h"
+
+extern "C" int egotap_hmtrain_conv_fwd(egotap_handle h, const float* x, const float* w, const float* bias, const float* res, float* y,
+                                       int Nimg, int Cin, int Cout, int wout, int taps, int stride, int relu, int64_t in_istride,
+                                       int64_t out_istride, int64_t res_istride, void* stream) {
+    EGO_CHECK(h && x && w && bias && y, "egotap_hmtrain_conv_fwd: null argument");
+    ConvArgs a{x, w, y, res, nullptr, nullptr, nullptr, nullptr, bias, in_istride, out_istride, res_istride, Nimg, Cin, Cout, relu, 0, 0};
+    hipError_t e = conv_any(h, "hmtrain.conv", taps, stride, wout, a, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) { egotap_set_error("egotap_hmtrain_conv_fwd: unsupported conv taps=%d stride=%d wout=%d Cin=%d Cout=%d", taps, stride, wout, Cin, Cout); return EGOTAP_ERR_INVALID; }
+    EGO_HIP(e);
+    return EGOTAP_OK;
+}
+
+// conv 7x7 / 2 of the ResNet stem without BatchNorm: z [2B, 64, S0/2, S0/2], image n = 2b + eye
+extern "C" int egotap_hmtrain_stem_fwd(const float* left, const float* right, const float* w, float* z, int B, int S0, void* stream) {
+    EGO_CHECK(left && right && w && z && B > 0 && S0 % 32 == 0, "egotap_hmtrain_stem_fwd: bad argument");
+    hipLaunchKernelGGL(stem_conv7_kernel, dim3(S0 / 32, S0 / 32, 2 * B), dim3(256), 0, (hipStream_t)stream, left, right, w, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, z, S0);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+static int bn_splits(int N, int C) { int s = (1024 + C - 1) / C; if (s > N) s = N; if (s < 1) s = 1; return s; }
+
+extern "C" int egotap_hmtrain_bn2d_fwd(const float* z, float* y, const float* res, const float* gamma, const float* beta, float* mean, float* rstd,
+                                       float* run_mean, float* run_var, int N, int C, int HW, int64_t z_istride, int64_t y_istride,
+                                       int64_t res_istride, int relu, float eps, float momentum, void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(z && y && gamma && beta && mean && rstd && ws, "egotap_hmtrain_bn2d_fwd: null argument");
+    EGO_CHECK(HW % 4 == 0 && N > 0 && C > 0, "egotap_hmtrain_bn2d_fwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int splits = bn_splits(N, C), per = (N + splits - 1) / splits;
+    EGO_CHECK((size_t)splits * C * 2 * 8 <= ws_bytes, "egotap_hmtrain_bn2d_fwd: workspace too small");
+    hipLaunchKernelGGL(chan_sums_kernel<0>, dim3(C, splits), dim3(256), 0, s, z, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (double*)ws, N, C, HW, (long)z_istride, (long)z_istride, 0, per);
+    hipLaunchKernelGGL(bn2d_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)ws, splits, C, (double)N * HW, eps, momentum, mean, rstd,
+                       run_mean, run_var);
+    const long total = (long)N * C * (HW / 4);
+    hipLaunchKernelGGL(bn2d_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, y, res, gamma, beta, (const float*)mean, (const float*)rstd,
+                       N, C, HW, (long)z_istride, (long)y_istride, (long)res_istride, relu);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_hmtrain_bn2d_bwd(const float* z, const float* y, const float* dy, const float* gamma, const float* mean, const float* rstd,
+                                       float* dz, float* dres, float* dgamma, float* dbeta, int N, int C, int HW, int64_t z_istride,
+                                       int64_t dy_istride, int relu, int accumulate, int dres_accumulate, void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(z && dy && gamma && mean && rstd && dz && dgamma && dbeta && ws, "egotap_hmtrain_bn2d_bwd: null argument");
+    EGO_CHECK(!relu || y, "egotap_hmtrain_bn2d_bwd: the ReLU mask needs y");
+    EGO_CHECK(HW % 4 == 0 && N > 0 && C > 0, "egotap_hmtrain_bn2d_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int splits = bn_splits(N, C), per = (N + splits - 1) / splits;
+    const size_t need = (size_t)splits * C * 2 * 8 + (size_t)C * 2 * 4;
+    EGO_CHECK(need <= ws_bytes, "egotap_hmtrain_bn2d_bwd: workspace too small");
+    double* part = (double*)ws;
+    float* sums = (float*)((char*)ws + (size_t)splits * C * 2 * 8);
+    hipLaunchKernelGGL(chan_sums_kernel<1>, dim3(C, splits), dim3(256), 0, s, dy, z, y, mean, rstd, part, N, C, HW, (long)dy_istride, (long)z_istride,
+                       relu, per);
+    hipLaunchKernelGGL(bn2d_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)part, splits, C, sums, dgamma, dbeta, accumulate);
+    const long total = (long)N * C * (HW / 4);
+    hipLaunchKernelGGL(bn2d_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, y, dy, gamma, mean, rstd, (const float*)sums, dz, dres,
+                       N, C, HW, (long)z_istride, (long)dy_istride, 1.0f / ((float)N * HW), relu, dres_accumulate);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+__global__ void chansum_finish_kernel(const double* __restrict__ part, int splits, int C, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0;
+    for (int k = 0; k < splits; ++k) s0 += part[((long)k * C + c) * 2];
+    out[c] = (accumulate ? out[c] : 0.f) + (float)s0;
+}
+
+// per-channel sums over N*H*W (bias gradients)
+extern "C" int egotap_hmtrain_chansum(const float* dy, float* out, int N, int C, int HW, int64_t istride, int accumulate, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    EGO_CHECK(dy && out && ws && HW % 4 == 0, "egotap_hmtrain_chansum: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int splits = bn_splits(N, C), per = (N + splits - 1) / splits;
+    EGO_CHECK((size_t)splits * C * 2 * 8 <= ws_bytes, "egotap_hmtrain_chansum: workspace too small");
+    hipLaunchKernelGGL(chan_sums_kernel<0>, dim3(C, splits), dim3(256), 0, s, dy, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (double*)ws, N, C, HW, (long)istride, (long)istride, 0, per);
+    hipLaunchKernelGGL(chansum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)ws, splits, C, out, accumulate);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_hmtrain_conv_wt(const float* w, float* wt, int Cout, int Cin, int taps, void* stream) {
+    EGO_CHECK(w && wt && Cout > 0 && Cin > 0 && taps > 0, "egotap_hmtrain_conv_wt: bad argument");
+    const long total = (long)Cout * Cin * taps;
+    hipLaunchKernelGGL(conv_wt_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, wt, Cout, Cin, taps);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_hmtrain_zero_upsample(const float* in, float* out, int N, int C, int H, int64_t in_istride, int64_t out_istride, void* stream) {
+    EGO_CHECK(in && out && N > 0 && C > 0 && H > 0, "egotap_hmtrain_zero_upsample: bad argument");
+    const long total = (long)N * C * 4 * H * H;
+    hipLaunchKernelGGL(zero_upsample2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, (long)N * C, H,
+                       (long)in_istride, (long)out_istride, C);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+template <int KS, int STRIDE, int CI_T>
+static hipError_t wgrad_w(int wout, const WgArgs& a, float* dw, size_t sb, int acc, hipStream_t s) {
+    const int cu = device_cu_count();
+    switch (wout) {
+        case 128: if constexpr (KS == 7) return conv_wgrad_launch<WgCfg<KS, STRIDE, 7, CI_T>>(a, dw, sb, cu, acc, s); else return hipErrorInvalidValue;
+        case 64: if constexpr (KS != 7 && STRIDE == 1) return conv_wgrad_launch<WgCfg<KS, STRIDE, 6, CI_T>>(a, dw, sb, cu, acc, s); else return hipErrorInvalidValue;
+        case 32: if constexpr (KS != 7) return conv_wgrad_launch<WgCfg<KS, STRIDE, 5, CI_T>>(a, dw, sb, cu, acc, s); else return hipErrorInvalidValue;
+        case 16: if constexpr (KS != 7) return conv_wgrad_launch<WgCfg<KS, STRIDE, 4, CI_T>>(a, dw, sb, cu, acc, s); else return hipErrorInvalidValue;
+        case 8: if constexpr (KS != 7) return conv_wgrad_launch<WgCfg<KS, STRIDE, 3, CI_T>>(a, dw, sb, cu, acc, s); else return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// dW[Cout][Cin][ks][ks] (+)= sum over images and pixels of dY x shifted X   (ks in {1, 3, 7}, stride in {1, 2}, pad (ks-1)/2)
+extern "C" int egotap_hmtrain_conv_wgrad(const float* dy, const float* x, float* dw, int Nimg, int Cin, int Cout, int wout, int ks, int stride,
+                                         int64_t dy_istride, int64_t x_istride, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(dy && x && dw && ws, "egotap_hmtrain_conv_wgrad: null argument");
+    WgArgs a{dy, x, (float*)ws, dy_istride, x_istride, Nimg, Cin, Cout, 0, 0, 1};
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipErrorInvalidValue;
+    if (ks == 3 && stride == 1) e = wgrad_w<3, 1, 32>(wout, a, dw, ws_bytes, accumulate, s);
+    else if (ks == 3 && stride == 2) e = wgrad_w<3, 2, 32>(wout, a, dw, ws_bytes, accumulate, s);
+    else if (ks == 1 && stride == 1) e = wgrad_w<1, 1, 96>(wout, a, dw, ws_bytes, accumulate, s);
+    else if (ks == 1 && stride == 2) e = wgrad_w<1, 2, 96>(wout, a, dw, ws_bytes, accumulate, s);
+    else if (ks == 7 && stride == 2) e = wgrad_w<7, 2, 3>(wout, a, dw, ws_bytes, accumulate, s);
+    if (e == hipErrorInvalidValue) { egotap_set_error("egotap_hmtrain_conv_wgrad: unsupported ks=%d stride=%d wout=%d", ks, stride, wout); return EGOTAP_ERR_INVALID; }
+    if (e == hipErrorOutOfMemory) { egotap_set_error("egotap_hmtrain_conv_wgrad: workspace too small (%zu bytes)", ws_bytes); return EGOTAP_ERR_WORKSPACE; }
+    EGO_HIP(e);
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_hmtrain_relu_bwd(const float* y, const float* dy, float* dz, int N, int C, int HW, int64_t y_istride, int64_t dy_istride,
+                                       int64_t dz_istride, void* stream) {
+    EGO_CHECK(y && dy && dz && HW % 4 == 0, "egotap_hmtrain_relu_bwd: bad argument");
+    const long total = (long)N * C * (HW / 4);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, dy, dz, N, C, HW, (long)y_istride,
+                       (long)dy_istride, (long)dz_istride);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_hmtrain_maxpool_bwd(const float* x, const float* dy, float* dx, int64_t planes, int HIN, void* stream) {
+    EGO_CHECK(x && dy && dx && planes > 0 && HIN % 2 == 0, "egotap_hmtrain_maxpool_bwd: bad argument");
+    const long total = planes * HIN * HIN;
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)planes, HIN);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_hmtrain_upsample_bwd(const float* dy, float* dx, int N, int C, int HIN, int64_t dy_istride, int64_t dx_istride, void* stream) {
+    EGO_CHECK(dy && dx && N > 0 && C > 0 && HIN > 1, "egotap_hmtrain_upsample_bwd: bad argument");
+    const long total = (long)N * C * HIN * HIN;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, C, HIN, (long)dy_istride,
+                       (long)dx_istride);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+// loss[0] = lambda * (mean_left + mean_right) of (pred - gt)^2 / plen,  dpred = d loss / d pred   (pred, gt contiguous [B, Cn, HW])
+extern "C" int egotap_hmtrain_mse(const float* pred, const float* gt, const float* plen, float* dpred, float* loss, int B, int Cn, int HW,
+                                  float lambda, void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(pred && gt && dpred && loss && ws && HW % 4 == 0 && Cn % 2 == 0, "egotap_hmtrain_mse: bad argument");
+    const int blocks = 512;
+    EGO_CHECK((size_t)blocks * 8 <= ws_bytes, "egotap_hmtrain_mse: workspace too small");
+    const float coef = lambda / ((float)B * (Cn / 2) * HW);
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, gt, plen, dpred, (double*)ws, B, Cn, HW, coef);
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const double*)ws, blocks, coef, loss);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}

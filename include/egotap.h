@@ -188,6 +188,38 @@ int egotap_train_pose_loss(egotap_handle h, const float* pred, const float* gt, 
 int egotap_train_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                        float weight_decay, int step, void* stream);
 
+/* ---- heatmap-estimator training operators (fp32), called by the autograd glue (egotap_amd/hm_training.py) ----------------
+ * One optimisation step of the stage-1 model (model/heatmap_shared_model.py:98-172): HeatMap_UnrealEgo_Shared in train mode
+ * (model/net_architecture.py:25-173: BatchNorm2d on batch statistics), MSE / limb-length-normalised MSE losses, Adam.
+ * All tensors NCHW fp32 with explicit image strides (floats), so concat slices are read and written in place.
+ *   conv_fwd     convolution + bias (+ residual) (+ ReLU) on the forward kernels; also the INPUT gradient: dX = conv(dY, conv_wt(W)),
+ *                stride-2 layers after zero_upsample(dY)
+ *   conv_wgrad   dW[Cout][Cin][ks][ks] (+)= sum_{n,y,x} dY * shifted X  (ks 1 / 3 / 7, stride 1 / 2; split over images,
+ *                fixed-order reduction: bitwise reproducible)
+ *   bn2d_fwd     batch statistics over N*H*W, running-stat update (momentum, unbiased variance), y = [relu](bn(z) [+ res])
+ *   bn2d_bwd     dz, dgamma, dbeta (and the residual branch's gradient dres = dy * [y > 0]) */
+int egotap_hmtrain_conv_fwd(egotap_handle h, const float* x, const float* w, const float* bias, const float* res, float* y, int Nimg, int Cin,
+                            int Cout, int wout, int taps, int stride, int relu, int64_t in_istride, int64_t out_istride, int64_t res_istride,
+                            void* stream);
+int egotap_hmtrain_stem_fwd(const float* left, const float* right, const float* w, float* z, int B, int S0, void* stream);
+int egotap_hmtrain_bn2d_fwd(const float* z, float* y, const float* res, const float* gamma, const float* beta, float* mean, float* rstd,
+                            float* run_mean, float* run_var, int N, int C, int HW, int64_t z_istride, int64_t y_istride, int64_t res_istride,
+                            int relu, float eps, float momentum, void* ws, size_t ws_bytes, void* stream);
+int egotap_hmtrain_bn2d_bwd(const float* z, const float* y, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dz,
+                            float* dres, float* dgamma, float* dbeta, int N, int C, int HW, int64_t z_istride, int64_t dy_istride, int relu,
+                            int accumulate, int dres_accumulate, void* ws, size_t ws_bytes, void* stream);
+int egotap_hmtrain_chansum(const float* dy, float* out, int N, int C, int HW, int64_t istride, int accumulate, void* ws, size_t ws_bytes, void* stream);
+int egotap_hmtrain_conv_wt(const float* w, float* wt, int Cout, int Cin, int taps, void* stream);
+int egotap_hmtrain_zero_upsample(const float* in, float* out, int N, int C, int H, int64_t in_istride, int64_t out_istride, void* stream);
+int egotap_hmtrain_conv_wgrad(const float* dy, const float* x, float* dw, int Nimg, int Cin, int Cout, int wout, int ks, int stride,
+                              int64_t dy_istride, int64_t x_istride, int accumulate, void* ws, size_t ws_bytes, void* stream);
+int egotap_hmtrain_relu_bwd(const float* y, const float* dy, float* dz, int N, int C, int HW, int64_t y_istride, int64_t dy_istride,
+                            int64_t dz_istride, void* stream);
+int egotap_hmtrain_maxpool_bwd(const float* x, const float* dy, float* dx, int64_t planes, int HIN, void* stream);
+int egotap_hmtrain_upsample_bwd(const float* dy, float* dx, int N, int C, int HIN, int64_t dy_istride, int64_t dx_istride, void* stream);
+int egotap_hmtrain_mse(const float* pred, const float* gt, const float* plen, float* dpred, float* loss, int B, int Cn, int HW, float lambda,
+                       void* ws, size_t ws_bytes, void* stream);
+
 /* ---- measurement hooks (bench.py roofline) ---- */
 /* when enabled, every GEMM launch of the handle is bracketed by HIP events on the caller's stream */
 int egotap_timing_enable(egotap_handle h, int enable);
