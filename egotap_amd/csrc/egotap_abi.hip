@@ -1691,3 +1691,19 @@ extern "C" int egotap_hmtrain_mse(const float* pred, const float* gt, const floa
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+
+extern "C" int egotap_hmtrain_maxpool_fwd(const float* x, float* y, int64_t planes, int HIN, void* stream) {
+    EGO_CHECK(x && y && planes > 0 && HIN % 2 == 0, "egotap_hmtrain_maxpool_fwd: bad argument");
+    hipLaunchKernelGGL(maxpool3s2_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, y, (long)planes, HIN);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_hmtrain_upsample_fwd(const float* x, float* y, int N, int C, int HIN, int64_t in_istride, int64_t out_istride, void* stream) {
+    EGO_CHECK(x && y && N > 0 && C > 0 && HIN > 1, "egotap_hmtrain_upsample_fwd: bad argument");
+    const long threads = (long)N * C * (2 * HIN) * (2 * HIN / 4);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, HIN, (long)in_istride,
+                       (long)out_istride);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}

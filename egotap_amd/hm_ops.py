@@ -65,6 +65,12 @@ def conv_dgrad(h, dy, w, dx, taps=9, stride=1, accumulate=False):
     """dx (+)= d/dx of conv(x, w): the forward kernels on flipped / channel-swapped weights (stride 2: dY spread over the even pixels)"""
     dy, dx = V(dy), V(dx)
     Cout, Cin = w.shape[0], w.shape[1]
+    if (Cout * taps) % 4 != 0:          # the forward kernels stage weights by float4: pad the contracted channels (30 -> 32) with zeros
+        pad = (-Cout) % 4
+        w = torch.cat([w, torch.zeros((pad,) + tuple(w.shape[1:]), device=w.device)], 0).contiguous()
+        dyp = torch.zeros((dy.N, Cout + pad, dy.H, dy.W), device=w.device)
+        dyp[:, :Cout] = dy.tensor()
+        dy, Cout = V(dyp), Cout + pad
     wt = torch.empty((Cin, Cout) + tuple(w.shape[2:]), device=w.device)
     _lib.check(_lib.load().egotap_hmtrain_conv_wt(_p(w), _p(wt), Cout, Cin, taps, _s()))
     src = dy
@@ -122,6 +128,15 @@ def maxpool_bwd(x, dy, dx):
 def upsample_bwd(dy, dx):
     dy, dx = V(dy), V(dx)
     _lib.check(_lib.load().egotap_hmtrain_upsample_bwd(dy.ptr, dx.ptr, dx.N, dx.C, dx.H, dy.istride, dx.istride, _s()))
+
+
+def maxpool_fwd(x, y):
+    _lib.check(_lib.load().egotap_hmtrain_maxpool_fwd(_p(x), _p(y), x.shape[0] * x.shape[1], x.shape[2], _s()))
+
+
+def upsample_fwd(x, y):
+    x, y = V(x), V(y)
+    _lib.check(_lib.load().egotap_hmtrain_upsample_fwd(x.ptr, y.ptr, x.N, x.C, x.H, x.istride, y.istride, _s()))
 
 
 def stem_fwd(left, right, w, z):

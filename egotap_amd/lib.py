@@ -90,6 +90,8 @@ _PROTOS = {
     "egotap_hmtrain_relu_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_int64] * 3 + [C.c_void_p]),
     "egotap_hmtrain_maxpool_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_void_p]),
     "egotap_hmtrain_upsample_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "egotap_hmtrain_maxpool_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "egotap_hmtrain_upsample_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "egotap_hmtrain_mse": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 

@@ -351,9 +351,12 @@ class HeatMap_UnrealEgo_Shared(nn.Module):
     def forward(self, *inputs):
         if len(inputs) != 2:
             raise NotImplementedError("stereo input (left, right) expected")
-        left, right = (t.detach().float().contiguous() for t in inputs)
-        if not left.is_cuda:
+        if not inputs[0].is_cuda:
             raise _lib.EgotapError("HeatMap_UnrealEgo_Shared runs on the GPU only (no CPU fallback)")
+        if self.training and torch.is_grad_enabled():
+            from .hm_training import hm_train_forward          # train mode: batch-statistics BatchNorm2d, differentiable
+            return hm_train_forward(self, inputs[0], inputs[1])
+        left, right = (t.detach().float().contiguous() for t in inputs)
         out = torch.empty((left.shape[0], 2 * self.num_heatmap, self.hm_size, self.hm_size), dtype=torch.float32,
                           device=left.device)
         return self.forward_into(left, right, out)

@@ -217,6 +217,8 @@ int egotap_hmtrain_relu_bwd(const float* y, const float* dy, float* dz, int N, i
                             int64_t dz_istride, void* stream);
 int egotap_hmtrain_maxpool_bwd(const float* x, const float* dy, float* dx, int64_t planes, int HIN, void* stream);
 int egotap_hmtrain_upsample_bwd(const float* dy, float* dx, int N, int C, int HIN, int64_t dy_istride, int64_t dx_istride, void* stream);
+int egotap_hmtrain_maxpool_fwd(const float* x, float* y, int64_t planes, int HIN, void* stream);
+int egotap_hmtrain_upsample_fwd(const float* x, float* y, int N, int C, int HIN, int64_t in_istride, int64_t out_istride, void* stream);
 int egotap_hmtrain_mse(const float* pred, const float* gt, const float* plen, float* dpred, float* loss, int B, int Cn, int HW, float lambda,
                        void* ws, size_t ws_bytes, void* stream);
 

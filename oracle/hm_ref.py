@@ -68,8 +68,19 @@ class ResNet18Holder(nn.Module):
 
 
 # ----------------------------------------------------------------------------- functional restatement
+_TRAIN = {"on": False, "stats": None}     # train-mode BatchNorm (batch statistics) for the stage-1 training oracle
+
+
 def _bn(x, sd, pre, eps=1e-5):
     w, b, m, v = sd[pre + ".weight"], sd[pre + ".bias"], sd[pre + ".running_mean"], sd[pre + ".running_var"]
+    if _TRAIN["on"]:
+        # the backbone runs once per eye (net_architecture.py:45-50): the right eye's update lands on top of the left eye's
+        st = _TRAIN["stats"]
+        rm = st.get(pre + ".running_mean", m).detach().clone()
+        rv = st.get(pre + ".running_var", v).detach().clone()
+        y = F.batch_norm(x, rm, rv, w, b, True, 0.1, eps)          # nn.BatchNorm2d in train mode (momentum 0.1, unbiased running var)
+        _TRAIN["stats"][pre + ".running_mean"], _TRAIN["stats"][pre + ".running_var"] = rm, rv
+        return y
     return (x - m[None, :, None, None]) / torch.sqrt(v[None, :, None, None] + eps) * w[None, :, None, None] + b[None, :, None, None]
 
 
@@ -128,6 +139,26 @@ def hm_forward(left, right, sd, trace=None):
         for i, t in enumerate(pr):
             trace[f"pyr{i}"] = t
     return after_backbone(pl, pr, sd, trace=trace)
+
+
+def hm_train_step(left, right, gt, plen, sd, lam=1.0):
+    """One stage-1 training forward + backward (model/heatmap_shared_model.py:98-151): train-mode forward, loss =
+    lam * (MSE(left half) + MSE(right half)) with the limb maps divided by sqrt(gt_plength) first (plen [B, C] or None).
+    Returns (pred, loss, {key: grad}, {bn key: updated running stat}); sd tensors must be leaf tensors with requires_grad."""
+    _TRAIN["on"], _TRAIN["stats"] = True, {}
+    try:
+        pred = hm_forward(left, right, sd)
+    finally:
+        _TRAIN["on"] = False
+    n = pred.shape[1] // 2
+    if plen is not None:
+        sq = torch.sqrt(plen)[..., None, None]
+        loss = lam * (F.mse_loss(pred[:, :n] / sq[:, :n], gt[:, :n] / sq[:, :n]) + F.mse_loss(pred[:, n:] / sq[:, n:], gt[:, n:] / sq[:, n:]))
+    else:
+        loss = lam * (F.mse_loss(pred[:, :n], gt[:, :n]) + F.mse_loss(pred[:, n:], gt[:, n:]))
+    keys = [k for k, v in sd.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [sd[k] for k in keys], allow_unused=True)
+    return pred.detach(), loss.detach(), dict(zip(keys, grads)), dict(_TRAIN["stats"])
 
 
 def to_torch_sd(np_sd, dtype=torch.float32):
