@@ -1682,10 +1682,10 @@ extern "C" int egotap_hmtrain_upsample_bwd(const float* dy, float* dx, int N, in
 // loss[0] = lambda * (mean_left + mean_right) of (pred - gt)^2 / plen,  dpred = d loss / d pred   (pred, gt contiguous [B, Cn, HW])
 extern "C" int egotap_hmtrain_mse(const float* pred, const float* gt, const float* plen, float* dpred, float* loss, int B, int Cn, int HW,
                                   float lambda, void* ws, size_t ws_bytes, void* stream) {
-    EGO_CHECK(pred && gt && dpred && loss && ws && HW % 4 == 0 && Cn % 2 == 0, "egotap_hmtrain_mse: bad argument");
+    EGO_CHECK(pred && gt && dpred && loss && ws && HW % 4 == 0 && Cn > 0, "egotap_hmtrain_mse: bad argument");
     const int blocks = 512;
     EGO_CHECK((size_t)blocks * 8 <= ws_bytes, "egotap_hmtrain_mse: workspace too small");
-    const float coef = lambda / ((float)B * (Cn / 2) * HW);
+    const float coef = lambda / ((float)B * (0.5f * Cn) * HW);      // two halves (left, right), each a mean over B * Cn/2 * HW
     hipLaunchKernelGGL(mse_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, gt, plen, dpred, (double*)ws, B, Cn, HW, coef);
     hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const double*)ws, blocks, coef, loss);
     EGO_HIP(hipGetLastError());

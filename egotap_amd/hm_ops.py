@@ -151,3 +151,23 @@ def mse(pred, gt, plen, lam):
     _lib.check(_lib.load().egotap_hmtrain_mse(_p(pred), _p(gt), _p(plen) if plen is not None else None, _p(dpred), _p(loss), B, Cn, H * W, float(lam),
                                               ws, n, _s()))
     return loss, dpred
+
+
+def mse_halves(pred, gt, plen, lam):
+    """(loss_left, loss_right) [2] and dpred for lam * MSE(left half) + lam * MSE(right half) of pred / gt [B, 2n, H, W]
+    (the reference keeps the two terms as separate loss_* attributes); plen [B, 2n] or None"""
+    B, C2, Hh, W = pred.shape
+    n = C2 // 2
+    dpred = torch.empty_like(pred)
+    losses = torch.empty(2, device=pred.device)
+    ws, nb = _ws(pred.device)
+    for half in range(2):
+        p_ = pred[:, half * n:(half + 1) * n].contiguous()
+        g_ = gt[:, half * n:(half + 1) * n].contiguous()
+        l_ = plen[:, half * n:(half + 1) * n].contiguous() if plen is not None else None
+        d_ = torch.empty_like(p_)
+        # one half = "left + right" of a [B, n] problem whose second half is empty: run it as Cn = n with the mean over n channels
+        _lib.check(_lib.load().egotap_hmtrain_mse(_p(p_), _p(g_), _p(l_) if l_ is not None else None, _p(d_), _p(losses[half:half + 1]), B, n, Hh * W,
+                                                  float(lam) * 0.5, ws, nb, _s()))
+        dpred[:, half * n:(half + 1) * n] = d_
+    return losses, dpred

@@ -19,9 +19,13 @@ from . import networks
 
 
 def create_model(opt):
-    if getattr(opt, "model", "egotap_autoencoder") != "egotap_autoencoder":
-        raise ValueError("Model [%s] not recognized." % opt.model)
-    model = EgoTAPAutoEncoderModel()
+    name = getattr(opt, "model", "egotap_autoencoder")
+    if name == "egotap_autoencoder":
+        model = EgoTAPAutoEncoderModel()
+    elif name == "heatmap_shared":
+        model = HeatmapSharedModel()
+    else:
+        raise ValueError("Model [%s] not recognized." % name)
     model.initialize(opt)
     return model
 
@@ -256,3 +260,110 @@ class EgoTAPAutoEncoderModel(nn.Module):
     def update_learning_rate(self):
         for s in self.schedulers:
             s.step()
+
+
+class HeatmapSharedModel(nn.Module):
+    """Stage-1 wrapper: trains / evaluates one heatmap estimator (reference: model/heatmap_shared_model.py).  Same surface as the
+    reference (set_input keys, forward, optimize_parameters, evaluate -> mse_heatmap, loss_* attributes, save / load); the network,
+    the losses and the optimizer step run on HIP kernels (egotap_amd/hm_training.py), PyTorch is autograd glue only.
+    Built for the two shipped configurations: the position net (num_rot_heatmap = 0) or the sin/cos limb net (num_heatmap = 0)."""
+
+    def name(self):
+        return "Heatmap Shared model"
+
+    def initialize(self, opt):
+        self.opt = opt
+        self.gpu_ids = getattr(opt, "gpu_ids", [0])
+        self.isTrain = getattr(opt, "isTrain", False)
+        self.save_dir = os.path.join(getattr(opt, "log_dir", "./log"), getattr(opt, "experiment_name", "experiment"))
+        self.device = torch.device("cuda:{}".format(self.gpu_ids[0])) if self.gpu_ids else torch.device("cuda:0")
+        if getattr(opt, "use_amp", False):
+            raise NotImplementedError("fp16 autocast (--use_amp) is not reproduced; the HIP training path is fp32")
+        if not getattr(opt, "stereo", True):
+            raise NotImplementedError("only the stereo presets are built")
+        if opt.num_heatmap > 0 and opt.num_rot_heatmap > 0:
+            raise NotImplementedError("train the position net and the limb net separately (the shipped stage-1 scripts do)")
+        self.is_limb = opt.num_rot_heatmap > 0
+        self.loss_names = ["limb_heatmap_left", "limb_heatmap_right"] if self.is_limb else ["heatmap_left", "heatmap_right"]
+        self.model_names = ["HeatMap"]
+        self.visual_names, self.visual_pose_names = ["input_rgb_left", "input_rgb_right"], []
+        self.eval_key, self.cm2mm = "mse_heatmap", 10
+        self.net_HeatMap = networks.HeatMap_UnrealEgo_Shared(opt, getattr(opt, "model_name", "resnet18"), 2)
+        self.optimizers, self.schedulers = [], []
+        self.to(self.device)
+        if self.isTrain:
+            if getattr(opt, "weight_decay", 0.0) != 0.0:
+                raise NotImplementedError("torch.optim.Adam's L2 weight decay is not built (the shipped scripts use 0)")
+            from .training import EgotapAdamW, get_scheduler
+            # torch.optim.Adam(lr, weight_decay=0) == AdamW with zero decay: same kernel (heatmap_shared_model.py:69-73, eps 1e-8)
+            self.optimizer_HeatMap = EgotapAdamW(self.net_HeatMap.parameters(), lr=getattr(opt, "lr", 1e-3), eps=1e-8, weight_decay=0.0)
+            self.optimizers.append(self.optimizer_HeatMap)
+            if getattr(opt, "lr_policy", None):
+                self.schedulers = [get_scheduler(o, opt) for o in self.optimizers]
+
+    def set_input(self, data):
+        self.data = data
+        dev = self.device
+        self.input_rgb_left = data["input_rgb_left"].to(dev).float().contiguous()
+        self.input_rgb_right = data["input_rgb_right"].to(dev).float().contiguous()
+        if self.is_limb:
+            self.gt_limb_heatmap_left, self.gt_limb_heatmap_right = data["gt_limb_heatmap_left"].to(dev), data["gt_limb_heatmap_right"].to(dev)
+            self.gt_plength_left, self.gt_plength_right = data["gt_plength_left"].to(dev), data["gt_plength_right"].to(dev)
+            self._gt = torch.cat((self.gt_limb_heatmap_left, self.gt_limb_heatmap_right), 1).float().contiguous()
+            self._plen = torch.cat((self.gt_plength_left, self.gt_plength_right), 1).float().contiguous()
+        else:
+            self.gt_heatmap_left, self.gt_heatmap_right = data["gt_heatmap_left"].to(dev), data["gt_heatmap_right"].to(dev)
+            self._gt = torch.cat((self.gt_heatmap_left, self.gt_heatmap_right), 1).float().contiguous()
+            self._plen = None
+
+    def forward(self):
+        self.pred_heatmap_cat = self.net_HeatMap(self.input_rgb_left, self.input_rgb_right)
+        n = self.pred_heatmap_cat.shape[1] // 2
+        left, right = self.pred_heatmap_cat[:, :n], self.pred_heatmap_cat[:, n:]
+        if self.is_limb:
+            self.pred_limb_heatmap_left, self.pred_limb_heatmap_right = left, right
+        else:
+            self.pred_heatmap_left, self.pred_heatmap_right = left, right
+
+    def backward_HeatMap(self):
+        """lambda * (MSE(left) + MSE(right)); limb maps are divided by sqrt(gt_plength) first (heatmap_shared_model.py:109-151)"""
+        from . import hm_ops as H
+        lam = getattr(self.opt, "lambda_rot_heatmap" if self.is_limb else "lambda_heatmap", 1.0)
+        pred = self.pred_heatmap_cat
+        n = pred.shape[1] // 2
+        gl, dl = H.mse_halves(pred.detach().contiguous(), self._gt, self._plen, lam)
+        a, b = self.loss_names
+        setattr(self, "loss_" + a, gl[0])
+        setattr(self, "loss_" + b, gl[1])
+        pred.backward(dl)
+
+    def optimize_parameters(self):
+        if not self.isTrain:
+            raise RuntimeError("optimize_parameters() needs a model created with opt.isTrain = True")
+        self.net_HeatMap.train()
+        self.optimizer_HeatMap.zero_grad()
+        self.forward()
+        self.backward_HeatMap()
+        from . import parallel
+        parallel.allreduce_gradients(list(self.net_HeatMap.parameters()))
+        self.optimizer_HeatMap.step()
+
+    def evaluate(self, runnning_average_dict):
+        from . import hm_ops as H
+        self.net_HeatMap.eval()
+        with torch.no_grad():
+            self.forward()
+            pred = self.pred_heatmap_cat.contiguous()
+            for i in range(pred.shape[0]):                      # per-sample metric, as the reference's loop (:174-217)
+                gl, _ = H.mse_halves(pred[i:i + 1], self._gt[i:i + 1], self._plen[i:i + 1] if self._plen is not None else None, 1.0)
+                runnning_average_dict.update(dict(mse_heatmap=gl[0] + gl[1]))
+        return None, self.pred_heatmap_cat, runnning_average_dict
+
+    def set_eval_mode(self):
+        self.net_HeatMap.eval()
+
+    save_networks = EgoTAPAutoEncoderModel.save_networks
+    load_networks = EgoTAPAutoEncoderModel.load_networks
+    load_optimizers = EgoTAPAutoEncoderModel.load_optimizers
+    get_current_errors = EgoTAPAutoEncoderModel.get_current_errors
+    update_learning_rate = EgoTAPAutoEncoderModel.update_learning_rate

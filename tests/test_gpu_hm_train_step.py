@@ -82,3 +82,53 @@ def test_hm_train_forward_backward_matches_oracle(which):
     with torch.no_grad():
         y = net(left.cuda(), right.cuda())
     assert tuple(y.shape) == (B, n2, 64, 64) and not y.requires_grad
+
+
+@pytest.mark.parametrize("tag,nh,nr", [("pos", 15, 0), ("rot", 0, 15)])
+def test_wrapper_heatmap_shared_model_matches_reference_step(tag, nh, nr):
+    """create_model(opt) with opt.model = 'heatmap_shared': set_input -> optimize_parameters -> get_current_errors as train.py
+    drives it, against ONE optimize_parameters() of the reference's own HeatmapSharedModel (tests/golden/hm_train_step_*.npz)."""
+    import os
+    from egotap_amd import models
+    from egotap_amd.options import preset_defaults
+    from egotap_amd.synthetic import synth_hm_state_dict
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"hm_train_step_{tag}.npz"))
+    opt = preset_defaults("UnrealEgo")
+    opt.model, opt.isTrain, opt.num_heatmap, opt.num_rot_heatmap = "heatmap_shared", True, nh, nr
+    opt.lr, opt.weight_decay, opt.lr_policy, opt.niter, opt.niter_decay, opt.epoch_iter_cnt, opt.epoch_count = 1e-3, 0.0, "cos_anneal_warmup", 1, 3, 4, 1
+    opt.lambda_heatmap = opt.lambda_rot_heatmap = 1.0
+    m = models.create_model(opt)
+    C = nh + 2 * nr
+    m.net_HeatMap.load_state_dict({k: torch.from_numpy(v) for k, v in synth_hm_state_dict(C, f"hm_{tag}.").items()})
+    B = 2
+    data = {"input_rgb_left": torch.from_numpy(synth_input(f"tr_rgbL_{tag}", (B, 3, 256, 256), -2.0, 2.0)),
+            "input_rgb_right": torch.from_numpy(synth_input(f"tr_rgbR_{tag}", (B, 3, 256, 256), -2.0, 2.0))}
+    gt = torch.from_numpy(synth_input(f"tr_gt_{tag}", (B, 2 * C, 64, 64), 0.0, 1.0))
+    plen = torch.from_numpy(synth_input(f"tr_plen_{tag}", (B, 2 * C), 2.0, 40.0))
+    if tag == "pos":
+        data.update(gt_heatmap_left=gt[:, :C], gt_heatmap_right=gt[:, C:])
+    else:
+        data.update(gt_limb_heatmap_left=gt[:, :C], gt_limb_heatmap_right=gt[:, C:], gt_plength_left=plen[:, :C], gt_plength_right=plen[:, C:])
+    m.set_input(data)
+    m.optimize_parameters()
+    m.update_learning_rate()
+    errs = m.get_current_errors()
+    for name in m.loss_names:
+        np.testing.assert_allclose(errs[name], float(g["loss_" + name]), rtol=1e-4, err_msg=name)
+    np.testing.assert_allclose(m.pred_heatmap_cat.detach().reshape(-1)[::97].cpu().numpy(), g["pred_sample"], atol=1e-4)
+    norms = dict(zip(g["grad_keys"], g["grad_norms"]))
+    params = dict(m.net_HeatMap.named_parameters())
+    assert sorted(k for k, v in params.items() if v.grad is not None) == sorted(g["grad_keys"])
+    for k in g["grad_keys"]:
+        gr = params[k].grad
+        np.testing.assert_allclose(float(gr.double().norm()), norms[k], rtol=3e-2, err_msg=k)      # fp32 conditioning of this net: ~1e-2
+        got = gr.reshape(-1)[:: max(1, gr.numel() // 257)].cpu().numpy()
+        scale = norms[k] / np.sqrt(gr.numel())
+        assert np.abs(got - g["g:" + k]).max() <= 0.15 * scale + 1e-9, k
+    sd = m.net_HeatMap.state_dict()
+    for k in g.files:
+        if k.startswith("buf:"):
+            np.testing.assert_allclose(sd[k[4:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+    rad = {}
+    m.evaluate(type("D", (dict,), {"update": lambda self, d: rad.update({k: float(v) for k, v in d.items()})})())
+    assert "mse_heatmap" in rad and rad["mse_heatmap"] > 0

@@ -340,6 +340,60 @@ def gen_sched():
     print("lr_schedules ok", {k: len(v) for k, v in out.items()})
 
 
+def gen_hm_train():
+    """One optimize_parameters() of the reference's own stage-1 wrapper (model/heatmap_shared_model.py: train-mode forward of
+    HeatMap_UnrealEgo_Shared over this repo's ResNet-18 stand-in, MSE losses, torch.optim.Adam) on CPU: losses, a strided
+    sample + norm of every gradient, updated BatchNorm running statistics, updated parameters."""
+    from model.heatmap_shared_model import HeatmapSharedModel
+    from egotap_amd.synthetic import synth_hm_state_dict
+
+    for tag, nh, nr in (("pos", 15, 0), ("rot", 0, 15)):
+        opt = make_opt("UnrealEgo")
+        opt.num_heatmap, opt.num_rot_heatmap = nh, nr
+        opt.model, opt.isTrain, opt.use_amp, opt.gpu_ids = "heatmap_shared", True, False, []
+        opt.log_dir, opt.experiment_name, opt.init_type = "/tmp", "gold_hm", "kaiming"
+        opt.path_to_trained_heatmap = None
+        opt.lr, opt.weight_decay, opt.lr_policy = 1e-3, 0.0, "cos_anneal_warmup"
+        opt.niter, opt.niter_decay, opt.epoch_iter_cnt, opt.epoch_count = 1, 3, 4, 1
+        opt.lambda_heatmap, opt.lambda_rot_heatmap, opt.distributed = 1.0, 1.0, False
+        m = HeatmapSharedModel()
+        m.initialize(opt)
+        n = m.net_HeatMap
+        sd_np = synth_hm_state_dict(nh + 2 * nr, f"hm_{tag}.")
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+        B, C = 2, nh + 2 * nr
+        data = {"input_rgb_left": torch.from_numpy(synth_input(f"tr_rgbL_{tag}", (B, 3, 256, 256), -2.0, 2.0)),
+                "input_rgb_right": torch.from_numpy(synth_input(f"tr_rgbR_{tag}", (B, 3, 256, 256), -2.0, 2.0)),
+                "gt_local_pose": torch.zeros(B, 16, 3), "gt_limb_theta": torch.zeros(B, 15)}
+        gt = torch.from_numpy(synth_input(f"tr_gt_{tag}", (B, 2 * C, 64, 64), 0.0, 1.0))
+        plen = torch.from_numpy(synth_input(f"tr_plen_{tag}", (B, 2 * C), 2.0, 40.0))
+        if tag == "pos":
+            data.update(gt_heatmap_left=gt[:, :C], gt_heatmap_right=gt[:, C:])
+        else:
+            data.update(gt_heatmap_left=torch.zeros(B, 0, 64, 64), gt_heatmap_right=torch.zeros(B, 0, 64, 64),
+                        gt_limb_heatmap_left=gt[:, :C], gt_limb_heatmap_right=gt[:, C:], gt_plength_left=plen[:, :C], gt_plength_right=plen[:, C:])
+        m.set_input(data)
+        m.optimize_parameters()
+        out = {"pred_sample": sample(m.pred_heatmap_cat, 97), "pred_stats": stats(m.pred_heatmap_cat)}
+        for ln in m.loss_names:
+            out["loss_" + ln] = getattr(m, "loss_" + ln).detach().numpy()
+        names, norms = [], []
+        for k, prm in n.named_parameters():
+            if prm.grad is None:
+                continue
+            names.append(k)
+            norms.append(float(prm.grad.double().norm()))
+            out["g:" + k] = prm.grad.reshape(-1)[:: max(1, prm.numel() // 257)].numpy().copy()
+            out["p:" + k] = prm.detach().reshape(-1)[:: max(1, prm.numel() // 257)].numpy().copy()
+        out["grad_keys"], out["grad_norms"] = np.array(names), np.array(norms)
+        for k, v in n.state_dict().items():
+            if k.startswith("backbone.backbone.backbone.") and (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked")):
+                out["buf:" + k] = v.numpy().copy()
+        out["lr_after"] = np.array([m.optimizers[0].param_groups[0]["lr"]])
+        np.savez_compressed(os.path.join(GOLD, f"hm_train_step_{tag}.npz"), **out)
+        print(f"hm_train_step_{tag}:", {ln: float(getattr(m, "loss_" + ln)) for ln in m.loss_names}, len(names), "gradients")
+
+
 def gen_synth():
     """ground-truth heatmap synthesis by the reference's own coord2d_to_heatmap / get_limb_data; skimage.draw.line_aa (not
     installed) is supplied by oracle/heatmap_synth_ref.line_aa, so that one step is NOT pinned by this fixture"""
@@ -374,7 +428,7 @@ def gen_synth():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="lift,pu,fc,loss,hm,procrustes,train,sched,synth")
+    ap.add_argument("--only", default="lift,pu,fc,loss,hm,procrustes,train,sched,synth,hmtrain")
     args = ap.parse_args()
     which = set(args.only.split(","))
     os.makedirs(GOLD, exist_ok=True)
@@ -399,6 +453,8 @@ def main():
         gen_sched()
     if "synth" in which:
         gen_synth()
+    if "hmtrain" in which:
+        gen_hm_train()
 
 
 if __name__ == "__main__":
