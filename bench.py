@@ -279,6 +279,48 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None):
                     "S three times (8 MFMA products instead of 5), not counted in flops_per_frame"}
 
 
+def bench_stage1(args, p, dev, rank, world, barrier):
+    """Secondary measurement: one optimisation step of the stage-1 heatmap estimator (position net: train-mode forward with
+    per-eye BatchNorm statistics, MSE losses, full backward through decoder + ResNet-18, Adam), fp32."""
+    import torch
+    from egotap_amd import models, parallel
+    from egotap_amd.options import preset_defaults
+    from egotap_amd.synthetic import synth_hm_state_dict, synth_input
+    opt = preset_defaults(args.preset)
+    opt.model, opt.isTrain, opt.gpu_ids, opt.num_rot_heatmap = "heatmap_shared", True, [dev.index], 0
+    opt.lr, opt.weight_decay, opt.lambda_heatmap = 1e-3, 0.0, 1.0
+    m = models.create_model(opt)
+    J = p.n_joints_hm
+    m.net_HeatMap.load_state_dict({k: torch.from_numpy(v) for k, v in synth_hm_state_dict(J, "hm_pos.").items()})
+    B, S = args.stage1_batch, 4 * p.hm_size
+    torch.cuda.reset_peak_memory_stats(dev)
+    blk = min(B, 8)
+    rep = (B + blk - 1) // blk
+    data = {"input_rgb_left": torch.from_numpy(synth_input(f"s1_l_rank{rank}", (blk, 3, S, S), -2.0, 2.0)).to(dev).repeat(rep, 1, 1, 1)[:B],
+            "input_rgb_right": torch.from_numpy(synth_input(f"s1_r_rank{rank}", (blk, 3, S, S), -2.0, 2.0)).to(dev).repeat(rep, 1, 1, 1)[:B],
+            "gt_heatmap_left": torch.from_numpy(synth_input(f"s1_gl_rank{rank}", (blk, J, p.hm_size, p.hm_size))).to(dev).repeat(rep, 1, 1, 1)[:B],
+            "gt_heatmap_right": torch.from_numpy(synth_input(f"s1_gr_rank{rank}", (blk, J, p.hm_size, p.hm_size))).to(dev).repeat(rep, 1, 1, 1)[:B]}
+    m.set_input(data)
+    m.optimize_parameters()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        m.optimize_parameters()
+    torch.cuda.synchronize(dev)
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    barrier()
+    errs = m.get_current_errors()
+    fps = world * B * args.train_steps / elapsed
+    flops = 3.0 * hm_flops_per_frame(2 * J, S)
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    del m, data
+    torch.cuda.empty_cache()
+    return {"value": round(fps, 1), "unit": "stereo frames/s (stage-1 training step, position net)", "ms_per_step": round(1e3 * elapsed / args.train_steps, 2),
+            "steps": args.train_steps, "batch_per_gpu": B, "dtype": "f32", "flops_per_frame": flops,
+            "end_to_end_tflops_per_gpu": round(fps * flops / world / 1e12, 2), "loss_heatmap_left": errs.get("heatmap_left"),
+            "peak_hbm_gib": round(peak_gb, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,6 +336,7 @@ def main():
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary bf16x3 fast-mode measurement")
     ap.add_argument("--train-steps", type=int, default=2, help="timed optimisation steps of the secondary training measurement (0 = skip)")
     ap.add_argument("--train-batch", type=int, default=256)
+    ap.add_argument("--stage1-batch", type=int, default=32, help="per-GPU batch of the stage-1 heatmap-estimator training measurement")
     ap.add_argument("--train-batch-bf16", type=int, default=1024, help="per-GPU batch of the bf16 training measurement (BASELINE config 3)")
     args = ap.parse_args()
 
@@ -413,6 +456,7 @@ def main():
         train["bf16x3"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16x3")
         # BASELINE configs[2] / [3]: UnrealEgo training step (fwd+bwd+AdamW), bf16, batch 1024 per GPU (x N GPUs, gradient all-reduce)
         train["config3_bf16_b1024"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16", batch=args.train_batch_bf16)
+        train["stage1_heatmap_estimator"] = leg(bench_stage1, args, p, dev, rank, world, barrier)
 
     cpu = None
     gpu_vs_oracle = None
