@@ -279,7 +279,7 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None):
                     "S three times (8 MFMA products instead of 5), not counted in flops_per_frame"}
 
 
-def bench_stage1(args, p, dev, rank, world, barrier):
+def bench_stage1(args, p, dev, rank, world, barrier, mode="f32"):
     """Secondary measurement: one optimisation step of the stage-1 heatmap estimator (position net: train-mode forward with
     per-eye BatchNorm statistics, MSE losses, full backward through decoder + ResNet-18, Adam), fp32."""
     import torch
@@ -292,6 +292,7 @@ def bench_stage1(args, p, dev, rank, world, barrier):
     m = models.create_model(opt)
     J = p.n_joints_hm
     m.net_HeatMap.load_state_dict({k: torch.from_numpy(v) for k, v in synth_hm_state_dict(J, "hm_pos.").items()})
+    m.net_HeatMap.set_precision(mode)
     B, S = args.stage1_batch, 4 * p.hm_size
     torch.cuda.reset_peak_memory_stats(dev)
     blk = min(B, 8)
@@ -316,7 +317,7 @@ def bench_stage1(args, p, dev, rank, world, barrier):
     del m, data
     torch.cuda.empty_cache()
     return {"value": round(fps, 1), "unit": "stereo frames/s (stage-1 training step, position net)", "ms_per_step": round(1e3 * elapsed / args.train_steps, 2),
-            "steps": args.train_steps, "batch_per_gpu": B, "dtype": "f32", "flops_per_frame": flops,
+            "steps": args.train_steps, "batch_per_gpu": B, "dtype": mode, "flops_per_frame": flops,
             "end_to_end_tflops_per_gpu": round(fps * flops / world / 1e12, 2), "loss_heatmap_left": errs.get("heatmap_left"),
             "peak_hbm_gib": round(peak_gb, 1)}
 
@@ -457,6 +458,8 @@ def main():
         # BASELINE configs[2] / [3]: UnrealEgo training step (fwd+bwd+AdamW), bf16, batch 1024 per GPU (x N GPUs, gradient all-reduce)
         train["config3_bf16_b1024"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16", batch=args.train_batch_bf16)
         train["stage1_heatmap_estimator"] = leg(bench_stage1, args, p, dev, rank, world, barrier)
+        if not args.no_fast_mode:
+            train["stage1_heatmap_estimator"]["bf16x3"] = leg(bench_stage1, args, p, dev, rank, world, barrier, mode="bf16x3")
 
     cpu = None
     gpu_vs_oracle = None

@@ -1519,6 +1519,17 @@ extern "C" int egotap_train_qkv_fwd(egotap_handle h, const float* y, const float
 // NCHW fp32 device buffers with explicit image strides (so concat slices are read and written in place).
 #include "hm_train.h"
 
+// scratch for the repacked weights of the bf16 convolution kernels when the training operators run under a bf16 precision mode
+// (egotap_hm_forward takes it from its workspace); bytes >= egotap_hmtrain_pack_bytes()
+extern "C" int egotap_hmtrain_set_pack_buffer(egotap_handle h, void* buf, size_t bytes) {
+    EGO_CHECK(h, "null handle");
+    EGO_CHECK(buf == nullptr || bytes >= conv_bf16_pack_bytes(1024, 1540), "egotap_hmtrain_set_pack_buffer: buffer too small");
+    EGO_CHECK(((uintptr_t)buf & 15) == 0, "egotap_hmtrain_set_pack_buffer: 16-byte alignment");
+    h->conv_pack = (__bf16*)buf;
+    return EGOTAP_OK;
+}
+extern "C" size_t egotap_hmtrain_pack_bytes(void) { return conv_bf16_pack_bytes(1024, 1540); }
+
 extern "C" int egotap_hmtrain_conv_fwd(egotap_handle h, const float* x, const float* w, const float* bias, const float* res, float* y,
                                        int Nimg, int Cin, int Cout, int wout, int taps, int stride, int relu, int64_t in_istride,
                                        int64_t out_istride, int64_t res_istride, void* stream) {

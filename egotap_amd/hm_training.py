@@ -235,4 +235,10 @@ def hm_train_forward(net, left, right):
     """differentiable train-mode forward of HeatMap_UnrealEgo_Shared: [B,3,S0,S0] x 2 -> [B, 2n, S0/4, S0/4]"""
     params = [p for _, p in _param_items(net)]
     net._bind(left.device)
+    if getattr(net, "precision", "f32") != "f32":          # bf16 modes: scratch for the repacked conv weights (kept on the module)
+        from . import lib as _lib
+        import ctypes as C
+        if getattr(net, "_pack", None) is None or net._pack.device != left.device:
+            net._pack = torch.empty(_lib.load().egotap_hmtrain_pack_bytes(), dtype=torch.uint8, device=left.device)
+        _lib.check(_lib.load().egotap_hmtrain_set_pack_buffer(net._ensure_handle(), C.c_void_p(net._pack.data_ptr()), net._pack.numel()))
     return HmTrainFn.apply(net, left, right, *params)

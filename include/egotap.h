@@ -201,6 +201,10 @@ int egotap_train_adamw(float* p, const float* g, float* m, float* v, int64_t n, 
 int egotap_hmtrain_conv_fwd(egotap_handle h, const float* x, const float* w, const float* bias, const float* res, float* y, int Nimg, int Cin,
                             int Cout, int wout, int taps, int stride, int relu, int64_t in_istride, int64_t out_istride, int64_t res_istride,
                             void* stream);
+/* bf16 precision modes: the 3x3 stride-1 convolutions (forward and input gradient) of the training step run on conv_bf16 once a
+ * scratch buffer for their repacked weights is set (egotap_hmtrain_pack_bytes() bytes, caller-owned, 16-byte aligned) */
+int egotap_hmtrain_set_pack_buffer(egotap_handle h, void* buf, size_t bytes);
+size_t egotap_hmtrain_pack_bytes(void);
 int egotap_hmtrain_stem_fwd(const float* left, const float* right, const float* w, float* z, int B, int S0, void* stream);
 int egotap_hmtrain_bn2d_fwd(const float* z, float* y, const float* res, const float* gamma, const float* beta, float* mean, float* rstd,
                             float* run_mean, float* run_var, int N, int C, int HW, int64_t z_istride, int64_t y_istride, int64_t res_istride,

@@ -132,3 +132,30 @@ def test_wrapper_heatmap_shared_model_matches_reference_step(tag, nh, nr):
     rad = {}
     m.evaluate(type("D", (dict,), {"update": lambda self, d: rad.update({k: float(v) for k, v in d.items()})})())
     assert "mse_heatmap" in rad and rad["mse_heatmap"] > 0
+
+
+def test_hm_train_bf16x3_mode_tracks_fp32_step():
+    """bf16x3 mode in the stage-1 training step: the 3x3 stride-1 convolutions (forward and input gradient) run as split-bf16
+    products; prediction within 1e-4, gradients within the fp32 conditioning of this network of the exact-fp32 step"""
+    from egotap_amd import hm_ops as H
+    outs = {}
+    for mode in ("f32", "bf16x3"):
+        net, _ = _net("pos")
+        net.train()
+        net.set_precision(mode)
+        left = torch.from_numpy(synth_input("tr_rgbL_pos", (2, 3, 256, 256), -2.0, 2.0)).cuda()
+        right = torch.from_numpy(synth_input("tr_rgbR_pos", (2, 3, 256, 256), -2.0, 2.0)).cuda()
+        gt = torch.from_numpy(synth_input("tr_gt_pos", (2, 30, 64, 64), 0.0, 1.0)).cuda()
+        pred = net(left, right)
+        loss, dpred = H.mse(pred.detach().contiguous(), gt, None, 1.0)
+        pred.backward(dpred)
+        torch.cuda.synchronize()
+        outs[mode] = (pred.detach().clone(), float(loss), {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None})
+    assert float((outs["f32"][0] - outs["bf16x3"][0]).abs().max()) < 1e-4 * max(1.0, float(outs["f32"][0].abs().max()))
+    assert not torch.equal(outs["f32"][0], outs["bf16x3"][0])
+    np.testing.assert_allclose(outs["bf16x3"][1], outs["f32"][1], rtol=1e-4)
+    for k, g in outs["f32"][2].items():
+        a, b = outs["bf16x3"][2][k].double().flatten(), g.double().flatten()
+        if float(b.norm()) < 1e-9:
+            continue
+        assert float((a - b).norm() / b.norm()) < 5e-2 and float(a @ b / (a.norm() * b.norm())) > 0.999, k
