@@ -1636,7 +1636,7 @@ template <int KS, int STRIDE, int CI_T>
 static hipError_t wgrad_w(int wout, const WgArgs& a, float* dw, size_t sb, int acc, hipStream_t s) {
     const int cu = device_cu_count();
     switch (wout) {
-        case 128: if constexpr (KS == 7) return conv_wgrad_launch<WgCfg<KS, STRIDE, 7, CI_T>>(a, dw, sb, cu, acc, s); else return hipErrorInvalidValue;
+        case 128: if constexpr (KS == 7) return conv_wgrad_launch<WgCfg<KS, STRIDE, 7, CI_T, 64>>(a, dw, sb, cu, acc, s); else return hipErrorInvalidValue;
         case 64: if constexpr (KS != 7 && STRIDE == 1) return conv_wgrad_launch<WgCfg<KS, STRIDE, 6, CI_T>>(a, dw, sb, cu, acc, s); else return hipErrorInvalidValue;
         case 32: if constexpr (KS != 7) return conv_wgrad_launch<WgCfg<KS, STRIDE, 5, CI_T>>(a, dw, sb, cu, acc, s); else return hipErrorInvalidValue;
         case 16: if constexpr (KS != 7) return conv_wgrad_launch<WgCfg<KS, STRIDE, 4, CI_T>>(a, dw, sb, cu, acc, s); else return hipErrorInvalidValue;

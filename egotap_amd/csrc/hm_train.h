@@ -4,7 +4,8 @@
 //   * conv_wgrad_kernel   dW[co][ci][tap] = sum_{n,y,x} dY[n][co][y][x] * X[n][ci][y*s + ky - pad][x*s + kx - pad]
 //                         implicit GEMM on the fp32 matrix cores: the contraction index is the PIXEL; a slab is one output row
 //                         of one image: dY rows and the raw input rows (+ halo) are staged as they lie in memory and every
-//                         (ci, tap) column of the product is a fixed LDS offset per lane.  Split over images, partial
+//                         (ci, tap) column of the product is a fixed LDS offset per lane.  Tile 128 co x (32 ci x 9 taps): wave w
+//                         owns 32 output channels and all nine 32-column tiles (one dY read feeds nine MFMAs).  Split over images, partial
 //                         slabs summed in a fixed order (reduce_slabs_kernel): no float atomics, bitwise reproducible.
 //   * input gradients need no kernel of their own: dX = conv(dY, W^T flipped) runs on the forward kernels after
 //     conv_wt_kernel (flip + channel swap); stride-2 layers first spread dY over the even pixels (zero_upsample2_kernel).
@@ -15,12 +16,12 @@
 #include "gemm_tn_f32.h"
 
 // ------------------------------------------------------------------------------------------------- weight gradient
-template <int KS_, int STRIDE_, int LOG2W_, int CI_T_>
+template <int KS_, int STRIDE_, int LOG2W_, int CI_T_, int CO_T_ = 128>
 struct WgCfg {
     static constexpr int KS = KS_, TAPS = KS_ * KS_, PAD = (KS_ - 1) / 2, STRIDE = STRIDE_, W = 1 << LOG2W_, CI_T = CI_T_;
-    static constexpr int WIN = W * STRIDE, CO_T = 64, WAVES = 3, THREADS = 64 * WAVES;
+    static constexpr int WIN = W * STRIDE, CO_T = CO_T_, WAVES = CO_T_ / 32, THREADS = 64 * WAVES;   // wave w owns output channels 32w..32w+31
     static constexpr int NCOL = CI_T * TAPS;                         // product columns of a block: (ci_local, tap)
-    static constexpr int NT = (NCOL + 31) / 32, NT_W = (NT + WAVES - 1) / WAVES;   // 32-column tiles, per wave
+    static constexpr int NT = (NCOL + 31) / 32, NT_W = NT;           // 32-column tiles: every wave takes all of them
     static constexpr int ALD = W + 1;                                // dY row stride in LDS (floats): conflict-free b32
     static constexpr int ROWW = WIN + 2 * PAD + 1, CHS = KS * ROWW;  // staged input row / floats per channel
     static constexpr int A_FLOATS = CO_T * ALD, B_FLOATS = CI_T * CHS;
@@ -101,18 +102,16 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgArgs a) {
     bool bok[NT_W];
 #pragma unroll
     for (int t = 0; t < NT_W; ++t) {
-        const int ncol = (wid * NT_W + t) * 32 + l31;
+        const int ncol = t * 32 + l31;
         bok[t] = ncol < NCOL;
         const int cl = min(ncol, NCOL - 1) / TAPS, tap = min(ncol, NCOL - 1) - cl * TAPS;
         boff[t] = cl * CHS + (tap / KS) * ROWW + (tap % KS) + lh * STRIDE;
     }
-    f32x16 acc[2][NT_W];
+    f32x16 acc[NT_W];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int t = 0; t < NT_W; ++t)
 #pragma unroll
-        for (int t = 0; t < NT_W; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     if (nslab > 0) gload(0);
     __syncthreads();
@@ -121,16 +120,15 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgArgs a) {
     for (int s = 0; s < nslab; ++s) {
         const int buf = s & 1;
         if (s + 1 < nslab) gload(s + 1);
-        const float* As = wsm + buf * STAGE + l31 * ALD + lh;
+        const float* As = wsm + buf * STAGE + (wid * 32 + l31) * ALD + lh;
         const float* Bs = wsm + buf * STAGE + A_FLOATS;
 #pragma unroll 4
         for (int x0 = 0; x0 < W; x0 += 2) {                 // MFMA k = 2 pixels: lane half h takes pixel x0 + h
-            const float a0 = As[x0], a1 = As[32 * ALD + x0];
+            const float a0 = As[x0];
 #pragma unroll
             for (int t = 0; t < NT_W; ++t) {
                 const float bv = bok[t] ? Bs[boff[t] + x0 * STRIDE] : 0.f;
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[t], 0, 0, 0);
             }
         }
         if (s + 1 < nslab) lstore(buf ^ 1);
@@ -141,17 +139,15 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgArgs a) {
     float* out = a.slabs + (long)split * a.Cout * ldw;
 #pragma unroll
     for (int t = 0; t < NT_W; ++t) {
-        const int ncol = (wid * NT_W + t) * 32 + l31;
+        const int ncol = t * 32 + l31;
         const int cl = ncol / TAPS;
         if (ncol >= NCOL || ci0 + cl >= a.Cin) continue;
         const long col = (long)ci0 * TAPS + ncol;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co < a.Cout) out[(long)co * ldw + col] = acc[i][t][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (co < a.Cout) out[(long)co * ldw + col] = acc[t][r];
+        }
     }
 }
 
@@ -162,7 +158,7 @@ static hipError_t conv_wgrad_launch(WgArgs a, float* dw, size_t slab_bytes, int 
     a.tiles_ci = (a.Cin + Cfg::CI_T - 1) / Cfg::CI_T;
     const int tiles = a.tiles_co * a.tiles_ci;
     const long n = (long)a.Cout * a.Cin * Cfg::TAPS;
-    int splits = (3 * num_cu + tiles - 1) / tiles;          // ~3 blocks of 3 waves per CU
+    int splits = (2 * num_cu + tiles - 1) / tiles;          // ~2 blocks of 4 waves per CU where the LDS allows
     if (splits > a.Nimg) splits = a.Nimg;
     if (splits < 1) splits = 1;
     while ((size_t)splits * n * 4 > slab_bytes && splits > 1) --splits;
