@@ -165,6 +165,38 @@ def timed_lift(net, hm, steps, warmup, lib, L, h, barrier, dev, timing, world):
     return elapsed, pose, out
 
 
+def bench_config5(args, dev, rank, world, barrier, lib, L):
+    """Secondary measurement: the geometry of BASELINE configs[4] -- EgoCap preset (17 heatmaps per eye, 17 joints) on 128x128
+    heatmaps (512x512 RGB): 768^2 ViT image, 2304 tokens, fc1 K = 65536 / 32768 -- lifting head forward, fp32 and bf16x3."""
+    import torch
+    from egotap_amd import networks, spec
+    from egotap_amd.options import preset_defaults
+    from egotap_amd.synthetic import synth_input, synth_state_dict
+    p5 = spec.lift_preset("EgoCap", 128)
+    net = networks.EgoTAPAutoEncoder(preset_defaults("EgoCap", 128), input_channel_scale=2)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p5)).items()})
+    net = net.to(dev).eval()
+    B = args.config5_batch
+    hm = torch.from_numpy(synth_input(f"hm_c5_rank{rank}", (4, p5.in_channels, 128, 128))).to(dev).repeat(B // 4, 1, 1, 1).contiguous()
+    h = net._ensure_handle()
+    out = {"workload": f"EgoCap lifting head, heatmaps [B,102,128,128], batch {B} per GPU", "batch_per_gpu": B,
+           "flops_per_frame": lift_flops_per_frame(p5)}
+    ref = None
+    for mode in ("f32", "bf16x3"):
+        net.set_precision(mode)
+        el, pose, _ = timed_lift(net, hm, 3, 1, lib, L, h, barrier, dev, False, world)
+        fps = world * B * 3 / el
+        out[mode] = {"value": round(fps, 1), "unit": "stereo frames/s", "ms_per_step": round(1e3 * el / 3, 2),
+                     "end_to_end_tflops_per_gpu": round(fps * out["flops_per_frame"] / world / 1e12, 2)}
+        if ref is None:
+            ref = pose
+        else:
+            out[mode]["max_abs_diff_vs_f32_mode"] = float((pose - ref).abs().max())
+    del net, hm
+    torch.cuda.empty_cache()
+    return out
+
+
 def bench_full(args, p, dev, rank, world, barrier, lib, L, mode="f32"):
     """Secondary measurement: the whole path from RGB (two heatmap estimators + lifting head), same batch."""
     import torch
@@ -337,6 +369,7 @@ def main():
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary bf16x3 fast-mode measurement")
     ap.add_argument("--train-steps", type=int, default=2, help="timed optimisation steps of the secondary training measurement (0 = skip)")
     ap.add_argument("--train-batch", type=int, default=256)
+    ap.add_argument("--config5-batch", type=int, default=64, help="per-GPU batch of the EgoCap / 128x128-heatmap measurement (0 = skip)")
     ap.add_argument("--stage1-batch", type=int, default=32, help="per-GPU batch of the stage-1 heatmap-estimator training measurement")
     ap.add_argument("--train-batch-bf16", type=int, default=1024, help="per-GPU batch of the bf16 training measurement (BASELINE config 3)")
     args = ap.parse_args()
@@ -451,6 +484,10 @@ def main():
             full["fast_mode_bf16x3"] = ff
         full.pop("_pose", None)
 
+    config5 = None
+    if not args.lift_only and not args.no_fast_mode and args.config5_batch > 0:
+        config5 = leg(bench_config5, args, dev, rank, world, barrier, lib, L)
+
     train = None
     if not args.lift_only and args.train_steps > 0:
         train = leg(bench_train, args, p, dev, rank, world, barrier)
@@ -490,7 +527,8 @@ def main():
             "end_to_end_tflops_per_gpu": round(fps * flops_frame / world / 1e12, 2),
             "end_to_end_frac_of_f32_mfma_peak": round(fps * flops_frame / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roof, "cpu_baseline": cpu, "max_abs_diff_vs_oracle": gpu_vs_oracle,
-            "fast_mode_bf16x3": fast, "full_pipeline_from_rgb": full, "train_step_lifting_head": train,
+            "fast_mode_bf16x3": fast, "full_pipeline_from_rgb": full, "config5_geometry_egocap_hm128": config5,
+            "train_step_lifting_head": train,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
