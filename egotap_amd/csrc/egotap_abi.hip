@@ -1646,13 +1646,25 @@ static hipError_t wgrad_w(int wout, const WgArgs& a, float* dw, size_t sb, int a
 }
 
 // dW[Cout][Cin][ks][ks] (+)= sum over images and pixels of dY x shifted X   (ks in {1, 3, 7}, stride in {1, 2}, pad (ks-1)/2)
+template <int NP>
+static hipError_t wgrad_bf(int wout, const WgArgs& a, float* dw, size_t sb, int acc, hipStream_t s) {
+    const int cu = device_cu_count();
+    if (wout == 64) return conv_wgrad_bf16_launch<WgBfCfg<6, NP>>(a, dw, sb, cu, acc, s);
+    if (wout == 32) return conv_wgrad_bf16_launch<WgBfCfg<5, NP>>(a, dw, sb, cu, acc, s);
+    if (wout == 16) return conv_wgrad_bf16_launch<WgBfCfg<4, NP>>(a, dw, sb, cu, acc, s);
+    return hipErrorInvalidValue;
+}
+
 extern "C" int egotap_hmtrain_conv_wgrad(const float* dy, const float* x, float* dw, int Nimg, int Cin, int Cout, int wout, int ks, int stride,
-                                         int64_t dy_istride, int64_t x_istride, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+                                         int64_t dy_istride, int64_t x_istride, int accumulate, int precision, void* ws, size_t ws_bytes,
+                                         void* stream) {
     EGO_CHECK(dy && x && dw && ws, "egotap_hmtrain_conv_wgrad: null argument");
     WgArgs a{dy, x, (float*)ws, dy_istride, x_istride, Nimg, Cin, Cout, 0, 0, 1};
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipErrorInvalidValue;
-    if (ks == 3 && stride == 1) e = wgrad_w<3, 1, 32>(wout, a, dw, ws_bytes, accumulate, s);
+    if (ks == 3 && stride == 1 && precision != EGOTAP_PREC_F32 && (wout == 64 || wout == 32 || wout == 16))
+        e = precision == EGOTAP_PREC_BF16X3 ? wgrad_bf<3>(wout, a, dw, ws_bytes, accumulate, s) : wgrad_bf<1>(wout, a, dw, ws_bytes, accumulate, s);
+    else if (ks == 3 && stride == 1) e = wgrad_w<3, 1, 32>(wout, a, dw, ws_bytes, accumulate, s);
     else if (ks == 3 && stride == 2) e = wgrad_w<3, 2, 32>(wout, a, dw, ws_bytes, accumulate, s);
     else if (ks == 1 && stride == 1) e = wgrad_w<1, 1, 96>(wout, a, dw, ws_bytes, accumulate, s);
     else if (ks == 1 && stride == 2) e = wgrad_w<1, 2, 96>(wout, a, dw, ws_bytes, accumulate, s);

@@ -449,3 +449,204 @@ __global__ void mse_finish_kernel(const double* __restrict__ part, int n, float 
     for (int i = 0; i < n; ++i) s += part[i];
     out[0] = (float)(s * coef);
 }
+
+// ------------------------------------------------------------------------------------------------- weight gradient, bf16 pipe
+// 3x3 stride-1 weight gradient on v_mfma_f32_32x32x16_bf16 (opt-in modes; arithmetic as gemm_bf16.h: NP = 3 hi + lo split,
+// NP = 1 rounding).  The contraction index is the pixel, so a fragment is 8 CONSECUTIVE PIXELS of one dY row (A operand) or of
+// one input row shifted by the tap's kx (B operand).  A 16-byte LDS read must be 16-byte aligned, which a shift by one bf16
+// pixel is not: the input rows are staged THREE times, pre-shifted by kx = 0, 1, 2 (the neighbouring pixels come from the
+// adjacent lane by a shuffle; the row ends are the zero halo), so every fragment of every tap is one aligned ds_read_b128.
+// Slab = one output row of one image; tile 128 co (wave w = 32 channels) x 16 ci x 9 taps = 144 columns (five 32-column
+// tiles, the last half empty); LDS double buffered (2 x 76 KB at width 64); split over images + fixed-order slab reduction.
+#include "gemm_bf16.h"
+
+template <int LOG2W_, int NP_>
+struct WgBfCfg {
+    static constexpr int W = 1 << LOG2W_, NP = NP_, NIMG = NP_ == 3 ? 2 : 1;
+    static constexpr int CO_T = 128, CI_T = 16, THREADS = 256, NCOL = CI_T * 9, NT = (NCOL + 31) / 32;
+    static constexpr int AST = W + 8;                                  // image row stride in bf16 (odd multiple of 16 bytes)
+    static constexpr int AIMG = CO_T * AST, BIMG = CI_T * 9 * AST;     // per hi / lo part
+    static constexpr int STAGE = NIMG * (AIMG + BIMG);                 // bf16 per buffer
+    static constexpr int LDS_BYTES = 2 * STAGE * 2;
+    static constexpr int CPR = W / 8;                                  // 8-pixel chunks per row
+    static constexpr int A_CH = CO_T * CPR, B_CH = CI_T * 3 * CPR;
+    static constexpr int A_IT = (A_CH + THREADS - 1) / THREADS, B_IT = (B_CH + THREADS - 1) / THREADS;
+    static_assert(W >= 16 && (AST * 2 / 16) % 2 == 1, "row stride must be an odd number of 16-byte units");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_bf16_kernel(WgArgs a) {
+    constexpr int W = Cfg::W, NP = Cfg::NP, NIMG = Cfg::NIMG, CO_T = Cfg::CO_T, CI_T = Cfg::CI_T, THREADS = Cfg::THREADS;
+    constexpr int NCOL = Cfg::NCOL, NT = Cfg::NT, AST = Cfg::AST, AIMG = Cfg::AIMG, BIMG = Cfg::BIMG, STAGE = Cfg::STAGE;
+    constexpr int CPR = Cfg::CPR, A_CH = Cfg::A_CH, B_CH = Cfg::B_CH, A_IT = Cfg::A_IT, B_IT = Cfg::B_IT;
+    extern __shared__ __attribute__((aligned(16))) __bf16 gsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int split = blockIdx.x % a.splits, tile = blockIdx.x / a.splits;
+    const int tco = tile % a.tiles_co, tci = tile / a.tiles_co;
+    const int co0 = tco * CO_T, ci0 = tci * CI_T;
+    const int per = (a.Nimg + a.splits - 1) / a.splits;
+    const int n_lo = split * per, n_hi = min(a.Nimg, n_lo + per);
+    const int nslab = max(0, n_hi - n_lo) * W;
+
+    f32x4 pa[A_IT][2], pb[B_IT][2];
+    auto gload = [&](int s) __attribute__((always_inline)) {
+        const int n = n_lo + s / W, y = s - (s / W) * W;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int idx = tid + it * THREADS, row = idx / CPR, ch = idx - row * CPR;
+            const bool ok = idx < A_CH && co0 + row < a.Cout;
+            const float* p = a.dy + (long)n * a.dy_istride + ((long)(co0 + row) * W + y) * W + ch * 8;
+            pa[it][0] = ok ? *(const f32x4*)p : f32x4{0.f, 0.f, 0.f, 0.f};
+            pa[it][1] = ok ? *(const f32x4*)(p + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int idx = tid + it * THREADS, ch = idx % CPR, rowid = idx / CPR, kr = rowid % 3, cl = rowid / 3;
+            const int yin = y - 1 + kr;
+            const bool ok = idx < B_CH && ci0 + cl < a.Cin && yin >= 0 && yin < W;
+            const float* p = a.x + (long)n * a.x_istride + ((long)(ci0 + cl) * W + yin) * W + ch * 8;
+            pb[it][0] = ok ? *(const f32x4*)p : f32x4{0.f, 0.f, 0.f, 0.f};
+            pb[it][1] = ok ? *(const f32x4*)(p + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+        __bf16* Ah = gsm + buf * STAGE;                 // [NIMG][CO_T][AST]
+        __bf16* Bh = Ah + NIMG * AIMG;                  // [NIMG][CI_T][3 ky][3 kx][AST]
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int idx = tid + it * THREADS, row = idx / CPR, ch = idx - row * CPR;
+            bf16x8 h, l;
+            bf16_split8(pa[it][0], pa[it][1], h, l);
+            if (idx < A_CH) {
+                *(bf16x8*)(Ah + row * AST + ch * 8) = h;
+                if (NP == 3) *(bf16x8*)(Ah + AIMG + row * AST + ch * 8) = l;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int idx = tid + it * THREADS, ch = idx % CPR, rowid = idx / CPR;      // rowid = cl * 3 + kr
+            bf16x8 h, l;
+            bf16_split8(pb[it][0], pb[it][1], h, l);
+            // neighbours' edge pixels: left neighbour's pixel 7, right neighbour's pixel 0 (zero at the row ends = the x halo).
+            // Every lane takes part in the shuffles (no divergence around them).
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const i32x4 hv = __builtin_bit_cast(i32x4, h), lv = __builtin_bit_cast(i32x4, l);
+            int hl = __shfl_up(hv[3], 1, 64), hr = __shfl_down(hv[0], 1, 64), ll = __shfl_up(lv[3], 1, 64), lr = __shfl_down(lv[0], 1, 64);
+            if (ch == 0) { hl = 0; ll = 0; }
+            if (ch == CPR - 1) { hr = 0; lr = 0; }
+            auto shifted = [&](const i32x4& v, int left, int right, int kx) __attribute__((always_inline)) {
+                // bf16 elements e0..e7 packed two per dword (low half first).  kx = 0: [L7, e0..e6]; 1: [e0..e7]; 2: [e1..e7, R0]
+                i32x4 o = v;
+                if (kx == 0) {
+                    o[0] = (int)(((unsigned)left >> 16) | ((unsigned)v[0] << 16));
+                    o[1] = (int)(((unsigned)v[0] >> 16) | ((unsigned)v[1] << 16));
+                    o[2] = (int)(((unsigned)v[1] >> 16) | ((unsigned)v[2] << 16));
+                    o[3] = (int)(((unsigned)v[2] >> 16) | ((unsigned)v[3] << 16));
+                } else if (kx == 2) {
+                    o[0] = (int)(((unsigned)v[0] >> 16) | ((unsigned)v[1] << 16));
+                    o[1] = (int)(((unsigned)v[1] >> 16) | ((unsigned)v[2] << 16));
+                    o[2] = (int)(((unsigned)v[2] >> 16) | ((unsigned)v[3] << 16));
+                    o[3] = (int)(((unsigned)v[3] >> 16) | ((unsigned)right << 16));
+                }
+                return o;
+            };
+            if (idx < B_CH) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    __bf16* dst = Bh + (rowid * 3 + kx) * AST + ch * 8;
+                    *(i32x4*)dst = shifted(hv, hl, hr, kx);
+                    if (NP == 3) *(i32x4*)(dst + BIMG) = shifted(lv, ll, lr, kx);
+                }
+            }
+        }
+    };
+
+    int boff[NT];
+    bool bok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int ncol = t * 32 + l31;
+        bok[t] = ncol < NCOL;
+        boff[t] = min(ncol, NCOL - 1) * AST + 8 * lh;          // column n = ci_local * 9 + ky * 3 + kx  ==  image row index
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (nslab > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslab) gload(s + 1);
+        const __bf16* Ah = gsm + buf * STAGE + (wid * 32 + l31) * AST + 8 * lh;
+        const __bf16* Bh = gsm + buf * STAGE + NIMG * AIMG;
+#pragma unroll
+        for (int k = 0; k < W / 16; ++k) {
+            const bf16x8 ah = *(const bf16x8*)(Ah + 16 * k);
+            bf16x8 al;
+            if (NP == 3) al = *(const bf16x8*)(Ah + AIMG + 16 * k);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                bf16x8 bh = *(const bf16x8*)(Bh + boff[t] + 16 * k);
+                if (!bok[t]) bh = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                if (NP == 3) {
+                    bf16x8 bl = *(const bf16x8*)(Bh + BIMG + boff[t] + 16 * k);
+                    if (!bok[t]) bl = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        if (s + 1 < nslab) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    const long ldw = (long)a.Cin * 9;
+    float* out = a.slabs + (long)split * a.Cout * ldw;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int ncol = t * 32 + l31;
+        const int cl = ncol / 9;
+        if (ncol >= NCOL || ci0 + cl >= a.Cin) continue;
+        const long col = (long)ci0 * 9 + ncol;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (co < a.Cout) out[(long)co * ldw + col] = acc[t][r];
+        }
+    }
+}
+
+template <class Cfg>
+static hipError_t conv_wgrad_bf16_launch(WgArgs a, float* dw, size_t slab_bytes, int num_cu, int accumulate, hipStream_t stream) {
+    if (a.Nimg <= 0) return hipSuccess;
+    a.tiles_co = (a.Cout + Cfg::CO_T - 1) / Cfg::CO_T;
+    a.tiles_ci = (a.Cin + Cfg::CI_T - 1) / Cfg::CI_T;
+    const int tiles = a.tiles_co * a.tiles_ci;
+    const long n = (long)a.Cout * a.Cin * 9;
+    int splits = (num_cu + tiles - 1) / tiles;
+    if (splits > a.Nimg) splits = a.Nimg;
+    if (splits < 1) splits = 1;
+    while ((size_t)splits * n * 4 > slab_bytes && splits > 1) --splits;
+    if ((size_t)splits * n * 4 > slab_bytes) return hipErrorOutOfMemory;
+    a.splits = splits;
+    auto kern = conv_wgrad_bf16_kernel<Cfg>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (n % 4 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, a.slabs, dw, n, splits, accumulate);
+    return hipGetLastError();
+}

@@ -81,13 +81,13 @@ def conv_dgrad(h, dy, w, dx, taps=9, stride=1, accumulate=False):
     conv_fwd(h, src, wt, dx, res=dx if accumulate else None, taps=taps, stride=1)
 
 
-def conv_wgrad(dy, x, dw, ks=3, stride=1, accumulate=False):
+def conv_wgrad(dy, x, dw, ks=3, stride=1, accumulate=False, precision="f32"):
     dy, x = V(dy), V(x)
     Cout, Cin = dw.shape[0], dw.shape[1]
     assert dy.C == Cout and x.C == Cin
     ws, n = _ws(dw.device)
     _lib.check(_lib.load().egotap_hmtrain_conv_wgrad(dy.ptr, x.ptr, _p(dw), x.N, Cin, Cout, dy.W, ks, stride, dy.istride, x.istride, int(accumulate),
-                                                     ws, n, _s()))
+                                                     _lib.PRECISIONS[precision], ws, n, _s()))
 
 
 def bn2d_fwd(z, y, gamma, beta, run_mean, run_var, res=None, relu=True, eps=1e-5, momentum=0.1):

@@ -120,6 +120,7 @@ class HmTrainFn(torch.autograd.Function):
     def backward(ctx, dout):
         sv, net, keys, P = ctx.sv, ctx.net, ctx.keys, ctx.P
         h = net._ensure_handle()
+        prec = getattr(net, "precision", "f32")
         B = sv["B"]
         N2 = 2 * B
         dev = dout.device
@@ -135,7 +136,7 @@ class HmTrainFn(torch.autograd.Function):
             """y = conv(x, w) + b: dW, db, (dX) from dZ"""
             w = P[AB + name + ".weight"]
             ks = 3 if taps == 9 else 1
-            H.conv_wgrad(dy_view, x_view, grad_of(AB + name + ".weight"), ks=ks, stride=1)
+            H.conv_wgrad(dy_view, x_view, grad_of(AB + name + ".weight"), ks=ks, stride=1, precision=prec)
             H.chansum(dy_view, grad_of(AB + name + ".bias"))
             if want_dx:
                 H.conv_dgrad(h, dy_view, w, dx, taps=taps, stride=1)
@@ -198,12 +199,12 @@ class HmTrainFn(torch.autograd.Function):
                         H_add(dy, share)
                 dz2, dres = torch.empty_like(r["z2"]), torch.empty_like(r["z2"])
                 _bn_bwd(r["z2"], r["y2"], dy, P, k + "bn2", r["m2"], dz2, grad_of, B, dres=dres)
-                H.conv_wgrad(dz2, r["y1"], grad_of(k + "conv2.weight"), ks=3, stride=1)
+                H.conv_wgrad(dz2, r["y1"], grad_of(k + "conv2.weight"), ks=3, stride=1, precision=prec)
                 dy1 = torch.empty_like(r["y1"])
                 H.conv_dgrad(h, dz2, P[k + "conv2.weight"], dy1, taps=9, stride=1)
                 dz1 = torch.empty_like(r["z1"])
                 _bn_bwd(r["z1"], r["y1"], dy1, P, k + "bn1", r["m1"], dz1, grad_of, B)
-                H.conv_wgrad(dz1, r["xin"], grad_of(k + "conv1.weight"), ks=3, stride=stride)
+                H.conv_wgrad(dz1, r["xin"], grad_of(k + "conv1.weight"), ks=3, stride=stride, precision=prec)
                 need_dx = bi > 0 or True
                 dxin = torch.empty_like(r["xin"])
                 if "zd" in r:

@@ -88,7 +88,7 @@ _PROTOS = {
     "egotap_hmtrain_chansum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egotap_hmtrain_conv_wt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "egotap_hmtrain_zero_upsample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
-    "egotap_hmtrain_conv_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_int64] * 2 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_hmtrain_conv_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_int64] * 2 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egotap_hmtrain_relu_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_int64] * 3 + [C.c_void_p]),
     "egotap_hmtrain_maxpool_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_void_p]),
     "egotap_hmtrain_upsample_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),

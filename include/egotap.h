@@ -216,7 +216,7 @@ int egotap_hmtrain_chansum(const float* dy, float* out, int N, int C, int HW, in
 int egotap_hmtrain_conv_wt(const float* w, float* wt, int Cout, int Cin, int taps, void* stream);
 int egotap_hmtrain_zero_upsample(const float* in, float* out, int N, int C, int H, int64_t in_istride, int64_t out_istride, void* stream);
 int egotap_hmtrain_conv_wgrad(const float* dy, const float* x, float* dw, int Nimg, int Cin, int Cout, int wout, int ks, int stride,
-                              int64_t dy_istride, int64_t x_istride, int accumulate, void* ws, size_t ws_bytes, void* stream);
+                              int64_t dy_istride, int64_t x_istride, int accumulate, int precision, void* ws, size_t ws_bytes, void* stream);
 int egotap_hmtrain_relu_bwd(const float* y, const float* dy, float* dz, int N, int C, int HW, int64_t y_istride, int64_t dy_istride,
                             int64_t dz_istride, void* stream);
 int egotap_hmtrain_maxpool_bwd(const float* x, const float* dy, float* dx, int64_t planes, int HIN, void* stream);

@@ -158,3 +158,23 @@ def test_mse_loss(limb):
     l, dp = H.mse(pred.cuda(), gt.cuda(), plen.cuda() if limb else None, lam)
     np.testing.assert_allclose(float(l), float(loss.detach()), rtol=1e-5)
     _close(dp, pr.grad, 1e-9, rtol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("Cin,Cout,W,N", [(64, 64, 64, 2), (128, 128, 32, 3), (100, 200, 16, 4), (640, 512, 64, 1), (1540, 1024, 16, 2)])
+def test_conv_wgrad_bf16_modes(mode, Cin, Cout, W, N):
+    """3x3 stride-1 weight gradient on the bf16 matrix cores: pre-shifted input rows (shuffled edge pixels, zero halos), ragged
+    channel counts (Cin = 100, 1540), image split; bf16x3 against float64 with the 2^-16 error model, bf16 against the float64
+    gradient of the rounded operands"""
+    from egotap_amd import hm_ops as H
+    x, dy = _rand((N, Cin, W, W), 1), _rand((N, Cout, W, W), 3)
+    w = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    xs, ds = (x.double(), dy.double()) if mode == "bf16x3" else (x.bfloat16().double(), dy.bfloat16().double())
+    F.conv2d(xs, w, None, 1, 1).backward(ds)
+    dw = torch.full((Cout, Cin, 3, 3), 3.0, device="cuda")
+    H.conv_wgrad(dy.cuda(), x.cuda(), dw, ks=3, stride=1, precision=mode)
+    scale = float(w.grad.abs().mean())
+    _close(dw, w.grad, atol=(3e-4 if mode == "bf16x3" else 2e-4) * scale + 1e-5, msg="dw " + mode)
+    again = torch.empty_like(dw)
+    H.conv_wgrad(dy.cuda(), x.cuda(), again, ks=3, stride=1, precision=mode)
+    assert torch.equal(dw, again)
