@@ -246,7 +246,6 @@ static inline size_t conv_bf16_pack_bytes(int Cout, int Cin) { return (size_t)Co
 template <class Cfg>
 static hipError_t conv_bf16_launch(ConvArgs a, __bf16* wp, hipStream_t stream) {
     if (a.Nimg <= 0) return hipSuccess;
-    if (a.Cout % Cfg::CO_T != 0) return hipErrorInvalidValue;
     const int S = (a.Cin + 15) / 16;
     const long items = (long)a.Cout * S * 9;
     hipLaunchKernelGGL(conv_pack_w_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, a.w, wp, a.Cout, a.Cin, S);
@@ -259,7 +258,7 @@ static hipError_t conv_bf16_launch(ConvArgs a, __bf16* wp, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    a.tiles_co = a.Cout / Cfg::CO_T;
+    a.tiles_co = (a.Cout + Cfg::CO_T - 1) / Cfg::CO_T;      // a ragged last tile re-reads the last channel's weights and skips its stores
     a.tiles_px = Cfg::G == 1 ? (int)((long)a.Nimg * Cfg::W * Cfg::W / Cfg::PX_T) : (a.Nimg + Cfg::G - 1) / Cfg::G;
     hipLaunchKernelGGL(kern, dim3(a.tiles_co * a.tiles_px), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a, (const __bf16*)wp, S);
     return hipGetLastError();

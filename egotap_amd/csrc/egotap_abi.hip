@@ -678,7 +678,7 @@ static hipError_t conv_bf(Handle* h, const char* role, const ConvArgs& a, hipStr
 // dispatch on (taps, stride, output width); wout in {128, 64, 32, 16, 8}
 static hipError_t conv_any(Handle* h, const char* role, int taps, int stride, int wout, const ConvArgs& a, hipStream_t s) {
     // opt-in modes: 3x3 stride-1 convs with a multiple of 128 output channels at widths 64 / 32 / 16 run on the bf16 matrix cores
-    if (h->precision != EGOTAP_PREC_F32 && h->conv_pack && taps == 9 && stride == 1 && a.Cout % 128 == 0) {
+    if (h->precision != EGOTAP_PREC_F32 && h->conv_pack && taps == 9 && stride == 1 && a.Cout >= 128) {
         const bool x3 = h->precision == EGOTAP_PREC_BF16X3;
         if (wout == 64) return x3 ? conv_bf<ConvBfCfg<6, 3>>(h, role, a, s) : conv_bf<ConvBfCfg<6, 1>>(h, role, a, s);
         if (wout == 32) return x3 ? conv_bf<ConvBfCfg<5, 3>>(h, role, a, s) : conv_bf<ConvBfCfg<5, 1>>(h, role, a, s);
