@@ -77,6 +77,15 @@ struct SegMat {
     __device__ __forceinline__ const float* row(int n) const { return p[n / seg] + (long)(n % seg) * ld; }
 };
 
+// the same weight matrix already rounded to bf16 (plain-bf16 mode: a scratch copy made right before the launch, so the W operand
+// costs half the vector-memory bytes -- the 64 B/clk/CU L1 path, not the matrix pipe, bounds that mode)
+struct SegMatB {
+    const __bf16* p[3];
+    int seg;
+    long ld;  // row stride (bf16 elements)
+    __device__ __forceinline__ const __bf16* row(int n) const { return p[n / seg] + (long)(n % seg) * ld; }
+};
+
 static inline SegVec segvec1(const float* p, int n) {
     SegVec v;
     v.p[0] = p; v.p[1] = p; v.p[2] = p; v.seg = n > 0 ? n : 1;

@@ -107,6 +107,8 @@ struct egotap_handle_s {
     HmParams hp[EGOTAP_NET_COUNT];
     int debug_stop = 0;
     int precision = EGOTAP_PREC_F32;   // arithmetic of the large GEMMs (egotap_set_precision)
+    __bf16* wscratch = nullptr;        // scratch for the bf16 copy of a GEMM's weight matrix (plain-bf16 mode), caller-owned
+    size_t wscratch_bytes = 0;
     __bf16* conv_pack = nullptr;       // scratch for repacked conv weights (set per egotap_hm_forward call from the workspace)
     // timing
     bool timing = false;
@@ -422,6 +424,25 @@ static int device_cu_count() {
     return n;
 }
 
+// plain-bf16 GEMM: W rounded to bf16 into the handle's scratch right before the launch (stream ordered), so the W operand costs
+// half the vector-memory bytes; without a scratch (or if it is too small) the kernel converts fp32 weights on the fly
+template <class AL, class Epi>
+static hipError_t gemm_bf16_plain(Handle* h, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K, hipStream_t s) {
+    const int nseg = N / W.seg;
+    if (h && h->wscratch && (size_t)N * K * 2 <= h->wscratch_bytes && K % 8 == 0 && W.ld == K && nseg >= 1 && nseg <= 3 && nseg * W.seg == N) {
+        SegMatB B;
+        for (int i = 0; i < 3; ++i) B.p[i] = h->wscratch + (size_t)(i < nseg ? i : 0) * W.seg * K;
+        B.seg = W.seg; B.ld = K;
+        const long n8 = (long)W.seg * K / 8;
+        for (int i = 0; i < nseg; ++i)
+            hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, W.p[i], h->wscratch + (size_t)i * W.seg * K, n8);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return gemm_bf16_persist_launch<BfCfg<1, 1>, AL, Epi, SegMatB>(al, B, epi, C, ldc, M, N, K, device_cu_count(), s);
+    }
+    return gemm_bf16_persist_launch<BfCfg<1, 1>, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
+}
+
 template <class AL, class Epi>
 static hipError_t gemm_big(Handle* h, const char* role, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc,
                            int M, int N, int K, hipStream_t s) {
@@ -434,7 +455,7 @@ static hipError_t gemm_big(Handle* h, const char* role, const AL& al, const SegM
     if (h && h->precision == EGOTAP_PREC_BF16) {
         static const std::string kname1 = std::string("gemm_bf16_persist_kernel<256x256x32,bf16,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
         GemmTimer t(h, s, role, kname1.c_str(), 2.0 * M * N * K);
-        return gemm_bf16_persist_launch<BfCfg<1, 1>, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
+        return gemm_bf16_plain(h, al, W, epi, C, ldc, M, N, K, s);
     }
     static const std::string kname = std::string("gemm_f32_persist_kernel<256x256x16,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
     GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
@@ -484,6 +505,14 @@ extern "C" int egotap_set_precision(egotap_handle h, int mode) {
     EGO_CHECK(h, "null handle");
     EGO_CHECK(mode == EGOTAP_PREC_F32 || mode == EGOTAP_PREC_BF16X3 || mode == EGOTAP_PREC_BF16, "egotap_set_precision: unknown mode %d", mode);
     h->precision = mode;
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_set_weight_scratch(egotap_handle h, void* buf, size_t bytes) {
+    EGO_CHECK(h, "null handle");
+    EGO_CHECK(((uintptr_t)buf & 15) == 0, "egotap_set_weight_scratch: 16-byte alignment");
+    h->wscratch = (__bf16*)buf;
+    h->wscratch_bytes = buf ? bytes : 0;
     return EGOTAP_OK;
 }
 
@@ -995,7 +1024,7 @@ static hipError_t nt_any(Handle* h, const AL& al, const SegMat& W, const Epi& ep
     if (N % 256 == 0 && K % 32 == 0 && M >= 1024 && h->precision == EGOTAP_PREC_BF16X3)
         return gemm_bf16_persist_launch<BfCfg<3, 1>, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
     if (N % 256 == 0 && K % 32 == 0 && M >= 1024 && h->precision == EGOTAP_PREC_BF16)
-        return gemm_bf16_persist_launch<BfCfg<1, 1>, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
+        return gemm_bf16_plain(h, al, W, epi, C, ldc, M, N, K, s);
     if (N % 256 == 0 && K % 16 == 0 && M >= 1024) return gemm_f32_persist_launch<PipeD, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
     if (N % 128 == 0 && K % 32 == 0) return gemm_f32_launch<TileA, AL, Epi>(al, W, epi, C, ldc, M, N, K, s);
     return hipErrorInvalidValue;

@@ -65,9 +65,11 @@ __device__ __forceinline__ void bf16_split8(const f32x4& x0, const f32x4& x1, bf
     }
 }
 
-template <class Cfg, class ALoad, class Epi>
+template <class Cfg, class ALoad, class Epi, class WMat = SegMat>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_kernel(
-    ALoad al, SegMat W, Epi epi, float* C, long ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    ALoad al, WMat W, Epi epi, float* C, long ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr bool WB = std::is_same<WMat, SegMatB>::value;      // W already bf16 (NP = 1 only): loaded as 2 x 16 bytes, no conversion
+    static_assert(!WB || Cfg::NP == 1, "bf16 weights make sense for the plain-bf16 arithmetic only");
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, LDR = Cfg::LDR, NS = Cfg::NS, NP = Cfg::NP;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, V4 = Cfg::V4, ELD = 36;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_ker
     };
 
     typename ALoad::Row arow;
-    const float* brow;
+    decltype(W.row(0)) brow;
     int l_tile = 0, l_kt = 0;           // load position in this block's slab stream
     auto set_rows = [&](int i) __attribute__((always_inline)) {
         int tm, tn;
@@ -130,7 +132,12 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_ker
     {                                                                                                \
         const int k0_ = l_kt * BK + sg * (BK / 2);                                                   \
         _Pragma("unroll") for (int v = 0; v < V4; ++v) ga[SET][v] = al.load(arow, k0_ + 4 * v);      \
-        _Pragma("unroll") for (int v = 0; v < V4; ++v) gb[SET][v] = *(const f32x4*)(brow + k0_ + 4 * v); \
+        if (WB) {                                                                                    \
+            gb[SET][0] = *(const f32x4*)(brow + k0_);                                                \
+            gb[SET][1] = *(const f32x4*)(brow + k0_ + 8);                                            \
+        } else {                                                                                     \
+            _Pragma("unroll") for (int v = 0; v < V4; ++v) gb[SET][v] = *(const f32x4*)(brow + k0_ + 4 * v); \
+        }                                                                                            \
         if (++l_kt == KT) {                                                                          \
             l_kt = 0;                                                                                \
             if (++l_tile < my_n) set_rows(l_tile);                                                   \
@@ -152,6 +159,12 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_ker
             cv1_ = bf16_round8(G[V4 - 2], G[V4 - 1]);                                                \
         }                                                                                            \
     }
+#define CONV_HALF_B(G, H)                                                                            \
+    {                                                                                                \
+        if (WB) {                                                                                    \
+            if ((H) == 0) cv0_ = __builtin_bit_cast(bf16x8, G[0]); else cv1_ = __builtin_bit_cast(bf16x8, G[1]); \
+        } else CONV_HALF(G, H)                                                                       \
+    }
     // ... and into LDS: NP = 3: hi -> group 0, lo -> group 1, each at half sg; NP = 1: the two halves of group sg
 #define CWRITE(BASE)                                                                                 \
     {                                                                                                \
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_ker
 #define LSTORE(SET, BUF)                                                                             \
     {                                                                                                \
         CONV_HALF(ga[SET], 0) CONV_HALF(ga[SET], 1) CWRITE(As + (BUF) * BM * LDR)                    \
-        CONV_HALF(gb[SET], 0) CONV_HALF(gb[SET], 1) CWRITE(Bs + (BUF) * BN * LDR)                    \
+        CONV_HALF_B(gb[SET], 0) CONV_HALF_B(gb[SET], 1) CWRITE(Bs + (BUF) * BN * LDR)                    \
     }
 #define AFRAG(BUF, I)                                                                                \
     {                                                                                                \
@@ -271,7 +284,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_ker
             for (int i = 0; i < TM; ++i) {
                 MFMAS_I(i, j & 1, j)
                 if (conv) {
-                    if (j == TN - 2) CONV_HALF(ga[P], i) else CONV_HALF(gb[P], i)
+                    if (j == TN - 2) CONV_HALF(ga[P], i) else CONV_HALF_B(gb[P], i)
                     INTERLEAVE(NMI, NV)
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -309,6 +322,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_ker
     if (gs < total) body(std::integral_constant<int, 0>{}, gs);
 #undef GLOAD
 #undef CONV_HALF
+#undef CONV_HALF_B
 #undef CWRITE
 #undef LSTORE
 #undef AFRAG
@@ -317,12 +331,19 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_ker
 #undef INTERLEAVE
 }
 
-template <class Cfg, class ALoad, class Epi>
-static hipError_t gemm_bf16_persist_launch(const ALoad& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N,
+// f32 -> bf16 (round to nearest even), 8 elements per thread: the scratch copy of W for the plain-bf16 GEMM
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    *(bf16x8*)(dst + i * 8) = bf16_round8(*(const f32x4*)(src + i * 8), *(const f32x4*)(src + i * 8 + 4));
+}
+
+template <class Cfg, class ALoad, class Epi, class WMat = SegMat>
+static hipError_t gemm_bf16_persist_launch(const ALoad& al, const WMat& W, const Epi& epi, float* C, long ldc, int M, int N,
                                            int K, int num_cu, hipStream_t stream) {
     if (M <= 0) return hipSuccess;
     if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0) return hipErrorInvalidValue;
-    auto kern = gemm_bf16_persist_kernel<Cfg, ALoad, Epi>;
+    auto kern = gemm_bf16_persist_kernel<Cfg, ALoad, Epi, WMat>;
     constexpr int LDS = Cfg::LDS_BYTES + (Cfg::THREADS / 64) * 32 * 36 * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget (3 slabs + per-wave transpose patches)");
     static bool attr_done = false;

@@ -6,6 +6,7 @@ from __future__ import annotations
 import torch
 
 from . import hm_ops as H
+from . import train_ops as T
 
 STAGES = ((64, 1), (128, 2), (256, 2), (512, 2))
 BB = "backbone.backbone.backbone."
@@ -196,7 +197,7 @@ class HmTrainFn(torch.autograd.Function):
                     if dy is None:
                         dy = share
                     else:
-                        H_add(dy, share)
+                        T.add_inplace(dy, share)
                 dz2, dres = torch.empty_like(r["z2"]), torch.empty_like(r["z2"])
                 _bn_bwd(r["z2"], r["y2"], dy, P, k + "bn2", r["m2"], dz2, grad_of, B, dres=dres)
                 H.conv_wgrad(dz2, r["y1"], grad_of(k + "conv2.weight"), ks=3, stride=1, precision=prec)
@@ -205,7 +206,6 @@ class HmTrainFn(torch.autograd.Function):
                 dz1 = torch.empty_like(r["z1"])
                 _bn_bwd(r["z1"], r["y1"], dy1, P, k + "bn1", r["m1"], dz1, grad_of, B)
                 H.conv_wgrad(dz1, r["xin"], grad_of(k + "conv1.weight"), ks=3, stride=stride, precision=prec)
-                need_dx = bi > 0 or True
                 dxin = torch.empty_like(r["xin"])
                 if "zd" in r:
                     dzd = torch.empty_like(r["zd"])
@@ -225,11 +225,6 @@ class HmTrainFn(torch.autograd.Function):
             H.conv_wgrad(dz0, sv["x0"], grad_of(BB + "conv1.weight"), ks=7, stride=2)
         ctx.sv = None
         return (None, None, None) + tuple(G.get(k) for k in keys)
-
-
-def H_add(a, b):
-    from . import train_ops as T
-    T.add_inplace(a, b)
 
 
 def hm_train_forward(net, left, right):

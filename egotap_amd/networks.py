@@ -147,6 +147,13 @@ class EgoTAPAutoEncoder(nn.Module):
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
         _lib.check(_lib.load().egotap_set_precision(self._ensure_handle(), _lib.PRECISIONS[mode]))
         self.precision = mode
+        if mode == "bf16":             # scratch for the bf16 copy of a GEMM's weights (largest: fc1 of the position encoder)
+            dev = next(self.parameters()).device
+            if dev.type == "cuda" and (getattr(self, "_wscratch", None) is None or self._wscratch.device != dev):
+                need = 2 * max(p.numel() for p in self.parameters() if p.dim() >= 2)
+                self._wscratch = torch.empty(need, dtype=torch.uint8, device=dev)
+            if getattr(self, "_wscratch", None) is not None:
+                _lib.check(_lib.load().egotap_set_weight_scratch(self._ensure_handle(), C.c_void_p(self._wscratch.data_ptr()), self._wscratch.numel()))
         return self
 
     def intermediate(self, name: str, B: int):

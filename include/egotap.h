@@ -104,6 +104,10 @@ int egotap_hm_intermediate(egotap_handle h, int B, const char* name, size_t* off
  * weight-gradient GEMMs of the training step) for shapes the bf16 kernels cover (N, K multiples of 256, M >= 1024). */
 enum { EGOTAP_PREC_F32 = 0, EGOTAP_PREC_BF16X3 = 1, EGOTAP_PREC_BF16 = 2 };
 int egotap_set_precision(egotap_handle h, int mode);
+/* EGOTAP_PREC_BF16 only: caller-owned device scratch (16-byte aligned) into which a GEMM's weight matrix is rounded to bf16 right
+ * before the launch (stream ordered; nothing is cached, the live fp32 parameters stay the source of truth).  Halves the W operand's
+ * vector-memory bytes, which bound that mode.  bytes >= 2 * the largest N*K (67 MB for fc1 of the position encoder); NULL = off. */
+int egotap_set_weight_scratch(egotap_handle h, void* buf, size_t bytes);
 
 /* debugging aid for parity tests: 0 = full forward (default); 1 = return after the embeddings;
  * 2+i = return after ViT layer i.  The state is then readable as intermediate "x". */
