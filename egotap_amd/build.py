@@ -31,17 +31,38 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+PARTS = (0, 1, 2)      # egotap_abi.hip compiled as three translation units in parallel (-DEGOTAP_PART=n), then linked
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
-    cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-o", LIB + ".tmp"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    hipcc = _hipcc()
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    common = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
+    procs, objs = [], []
+    for src in SOURCES:
+        for part in PARTS:
+            obj = os.path.join(objdir, f"{os.path.splitext(src)[0]}_part{part}.o")
+            cmd = common + [f"-DEGOTAP_PART={part}", "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+            objs.append(obj)
+    for cmd, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            for _, other in procs:
+                if other.poll() is None:
+                    other.kill()
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
     if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
+        print(" ".join(link))
+    res = subprocess.run(link, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

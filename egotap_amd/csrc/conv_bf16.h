@@ -20,7 +20,7 @@
 #include "gemm_bf16.h"
 
 // W[Cout][Cin][9] fp32 -> Wp[Cout][S][9][hi 16 | lo 16] bf16, S = ceil(Cin / 16); channels past Cin are zero
-__global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int Cout, int Cin,
+static __global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int Cout, int Cin,
                                                           int S) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)Cout * S * 9) return;

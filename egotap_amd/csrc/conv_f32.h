@@ -251,7 +251,7 @@ static hipError_t conv_f32_launch(ConvArgs a, hipStream_t stream) {
 // convolution, 16 x 16 output pixels per block (one per thread), all 64 channels per thread, weights through
 // wave-uniform (scalar) loads from a [tap][co] transposed copy in LDS.
 // Two input pointers: image n = 2*b + eye reads eye ? right : left (the stereo pair is never concatenated).
-__global__ __launch_bounds__(256) void stem_conv7_kernel(const float* __restrict__ left, const float* __restrict__ right,
+static __global__ __launch_bounds__(256) void stem_conv7_kernel(const float* __restrict__ left, const float* __restrict__ right,
                                                          const float* __restrict__ w, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ mean,
                                                          const float* __restrict__ var, float* __restrict__ out, int HIN) {
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void stem_conv7_kernel(const float* __restrict
 }
 
 // MaxPool2d(3, stride 2, pad 1) on [N*C] planes of HIN x HIN (torchvision resnet18.maxpool)
-__global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
+static __global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
                                                          int HIN) {
     const int HO = HIN / 2;
     const long total = planes * HO * HO;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict
 // channel slice of the next concat buffer: out[n][c] at out + n*out_istride + c*4*HIN*HIN.
 // One thread = four consecutive x of one output row (float4 store); NO grid-stride loop: with a loop hipcc emits a
 // peeled and an unrolled copy of the body that round differently, and a pixel's value then depends on the batch size.
-__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C,
+static __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C,
                                                          int HIN, long in_istride, long out_istride) {
     const int HO = 2 * HIN, Q = HO / 4;
     const float scale = (float)(HIN - 1) / (float)(HO - 1);

@@ -21,7 +21,16 @@
 #include "heatmap_synth.h"
 #include "pu_chain.h"
 
+// The library is ONE source compiled as three translation units in parallel (egotap_amd/build.py: -DEGOTAP_PART=0 core and
+// inference, 1 lifting-head training operators, 2 heatmap-estimator training operators); every exported function belongs to one
+// part, the static helpers and kernel templates are visible to all.  Without EGOTAP_PART the file is a single translation unit.
+#ifndef EGOTAP_PART
+#define EGOTAP_PART -1
+#endif
+#define EGOTAP_IN(n) (EGOTAP_PART < 0 || EGOTAP_PART == (n))
+
 // ------------------------------------------------------------------------------------------------ errors
+#if EGOTAP_IN(0)
 static thread_local char g_err[1024] = "";
 void egotap_set_error(const char* fmt, ...) {
     va_list ap;
@@ -29,8 +38,13 @@ void egotap_set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+#endif
+#if EGOTAP_IN(0)
 extern "C" const char* egotap_last_error(void) { return g_err; }
+#endif
+#if EGOTAP_IN(0)
 extern "C" int egotap_abi_version(void) { return EGOTAP_ABI_VERSION; }
+#endif
 
 // ------------------------------------------------------------------------------------------------ tiles
 using TileA = GemmCfg<128, 128, 32, 2, 2, 2>;   // 4 waves, 64x64 per wave, 2 blocks/CU
@@ -45,6 +59,7 @@ using PipeB = PipeCfg<128, 128, 32, 2, 2, 1>;   // pipelined: 3 x 36 KiB slabs, 
 using PipeC = PipeCfg<256, 128, 16, 4, 2, 2>;   // pipelined, 8 waves: 3 x 30 KiB slabs, 1 block/CU
 using PipeD = PipeCfg<256, 256, 16, 4, 2, 2>;   // pipelined, 8 waves 64x128 per wave: 3 x 40 KiB slabs
 
+#if EGOTAP_IN(0)
 extern "C" const char* egotap_gemm_tile_name(int tile) {
     switch (tile) {
         case 0: case 1: return "128x128x32/4w";
@@ -66,6 +81,7 @@ extern "C" const char* egotap_gemm_tile_name(int tile) {
         default: return nullptr;
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ handle
 struct Param {
@@ -194,6 +210,7 @@ static void hm_expect(Handle* h, int net, int n_out) {
     cv("conv_heatmap", n_out, 512, 1);
 }
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_create(const egotap_config* cfg, egotap_handle* out) {
     EGO_CHECK(cfg && out, "egotap_create: null argument");
     EGO_CHECK(cfg->struct_bytes == (int32_t)sizeof(egotap_config), "egotap_create: egotap_config is %d bytes, library expects %d",
@@ -225,13 +242,17 @@ extern "C" int egotap_create(const egotap_config* cfg, egotap_handle* out) {
     *out = h;
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(0)
 extern "C" void egotap_destroy(egotap_handle h) {
     if (!h) return;
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
 }
+#endif
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_bind_param(egotap_handle h, int net, const char* key, void* dev_ptr, int64_t numel, int dtype) {
     EGO_CHECK(h && key, "egotap_bind_param: null argument");
     EGO_CHECK(net >= 0 && net < EGOTAP_NET_COUNT, "egotap_bind_param: bad net id %d", net);
@@ -250,7 +271,9 @@ extern "C" int egotap_bind_param(egotap_handle h, int net, const char* key, void
     else h->hm_resolved[net] = false;
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_unbound_count(egotap_handle h, int net, int* count) {
     EGO_CHECK(h && count, "egotap_unbound_count: null argument");
     EGO_CHECK(net >= 0 && net < EGOTAP_NET_COUNT, "bad net id %d", net);
@@ -260,6 +283,7 @@ extern "C" int egotap_unbound_count(egotap_handle h, int net, int* count) {
     *count = n;
     return EGOTAP_OK;
 }
+#endif
 
 static const float* P(Handle* h, int net, const std::string& key, bool& ok) {
     auto it = h->bound[net].find(key);
@@ -324,11 +348,14 @@ static int lift_resolve(Handle* h) {
 }
 
 // ------------------------------------------------------------------------------------------------ timing
+#if EGOTAP_IN(0)
 extern "C" int egotap_timing_enable(egotap_handle h, int enable) {
     EGO_CHECK(h, "null handle");
     h->timing = enable != 0;
     return EGOTAP_OK;
 }
+#endif
+#if EGOTAP_IN(0)
 extern "C" int egotap_timing_read(egotap_handle h, int* launches, double* total_ms, double* total_flops) {
     EGO_CHECK(h && launches && total_ms && total_flops, "null argument");
     struct Agg { std::string role, kernel; int n = 0; double ms = 0, flops = 0; };
@@ -363,7 +390,10 @@ extern "C" int egotap_timing_read(egotap_handle h, int* launches, double* total_
     h->rec.clear();
     return EGOTAP_OK;
 }
+#endif
+#if EGOTAP_IN(0)
 extern "C" const char* egotap_timing_detail(egotap_handle h) { return h ? h->detail.c_str() : ""; }
+#endif
 
 struct GemmTimer {   // brackets one GEMM launch when the handle's timing hook is on
     Handle* h;
@@ -481,13 +511,16 @@ static LiftWs lift_ws(const Handle* h, int B) {
     return w;
 }
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_lift_workspace_bytes(egotap_handle h, int B, size_t* bytes) {
     EGO_CHECK(h && bytes, "null argument");
     EGO_CHECK(B >= 0, "negative batch");
     *bytes = lift_ws(h, B > 0 ? B : 1).total;
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_lift_intermediate(egotap_handle h, int B, const char* name, size_t* offset, int64_t* numel) {
     EGO_CHECK(h && name && offset && numel, "null argument");
     const LiftWs w = lift_ws(h, B > 0 ? B : 1);
@@ -500,14 +533,18 @@ extern "C" int egotap_lift_intermediate(egotap_handle h, int B, const char* name
     else { egotap_set_error("unknown intermediate '%s'", name); return EGOTAP_ERR_INVALID; }
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_set_precision(egotap_handle h, int mode) {
     EGO_CHECK(h, "null handle");
     EGO_CHECK(mode == EGOTAP_PREC_F32 || mode == EGOTAP_PREC_BF16X3 || mode == EGOTAP_PREC_BF16, "egotap_set_precision: unknown mode %d", mode);
     h->precision = mode;
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_set_weight_scratch(egotap_handle h, void* buf, size_t bytes) {
     EGO_CHECK(h, "null handle");
     EGO_CHECK(((uintptr_t)buf & 15) == 0, "egotap_set_weight_scratch: 16-byte alignment");
@@ -515,12 +552,15 @@ extern "C" int egotap_set_weight_scratch(egotap_handle h, void* buf, size_t byte
     h->wscratch_bytes = buf ? bytes : 0;
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_lift_debug_stop(egotap_handle h, int stage) {
     EGO_CHECK(h, "null handle");
     h->debug_stop = stage;   // 0: full forward; 1: after embeddings; 2+i: after ViT layer i  ("x" holds the state)
     return EGOTAP_OK;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ forward
 static hipError_t launch_ln(const float* x, float* y, const float* g, const float* b, int rows, float eps, hipStream_t s) {
@@ -530,6 +570,7 @@ static hipError_t launch_ln(const float* x, float* y, const float* g, const floa
     return hipGetLastError();
 }
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, float* pose, void* ws, size_t ws_bytes,
                                    void* stream) {
     EGO_CHECK(h, "null handle");
@@ -629,6 +670,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ heatmap estimator
 static int hm_resolve(Handle* h, int net) {
@@ -766,13 +808,16 @@ static HmWs hm_ws(const Handle* h, int B) {
     return w;
 }
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_hm_workspace_bytes(egotap_handle h, int B, size_t* bytes) {
     EGO_CHECK(h && bytes, "null argument");
     EGO_CHECK(B >= 0, "negative batch");
     *bytes = hm_ws(h, B > 0 ? B : 1).total;
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_hm_intermediate(egotap_handle h, int B, const char* name, size_t* offset, int64_t* numel) {
     EGO_CHECK(h && name && offset && numel, "null argument");
     const HmWs w = hm_ws(h, B > 0 ? B : 1);
@@ -793,8 +838,10 @@ extern "C" int egotap_hm_intermediate(egotap_handle h, int B, const char* name, 
     else { egotap_set_error("unknown intermediate '%s'", name); return EGOTAP_ERR_INVALID; }
     return EGOTAP_OK;
 }
+#endif
 
 // HeatMap_UnrealEgo_Shared.forward(left, right) (model/net_architecture.py:32-36, 45-51, 75-85, 139-173), eval mode.
+#if EGOTAP_IN(0)
 extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, const float* right, int B, float* out,
                                  int64_t out_image_stride, void* ws, size_t ws_bytes, void* stream) {
     EGO_CHECK(h, "null handle");
@@ -888,6 +935,7 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
     EGO_HIP(biasconv("hm.conv_heatmap", 1, s64, X1, 512 * p64, p.head, 512, p.n_out, out, out_image_stride, 0));
     return EGOTAP_OK;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ single operators
 template <class Cfg>
@@ -905,6 +953,7 @@ static hipError_t linear_tile(const float* x, const float* w, const float* b, fl
     }
 }
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_linear_f32(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int epi,
                                  const float* r, const float* g, const float* beta, const float* mean, const float* var,
                                  int tile, void* stream) {
@@ -942,7 +991,9 @@ extern "C" int egotap_linear_f32(const float* x, const float* w, const float* b,
     EGO_HIP(e);
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_layernorm_f32(const float* x, float* y, const float* gamma, const float* beta, int rows, int dim,
                                     float eps, void* stream) {
     EGO_CHECK(x && y && gamma && beta, "egotap_layernorm_f32: null argument");
@@ -950,7 +1001,9 @@ extern "C" int egotap_layernorm_f32(const float* x, float* y, const float* gamma
     EGO_HIP(launch_ln(x, y, gamma, beta, rows, eps, (hipStream_t)stream));
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(0)
 extern "C" int egotap_attention_f32(const float* qkv, float* ctx, int B, int N, int heads, void* stream) {
     EGO_CHECK(qkv && ctx, "egotap_attention_f32: null argument");
     EGO_CHECK(N > 0 && N % 32 == 0, "egotap_attention_f32: sequence length must be a multiple of 32");
@@ -958,8 +1011,10 @@ extern "C" int egotap_attention_f32(const float* qkv, float* ctx, int B, int N, 
     EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, (hipStream_t)stream));
     return EGOTAP_OK;
 }
+#endif
 
 // per-sample MPJPE / PA-MPJPE of a batch of poses (egotap_autoencoder_model.py:329-350, utils/util.py:328-379)
+#if EGOTAP_IN(0)
 extern "C" int egotap_pose_metrics(const float* pred, const float* gt, int B, int J, float* mpjpe, float* pa_mpjpe, float* aligned,
                                    void* stream) {
     if (B == 0) return EGOTAP_OK;
@@ -969,8 +1024,10 @@ extern "C" int egotap_pose_metrics(const float* pred, const float* gt, int B, in
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 // joints -> ground-truth heatmaps in the lifting head's input layout (dataloader/data_loader.py:76-215 with --use_gt_heatmap)
+#if EGOTAP_IN(0)
 extern "C" int egotap_synth_heatmaps(const float* pts2d_left, const float* pts2d_right, const float* pose3d, const int* parents, int B,
                                      int J, int res, float* hm, float* plength, float* theta, void* stream) {
     if (B == 0) return EGOTAP_OK;
@@ -991,8 +1048,10 @@ extern "C" int egotap_synth_heatmaps(const float* pts2d_left, const float* pts2d
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 // same operator with the arithmetic of egotap_set_precision (EGOTAP_PREC_*): fp32 MFMA, bf16x3 split or plain bf16
+#if EGOTAP_IN(0)
 extern "C" int egotap_attention(const float* qkv, float* ctx, int B, int N, int heads, int precision, void* stream) {
     EGO_CHECK(qkv && ctx, "egotap_attention: null argument");
     EGO_CHECK(N > 0 && N % 32 == 0, "egotap_attention: sequence length must be a multiple of 32");
@@ -1003,6 +1062,7 @@ extern "C" int egotap_attention(const float* qkv, float* ctx, int B, int N, int 
     else { egotap_set_error("egotap_attention: unknown precision %d", precision); return EGOTAP_ERR_INVALID; }
     return EGOTAP_OK;
 }
+#endif
 
 // ================================================================================================ training operators
 // Building blocks of the training step (egotap_autoencoder_model.py:299-323), called by the autograd glue in
@@ -1034,19 +1094,27 @@ template <class AL>
 static hipError_t nt_epi(const AL& al, const float* w, const float* b, float* y, int M, int N, int K, int epi, const float* r,
                          float* z, const LiftParams* lp, Handle* h, hipStream_t s) {
     const SegMat W = segmat1(w, N, K);
-    switch (epi) {
-        case TE_NONE: return nt_any(h, al, W, EpiNone{}, y, N, M, N, K, s);
-        case TE_BIAS: return nt_any(h, al, W, EpiBias{segvec1(b, N)}, y, N, M, N, K, s);
-        case TE_BIAS_RES: return nt_any(h, al, W, EpiBiasRes{segvec1(b, N), r, N}, y, N, M, N, K, s);
-        case TE_BIAS_GELU_SAVE: return nt_any(h, al, W, EpiBiasGeluSave{segvec1(b, N), z, N}, y, N, M, N, K, s);
-        case TE_ACCUM: return nt_any(h, al, W, EpiAccum{r, N}, y, N, M, N, K, s);
-        case TE_GELU_GRAD: return nt_any(h, al, W, EpiGeluGrad{r, N}, y, N, M, N, K, s);
-        default: return hipErrorInvalidValue;
+    if constexpr (!std::is_same<AL, ALoadPlain>::value) {
+        // gathering loaders feed first layers only (fc1 of the two encoders, the PU projections): bias epilogue, nothing else is
+        // instantiated (each combination is four GEMM kernels: compile time)
+        if (epi == TE_BIAS) return nt_any(h, al, W, EpiBias{segvec1(b, N)}, y, N, M, N, K, s);
+        return hipErrorInvalidValue;
+    } else {
+        switch (epi) {
+            case TE_NONE: return nt_any(h, al, W, EpiNone{}, y, N, M, N, K, s);
+            case TE_BIAS: return nt_any(h, al, W, EpiBias{segvec1(b, N)}, y, N, M, N, K, s);
+            case TE_BIAS_RES: return nt_any(h, al, W, EpiBiasRes{segvec1(b, N), r, N}, y, N, M, N, K, s);
+            case TE_BIAS_GELU_SAVE: return nt_any(h, al, W, EpiBiasGeluSave{segvec1(b, N), z, N}, y, N, M, N, K, s);
+            case TE_ACCUM: return nt_any(h, al, W, EpiAccum{r, N}, y, N, M, N, K, s);
+            case TE_GELU_GRAD: return nt_any(h, al, W, EpiGeluGrad{r, N}, y, N, M, N, K, s);
+            default: return hipErrorInvalidValue;
+        }
     }
 }
 
 // y[M,N] = epi(A(x) W^T (+ b)); `loader` gathers A from x exactly as the eval forward does; aux = gate source (F) for LD_STEREO_GATED.
 // r: residual / accumulate source / saved pre-activation (by epi); z: pre-activation output for TE_BIAS_GELU_SAVE.
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_gemm_nt(egotap_handle h, int loader, const float* x, int64_t lda, const float* aux, const float* w, const float* b,
                                     float* y, int M, int N, int K, int epi, const float* r, float* z, int Bsz, void* stream) {
     EGO_CHECK(h && x && w && y, "egotap_train_gemm_nt: null argument");
@@ -1068,8 +1136,10 @@ extern "C" int egotap_train_gemm_nt(egotap_handle h, int loader, const float* x,
     EGO_HIP(e);
     return EGOTAP_OK;
 }
+#endif
 
 // patch embedding forward in training (same kernel as eval): hm [B,C,S,S] -> x [B*seq, D]
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_patch_fwd(egotap_handle h, const float* hm, int B, const float* w, const float* b, const float* mask_tok,
                                       const float* pos, float* x, void* stream) {
     EGO_CHECK(h && hm && w && b && mask_tok && pos && x, "egotap_train_patch_fwd: null argument");
@@ -1079,6 +1149,7 @@ extern "C" int egotap_train_patch_fwd(egotap_handle h, const float* hm, int B, c
     EGO_HIP((gemm_big(h, "patch_embed", al, segmat1(w, D, 256), ep, x, D, M, D, 256, (hipStream_t)stream)));
     return EGOTAP_OK;
 }
+#endif
 
 template <class XL>
 static hipError_t tn_any(Handle* h, const float* dy, const XL& xl, float* dw, float* ws, size_t ws_bytes, int M, int N, int K, int acc, hipStream_t s,
@@ -1094,6 +1165,7 @@ static hipError_t tn_any(Handle* h, const float* dy, const XL& xl, float* dw, fl
 }
 
 // dW[N,K] (+)= dY[M,N]^T A(x)[M,K]   (weight gradient; x goes through the forward's loader)
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_gemm_tn(egotap_handle h, int loader, const float* dy, int64_t ldy, const float* x, const float* aux, float* dw, int M,
                                     int N, int K, int accumulate, int Bsz, void* ws, size_t ws_bytes, void* stream) {
     EGO_CHECK(h && dy && x && dw && ws, "egotap_train_gemm_tn: null argument");
@@ -1117,21 +1189,27 @@ extern "C" int egotap_train_gemm_tn(egotap_handle h, int loader, const float* dy
     EGO_HIP(e);
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_colsum(const float* y, int64_t ldy, float* out, int M, int N, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     EGO_CHECK(y && out && ws, "egotap_train_colsum: null argument");
     EGO_CHECK(N % 4 == 0, "egotap_train_colsum: N must be a multiple of 4");
     EGO_HIP(colsum_f32_launch(y, ldy > 0 ? ldy : N, out, (float*)ws, ws_bytes, M, N, accumulate, (hipStream_t)stream));
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_transpose(const float* in, float* out, int R, int C, int64_t ldo, void* stream) {
     EGO_CHECK(in && out, "egotap_train_transpose: null argument");
     hipLaunchKernelGGL(transpose_f32_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, out, R, C, (long)(ldo > 0 ? ldo : R));
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_layernorm_fwd(const float* x, float* y, const float* g, const float* b, float* mean, float* rstd, int rows,
                                           float eps, void* stream) {
     EGO_CHECK(x && y && g && b && mean && rstd, "egotap_train_layernorm_fwd: null argument");
@@ -1139,8 +1217,10 @@ extern "C" int egotap_train_layernorm_fwd(const float* x, float* y, const float*
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 // dx = LN'(dy) (+ dres); dgamma / dbeta (+)= column sums.  ws: >= ceil(rows/64) * 2 * 1024 floats
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_layernorm_bwd(const float* x, const float* dy, const float* g, const float* mean, const float* rstd,
                                           const float* dres, float* dx, float* dgamma, float* dbeta, int rows, int accumulate,
                                           void* ws, size_t ws_bytes, void* stream) {
@@ -1162,9 +1242,11 @@ extern "C" int egotap_train_layernorm_bwd(const float* x, const float* dy, const
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 // BatchNorm1d (training mode) + LeakyReLU(0.2) over z [R, C]: y, saved mean / rstd, running-stat update
 // (network_utils.py:123-142; momentum 0.1, unbiased running variance).  ws >= (2 * ceil(R/256) * C + 2C) floats
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_bn_lrelu_fwd(const float* z, float* y, const float* gamma, const float* beta, float* mean, float* rstd,
                                          float* run_mean, float* run_var, int R, int C, float eps, float momentum, void* ws,
                                          size_t ws_bytes, void* stream) {
@@ -1187,7 +1269,9 @@ extern "C" int egotap_train_bn_lrelu_fwd(const float* z, float* y, const float* 
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_bn_lrelu_bwd(const float* z, const float* y, const float* dy, const float* gamma, const float* mean,
                                          const float* rstd, float* dz, float* dgamma, float* dbeta, int R, int C, int accumulate,
                                          void* ws, size_t ws_bytes, void* stream) {
@@ -1207,7 +1291,9 @@ extern "C" int egotap_train_bn_lrelu_bwd(const float* z, const float* y, const f
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_attention_fwd(const float* qkv, float* ctx, float* lse, int B, int N, int heads, int precision, void* stream) {
     EGO_CHECK(qkv && ctx && lse, "egotap_train_attention_fwd: null argument");
     EGO_CHECK(N > 0 && N % 32 == 0 && heads > 0, "egotap_train_attention_fwd: bad shape");
@@ -1217,7 +1303,9 @@ extern "C" int egotap_train_attention_fwd(const float* qkv, float* ctx, float* l
     else EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, s, lse));
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_attention_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* delta,
                                           float* dqkv, int B, int N, int heads, int precision, void* stream) {
     EGO_CHECK(qkv && ctx && dctx && lse && delta && dqkv, "egotap_train_attention_bwd: null argument");
@@ -1228,7 +1316,9 @@ extern "C" int egotap_train_attention_bwd(const float* qkv, const float* ctx, co
     else EGO_HIP(attention_bwd_f32_launch(qkv, ctx, dctx, lse, delta, dqkv, B, N, heads, s));
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_pose_loss(egotap_handle h, const float* pred, const float* gt, float* dpred, float* out, float* partial,
                                       int B, float lambda_mpjpe, float lambda_cos_sim, void* stream) {
     EGO_CHECK(h && pred && gt && dpred && out && partial, "egotap_train_pose_loss: null argument");
@@ -1247,7 +1337,9 @@ extern "C" int egotap_train_pose_loss(egotap_handle h, const float* pred, const 
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                                   float weight_decay, int step, void* stream) {
     EGO_CHECK(p && g && m && v && step >= 1, "egotap_train_adamw: bad argument");
@@ -1257,13 +1349,16 @@ extern "C" int egotap_train_adamw(float* p, const float* g, float* m, float* v, 
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_add_inplace(float* out, const float* in, int64_t n, void* stream) {
     EGO_CHECK(out && in && n % 4 == 0, "egotap_train_add_inplace: bad argument");
     hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, in, (long)(n / 4));
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ PU chain + pose head (training)
 struct PuSaved { size_t F0, G0, HS0, C0, F1, G1, HS1, C1, ZERO, total; };
@@ -1278,6 +1373,7 @@ static PuSaved pu_saved(const Handle* h, int B) {
     w.total = o;
     return w;
 }
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_pu_saved_bytes(egotap_handle h, int B, size_t* bytes, size_t* hs1_offset) {
     EGO_CHECK(h && bytes && hs1_offset, "null argument");
     const PuSaved w = pu_saved(h, B > 0 ? B : 1);
@@ -1285,8 +1381,10 @@ extern "C" int egotap_train_pu_saved_bytes(egotap_handle h, int B, size_t* bytes
     *hs1_offset = w.HS1;
     return EGOTAP_OK;
 }
+#endif
 
 // SkelNet(mode "PU") forward keeping what the backward needs: posz, rotz [B*2J, hid] -> saved[HS1] = skel_embed [J, B, H]
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_pu_fwd(egotap_handle h, const float* posz, const float* rotz, int B, void* saved, size_t saved_bytes,
                                    void* stream) {
     EGO_CHECK(h && posz && rotz && saved, "egotap_train_pu_fwd: null argument");
@@ -1330,6 +1428,7 @@ extern "C" int egotap_train_pu_fwd(egotap_handle h, const float* posz, const flo
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 struct PuBwdWs { size_t dG, dF, HP, dHS0, dXs, dBp, DHP, dHrec[2], dC[2], WT, part, total; };
 static PuBwdWs pu_bwd_ws(const Handle* h, int B) {
@@ -1344,15 +1443,18 @@ static PuBwdWs pu_bwd_ws(const Handle* h, int B) {
     w.total = o;
     return w;
 }
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_pu_bwd_ws_bytes(egotap_handle h, int B, size_t* bytes) {
     EGO_CHECK(h && bytes, "null argument");
     *bytes = pu_bwd_ws(h, B > 0 ? B : 1).total;
     return EGOTAP_OK;
 }
+#endif
 
 // Backward of egotap_train_pu_fwd.  dhs1: gradient w.r.t. skel_embed [J,B,H]; dposz is ACCUMULATED into (the pose head's
 // contribution is already there), drotz is written; grads[14] (state_dict order of skel_sequential_layer) are accumulated
 // when accumulate != 0, else overwritten.
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_pu_bwd(egotap_handle h, const float* posz, const float* rotz, int B, const void* saved,
                                    const float* dhs1, float* dposz, float* drotz, float* const* grads, int accumulate, void* ws,
                                    size_t ws_bytes, void* stream) {
@@ -1450,8 +1552,10 @@ extern "C" int egotap_train_pu_bwd(egotap_handle h, const float* posz, const flo
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 // pose head (training): forward = the eval kernel; backward: data gradients + weight gradients
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_pose_head_fwd(egotap_handle h, const float* posz, const float* hs1, int B, float* pose, void* stream) {
     EGO_CHECK(h && posz && hs1 && pose, "egotap_train_pose_head_fwd: null argument");
     int rc = lift_resolve(h);
@@ -1462,6 +1566,8 @@ extern "C" int egotap_train_pose_head_fwd(egotap_handle h, const float* posz, co
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_pose_head_bwd(egotap_handle h, const float* posz, const float* hs1, const float* dpose, int B, float* dposz,
                                           float* dhs1, float* dWp, float* dbp, float* dWg, float* dbg, int accumulate, void* stream) {
     EGO_CHECK(h && posz && hs1 && dpose && dposz && dhs1 && dWp && dbp, "egotap_train_pose_head_bwd: null argument");
@@ -1478,10 +1584,11 @@ extern "C" int egotap_train_pose_head_bwd(egotap_handle h, const float* posz, co
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 
 // patch-embedding bias / mask-token gradients from dpos[seq, D] = sum_b dx[b]: rows of real cells -> dbias, dummy cells -> dmask
-__global__ __launch_bounds__(256) void patch_split_kernel(const float* __restrict__ dpos, float* __restrict__ dbias, float* __restrict__ dmask,
+static __global__ __launch_bounds__(256) void patch_split_kernel(const float* __restrict__ dpos, float* __restrict__ dbias, float* __restrict__ dmask,
                                                           int D, int seq, int side, int ppd, int grid, int T, int accumulate) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= D) return;
@@ -1494,6 +1601,7 @@ __global__ __launch_bounds__(256) void patch_split_kernel(const float* __restric
     dbias[n] = (accumulate ? dbias[n] : 0.f) + sb;
     dmask[n] = (accumulate ? dmask[n] : 0.f) + sm;
 }
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_patch_split(egotap_handle h, const float* dpos, float* dbias, float* dmask, int accumulate, void* stream) {
     EGO_CHECK(h && dpos && dbias && dmask, "egotap_train_patch_split: null argument");
     hipLaunchKernelGGL(patch_split_kernel, dim3((h->D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dpos, dbias, dmask, h->D, h->seq,
@@ -1501,9 +1609,10 @@ extern "C" int egotap_train_patch_split(egotap_handle h, const float* dpos, floa
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 // input gradient of fc1 (position encoder): dA [B*T, ppd*ppd*D] (heatmap-major) -> dtokens [B*seq, D]; dummy tokens get zero
-__global__ __launch_bounds__(256) void tokens_scatter_kernel(const float* __restrict__ dA, float* __restrict__ dtok, int B, int T, int D,
+static __global__ __launch_bounds__(256) void tokens_scatter_kernel(const float* __restrict__ dA, float* __restrict__ dtok, int B, int T, int D,
                                                              int seq, int side, int ppd, int grid) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index over [B*seq, D/4]
     const int D4 = D / 4;
@@ -1520,6 +1629,7 @@ __global__ __launch_bounds__(256) void tokens_scatter_kernel(const float* __rest
     }
     *(f32x4*)(dtok + bt * D + c4 * 4) = v;
 }
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_tokens_scatter(egotap_handle h, const float* dA, float* dtok, int B, void* stream) {
     EGO_CHECK(h && dA && dtok, "egotap_train_tokens_scatter: null argument");
     const long n = (long)B * h->seq * (h->D / 4);
@@ -1528,9 +1638,11 @@ extern "C" int egotap_train_tokens_scatter(egotap_handle h, const float* dA, flo
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 
 // fused Q|K|V projection (three nn.Linear of ViTSelfAttention, modeling_vit.py:212-214) into one [M, 3D] buffer
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_qkv_fwd(egotap_handle h, const float* y, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv,
                                     const float* bv, float* qkv, int M, int D, void* stream) {
     EGO_CHECK(h && y && wq && bq && wk && bk && wv && bv && qkv, "egotap_train_qkv_fwd: null argument");
@@ -1540,6 +1652,7 @@ extern "C" int egotap_train_qkv_fwd(egotap_handle h, const float* y, const float
     EGO_HIP((gemm_big(h, "qkv", ALoadPlain{y, D}, W, EpiBias{b}, qkv, 3L * D, M, 3 * D, D, (hipStream_t)stream)));
     return EGOTAP_OK;
 }
+#endif
 
 
 // ================================================================================================ heatmap-estimator training
@@ -1550,6 +1663,7 @@ extern "C" int egotap_train_qkv_fwd(egotap_handle h, const float* y, const float
 
 // scratch for the repacked weights of the bf16 convolution kernels when the training operators run under a bf16 precision mode
 // (egotap_hm_forward takes it from its workspace); bytes >= egotap_hmtrain_pack_bytes()
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_set_pack_buffer(egotap_handle h, void* buf, size_t bytes) {
     EGO_CHECK(h, "null handle");
     EGO_CHECK(buf == nullptr || bytes >= conv_bf16_pack_bytes(1024, 1540), "egotap_hmtrain_set_pack_buffer: buffer too small");
@@ -1557,8 +1671,12 @@ extern "C" int egotap_hmtrain_set_pack_buffer(egotap_handle h, void* buf, size_t
     h->conv_pack = (__bf16*)buf;
     return EGOTAP_OK;
 }
+#endif
+#if EGOTAP_IN(2)
 extern "C" size_t egotap_hmtrain_pack_bytes(void) { return conv_bf16_pack_bytes(1024, 1540); }
+#endif
 
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_conv_fwd(egotap_handle h, const float* x, const float* w, const float* bias, const float* res, float* y,
                                        int Nimg, int Cin, int Cout, int wout, int taps, int stride, int relu, int64_t in_istride,
                                        int64_t out_istride, int64_t res_istride, void* stream) {
@@ -1569,8 +1687,10 @@ extern "C" int egotap_hmtrain_conv_fwd(egotap_handle h, const float* x, const fl
     EGO_HIP(e);
     return EGOTAP_OK;
 }
+#endif
 
 // conv 7x7 / 2 of the ResNet stem without BatchNorm: z [2B, 64, S0/2, S0/2], image n = 2b + eye
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_stem_fwd(const float* left, const float* right, const float* w, float* z, int B, int S0, void* stream) {
     EGO_CHECK(left && right && w && z && B > 0 && S0 % 32 == 0, "egotap_hmtrain_stem_fwd: bad argument");
     hipLaunchKernelGGL(stem_conv7_kernel, dim3(S0 / 32, S0 / 32, 2 * B), dim3(256), 0, (hipStream_t)stream, left, right, w, (const float*)nullptr,
@@ -1578,9 +1698,11 @@ extern "C" int egotap_hmtrain_stem_fwd(const float* left, const float* right, co
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 static int bn_splits(int N, int C) { int s = (1024 + C - 1) / C; if (s > N) s = N; if (s < 1) s = 1; return s; }
 
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_bn2d_fwd(const float* z, float* y, const float* res, const float* gamma, const float* beta, float* mean, float* rstd,
                                        float* run_mean, float* run_var, int N, int C, int HW, int64_t z_istride, int64_t y_istride,
                                        int64_t res_istride, int relu, float eps, float momentum, void* ws, size_t ws_bytes, void* stream) {
@@ -1599,7 +1721,9 @@ extern "C" int egotap_hmtrain_bn2d_fwd(const float* z, float* y, const float* re
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_bn2d_bwd(const float* z, const float* y, const float* dy, const float* gamma, const float* mean, const float* rstd,
                                        float* dz, float* dres, float* dgamma, float* dbeta, int N, int C, int HW, int64_t z_istride,
                                        int64_t dy_istride, int relu, int accumulate, int dres_accumulate, void* ws, size_t ws_bytes, void* stream) {
@@ -1621,8 +1745,9 @@ extern "C" int egotap_hmtrain_bn2d_bwd(const float* z, const float* y, const flo
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
-__global__ void chansum_finish_kernel(const double* __restrict__ part, int splits, int C, float* __restrict__ out, int accumulate) {
+static __global__ void chansum_finish_kernel(const double* __restrict__ part, int splits, int C, float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s0 = 0.0;
@@ -1631,6 +1756,7 @@ __global__ void chansum_finish_kernel(const double* __restrict__ part, int split
 }
 
 // per-channel sums over N*H*W (bias gradients)
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_chansum(const float* dy, float* out, int N, int C, int HW, int64_t istride, int accumulate, void* ws, size_t ws_bytes,
                                       void* stream) {
     EGO_CHECK(dy && out && ws && HW % 4 == 0, "egotap_hmtrain_chansum: bad argument");
@@ -1643,7 +1769,9 @@ extern "C" int egotap_hmtrain_chansum(const float* dy, float* out, int N, int C,
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_conv_wt(const float* w, float* wt, int Cout, int Cin, int taps, void* stream) {
     EGO_CHECK(w && wt && Cout > 0 && Cin > 0 && taps > 0, "egotap_hmtrain_conv_wt: bad argument");
     const long total = (long)Cout * Cin * taps;
@@ -1651,7 +1779,9 @@ extern "C" int egotap_hmtrain_conv_wt(const float* w, float* wt, int Cout, int C
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_zero_upsample(const float* in, float* out, int N, int C, int H, int64_t in_istride, int64_t out_istride, void* stream) {
     EGO_CHECK(in && out && N > 0 && C > 0 && H > 0, "egotap_hmtrain_zero_upsample: bad argument");
     const long total = (long)N * C * 4 * H * H;
@@ -1660,6 +1790,7 @@ extern "C" int egotap_hmtrain_zero_upsample(const float* in, float* out, int N, 
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 template <int KS, int STRIDE, int CI_T>
 static hipError_t wgrad_w(int wout, const WgArgs& a, float* dw, size_t sb, int acc, hipStream_t s) {
@@ -1684,6 +1815,7 @@ static hipError_t wgrad_bf(int wout, const WgArgs& a, float* dw, size_t sb, int 
     return hipErrorInvalidValue;
 }
 
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_conv_wgrad(const float* dy, const float* x, float* dw, int Nimg, int Cin, int Cout, int wout, int ks, int stride,
                                          int64_t dy_istride, int64_t x_istride, int accumulate, int precision, void* ws, size_t ws_bytes,
                                          void* stream) {
@@ -1703,7 +1835,9 @@ extern "C" int egotap_hmtrain_conv_wgrad(const float* dy, const float* x, float*
     EGO_HIP(e);
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_relu_bwd(const float* y, const float* dy, float* dz, int N, int C, int HW, int64_t y_istride, int64_t dy_istride,
                                        int64_t dz_istride, void* stream) {
     EGO_CHECK(y && dy && dz && HW % 4 == 0, "egotap_hmtrain_relu_bwd: bad argument");
@@ -1713,7 +1847,9 @@ extern "C" int egotap_hmtrain_relu_bwd(const float* y, const float* dy, float* d
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_maxpool_bwd(const float* x, const float* dy, float* dx, int64_t planes, int HIN, void* stream) {
     EGO_CHECK(x && dy && dx && planes > 0 && HIN % 2 == 0, "egotap_hmtrain_maxpool_bwd: bad argument");
     const long total = planes * HIN * HIN;
@@ -1721,7 +1857,9 @@ extern "C" int egotap_hmtrain_maxpool_bwd(const float* x, const float* dy, float
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_upsample_bwd(const float* dy, float* dx, int N, int C, int HIN, int64_t dy_istride, int64_t dx_istride, void* stream) {
     EGO_CHECK(dy && dx && N > 0 && C > 0 && HIN > 1, "egotap_hmtrain_upsample_bwd: bad argument");
     const long total = (long)N * C * HIN * HIN;
@@ -1730,8 +1868,10 @@ extern "C" int egotap_hmtrain_upsample_bwd(const float* dy, float* dx, int N, in
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
 // loss[0] = lambda * (mean_left + mean_right) of (pred - gt)^2 / plen,  dpred = d loss / d pred   (pred, gt contiguous [B, Cn, HW])
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_mse(const float* pred, const float* gt, const float* plen, float* dpred, float* loss, int B, int Cn, int HW,
                                   float lambda, void* ws, size_t ws_bytes, void* stream) {
     EGO_CHECK(pred && gt && dpred && loss && ws && HW % 4 == 0 && Cn > 0, "egotap_hmtrain_mse: bad argument");
@@ -1743,14 +1883,18 @@ extern "C" int egotap_hmtrain_mse(const float* pred, const float* gt, const floa
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_maxpool_fwd(const float* x, float* y, int64_t planes, int HIN, void* stream) {
     EGO_CHECK(x && y && planes > 0 && HIN % 2 == 0, "egotap_hmtrain_maxpool_fwd: bad argument");
     hipLaunchKernelGGL(maxpool3s2_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, y, (long)planes, HIN);
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif
 
+#if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_upsample_fwd(const float* x, float* y, int N, int C, int HIN, int64_t in_istride, int64_t out_istride, void* stream) {
     EGO_CHECK(x && y && N > 0 && C > 0 && HIN > 1, "egotap_hmtrain_upsample_fwd: bad argument");
     const long threads = (long)N * C * (2 * HIN) * (2 * HIN / 4);
@@ -1759,3 +1903,4 @@ extern "C" int egotap_hmtrain_upsample_fwd(const float* x, float* y, int N, int 
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
+#endif

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_bf16_persist_ker
 }
 
 // f32 -> bf16 (round to nearest even), 8 elements per thread: the scratch copy of W for the plain-bf16 GEMM
-__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n8) {
+static __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n8) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
     *(bf16x8*)(dst + i * 8) = bf16_round8(*(const f32x4*)(src + i * 8), *(const f32x4*)(src + i * 8 + 4));

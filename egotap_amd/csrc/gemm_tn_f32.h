@@ -126,7 +126,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void gemm_tn_f32_kernel(const floa
 }
 
 // dst[i] = (accumulate ? dst[i] : 0) + sum_s slabs[s][i], fixed summation order
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ dst, long n,
+static __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ dst, long n,
                                                            int splits, int accumulate) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 
 // column sums (bias gradients): out[n] = (accumulate ? out[n] : 0) + sum_m Y[m][n].  Two stages, fixed order:
 // stage 1 writes one partial row per block into part[gridDim.y][N]; stage 2 is reduce_slabs_kernel over those rows.
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ Y, long ldy, float* __restrict__ part,
+static __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ Y, long ldy, float* __restrict__ part,
                                                              int M, int N, int rows_per_block) {
     __shared__ f32x4 red[4][64];
     const int c4 = blockIdx.x * 64 + (threadIdx.x & 63);      // float4 column
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 }
 
 // out[C, ldo >= R] = in[R,C]^T (weights for the input-gradient GEMM; 32x32 tiles through LDS)
-__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C, long ldo) {
+static __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C, long ldo) {
     __shared__ float t[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8

@@ -51,7 +51,7 @@ __device__ __forceinline__ int line_aa_draw(float* tile, int S, int r0, int c0, 
 }
 
 // grid: B * 2 * J blocks; pts2d_l / pts2d_r [B, J+1, 2] (x, y in the 1024-pixel frame), pose3d [B, J+1, 3], parents [J+1]
-__global__ __launch_bounds__(256) void heatmap_synth_kernel(const float* __restrict__ p2l, const float* __restrict__ p2r,
+static __global__ __launch_bounds__(256) void heatmap_synth_kernel(const float* __restrict__ p2l, const float* __restrict__ p2r,
                                                             const float* __restrict__ p3, const int* __restrict__ parents, int B, int J,
                                                             int S, GaussTaps g, float* __restrict__ hm, float* __restrict__ plength,
                                                             float* __restrict__ theta_out) {

@@ -181,7 +181,7 @@ static hipError_t conv_wgrad_launch(WgArgs a, float* dw, size_t slab_bytes, int 
 
 // ------------------------------------------------------------------------------------------------- input-gradient helpers
 // wt[ci][co][KS*KS - 1 - tap] = w[co][ci][tap]: the weights of the convolution that maps dY to dX
-__global__ __launch_bounds__(256) void conv_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int taps) {
+static __global__ __launch_bounds__(256) void conv_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int taps) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x, total = (long)Cout * Cin * taps;
     if (i >= total) return;
     const int tap = (int)(i % taps);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_wt_kernel(const float* __restrict__ 
 }
 
 // out[plane][2y][2x] = in[plane][y][x], zero elsewhere (the adjoint of a stride-2 subsampling); planes = N * C
-__global__ __launch_bounds__(256) void zero_upsample2_kernel(const float* __restrict__ in, float* __restrict__ out, long planes, int H,
+static __global__ __launch_bounds__(256) void zero_upsample2_kernel(const float* __restrict__ in, float* __restrict__ out, long planes, int H,
                                                               long in_istride, long out_istride, int C) {
     const int HO = 2 * H;
     const long total = planes * HO * HO, i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const float* __restrict_
 }
 
 // statistics -> mean, rstd (biased variance), running stats (momentum, unbiased variance): nn.BatchNorm2d in train mode
-__global__ __launch_bounds__(256) void bn2d_finish_kernel(const double* __restrict__ part, int splits, int C, double count, float eps,
+static __global__ __launch_bounds__(256) void bn2d_finish_kernel(const double* __restrict__ part, int splits, int C, double count, float eps,
                                                           float momentum, float* __restrict__ mean, float* __restrict__ rstd,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void bn2d_finish_kernel(const double* __restri
 }
 
 // y = [relu]( (z - mean) * rstd * gamma + beta [+ res] ), float4 per thread; all tensors [N][C][HW] with their own image strides
-__global__ __launch_bounds__(256) void bn2d_apply_kernel(const float* __restrict__ Z, float* __restrict__ Y, const float* __restrict__ R,
+static __global__ __launch_bounds__(256) void bn2d_apply_kernel(const float* __restrict__ Z, float* __restrict__ Y, const float* __restrict__ R,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd, int N, int C, int HW,
                                                          long z_istride, long y_istride, long r_istride, int relu) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void bn2d_apply_kernel(const float* __restrict
 }
 
 // sums -> dgamma, dbeta (per channel)
-__global__ __launch_bounds__(256) void bn2d_bwd_finish_kernel(const double* __restrict__ part, int splits, int C, float* __restrict__ sums,
+static __global__ __launch_bounds__(256) void bn2d_bwd_finish_kernel(const double* __restrict__ part, int splits, int C, float* __restrict__ sums,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void bn2d_bwd_finish_kernel(const double* __re
 }
 
 // dz = gamma * rstd * (dy' - sum(dy')/M - zhat * sum(dy' zhat)/M),  dy' = dy * [y > 0];  optional dres = dy' (residual branch)
-__global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const float* __restrict__ Z, const float* __restrict__ Y, const float* __restrict__ dY,
+static __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const float* __restrict__ Z, const float* __restrict__ Y, const float* __restrict__ dY,
                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ sums, float* __restrict__ dZ,
                                                              float* __restrict__ dR, int N, int C, int HW, long z_istride, long dy_istride,
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const float* __rest
 
 // ------------------------------------------------------------------------------------------------- pointwise backward
 // dz = dy * [y > 0] on [N][C][HW] slices with image strides (decoder convrelu blocks write into concat slices)
-__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ Y, const float* __restrict__ dY, float* __restrict__ dZ, int N, int C,
+static __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ Y, const float* __restrict__ dY, float* __restrict__ dZ, int N, int C,
                                                        int HW, long y_istride, long dy_istride, long dz_istride) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x, per = HW / 4, total = (long)N * C * per;
     if (q >= total) return;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
 
 // MaxPool2d(3, 2, 1) backward: every input pixel collects dy of the (up to 4) windows whose FIRST maximum it is
 // (row-major window scan, as torch's max_pool2d_with_indices picks)
-__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ dX,
+static __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ dX,
                                                              long planes, int HIN) {
     const int HO = HIN / 2;
     const long total = planes * HIN * HIN, i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __rest
 }
 
 // adjoint of nn.Upsample(scale 2, bilinear, align_corners=True): gather form, one thread per INPUT pixel
-__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dY, float* __restrict__ dX, int N, int C, int HIN,
+static __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dY, float* __restrict__ dX, int N, int C, int HIN,
                                                              long dy_istride, long dx_istride) {
     const int HO = 2 * HIN;
     const long total = (long)N * C * HIN * HIN, i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
 
 // MSE losses of heatmap_shared_model.py:109-151 on one [B][Cn][HW] prediction: loss = lambda * (mean over the left half +
 // mean over the right half) of (p - g)^2 / plen, plen = gt_plength (limb maps) or 1; dpred likewise.  part[blocks] partial sums.
-__global__ __launch_bounds__(256) void mse_loss_kernel(const float* __restrict__ P, const float* __restrict__ G, const float* __restrict__ plen,
+static __global__ __launch_bounds__(256) void mse_loss_kernel(const float* __restrict__ P, const float* __restrict__ G, const float* __restrict__ plen,
                                                        float* __restrict__ dP, double* __restrict__ part, int B, int Cn, int HW, float coef) {
     __shared__ double red[256];
     const long total = (long)B * Cn * (HW / 4);
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void mse_loss_kernel(const float* __restrict__
     }
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
-__global__ void mse_finish_kernel(const double* __restrict__ part, int n, float coef, float* __restrict__ out) {
+static __global__ void mse_finish_kernel(const double* __restrict__ part, int n, float coef, float* __restrict__ out) {
     double s = 0.0;
     for (int i = 0; i < n; ++i) s += part[i];
     out[0] = (float)(s * coef);

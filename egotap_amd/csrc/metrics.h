@@ -50,7 +50,7 @@ __device__ __forceinline__ void jacobi_eig3(double A[3][3], double V[3][3]) {
     }
 }
 
-__global__ __launch_bounds__(64) void pose_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int B, int J,
+static __global__ __launch_bounds__(64) void pose_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int B, int J,
                                                           float* __restrict__ mpjpe, float* __restrict__ pa_mpjpe,
                                                           float* __restrict__ aligned) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;

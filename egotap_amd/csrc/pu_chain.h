@@ -17,7 +17,7 @@
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ __launch_bounds__(256) void pu_step_kernel(const float* __restrict__ F_t, int ldf,
+static __global__ __launch_bounds__(256) void pu_step_kernel(const float* __restrict__ F_t, int ldf,
                                                       const float* __restrict__ Gin_t,
                                                       const float* __restrict__ Whh,
                                                       const float* __restrict__ bhh,
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void pu_step_kernel(const float* __restrict__ 
 // Pose head: one block per sample.
 //   pose_j = Wp . [left_j | right_j | skel_j] + bp  (+ global offset) ; UnrealEgo: head joint = global_mlp[3:6], output LAST.
 // posz: [B*2J, hid] position embeddings (eye-major), hseq: [J, B, H] PU output (time-major).
-__global__ __launch_bounds__(256) void pose_head_kernel(const float* __restrict__ posz, const float* __restrict__ hseq,
+static __global__ __launch_bounds__(256) void pose_head_kernel(const float* __restrict__ posz, const float* __restrict__ hseq,
                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
                                                         const float* __restrict__ Wg, const float* __restrict__ bg,
                                                         float* __restrict__ pose, int B, int J, int hid, int H,
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void pose_head_kernel(const float* __restrict_
 // One recurrent step, reverse time.  Pointwise part A (LSTM gates): from the total gradient on h_t and c_t to the
 // gradient of the four gate pre-activations and of c_{t-1}.  The matrix part dhp = dG . Whh runs on the GEMM kernel
 // (transposed weights); pointwise part B turns dhp into the gradient of h_{t-1} and of the x2f "forget" logits.
-__global__ __launch_bounds__(256) void pu_gates_bwd_kernel(const float* __restrict__ gpre, const float* __restrict__ c_prev,
+static __global__ __launch_bounds__(256) void pu_gates_bwd_kernel(const float* __restrict__ gpre, const float* __restrict__ c_prev,
                                                            const float* __restrict__ c_t, const float* __restrict__ dh_ext,
                                                            const float* __restrict__ dh_rec, const float* __restrict__ dc_next,
                                                            float* __restrict__ dG, float* __restrict__ dc_prev, int B, int H) {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void pu_gates_bwd_kernel(const float* __restri
 
 // hp = sigmoid(f) * h_prev :  dh_prev = dhp * sigmoid(f) ;  df = dhp * h_prev * sigmoid'(f) ;  also emits hp (the
 // operand of the h2h weight gradient)
-__global__ __launch_bounds__(256) void pu_hp_bwd_kernel(const float* __restrict__ dhp, const float* __restrict__ F_t, int ldf,
+static __global__ __launch_bounds__(256) void pu_hp_bwd_kernel(const float* __restrict__ dhp, const float* __restrict__ F_t, int ldf,
                                                         const float* __restrict__ h_prev, float* __restrict__ dh_rec_prev,
                                                         float* __restrict__ dF_t, int lddf, float* __restrict__ hp_out, int B, int H) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void pu_hp_bwd_kernel(const float* __restrict_
 
 // bridge gate of layer 0: b' = sigmoid(fb) * bridge ;  dfb = db' * bridge * sigmoid'(fb) (written into dF[:, H:]) ;
 // dbridge = db' * sigmoid(fb) scattered back to the eye-major embedding layout [(b*2 + eye)*J + t, hid]
-__global__ __launch_bounds__(256) void pu_bridge_bwd_kernel(const float* __restrict__ dbp, const float* __restrict__ F, int ldf,
+static __global__ __launch_bounds__(256) void pu_bridge_bwd_kernel(const float* __restrict__ dbp, const float* __restrict__ F, int ldf,
                                                             int fcol0, const float* __restrict__ rotz, float* __restrict__ dF,
                                                             float* __restrict__ drotz, int B, int J, int hid) {
     const int x = 2 * hid;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void pu_bridge_bwd_kernel(const float* __restr
 }
 
 // dposz[(b*2+eye)*J + t, c] = dxs[t*B + b, eye*hid + c] + dpose_feat contribution (already in dposz if accumulate)
-__global__ __launch_bounds__(256) void stereo_scatter_kernel(const float* __restrict__ dxs, float* __restrict__ dz, int B, int J,
+static __global__ __launch_bounds__(256) void stereo_scatter_kernel(const float* __restrict__ dxs, float* __restrict__ dz, int B, int J,
                                                              int hid, int accumulate) {
     const int x = 2 * hid;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void stereo_scatter_kernel(const float* __rest
 // Pose head backward.  Data gradients: one block per sample.
 //   dpos[(b*2+eye)*J + j, c] = sum_k dpose'[b,j,k] Wp[k, eye*hid + c] ;  dskel[j,b,u] = sum_k dpose'[b,j,k] Wp[k, 2hid + u]
 //                              + sum_o dother[b,o] Wg[o, j*H + u]   with dother[0:3] = sum_j dpose[b,j,:], dother[3:6] = dpose[b,J,:]
-__global__ __launch_bounds__(256) void pose_head_bwd_data_kernel(const float* __restrict__ dpose, const float* __restrict__ Wp,
+static __global__ __launch_bounds__(256) void pose_head_bwd_data_kernel(const float* __restrict__ dpose, const float* __restrict__ Wp,
                                                                  const float* __restrict__ Wg, float* __restrict__ dposz,
                                                                  float* __restrict__ dhseq, int B, int J, int hid, int H,
                                                                  int estimate_head) {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void pose_head_bwd_data_kernel(const float* __
 }
 
 // Pose head weight gradients (tiny N): one thread per weight column, fixed (b, j) order.
-__global__ __launch_bounds__(256) void pose_head_bwd_weight_kernel(const float* __restrict__ dpose, const float* __restrict__ posz,
+static __global__ __launch_bounds__(256) void pose_head_bwd_weight_kernel(const float* __restrict__ dpose, const float* __restrict__ posz,
                                                                    const float* __restrict__ hseq, float* __restrict__ dWp,
                                                                    float* __restrict__ dbp, float* __restrict__ dWg,
                                                                    float* __restrict__ dbg, int B, int J, int hid, int H,

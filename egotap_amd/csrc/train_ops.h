@@ -21,7 +21,7 @@ struct LossArgs {
     int parents[20];
 };
 
-__global__ __launch_bounds__(64) void pose_loss_kernel(LossArgs a) {
+static __global__ __launch_bounds__(64) void pose_loss_kernel(LossArgs a) {
     __shared__ float P[20][3], G[20][3], Gb[20][3];     // Gb[t]: d loss / d bone_t (child side), zero where no bone
     const int b = blockIdx.x, t = threadIdx.x;
     const int J = a.J, off = a.estimate_head ? 0 : 1, JJ = J + off;     // JJ joints incl. the virtual EgoCap root
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(LossArgs a) {
     if (t == 0) { a.partial[2 * b] = dist; a.partial[2 * b + 1] = cosv; }
 }
 
-__global__ void pose_loss_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int B, int J, float lam_pose,
+static __global__ void pose_loss_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int B, int J, float lam_pose,
                                         float lam_cos) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float sd = 0.f, sc = 0.f;
@@ -84,7 +84,7 @@ __global__ void pose_loss_finish_kernel(const float* __restrict__ partial, float
 
 // ----------------------------------------------------------------------------- AdamW (torch.optim.AdamW semantics)
 // p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+static __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2_sqrt) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
 }
 
 // y = LeakyReLU((z - mean) * rstd * gamma + beta)
-__global__ __launch_bounds__(256) void bn_apply_lrelu_kernel(const float* __restrict__ Z, float* __restrict__ Y,
+static __global__ __launch_bounds__(256) void bn_apply_lrelu_kernel(const float* __restrict__ Z, float* __restrict__ Y,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              long n4, int C, float slope) {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void bn_apply_lrelu_kernel(const float* __rest
 }
 
 // dz = gamma * rstd * (dyb - m1 - xhat * m2),  m1 = mean(dyb), m2 = mean(dyb * xhat)  (sums s1, s2 over R rows)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ Z, const float* __restrict__ Yv,
+static __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ Z, const float* __restrict__ Yv,
                                                            const float* __restrict__ dY, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ s1, const float* __restrict__ s2,
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // finish of the statistics pass: mean = s1/R ; (second pass) var = s2/R, rstd, running stats (momentum, unbiased var)
-__global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ s, float* __restrict__ mean_or_rstd, int C, int R,
+static __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ s, float* __restrict__ mean_or_rstd, int C, int R,
                                                         int stage, float eps, float momentum, float* __restrict__ run_mean,
                                                         float* __restrict__ run_var, const float* __restrict__ mean_in) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict_
 
 // ----------------------------------------------------------------------------- GELU backward (exact erf form)
 // dz = dh * (0.5 (1 + erf(z/sqrt2)) + z * exp(-z^2/2) / sqrt(2 pi))
-__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ Zp, const float* __restrict__ dH, float* __restrict__ dZ,
+static __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ Zp, const float* __restrict__ dH, float* __restrict__ dZ,
                                                        long n4) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
 }
 
 // out[i] += in[i] (gradient accumulation of a residual branch), n4 float4
-__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ out, const float* __restrict__ in, long n4) {
+static __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ out, const float* __restrict__ in, long n4) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     *(f32x4*)(out + i * 4) = *(const f32x4*)(out + i * 4) + *(const f32x4*)(in + i * 4);
