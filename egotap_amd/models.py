@@ -3,8 +3,9 @@
 ``create_model(opt)`` / ``EgoTAPAutoEncoderModel`` keep the surface ``test.py`` / ``utils/evaluate.py`` touch
 (reference: model/models.py:2-17, model/egotap_autoencoder_model.py:13-350, model/base_model.py): ``set_input``,
 ``forward(evaluate=)``, ``evaluate(dict)``, ``set_eval_mode``, ``eval_key``, ``load_networks`` / ``save_networks``,
-the ``pred_*`` attributes.  The three networks run through libegotap_hip.so; this file is plumbing only.
-Training (``optimize_parameters``) is the next scope row and raises.
+the ``pred_*`` attributes, ``optimize_parameters`` / ``update_learning_rate`` for training, and ``HeatmapSharedModel`` for
+stage-1 training of one heatmap estimator (model/heatmap_shared_model.py).  The networks run through libegotap_hip.so; this file
+is plumbing only.
 """
 from __future__ import annotations
 
@@ -330,7 +331,6 @@ class HeatmapSharedModel(nn.Module):
         from . import hm_ops as H
         lam = getattr(self.opt, "lambda_rot_heatmap" if self.is_limb else "lambda_heatmap", 1.0)
         pred = self.pred_heatmap_cat
-        n = pred.shape[1] // 2
         gl, dl = H.mse_halves(pred.detach().contiguous(), self._gt, self._plen, lam)
         a, b = self.loss_names
         setattr(self, "loss_" + a, gl[0])

@@ -330,7 +330,7 @@ class HeatMap_UnrealEgo_Shared(nn.Module):
     def forward_into(self, left, right, out, channel_offset: int = 0, workspace=None):
         """Write this net's [B, 2*n_hm, S, S] output into out[:, channel_offset : channel_offset + 2*n_hm]."""
         if self.training:
-            raise NotImplementedError("egotap_amd builds the eval-mode forward (folded BatchNorm); call .eval()")
+            raise NotImplementedError("forward_into writes the eval-mode result (folded BatchNorm) into a caller's slice; in train mode call the module itself (differentiable path) or .eval() first")
         for t in (left, right, out):
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
                 raise _lib.EgotapError("heatmap estimator needs contiguous float32 CUDA tensors (no CPU fallback)")
