@@ -103,3 +103,34 @@ def test_module_mirror_has_reference_state_dict():
     net.train()
     with pytest.raises(L.EgotapError):
         net(torch.zeros(1, 90, 64, 64))          # training mode: same rule, no CPU path
+
+
+def test_host_side_argument_checks_of_the_newer_entry_points():
+    """no GPU here: everything below must be rejected (or accepted) by host-side checks before any launch"""
+    import torch
+    from oracle import heatmap_synth_ref as R
+    lib = L.load()
+    h = C.c_void_p()
+    L.check(lib.egotap_create(C.byref(_cfg()), C.byref(h)))
+    try:
+        for mode in (0, 1, 2):
+            L.check(lib.egotap_set_precision(h, mode))
+        assert lib.egotap_set_precision(h, 7) == 1 and b"unknown mode" in lib.egotap_last_error()
+        assert lib.egotap_set_weight_scratch(h, C.c_void_p(8), 1024) == 1            # misaligned
+        L.check(lib.egotap_set_weight_scratch(h, C.c_void_p(0), 0))                  # off
+        assert lib.egotap_hmtrain_set_pack_buffer(h, C.c_void_p(4096), 16) == 1      # too small
+        assert lib.egotap_hmtrain_pack_bytes() >= 1024 * 97 * 9 * 64
+        # batch 0 is a no-op for the batched entry points, null pointers otherwise are errors
+        L.check(lib.egotap_pose_metrics(None, None, 0, 16, None, None, None, None))
+        assert lib.egotap_pose_metrics(None, None, 4, 16, None, None, None, None) == 1
+        assert lib.egotap_attention(None, None, 1, 64, 1, 0, None) == 1
+        assert lib.egotap_hmtrain_conv_wgrad(None, None, None, 1, 8, 8, 16, 3, 1, 0, 0, 0, 0, None, 0, None) == 1
+    finally:
+        lib.egotap_destroy(h)
+    # Python wrappers refuse CPU tensors (no CPU fallback) and inconsistent shapes
+    with pytest.raises(L.EgotapError):
+        L.synth_heatmaps(torch.zeros(1, 16, 2), torch.zeros(1, 16, 2), torch.zeros(1, 16, 3))
+    with pytest.raises(L.EgotapError):
+        L.pose_metrics(torch.zeros(2, 16, 3), torch.zeros(2, 16, 3))
+    assert L.KINEMATIC_PARENTS == R.KINEMATIC_PARENTS and len(L.KINEMATIC_PARENTS["EgoCap"]) == 18
+    assert sorted(L.PRECISIONS) == ["bf16", "bf16x3", "f32"]
