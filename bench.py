@@ -390,10 +390,14 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    # rehearsal on a one-GPU box: EGOTAP_DIST_BACKEND=gloo lets several ranks share cuda:0 (RCCL needs one device per rank)
+    backend = os.environ.get("EGOTAP_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from egotap_amd import parallel
-    parallel.init_from_env("nccl", dev)      # "nccl" is RCCL on ROCm; no-op for one rank
+    parallel.init_from_env(backend, dev)     # "nccl" is RCCL on ROCm; no-op for one rank
 
     p = spec.lift_preset(args.preset)
     sd_np = synth_state_dict(spec.lift_state_spec(p))
