@@ -150,3 +150,33 @@ def test_lift_forward_hm128_egocap_matches_oracle():
     torch.cuda.synchronize()
     np.testing.assert_allclose(pose.cpu().numpy(), ref, atol=TOL, rtol=0)
     np.testing.assert_allclose(fast.cpu().numpy(), ref, atol=TOL, rtol=0)
+
+
+def test_lift_forward_on_synthesised_ground_truth_heatmaps():
+    """Realistic (sparse) inputs: joints -> device-rendered Gaussian / limb heatmaps (egotap_synth_heatmaps) -> lifting head, in
+    fp32 and bf16x3, against the float64 oracle run on the CPU-rendered heatmaps (oracle/heatmap_synth_ref.py): the whole
+    use_gt_heatmap input path in one test."""
+    from egotap_amd import lib
+    from gpu_util import lift_net
+    from oracle import heatmap_synth_ref as R
+    from oracle import lift_ref as O
+    net, sd_np, p = lift_net("UnrealEgo")
+    B = 3
+    p2l, p2r = synth_input("rl_p2l", (B, 16, 2), 100.0, 900.0), synth_input("rl_p2r", (B, 16, 2), 100.0, 900.0)
+    p3 = synth_input("rl_p3", (B, 16, 3), -40.0, 40.0)
+    syn = lib.synth_heatmaps(torch.from_numpy(p2l).cuda(), torch.from_numpy(p2r).cuda(), torch.from_numpy(p3).cuda(), "UnrealEgo", 64)
+    cat_ref = np.stack([R.process_frame(p2l[b].astype(np.float64), p2r[b].astype(np.float64), p3[b].astype(np.float64))[0] for b in range(B)])
+    np.testing.assert_allclose(syn["cat"].cpu().numpy(), cat_ref, atol=2e-6, rtol=0)
+    assert float((syn["cat"] == 0).float().mean()) > 0.5            # sparse: most pixels are exactly zero
+    sd = O.to_torch_sd(sd_np, torch.float64)
+    with torch.no_grad():
+        ref = O.lift_forward(torch.from_numpy(cat_ref).double(), sd, p).numpy()
+    pose = net.predict_pose(syn["cat"])
+    try:
+        net.set_precision("bf16x3")
+        fast = net.predict_pose(syn["cat"])
+    finally:
+        net.set_precision("f32")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pose.cpu().numpy(), ref, atol=TOL, rtol=0)
+    np.testing.assert_allclose(fast.cpu().numpy(), ref, atol=TOL, rtol=0)
