@@ -492,9 +492,24 @@ static hipError_t gemm_big(Handle* h, const char* role, const AL& al, const SegM
     return gemm_f32_persist_launch<Cfg, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
 }
 
+// Small batches (serving): the 256x256 persistent tiling leaves most CUs idle (B = 1: 12 tiles for attn_out / mlp_down, one
+// tile row for fc1).  Below `fill` tiles the GEMM runs as exact-fp32 128x128 tiles with K split over blockIdx.y
+// (gemm_f32_splitk_launch) in every precision mode; at and above it gemm_big as before, so large-batch results do not change.
+static constexpr size_t SPLITK_FLOATS = (size_t)1 << 24;
+template <class AL, class Epi>
+static hipError_t gemm_small(Handle* h, const char* role, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc,
+                             int M, int N, int K, float* P, hipStream_t s) {
+    const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    const long fill = (h && h->precision != EGOTAP_PREC_F32) ? 64 : 160;
+    if (tiles256 >= fill || N % 128 != 0 || K % 32 != 0 || W.seg % 128 != 0) return gemm_big(h, role, al, W, epi, C, ldc, M, N, K, s);
+    static const std::string kname = std::string("gemm_f32_splitk_kernel<128x128x32,") + AlName<AL>::v + ">+splitk_reduce_kernel<" + EpiName<Epi>::v + ">";
+    GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
+    return gemm_f32_splitk_launch<TileA>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s);
+}
+
 // ------------------------------------------------------------------------------------------------ workspace
 struct LiftWs {
-    size_t X, Y, QKV, CTX, HID, Z1, Z2, POSZ, ROTZ, F0, G0, HS0, F1, G1, HS1, C0, C1, ZERO, total;
+    size_t X, Y, QKV, CTX, HID, Z1, Z2, POSZ, ROTZ, F0, G0, HS0, F1, G1, HS1, C0, C1, ZERO, SPLITK, total;
 };
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static LiftWs lift_ws(const Handle* h, int B) {
@@ -507,6 +522,7 @@ static LiftWs lift_ws(const Handle* h, int B) {
     w.F0 = take(JB * (H + 2 * h->hid)); w.G0 = take(JB * 4 * H); w.HS0 = take(JB * H);
     w.F1 = take(JB * H); w.G1 = take(JB * 4 * H); w.HS1 = take(JB * H);
     w.C0 = take((size_t)B * H); w.C1 = take((size_t)B * H); w.ZERO = take((size_t)B * H);
+    w.SPLITK = take(SPLITK_FLOATS);       // split-K partial sums of the small-batch GEMMs (gemm_small)
     w.total = o;
     return w;
 }
@@ -589,18 +605,20 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     char* base = (char*)ws;
     auto F = [&](size_t off) { return (float*)(base + off); };
     float *X = F(w.X), *Y = F(w.Y), *QKV = F(w.QKV), *CTX = F(w.CTX), *HID = F(w.HID);
+    float* SPK = F(w.SPLITK);
     float *Z1 = F(w.Z1), *Z2 = F(w.Z2), *POSZ = F(w.POSZ), *ROTZ = F(w.ROTZ);
     float *F0 = F(w.F0), *G0 = F(w.G0), *HS0 = F(w.HS0), *F1 = F(w.F1), *G1 = F(w.G1), *HS1 = F(w.HS1);
     float *C0 = F(w.C0), *C1 = F(w.C1), *ZERO = F(w.ZERO);
     const int D = h->D, M = B * h->seq, BT = B * h->T, J = h->J, H = h->H, hid = h->hid, JB = J * B;
     const int S = h->cfg.hm_size, HW = S * S;
     using Tile = TileA;
+    constexpr int SKINNY_ROWS = 1024;       // fc1 below this many rows (B <= 34) runs split-K
 
     // H1+H2: tile -> patch embed -> mask token -> + position embeddings
     {
         ALoadPatch al{hm, h->C, S, h->seq, h->side, h->ppd, h->grid, h->T};
         EpiPatch ep{p.patch_b, p.mask_tok, p.pos_emb, D, h->seq, h->side, h->ppd, h->grid, h->T};
-        EGO_HIP((gemm_big(h, "patch_embed", al, segmat1(p.patch_w, D, 256), ep, X, D, M, D, 256, s)));
+        EGO_HIP((gemm_small(h, "patch_embed", al, segmat1(p.patch_w, D, 256), ep, X, D, M, D, 256, SPK, s)));
     }
     if (h->debug_stop == 1) return EGOTAP_OK;
     // H3-H8: pre-LN transformer layers
@@ -610,15 +628,15 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
         {
             SegMat Wqkv; Wqkv.p[0] = L.q_w; Wqkv.p[1] = L.k_w; Wqkv.p[2] = L.v_w; Wqkv.seg = D; Wqkv.ld = D;
             SegVec bqkv; bqkv.p[0] = L.q_b; bqkv.p[1] = L.k_b; bqkv.p[2] = L.v_b; bqkv.seg = D;
-            EGO_HIP((gemm_big(h, "qkv", ALoadPlain{Y, D}, Wqkv, EpiBias{bqkv}, QKV, 3L * D, M, 3 * D, D, s)));
+            EGO_HIP((gemm_small(h, "qkv", ALoadPlain{Y, D}, Wqkv, EpiBias{bqkv}, QKV, 3L * D, M, 3 * D, D, SPK, s)));
         }
         if (h->precision == EGOTAP_PREC_BF16X3) EGO_HIP(attention_bf16_launch<3>(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
         else if (h->precision == EGOTAP_PREC_BF16) EGO_HIP(attention_bf16_launch<1>(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
         else EGO_HIP(attention_f32_launch(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
-        EGO_HIP((gemm_big(h, "attn_out", ALoadPlain{CTX, D}, segmat1(L.o_w, D, D), EpiBiasRes{segvec1(L.o_b, D), X, D}, X, D, M, D, D, s)));
+        EGO_HIP((gemm_small(h, "attn_out", ALoadPlain{CTX, D}, segmat1(L.o_w, D, D), EpiBiasRes{segvec1(L.o_b, D), X, D}, X, D, M, D, D, SPK, s)));
         EGO_HIP(launch_ln(X, Y, L.ln2_g, L.ln2_b, M, 1e-12f, s));
-        EGO_HIP((gemm_big(h, "mlp_up", ALoadPlain{Y, D}, segmat1(L.up_w, 4 * D, D), EpiBiasGelu{segvec1(L.up_b, 4 * D)}, HID, 4L * D, M, 4 * D, D, s)));
-        EGO_HIP((gemm_big(h, "mlp_down", ALoadPlain{HID, 4L * D}, segmat1(L.dn_w, D, 4L * D), EpiBiasRes{segvec1(L.dn_b, D), X, D}, X, D, M, D, 4 * D, s)));
+        EGO_HIP((gemm_small(h, "mlp_up", ALoadPlain{Y, D}, segmat1(L.up_w, 4 * D, D), EpiBiasGelu{segvec1(L.up_b, 4 * D)}, HID, 4L * D, M, 4 * D, D, SPK, s)));
+        EGO_HIP((gemm_small(h, "mlp_down", ALoadPlain{HID, 4L * D}, segmat1(L.dn_w, D, 4L * D), EpiBiasRes{segvec1(L.dn_b, D), X, D}, X, D, M, D, 4 * D, SPK, s)));
         if (h->debug_stop == 2 + i) return EGOTAP_OK;
     }
     EGO_HIP(launch_ln(X, Y, p.lnf_g, p.lnf_b, M, 1e-12f, s));
@@ -627,14 +645,20 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     {
         const int K1 = h->ppd * h->ppd * D;
         ALoadTokens al{Y, h->T, D, h->seq, h->side, h->ppd, h->grid};
-        EGO_HIP((gemm_big(h, "pos_fc1", al, segmat1(p.pos_fc[0].w, 2048, K1), bn(p.pos_fc[0]), Z1, 2048, BT, 2048, K1, s)));
+        if (BT < SKINNY_ROWS)      // small batch: skinny GEMM, split K over the CUs 
+            EGO_HIP((gemm_f32_splitk_launch<TileA>(al, segmat1(p.pos_fc[0].w, 2048, K1), bn(p.pos_fc[0]), Z1, 2048, SPK, SPLITK_FLOATS, BT, 2048, K1, s)));
+        else
+            EGO_HIP((gemm_big(h, "pos_fc1", al, segmat1(p.pos_fc[0].w, 2048, K1), bn(p.pos_fc[0]), Z1, 2048, BT, 2048, K1, s)));
         EGO_HIP((gemm<Tile>(h, "pos_fc2", ALoadPlain{Z1, 2048}, segmat1(p.pos_fc[1].w, 512, 2048), bn(p.pos_fc[1]), Z2, 512, BT, 512, 2048, s)));
         EGO_HIP((gemm<Tile>(h, "pos_fc3", ALoadPlain{Z2, 512}, segmat1(p.pos_fc[2].w, hid, 512), bn(p.pos_fc[2]), POSZ, hid, BT, hid, 512, s)));
     }
     // H11-H12: rotation (cos/sin) heatmaps straight from the input tensor
     {
         ALoadRot al{hm, h->C, J, HW};
-        EGO_HIP((gemm_big(h, "rot_fc1", al, segmat1(p.rot_fc[0].w, 2048, 2L * HW), bn(p.rot_fc[0]), Z1, 2048, BT, 2048, 2 * HW, s)));
+        if (BT < SKINNY_ROWS)
+            EGO_HIP((gemm_f32_splitk_launch<TileA>(al, segmat1(p.rot_fc[0].w, 2048, 2L * HW), bn(p.rot_fc[0]), Z1, 2048, SPK, SPLITK_FLOATS, BT, 2048, 2 * HW, s)));
+        else
+            EGO_HIP((gemm_big(h, "rot_fc1", al, segmat1(p.rot_fc[0].w, 2048, 2L * HW), bn(p.rot_fc[0]), Z1, 2048, BT, 2048, 2 * HW, s)));
         EGO_HIP((gemm<Tile>(h, "rot_fc2", ALoadPlain{Z1, 2048}, segmat1(p.rot_fc[1].w, 512, 2048), bn(p.rot_fc[1]), Z2, 512, BT, 512, 2048, s)));
         EGO_HIP((gemm<Tile>(h, "rot_fc3", ALoadPlain{Z2, 512}, segmat1(p.rot_fc[2].w, hid, 512), bn(p.rot_fc[2]), ROTZ, hid, BT, hid, 512, s)));
     }

@@ -782,3 +782,132 @@ static hipError_t gemm_f32_launch(const ALoad& al, const SegMat& W, const Epi& e
                        N, K, tiles_m, tiles_n);
     return hipGetLastError();
 }
+
+// ----------------------------------------------------------------------------- split-K for skinny problems
+// Small batches make fc1 of the two encoders a skinny GEMM (M = 30 rows per frame, N = 2048, K = 16384 / 8192): one row of
+// output tiles would walk the whole K on 16 CUs (3.5 ms at B = 1, a quarter of the forward).  gemm_f32_splitk_kernel is
+// gemm_f32_kernel over a K range per blockIdx.y writing raw partial sums P[split][M][N]; splitk_reduce_kernel adds the
+// partials in a fixed order and applies the epilogue.  Used only below a row threshold, so large-batch results (and their
+// bit-identity across batch sizes) are untouched.
+template <class Cfg, class ALoad>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_splitk_kernel(ALoad al, SegMat W, float* P, int M, int N, int K, int tiles_m,
+                                                                                 int tiles_n, int kper) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, LDK = Cfg::LDK;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, A_V4 = Cfg::A_V4, B_V4 = Cfg::B_V4, RPP = Cfg::ROWS_PER_PASS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDK;
+    const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m, split = blockIdx.y;
+    const int bm = tm * BM, bn = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / Cfg::WN, wn = wid % Cfg::WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int c4 = tid % (BK / 4), r0 = tid / (BK / 4);
+    typename ALoad::Row arow[A_V4];
+    const float* brow[B_V4];
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) arow[i] = al.row(min(bm + r0 + i * RPP, M - 1));
+#pragma unroll
+    for (int i = 0; i < B_V4; ++i) brow[i] = W.row(bn + r0 + i * RPP);
+    f32x4 pa[A_V4], pb[B_V4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) pa[i] = al.load(arow[i], k0 + c4 * 4);
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) pb[i] = *(const f32x4*)(brow[i] + k0 + c4 * 4);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) *(f32x4*)(As + (buf * BM + r0 + i * RPP) * LDK + c4 * 4) = pa[i];
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) *(f32x4*)(Bs + (buf * BN + r0 + i * RPP) * LDK + c4 * 4) = pb[i];
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int k_lo = split * kper, k_hi = min(K, k_lo + kper);
+    const int KT = (k_hi - k_lo) / BK;
+    if (KT > 0) {
+        gload(k_lo);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) gload(k_lo + (kt + 1) * BK);
+        const float* Ab = As + (buf * BM + wm * (TM * 32) + l31) * LDK + 4 * lh;
+        const float* Bb = Bs + (buf * BN + wn * (TN * 32) + l31) * LDK + 4 * lh;
+#pragma unroll
+        for (int t = 0; t < BK / 8; ++t) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(Ab + i * 32 * LDK + 8 * t);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(Bb + j * 32 * LDK + 8 * t);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[j][u], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = P + (long)split * M * N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = bn + wn * (TN * 32) + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mbase = bm + wm * (TM * 32) + i * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m < M) out[(long)m * N + n] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+template <class Epi>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ P, Epi epi, float* __restrict__ C, long ldc, int M, int N,
+                                                            int splits) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * N) return;
+    const int m = (int)(i / N), n = (int)(i - (long)m * N);
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += P[(long)k * M * N + i];
+    C[(long)m * ldc + n] = epi.apply(s, epi.col(n), m, n);
+}
+
+// P: scratch of at least splits * M * N floats; returns hipErrorInvalidValue for shapes the tile does not cover
+template <class Cfg, class ALoad, class Epi>
+static hipError_t gemm_f32_splitk_launch(const ALoad& al, const SegMat& W, const Epi& epi, float* C, long ldc, float* P, size_t p_floats, int M,
+                                         int N, int K, hipStream_t stream) {
+    if (M <= 0) return hipSuccess;
+    if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0) return hipErrorInvalidValue;
+    const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
+    int splits = 1;      // enough K ranges to put ~2 workgroups on every CU, each range at least 4 slabs, partials within the scratch
+    while (splits < 32 && tiles_m * tiles_n * splits < 512 && (size_t)(2 * splits) * M * N <= p_floats && K / (2 * splits) >= 4 * Cfg::BK) splits <<= 1;
+    if ((size_t)splits * M * N > p_floats) return hipErrorInvalidValue;
+    const int kper = ((K / Cfg::BK + splits - 1) / splits) * Cfg::BK;
+    auto kern = gemm_f32_splitk_kernel<Cfg, ALoad>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, al, W, P, M, N, K, tiles_m, tiles_n, kper);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long total = (long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel<Epi>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const float*)P, epi, C, ldc, M, N, splits);
+    return hipGetLastError();
+}
