@@ -354,6 +354,30 @@ def bench_stage1(args, p, dev, rank, world, barrier, mode="f32"):
             "peak_hbm_gib": round(peak_gb, 1)}
 
 
+def bench_latency(net, p, dev):
+    """Serving-shaped leg: latency of the lifting head at B = 1 and 8 (split-K small-batch GEMM path), per precision mode."""
+    import torch
+    from egotap_amd.synthetic import synth_input
+    out = {"unit": "ms per forward (median of 20, synchronised)"}
+    for B in (1, 8):
+        hm = torch.from_numpy(synth_input("hm_lat", (B, p.in_channels, p.hm_size, p.hm_size))).to(dev)
+        for mode in ("f32", "bf16x3"):
+            net.set_precision(mode)
+            for _ in range(3):
+                net.predict_pose(hm)
+            ts = []
+            for _ in range(20):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                net.predict_pose(hm)
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            out[f"b{B}_{mode}"] = round(1e3 * ts[len(ts) // 2], 3)
+    net.set_precision("f32")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -502,6 +526,10 @@ def main():
         if not args.no_fast_mode:
             train["stage1_heatmap_estimator"]["bf16x3"] = leg(bench_stage1, args, p, dev, rank, world, barrier, mode="bf16x3")
 
+    latency = None
+    if rank == 0 and world == 1 and not args.lift_only:
+        latency = leg(bench_latency, net, p, dev)
+
     cpu = None
     gpu_vs_oracle = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -532,7 +560,7 @@ def main():
             "end_to_end_frac_of_f32_mfma_peak": round(fps * flops_frame / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roof, "cpu_baseline": cpu, "max_abs_diff_vs_oracle": gpu_vs_oracle,
             "fast_mode_bf16x3": fast, "full_pipeline_from_rgb": full, "config5_geometry_egocap_hm128": config5,
-            "train_step_lifting_head": train,
+            "train_step_lifting_head": train, "small_batch_latency": latency,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

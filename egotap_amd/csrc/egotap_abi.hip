@@ -507,6 +507,15 @@ static hipError_t gemm_small(Handle* h, const char* role, const AL& al, const Se
     return gemm_f32_splitk_launch<TileA>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s);
 }
 
+// fc2 / fc3 of the two encoders: one or two 128-row tiles at small batch -> split K as fc1 does (same row threshold)
+static constexpr int SKINNY_ROWS = 1024;       // encoder rows (30 or 34 per frame) below which the fc GEMMs run split-K: B <= 34 / 30
+template <class AL, class Epi>
+static hipError_t fc_gemm(Handle* h, const char* role, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K,
+                          float* P, hipStream_t s) {
+    if (M >= SKINNY_ROWS || N % 128 != 0 || K % 32 != 0) return gemm<TileA>(h, role, al, W, epi, C, ldc, M, N, K, s);
+    return gemm_f32_splitk_launch<TileA>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s);
+}
+
 // ------------------------------------------------------------------------------------------------ workspace
 struct LiftWs {
     size_t X, Y, QKV, CTX, HID, Z1, Z2, POSZ, ROTZ, F0, G0, HS0, F1, G1, HS1, C0, C1, ZERO, SPLITK, total;
@@ -612,7 +621,6 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     const int D = h->D, M = B * h->seq, BT = B * h->T, J = h->J, H = h->H, hid = h->hid, JB = J * B;
     const int S = h->cfg.hm_size, HW = S * S;
     using Tile = TileA;
-    constexpr int SKINNY_ROWS = 1024;       // fc1 below this many rows (B <= 34) runs split-K
 
     // H1+H2: tile -> patch embed -> mask token -> + position embeddings
     {
@@ -649,8 +657,8 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
             EGO_HIP((gemm_f32_splitk_launch<TileA>(al, segmat1(p.pos_fc[0].w, 2048, K1), bn(p.pos_fc[0]), Z1, 2048, SPK, SPLITK_FLOATS, BT, 2048, K1, s)));
         else
             EGO_HIP((gemm_big(h, "pos_fc1", al, segmat1(p.pos_fc[0].w, 2048, K1), bn(p.pos_fc[0]), Z1, 2048, BT, 2048, K1, s)));
-        EGO_HIP((gemm<Tile>(h, "pos_fc2", ALoadPlain{Z1, 2048}, segmat1(p.pos_fc[1].w, 512, 2048), bn(p.pos_fc[1]), Z2, 512, BT, 512, 2048, s)));
-        EGO_HIP((gemm<Tile>(h, "pos_fc3", ALoadPlain{Z2, 512}, segmat1(p.pos_fc[2].w, hid, 512), bn(p.pos_fc[2]), POSZ, hid, BT, hid, 512, s)));
+        EGO_HIP((fc_gemm(h, "pos_fc2", ALoadPlain{Z1, 2048}, segmat1(p.pos_fc[1].w, 512, 2048), bn(p.pos_fc[1]), Z2, 512, BT, 512, 2048, SPK, s)));
+        EGO_HIP((fc_gemm(h, "pos_fc3", ALoadPlain{Z2, 512}, segmat1(p.pos_fc[2].w, hid, 512), bn(p.pos_fc[2]), POSZ, hid, BT, hid, 512, SPK, s)));
     }
     // H11-H12: rotation (cos/sin) heatmaps straight from the input tensor
     {
@@ -659,8 +667,8 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
             EGO_HIP((gemm_f32_splitk_launch<TileA>(al, segmat1(p.rot_fc[0].w, 2048, 2L * HW), bn(p.rot_fc[0]), Z1, 2048, SPK, SPLITK_FLOATS, BT, 2048, 2 * HW, s)));
         else
             EGO_HIP((gemm_big(h, "rot_fc1", al, segmat1(p.rot_fc[0].w, 2048, 2L * HW), bn(p.rot_fc[0]), Z1, 2048, BT, 2048, 2 * HW, s)));
-        EGO_HIP((gemm<Tile>(h, "rot_fc2", ALoadPlain{Z1, 2048}, segmat1(p.rot_fc[1].w, 512, 2048), bn(p.rot_fc[1]), Z2, 512, BT, 512, 2048, s)));
-        EGO_HIP((gemm<Tile>(h, "rot_fc3", ALoadPlain{Z2, 512}, segmat1(p.rot_fc[2].w, hid, 512), bn(p.rot_fc[2]), ROTZ, hid, BT, hid, 512, s)));
+        EGO_HIP((fc_gemm(h, "rot_fc2", ALoadPlain{Z1, 2048}, segmat1(p.rot_fc[1].w, 512, 2048), bn(p.rot_fc[1]), Z2, 512, BT, 512, 2048, SPK, s)));
+        EGO_HIP((fc_gemm(h, "rot_fc3", ALoadPlain{Z2, 512}, segmat1(p.rot_fc[2].w, hid, 512), bn(p.rot_fc[2]), ROTZ, hid, BT, hid, 512, SPK, s)));
     }
     // H13-H14: propagation units.  State-independent projections of all J steps as GEMMs (rows time-major t*B+b) ...
     const int x = 2 * hid, NF0 = H + x;
