@@ -8,7 +8,8 @@ tests/ and tools/make_golden.py, never by the product path.
 Pinned: tests/golden/heatmap_synth.npz is produced by the reference's own coord2d_to_heatmap and get_limb_data
 (tools/make_golden.py gen_synth).  skimage is NOT installed here, so the reference's `from skimage.draw import line_aa` is
 satisfied with ``line_aa`` below, a restatement of skimage's published _line_aa (skimage/draw/_draw.pyx, Zingl's anti-aliased
-Bresenham): **parity unpinned for that one step**; the Gaussian filter is scipy's own (the reference's dependency).
+Bresenham): **parity unpinned for that one step** (its only check is the single example of skimage's published docstring,
+tests/test_oracle_synth_golden.py::test_line_aa_published_example); the Gaussian filter is scipy's own (the reference's dependency).
 """
 from __future__ import annotations
 

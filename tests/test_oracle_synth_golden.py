@@ -47,3 +47,18 @@ def test_line_aa_properties():
     assert set(zip(rr, cc)) >= {(i, 0) for i in range(11)} and np.all(val[(cc == 0)] == 1.0)
     rr, cc, val = R.line_aa(2, 3, 40, 17)
     assert (rr[0], cc[0]) == (2, 3) and (40, 17) in set(zip(rr, cc)) and np.all((val >= 0) & (val <= 1))
+
+
+def test_line_aa_published_example():
+    """The one known answer available without skimage: the example in skimage.draw.line_aa's published docstring
+    (line_aa(1, 1, 8, 8) painted as val * 255 into a 10x10 uint8 image: 255 on the diagonal, 74 beside it).  A single
+    diagonal vector -- the line walk stays 'parity unpinned' for general slopes (oracle header)."""
+    rr, cc, val = R.line_aa(1, 1, 8, 8)
+    img = np.zeros((10, 10), np.uint8)
+    img[rr, cc] = val * 255
+    want = np.zeros((10, 10), np.uint8)
+    for i in range(1, 9):
+        want[i, i] = 255
+        if i < 8:
+            want[i, i + 1] = want[i + 1, i] = 74
+    np.testing.assert_array_equal(img, want)
