@@ -15,6 +15,7 @@
 #include "conv_bf16.h"
 #include "gemm_f32.h"
 #include "gemm_bf16.h"
+#include "gemm_bf16_dma.h"
 #include "attention_bf16.h"
 #include "layernorm.h"
 #include "metrics.h"
@@ -78,6 +79,8 @@ extern "C" const char* egotap_gemm_tile_name(int tile) {
         case 14: return "persist256x256x32/8w/bf16";
         case 15: return "persist256x256x16/8w/bf16x3/interleaved";
         case 16: return "persist256x256x32/8w/bf16/interleaved";
+        case 17: return "dma256x256x32/8w/bf16 (bf16 operand copies + LDS-DMA)";
+        case 18: return "dma256x256x32/8w/bf16 (reusing the copies of the previous tile-17 call)";
         default: return nullptr;
     }
 }
@@ -125,6 +128,8 @@ struct egotap_handle_s {
     int precision = EGOTAP_PREC_F32;   // arithmetic of the large GEMMs (egotap_set_precision)
     __bf16* wscratch = nullptr;        // scratch for the bf16 copy of a GEMM's weight matrix (plain-bf16 mode), caller-owned
     size_t wscratch_bytes = 0;
+    __bf16* ascratch = nullptr;        // library-owned bf16 copy of a GEMM's activation operand (plain-bf16 mode, gemm_bf16_dma_kernel); grows on demand
+    size_t ascratch_bytes = 0;
     __bf16* conv_pack = nullptr;       // scratch for repacked conv weights (set per egotap_hm_forward call from the workspace)
     // timing
     bool timing = false;
@@ -248,6 +253,7 @@ extern "C" int egotap_create(const egotap_config* cfg, egotap_handle* out) {
 extern "C" void egotap_destroy(egotap_handle h) {
     if (!h) return;
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    if (h->ascratch) (void)hipFree(h->ascratch);
     delete h;
 }
 #endif
@@ -454,8 +460,28 @@ static int device_cu_count() {
     return n;
 }
 
+// rows of an fp32 matrix (row stride lda) -> dense bf16 [M, K]
+static __global__ __launch_bounds__(256) void f32_to_bf16_rows_kernel(const float* __restrict__ src, long lda, __bf16* __restrict__ dst, int k8, long n8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const long row = i / k8;
+    const float* p = src + row * lda + (i - row * k8) * 8;
+    *(bf16x8*)(dst + i * 8) = bf16_round8(*(const f32x4*)p, *(const f32x4*)(p + 4));
+}
+static __bf16* ensure_ascratch(Handle* h, size_t bytes) {
+    if (bytes <= h->ascratch_bytes) return h->ascratch;
+    if (h->ascratch) (void)hipFree(h->ascratch);          // hipFree waits for the work that still reads it
+    h->ascratch = nullptr; h->ascratch_bytes = 0;
+    const size_t want = bytes + bytes / 4;
+    if (hipMalloc((void**)&h->ascratch, want) != hipSuccess) { (void)hipGetLastError(); h->ascratch = nullptr; return nullptr; }
+    h->ascratch_bytes = want;
+    return h->ascratch;
+}
+
 // plain-bf16 GEMM: W rounded to bf16 into the handle's scratch right before the launch (stream ordered), so the W operand costs
-// half the vector-memory bytes; without a scratch (or if it is too small) the kernel converts fp32 weights on the fly
+// half the vector-memory bytes; without a scratch (or if it is too small) the kernel converts fp32 weights on the fly.
+// A plain row-major activation operand is rounded to bf16 the same way (library-owned scratch) and the product runs on the
+// LDS-DMA kernel (gemm_bf16_dma.h): same rounding of both operands, same fp32 accumulation order per output element.
 template <class AL, class Epi>
 static hipError_t gemm_bf16_plain(Handle* h, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K, hipStream_t s) {
     const int nseg = N / W.seg;
@@ -468,6 +494,19 @@ static hipError_t gemm_bf16_plain(Handle* h, const AL& al, const SegMat& W, cons
             hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, W.p[i], h->wscratch + (size_t)i * W.seg * K, n8);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
+        static const bool use_dma = []() { const char* v = getenv("EGOTAP_BF16_DMA"); return !(v && v[0] == '0'); }();   // A/B switch for measurements
+        if constexpr (std::is_same<AL, ALoadPlain>::value) {
+            if (use_dma && K % DmaCfg::BK == 0 && N % DmaCfg::BN == 0 && W.seg % DmaCfg::BN == 0 && al.lda % 4 == 0 && M >= 1024) {
+                __bf16* a = ensure_ascratch(h, (size_t)M * K * 2);
+                if (a) {
+                    const long a8 = (long)M * K / 8;
+                    hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3((unsigned)((a8 + 255) / 256)), dim3(256), 0, s, al.A, al.lda, a, K / 8, a8);
+                    e = hipGetLastError();
+                    if (e != hipSuccess) return e;
+                    return gemm_bf16_dma_launch(a, (long)K, B, epi, C, ldc, M, N, K, device_cu_count(), s);
+                }
+            }
+        }
         return gemm_bf16_persist_launch<BfCfg<1, 1>, AL, Epi, SegMatB>(al, B, epi, C, ldc, M, N, K, device_cu_count(), s);
     }
     return gemm_bf16_persist_launch<BfCfg<1, 1>, AL, Epi>(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
@@ -1014,6 +1053,29 @@ extern "C" int egotap_linear_f32(const float* x, const float* w, const float* b,
         case 14: e = gemm_bf16_persist_launch<BfCfg<1>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
         case 15: e = gemm_bf16_persist_launch<BfCfg<3, 1>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
         case 16: e = gemm_bf16_persist_launch<BfCfg<1, 1>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
+        case 17: case 18: {     // development hook (18: reuse the bf16 copies made by the previous call -- times the GEMM alone) for gemm_bf16_dma_kernel: bf16 copies of x and w in a lazily grown scratch
+            static __bf16* scratch = nullptr;
+            static size_t scratch_elems = 0;
+            const size_t need = (size_t)M * K + (size_t)N * K;
+            EGO_CHECK(tile == 17 || need <= scratch_elems, "tile 18: call tile 17 with the same shape first");
+            if (need > scratch_elems) {
+                if (scratch) EGO_HIP(hipFree(scratch));
+                scratch = nullptr; scratch_elems = 0;
+                EGO_HIP(hipMalloc((void**)&scratch, need * 2));
+                scratch_elems = need;
+            }
+            EGO_CHECK(K % 8 == 0, "tile 17: K must be a multiple of 8");
+            const long a8 = (long)M * K / 8, w8 = (long)N * K / 8;
+            if (tile == 17) {
+                hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((a8 + 255) / 256)), dim3(256), 0, s, x, scratch, a8);
+                hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, s, w, scratch + (size_t)M * K, w8);
+            }
+            SegMatB Bm;
+            for (int i = 0; i < 3; ++i) Bm.p[i] = scratch + (size_t)M * K;
+            Bm.seg = N; Bm.ld = K;
+            e = gemm_bf16_dma_launch(scratch, (long)K, Bm, EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s);
+            break;
+        }
         default: egotap_set_error("unknown tile id %d", tile); return EGOTAP_ERR_INVALID;
     }
     if (e == hipErrorInvalidValue) {

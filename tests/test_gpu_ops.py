@@ -156,6 +156,23 @@ def test_linear_bf16_plain(M, N, K):
     _close(y, ref, atol=2e-6 * math.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (300, 256, 96), (257, 512, 128), (1153, 768, 1024), (5000, 256, 64), (70000, 1024, 256)])
+def test_linear_bf16_dma(M, N, K):
+    """gemm_bf16_dma_kernel (tile 17: bf16 copies of both operands, global -> LDS DMA, xor-swizzled unpadded rows, 4 stages):
+    equals the float64 product of the bf16-rounded operands to fp32 rounding -- fewer slabs than stages, ragged M, tiles < CUs,
+    several tiles per workgroup (the last shape: 1100 tiles on 256 CUs) -- and bit for bit the register-staged bf16 kernel
+    (tile 16: same operand rounding, same k order per output element)."""
+    from egotap_amd import lib
+    x, w, b = _rand((M, K), 51), _rand((N, K), 52, -1.0, 1.0) / math.sqrt(K), _rand((N,), 53)
+    y = lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=17)
+    if M * N <= 4_000_000:
+        ref = x.bfloat16().double() @ w.bfloat16().double().T + b.double()
+        _close(y, ref, atol=2e-6 * math.sqrt(K))
+    y16 = lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=16)
+    assert torch.equal(y, y16)
+    assert torch.equal(y, lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=18))       # reuses the bf16 copies: GEMM alone, reproducible
+
+
 def test_linear_bf16x3_identity_asymmetric_and_ragged_rows():
     """A = I: hi+lo of 1.0 is exact, so the result is W^T rounded to 16 bits of mantissa; rows past M are never written."""
     from egotap_amd import lib
