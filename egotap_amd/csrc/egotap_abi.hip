@@ -1313,7 +1313,7 @@ extern "C" int egotap_train_layernorm_fwd(const float* x, float* y, const float*
 }
 #endif
 
-// dx = LN'(dy) (+ dres); dgamma / dbeta (+)= column sums.  ws: >= ceil(rows/64) * 2 * 1024 floats
+// dx = LN'(dy) (+ dres); dgamma / dbeta (+)= column sums.  ws: >= (b + 1 + ceil(b/64)) * 2048 floats, b = ceil(rows/64)
 #if EGOTAP_IN(1)
 extern "C" int egotap_train_layernorm_bwd(const float* x, const float* dy, const float* g, const float* mean, const float* rstd,
                                           const float* dres, float* dx, float* dgamma, float* dbeta, int rows, int accumulate,
@@ -1325,12 +1325,14 @@ extern "C" int egotap_train_layernorm_bwd(const float* x, const float* dy, const
     float* part = (float*)ws;
     hipLaunchKernelGGL(layernorm_bwd_kernel<1024>, dim3(blocks), dim3(256), 0, s, x, dy, g, mean, rstd, dres, dx, part, rows, rows_per_wave);
     EGO_HIP(hipGetLastError());
-    // part[block][2][1024] -> treat as 'blocks' slabs of 2048 floats: slab k = (dgamma_k | dbeta_k)
-    // reduce into a temporary pair laid out contiguously is not possible in place, so reduce the two halves separately:
-    // stride trick: slabs are 2048 apart, reduce_slabs_kernel assumes stride n -> run it on n = 2048 into a 2048 buffer at the end of ws
+    // part[block][2][1024] = 'blocks' rows of 2048 floats (dgamma_k | dbeta_k): column sums in two fixed-order stages -- 64 rows per
+    // workgroup into part2[gy][2048], then the gy rows into tmp (a single 2-workgroup pass over all rows took 0.85 ms at B = 256)
     float* tmp = part + (size_t)blocks * 2048;
-    EGO_CHECK(ws_bytes >= ((size_t)blocks * 2048 + 2048) * 4, "egotap_train_layernorm_bwd: workspace too small");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(2), dim3(256), 0, s, part, tmp, 2048L, blocks, 0);
+    float* part2 = tmp + 2048;
+    const int gy = (blocks + 63) / 64;
+    EGO_CHECK(ws_bytes >= ((size_t)blocks * 2048 + 2048 + (size_t)gy * 2048) * 4, "egotap_train_layernorm_bwd: workspace too small");
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(2048 / 4 / 64, gy), dim3(256), 0, s, (const float*)part, 2048L, part2, blocks, 2048, 64);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(2), dim3(256), 0, s, (const float*)part2, tmp, 2048L, gy, 0);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, tmp, dgamma, 1024L, 1, accumulate);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, tmp + 1024, dbeta, 1024L, 1, accumulate);
     EGO_HIP(hipGetLastError());

@@ -184,7 +184,8 @@ static hipError_t gemm_tn_f32_launch(const float* dY, long ldy, const XLoad& xl,
     if (splits > max_by_rows) splits = max_by_rows;
     if (splits < 1) splits = 1;
     while ((size_t)splits * N * K * 4 > slab_bytes && splits > 1) --splits;
-    if ((size_t)splits * N * K * 4 > slab_bytes) return hipErrorOutOfMemory;
+    const bool direct = splits == 1 && !accumulate;              // a single slab that is not added to anything IS the gradient
+    if (!direct && (size_t)splits * N * K * 4 > slab_bytes) return hipErrorOutOfMemory;
     auto kern = gemm_tn_f32_kernel<Cfg, XLoad>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -192,10 +193,10 @@ static hipError_t gemm_tn_f32_launch(const float* dY, long ldy, const XLoad& xl,
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, dY, ldy, xl, slabs, M, N, K,
+    hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, dY, ldy, xl, direct ? dW : slabs, M, N, K,
                        tiles_n, tiles_k, splits);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || direct) return e;
     const long n = (long)N * K;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, slabs, dW, n, splits,
                        accumulate);

@@ -85,7 +85,8 @@ def layernorm_fwd(x, g, b, eps=1e-12):
 def layernorm_bwd(x, dy, g, mean, rstd, dgamma, dbeta, dres=None, accumulate=False):
     rows = x.shape[0]
     dx = torch.empty_like(x)
-    ws = _scratch.get(((rows + 63) // 64 * 2048 + 2048) * 4 + 4096, x.device)
+    nb = (rows + 63) // 64
+    ws = _scratch.get((nb + 1 + (nb + 63) // 64) * 2048 * 4 + 4096, x.device)
     _lib.check(_lib.load().egotap_train_layernorm_bwd(_p(x), _p(dy), _p(g), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dgamma), _p(dbeta),
                                                       rows, int(accumulate), _p(ws), ws.numel(), _s()))
     return dx
