@@ -1,0 +1,196 @@
+// Exact-fp32 GEMM with global -> LDS DMA staging:  C[M,N] = epi( A[M,K] * W[N,K]^T ),  everything fp32.
+//
+// The staging scheme of gemm_bf16_dma.h applied to the exact-fp32 kernel: a 16-float slab row is 64 bytes = four 16-byte chunks,
+// the same geometry as 32 bf16, so the unpadded xor-swizzled LDS image, the lane -> (row, chunk) duty of the DMA and the fragment
+// addressing carry over unchanged; a fragment float4 feeds four v_mfma_f32_32x32x2_f32 (k-permutation of gemm_f32.h).  Against
+// gemm_f32_persist_kernel this removes the staging registers and every ds_write, and parks FOUR slabs in LDS (three in flight).
+// Plain row-major A only (lda % 4 == 0); k order per output element is that of every other fp32 tile: bit-identical results.
+#pragma once
+#include "gemm_f32.h"
+
+struct DmaF32Cfg {
+    static constexpr int BM = 256, BN = 256, BK = 16, WM = 4, WN = 2, THREADS = 512, NS = 4, TM = 2, TN = 4;
+    static constexpr int ROWB = 64;                               // bytes per LDS row
+    static constexpr int STAGE = (BM + BN) * ROWB;                // 32 KiB
+    static constexpr int ELD = 36, EPATCH = 16 * ELD * 4;         // per-wave epilogue patch: 16 rows x 36 floats
+    static constexpr int LDS_BYTES = NS * STAGE + (THREADS / 64) * EPATCH;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <class Epi>
+__global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda, SegMat W, Epi epi, float* C,
+                                                                          long ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    using Cfg = DmaF32Cfg;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NS = Cfg::NS, TM = Cfg::TM, TN = Cfg::TN, ROWB = Cfg::ROWB, ELD = Cfg::ELD;
+    extern __shared__ __attribute__((aligned(16))) char smem_dmaf[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / Cfg::WN, wn = wid % Cfg::WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* Es = (float*)(smem_dmaf + NS * Cfg::STAGE + wid * Cfg::EPATCH);
+
+    // tiles of this block (same walk as gemm_f32_persist_kernel)
+    const int ntiles = tiles_m * tiles_n, nb = gridDim.x, x8 = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int nbx = (nb >> 3) + (x8 < (nb & 7) ? 1 : 0);
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int lo_t = x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8;
+    const int cnt = q8 + (x8 < r8 ? 1 : 0);
+    const int my_n = cnt > jb ? (cnt - jb + nbx - 1) / nbx : 0;
+    const int KT = K / BK;
+    const int total = my_n * KT;
+    if (total == 0) return;
+    auto tile_of = [&](int i, int& tm, int& tn) __attribute__((always_inline)) {
+        const int lin = lo_t + jb + i * nbx;
+        const int per_group = 8 * tiles_n;
+        const int g = lin / per_group, first = g * 8;
+        const int gsz = min(tiles_m - first, 8);
+        const int in = lin - g * per_group;
+        tm = first + in % gsz;
+        tn = in / gsz;
+    };
+
+    // DMA duty of this wave per slab: 16-row chunks wid and wid + 8 of A and of W.  Lane -> (row lane >> 2 of the chunk, chunk
+    // position lane & 3), which holds logical chunk (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ (lane >> 4).
+    const int drow = lane >> 2, dchunk = (lane & 3) ^ (lane >> 4);
+    const float *pa0, *pa1, *pb0, *pb1;
+    int l_tile = 0, l_kt = 0;
+    auto set_rows = [&](int i) __attribute__((always_inline)) {
+        int tm, tn;
+        tile_of(i, tm, tn);
+        pa0 = A + (long)min(tm * BM + wid * 16 + drow, M - 1) * lda + dchunk * 4;
+        pa1 = A + (long)min(tm * BM + (wid + 8) * 16 + drow, M - 1) * lda + dchunk * 4;
+        // the segment of W is uniform over a tile (seg % 256 == 0): scalar selects, no indexed (vector) load of W.p[] whose
+        // vmcnt wait would drain the DMA pipeline at every tile switch
+        const int n0 = tn * BN, sidx = n0 / W.seg;
+        const float* wp = (sidx == 0 ? W.p[0] : (sidx == 1 ? W.p[1] : W.p[2])) + (long)(n0 - sidx * W.seg) * W.ld;
+        pb0 = wp + (long)(wid * 16 + drow) * W.ld + dchunk * 4;
+        pb1 = wp + (long)((wid + 8) * 16 + drow) * W.ld + dchunk * 4;
+    };
+    set_rows(0);
+    // The DMA goes through inline asm: the compiler's waitcnt pass treats __builtin_amdgcn_global_load_lds as a store to LDS that
+    // any later ds_read may alias and drains vmcnt(0) in front of every fragment read, which serialises the pipeline.  vmcnt for
+    // these instructions is counted by hand (constant number in flight, see the loop).
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_dmaf;
+    auto dma1 = [&](const float* g, unsigned lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+    };
+    // one slab of this block's slab stream -> stage st.  Unconditional (past the end it re-reads the last slab into a stage
+    // nobody reads) so that the number of DMA instructions in flight is a constant the waits below can count on.
+    auto dma = [&](int st) __attribute__((always_inline)) {
+        const unsigned sa = lds0 + st * Cfg::STAGE + wid * 1024;
+        const int k0 = l_kt * BK;
+        dma1(pa0 + k0, sa);
+        dma1(pa1 + k0, sa + 8 * 1024);
+        dma1(pb0 + k0, sa + BM * ROWB);
+        dma1(pb1 + k0, sa + BM * ROWB + 8 * 1024);
+        if (l_tile < my_n && ++l_kt == KT) {
+            l_kt = 0;
+            if (++l_tile < my_n) set_rows(l_tile);
+            else l_kt = KT - 1;                 // stream exhausted: keep pointing at the last slab
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // fragment byte offsets inside a stage: row l31 of a 32-row block, logical chunk 2 t + lh (floats 8 t + 4 lh ..)
+    const int sw = (l31 >> 2) & 3;
+    const int f0 = l31 * ROWB + ((lh ^ sw) << 4), f1 = l31 * ROWB + (((2 + lh) ^ sw) << 4);
+    const int a_base = (wm * (TM * 32)) * ROWB, b_base = (BM + wn * (TN * 32)) * ROWB;
+
+    int c_tile = 0, c_kt = 0;
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        int tm, tn;
+        tile_of(c_tile, tm, tn);
+        const int er = lane >> 3, ec = (lane & 7) * 4;
+        const int nb0 = tn * BN + wn * (TN * 32) + ec, mb0 = tm * BM + wm * (TM * 32) + er;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n0 = nb0 + j * 32;
+            const typename Epi::Col4 cc = epi.col4(n0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = mb0 + i * 32;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    f32x4 rs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                    if (Epi::HAS_RES) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) rs[s2] = epi.res4(min(mb + hf * 16 + s2 * 8, M - 1), n0);
+                    }
+#pragma unroll
+                    for (int r = 8 * hf; r < 8 * hf + 8; ++r) Es[((r & 3) + 8 * ((r >> 2) & 1) + 4 * lh) * ELD + l31] = acc[i][j][r];
+#pragma unroll
+                    for (int r = 8 * hf; r < 8 * hf + 8; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int m = mb + hf * 16 + s2 * 8;
+                        if (m < M) {
+                            const f32x4 o = epi.apply4(*(const f32x4*)(Es + (s2 * 8 + er) * ELD + ec), cc, rs[s2], m, n0);
+                            *(f32x4*)(C + (long)m * ldc + n0) = o;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    dma(0);
+    dma(1);
+    dma(2);
+    int st = 0;
+    for (int gs = 0; gs < total; ++gs) {
+        // slab gs has landed once at most the 8 DMA instructions of slabs gs+1, gs+2 are outstanding (vmcnt is in order; stores of
+        // an epilogue in between only make the wait longer); the barrier publishes it and retires every read of stage st-1
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __syncthreads();
+        dma(st == 0 ? NS - 1 : st - 1);
+        const char* sa = smem_dmaf + st * Cfg::STAGE;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int fo = t == 0 ? f0 : f1;
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(sa + a_base + i * 32 * ROWB + fo);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(sa + b_base + j * 32 * ROWB + fo);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[j][u], acc[i][j], 0, 0, 0);
+        }
+        st = st + 1 == NS ? 0 : st + 1;
+        if (++c_kt == KT) {
+            epilogue();
+            c_kt = 0;
+            ++c_tile;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing (dummy) DMAs must not outlive the workgroup's LDS
+}
+
+// A: fp32 [M, K] with row stride lda (multiple of 4 floats), W: fp32 rows (ld multiple of 4)
+template <class Epi>
+static hipError_t gemm_f32_dma_launch(const float* A, long lda, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K,
+                                       int num_cu, hipStream_t stream) {
+    using Cfg = DmaF32Cfg;
+    if (M <= 0) return hipSuccess;
+    if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0 || lda % 4 != 0 || W.ld % 4 != 0) return hipErrorInvalidValue;
+    auto kern = gemm_f32_dma_kernel<Epi>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
+    const int ntiles = tiles_m * tiles_n;
+    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, A, lda, W, epi, C, ldc, M, N, K, tiles_m, tiles_n);
+    return hipGetLastError();
+}

@@ -36,9 +36,24 @@ def speed(M, N, K, tiles=(12, 16, 17, 18)):
         row[f"tile{t}_tf"] = round(2.0 * M * N * K / ms / 1e9, 1)
     print(json.dumps(row), flush=True)
 
+def check_f32(M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.rand(M, K, device="cuda", generator=g) - 0.5
+    w = (torch.rand(N, K, device="cuda", generator=g) - 0.5) * 0.1
+    b = torch.rand(N, device="cuda", generator=g)
+    same = torch.equal(lib.linear(x, w, b, tile=19), lib.linear(x, w, b, tile=12))
+    print(json.dumps({"M": M, "N": N, "K": K, "f32_dma_bit_identical_to_persist": same}), flush=True)
+    assert same
+
 if __name__ == "__main__":
     for shp in ((256, 256, 32), (256, 256, 128), (300, 512, 1024), (1000, 1024, 4096), (8192, 3072, 1024)):
         check(*shp)
+    if len(sys.argv) > 1 and sys.argv[1] == "f32":
+        for shp in ((256, 256, 16), (300, 512, 48), (1153, 768, 1024), (5000, 256, 32)):
+            check_f32(*shp)
+        for shp in ((147456, 1024, 4096), (147456, 3072, 1024), (147456, 1024, 1024), (147456, 4096, 1024)):
+            speed(*shp, tiles=(12, 19))
+        sys.exit(0)
     speed(147456, 1024, 4096)
     speed(147456, 3072, 1024)
     speed(147456, 1024, 1024)
