@@ -138,34 +138,58 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(con
         }
     };
 
+    // Pipeline.  The barrier sits in the MIDDLE of a slab: [fragments t=1 of slab gs] [32 MFMAs t=0] wait + barrier (slab gs+1
+    // has landed for everyone, nobody reads stage gs-1 any more) [DMA slab gs+3 -> stage gs-1] [fragments t=0 of slab gs+1]
+    // [32 MFMAs t=1].  Every fragment read is issued one MFMA group ahead of its use, so no LDS latency is exposed after the
+    // barrier; a slab is in flight for two slab times (7 us at the fp32 MFMA rate).
     dma(0);
     dma(1);
     dma(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __syncthreads();
+    f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a0[i] = *(const f32x4*)(smem_dmaf + a_base + i * 32 * ROWB + f0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b0[j] = *(const f32x4*)(smem_dmaf + b_base + j * 32 * ROWB + f0);
     int st = 0;
+    bool after_epi = false;
     for (int gs = 0; gs < total; ++gs) {
-        // slab gs has landed once at most the 8 DMA instructions of slabs gs+1, gs+2 are outstanding (vmcnt is in order; stores of
-        // an epilogue in between only make the wait longer); the barrier publishes it and retires every read of stage st-1
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        const char* sa = smem_dmaf + st * Cfg::STAGE;
+        const int st1 = st + 1 == NS ? 0 : st + 1;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a1[i] = *(const f32x4*)(sa + a_base + i * 32 * ROWB + f1);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b1[j] = *(const f32x4*)(sa + b_base + j * 32 * ROWB + f1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][u], b0[j][u], acc[i][j], 0, 0, 0);
+        // slab gs+1 has landed once at most the 4 DMA instructions of slab gs+2 are outstanding (vmcnt is in order; stores of an
+        // epilogue in between only make the wait longer)
+        // ... which is why the wait is skipped right after an epilogue: it was done in front of the epilogue's stores (below), and
+        // repeated here it would sit until the 32 stores behind slab gs+1 in the queue have drained to HBM
+        if (!after_epi) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        after_epi = false;
         __syncthreads();
         dma(st == 0 ? NS - 1 : st - 1);
-        const char* sa = smem_dmaf + st * Cfg::STAGE;
+        const char* sn = smem_dmaf + st1 * Cfg::STAGE;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int fo = t == 0 ? f0 : f1;
-            f32x4 a[TM], b[TN];
+        for (int i = 0; i < TM; ++i) a0[i] = *(const f32x4*)(sn + a_base + i * 32 * ROWB + f0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(sa + a_base + i * 32 * ROWB + fo);
+        for (int j = 0; j < TN; ++j) b0[j] = *(const f32x4*)(sn + b_base + j * 32 * ROWB + f0);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(sa + b_base + j * 32 * ROWB + fo);
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[j][u], acc[i][j], 0, 0, 0);
-        }
-        st = st + 1 == NS ? 0 : st + 1;
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][u], b1[j][u], acc[i][j], 0, 0, 0);
+        st = st1;
         if (++c_kt == KT) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // slab gs+2 (only slab gs+3 may still be in flight)
+            after_epi = true;
             epilogue();
             c_kt = 0;
             ++c_tile;
