@@ -116,34 +116,36 @@ __global__ __launch_bounds__(DmaCfg::THREADS, 2) void gemm_bf16_dma_kernel(const
         tile_of(c_tile, tm, tn);
         const int er = lane >> 3, ec = (lane & 7) * 4;
         const int nb0 = tn * BN + wn * (TN * 32) + ec, mb0 = tm * BM + wm * (TM * 32) + er;
+        // 16 half blocks (32 columns x 16 rows) per wave; the residual rows of half block q+1 are requested before half block q
+        // goes through the LDS patch, so their latency hides behind it
+        f32x4 rs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, rn[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (Epi::HAS_RES) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n0 = nb0 + j * 32;
+            for (int s2 = 0; s2 < 2; ++s2) rs[s2] = epi.res4(min(mb0 + s2 * 8, M - 1), nb0);
+        }
+#pragma unroll
+        for (int q = 0; q < TN * TM * 2; ++q) {
+            const int j = q / (TM * 2), i = (q / 2) % TM, hf = q & 1;
+            const int n0 = nb0 + j * 32, mb = mb0 + i * 32;
             const typename Epi::Col4 cc = epi.col4(n0);
+            if (Epi::HAS_RES && q + 1 < TN * TM * 2) {
+                const int jn = (q + 1) / (TM * 2), in = ((q + 1) / 2) % TM, hn = (q + 1) & 1;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int mb = mb0 + i * 32;
+                for (int s2 = 0; s2 < 2; ++s2) rn[s2] = epi.res4(min(mb0 + in * 32 + hn * 16 + s2 * 8, M - 1), nb0 + jn * 32);
+            }
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    f32x4 rs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                    if (Epi::HAS_RES) {
+            for (int r = 8 * hf; r < 8 * hf + 8; ++r) Es[((r & 3) + 8 * ((r >> 2) & 1) + 4 * lh) * ELD + l31] = acc[i][j][r];
 #pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) rs[s2] = epi.res4(min(mb + hf * 16 + s2 * 8, M - 1), n0);
-                    }
+            for (int r = 8 * hf; r < 8 * hf + 8; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
-                    for (int r = 8 * hf; r < 8 * hf + 8; ++r) Es[((r & 3) + 8 * ((r >> 2) & 1) + 4 * lh) * ELD + l31] = acc[i][j][r];
-#pragma unroll
-                    for (int r = 8 * hf; r < 8 * hf + 8; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const int m = mb + hf * 16 + s2 * 8;
-                        if (m < M) {
-                            const f32x4 o = epi.apply4(*(const f32x4*)(Es + (s2 * 8 + er) * ELD + ec), cc, rs[s2], m, n0);
-                            *(f32x4*)(C + (long)m * ldc + n0) = o;
-                        }
-                    }
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int m = mb + hf * 16 + s2 * 8;
+                if (m < M) {
+                    const f32x4 o = epi.apply4(*(const f32x4*)(Es + (s2 * 8 + er) * ELD + ec), cc, rs[s2], m, n0);
+                    *(f32x4*)(C + (long)m * ldc + n0) = o;
                 }
             }
+            if (Epi::HAS_RES) { rs[0] = rn[0]; rs[1] = rn[1]; }
         }
     };
 
