@@ -449,7 +449,7 @@ def main():
             k["launches"] += d["launches"]; k["ms"] += d["ms"]; k["flops"] += d["flops"]
         achieved = fl_total / (ms_total * 1e-3) / 1e12 if ms_total > 0 else 0.0
         roof = {
-            "bound": "mfma", "kernel": "gemm_f32_kernel (all instantiations, v_mfma_f32_32x32x2_f32)",
+            "bound": "mfma", "kernel": "fp32 GEMM kernels (gemm_f32_dma_kernel for the ViT projections + gemm_f32_persist_kernel / gemm_f32_kernel, v_mfma_f32_32x32x2_f32)",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
             "algorithmic_bytes": None, "traffic_source": None,

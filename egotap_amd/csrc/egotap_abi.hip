@@ -533,7 +533,7 @@ static hipError_t gemm_big(Handle* h, const char* role, const AL& al, const SegM
         static const bool use_dma = []() { const char* v = getenv("EGOTAP_F32_DMA"); return !(v && v[0] == '0'); }();   // A/B switch for measurements
         if (use_dma && N % DmaF32Cfg::BN == 0 && K % DmaF32Cfg::BK == 0 && W.seg % DmaF32Cfg::BN == 0 && W.ld % 4 == 0 && al.lda % 4 == 0 &&
             ((uintptr_t)al.A & 15) == 0) {
-            static const std::string kdma = std::string("gemm_f32_dma_kernel<256x256x16,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
+            static const std::string kdma = std::string("gemm_f32_dma_kernel<256x256x16,") + EpiName<Epi>::v + ">";
             GemmTimer t(h, s, role, kdma.c_str(), 2.0 * M * N * K);
             return gemm_f32_dma_launch(al.A, al.lda, W, epi, C, ldc, M, N, K, device_cu_count(), s);
         }

@@ -15,6 +15,8 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "gpurun_out", "prof")
+HEADLINE_CMD = "python3 bench.py --steps 5 --warmup 2 --lift-only --no-fast-mode --no-cpu-baseline"
+ALL_CMD = "python3 bench.py --steps 2 --warmup 1 --full-steps 1 --train-steps 1 --train-batch-bf16 256 --no-cpu-baseline"
 
 
 def newest(pat):
@@ -42,7 +44,20 @@ def short(name):
 
 
 def main():
+    """profiles/<tag>_*: the HEADLINE command (what bench.py times: fp32 lifting head at B = 256 alone; per-launch HBM bytes are
+    meaningful because every launch of a kernel has the same shape); profiles/<tag>_all_legs_*: every secondary leg as well
+    (durations / MFMA busy only: launches of one kernel mix batch sizes there)."""
+    global SRC
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    one(tag, HEADLINE_CMD, "B = 256; the timed workload of bench.py alone: fp32 lifting head forward")
+    SRC = os.path.join(REPO, "gpurun_out", "prof_all")
+    if os.path.isdir(SRC):
+        one(tag + "_all_legs", ALL_CMD, "every leg: fp32 headline, bf16x3 fast mode, full pipeline in both modes, EgoCap / 128x128 geometry, "
+            "training steps in f32 / bf16x3 / bf16, stage-1 training, small-batch latency -- launches of one kernel mix batch sizes, "
+            "so the per-launch averages here are not comparable with the headline table", traffic_json=False)
+
+
+def one(tag, cmd, what, traffic_json=True):
     dst = os.path.join(REPO, "profiles")
     os.makedirs(dst, exist_ok=True)
     stats = rows("trace/*/*_kernel_stats.csv")
@@ -62,7 +77,7 @@ def main():
     for x in rows("pmc_write/*/*_counter_collection.csv"):
         write[short(x["Kernel_Name"])].append(float(x["Counter_Value"]))
     lines = [f"# rocprofv3 summary {tag}", "",
-             "Command: `python3 bench.py --steps 2 --warmup 1 --full-steps 1 --train-steps 1 --train-batch-bf16 256 --no-cpu-baseline` (B = 256; every leg: fp32 headline, bf16x3 fast mode, full pipeline in both modes, training step in f32 / bf16x3 / bf16) under",
+             f"Command: `{cmd}` ({what}) under",
              "`rocprofv3 --kernel-trace --stats` (durations) and separate `--pmc` passes (FETCH_SIZE; WRITE_SIZE; "
              "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY).",
              "HBM read MB = FETCH_SIZE[KiB] x 2 / 1024 (gfx950 counts 64 B per 128-B request), write MB = WRITE_SIZE[KiB] / 1024.", "",
@@ -84,10 +99,11 @@ def main():
         if fetch[k] and write[k]:
             traffic[k] = {"read_bytes": 2 * sum(fetch[k]) / len(fetch[k]) * 1024, "write_bytes": sum(write[k]) / len(write[k]) * 1024,
                           "launches_profiled": len(fetch[k]), "avg_ms": float(s["AverageNs"]) / 1e6}
-    json.dump({"tag": tag, "note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE, separate passes; "
+    if traffic_json:
+      json.dump({"tag": tag, "note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE, separate passes; "
                "B = 256 per GPU", "kernels": traffic}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
     open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines))
+    print("\n".join(lines[:40]))
 
 
 if __name__ == "__main__":
