@@ -528,14 +528,13 @@ static hipError_t gemm_big(Handle* h, const char* role, const AL& al, const SegM
         GemmTimer t(h, s, role, kname1.c_str(), 2.0 * M * N * K);
         return gemm_bf16_plain(h, al, W, epi, C, ldc, M, N, K, s);
     }
-    if constexpr (std::is_same<AL, ALoadPlain>::value) {
-        // plain row-major A: same tile, same k order (bit-identical), slabs staged global -> LDS by DMA (gemm_f32_dma.h)
+    if constexpr (AL::HAS_PTR) {
+        // loaders that are pure address math: same tile, same k order (bit-identical), slabs staged global -> LDS by DMA (gemm_f32_dma.h)
         static const bool use_dma = []() { const char* v = getenv("EGOTAP_F32_DMA"); return !(v && v[0] == '0'); }();   // A/B switch for measurements
-        if (use_dma && N % DmaF32Cfg::BN == 0 && K % DmaF32Cfg::BK == 0 && W.seg % DmaF32Cfg::BN == 0 && W.ld % 4 == 0 && al.lda % 4 == 0 &&
-            ((uintptr_t)al.A & 15) == 0) {
-            static const std::string kdma = std::string("gemm_f32_dma_kernel<256x256x16,") + EpiName<Epi>::v + ">";
+        if (use_dma && N % DmaF32Cfg::BN == 0 && K % DmaF32Cfg::BK == 0 && W.seg % DmaF32Cfg::BN == 0 && W.ld % 4 == 0 && al.dma_ok()) {
+            static const std::string kdma = std::string("gemm_f32_dma_kernel<256x256x16,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
             GemmTimer t(h, s, role, kdma.c_str(), 2.0 * M * N * K);
-            return gemm_f32_dma_launch(al.A, al.lda, W, epi, C, ldc, M, N, K, device_cu_count(), s);
+            return gemm_f32_dma_launch(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
         }
     }
     static const std::string kname = std::string("gemm_f32_persist_kernel<256x256x16,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
@@ -1065,7 +1064,7 @@ extern "C" int egotap_linear_f32(const float* x, const float* w, const float* b,
         case 14: e = gemm_bf16_persist_launch<BfCfg<1>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
         case 15: e = gemm_bf16_persist_launch<BfCfg<3, 1>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
         case 16: e = gemm_bf16_persist_launch<BfCfg<1, 1>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
-        case 19: e = gemm_f32_dma_launch(x, (long)K, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
+        case 19: e = gemm_f32_dma_launch(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
         case 17: case 18: {     // development hook (18: reuse the bf16 copies made by the previous call -- times the GEMM alone) for gemm_bf16_dma_kernel: bf16 copies of x and w in a lazily grown scratch
             static __bf16* scratch = nullptr;
             static size_t scratch_elems = 0;

@@ -27,6 +27,10 @@ struct ALoadPlain {
     struct Row { const float* p; };
     __device__ __forceinline__ Row row(int m) const { return Row{A + (long)m * lda}; }
     __device__ __forceinline__ f32x4 load(const Row& r, int k) const { return *(const f32x4*)(r.p + k); }
+    // address of the 4 floats load() returns: loaders that are pure address math can feed the global -> LDS DMA (gemm_f32_dma.h)
+    static constexpr bool HAS_PTR = true;
+    __device__ __forceinline__ const float* ptr(const Row& r, int k) const { return r.p + k; }
+    __host__ bool dma_ok() const { return lda % 4 == 0 && ((uintptr_t)A & 15) == 0; }
 };
 
 // ViT patch embedding input: token (b, pr, pc) of the tiled (grid*hm)^2 image, K = 16*16
@@ -34,6 +38,7 @@ struct ALoadPlain {
 struct ALoadPatch {
     const float* hm;   // [B, C, S, S] heatmaps, position channels first
     int C, S, seq, side, ppd, grid, T;
+    static constexpr bool HAS_PTR = false;      // dummy cells are zeros, not memory
     struct Row { const float* p; };   // nullptr: dummy cell (zeros)
     __device__ __forceinline__ Row row(int m) const {
         const int b = m / seq, tok = m - b * seq;
@@ -63,6 +68,13 @@ struct ALoadTokens {
         const int prl = s / ppd, pcl = s - prl * ppd;
         return *(const f32x4*)(r.p + (long)(prl * side + pcl) * D + c);
     }
+    static constexpr bool HAS_PTR = true;
+    __device__ __forceinline__ const float* ptr(const Row& r, int k) const {
+        const int s = k / D, c = k - s * D;
+        const int prl = s / ppd, pcl = s - prl * ppd;
+        return r.p + (long)(prl * side + pcl) * D + c;
+    }
+    __host__ bool dma_ok() const { return D % 4 == 0 && ((uintptr_t)Y & 15) == 0; }
 };
 
 // fc1 of the rotation encoder: row (b, eye*J + j) = [cos map | sin map] of limb j of that eye.
@@ -81,11 +93,18 @@ struct ALoadRot {
         const int cs = k / HW;
         return *(const f32x4*)(r.p + (long)cs * J * HW + (k - cs * HW));
     }
+    static constexpr bool HAS_PTR = true;
+    __device__ __forceinline__ const float* ptr(const Row& r, int k) const {
+        const int cs = k / HW;
+        return r.p + (long)cs * J * HW + (k - cs * HW);
+    }
+    __host__ bool dma_ok() const { return HW % 4 == 0 && ((uintptr_t)hm & 15) == 0; }
 };
 
 // Propagation-unit inputs, time-major rows m = t*B + b: [left_t | right_t] features of
 // joint t from Z[(b*2 + eye)*J + t, hid].  Reference: net_architecture.py:699-705, 722-723.
 struct ALoadStereo {
+    static constexpr bool HAS_PTR = false;      // small PU GEMMs only
     const float* Z;
     int B, J, hid;
     struct Row { const float* p; };
@@ -101,6 +120,7 @@ struct ALoadStereo {
 
 // Bridge operand of PU layer 0: b' = sigmoid(F[m, fcol0 + k]) * bridge(m, k)   (custom_cells.py:102).
 struct ALoadStereoGated {
+    static constexpr bool HAS_PTR = false;      // the gate is arithmetic on the operand
     ALoadStereo z;
     const float* F;    // [J*B, ldf] x2f output
     int ldf, fcol0;

@@ -4,7 +4,8 @@
 // the same geometry as 32 bf16, so the unpadded xor-swizzled LDS image, the lane -> (row, chunk) duty of the DMA and the fragment
 // addressing carry over unchanged; a fragment float4 feeds four v_mfma_f32_32x32x2_f32 (k-permutation of gemm_f32.h).  Against
 // gemm_f32_persist_kernel this removes the staging registers and every ds_write, and parks FOUR slabs in LDS (three in flight).
-// Plain row-major A only (lda % 4 == 0); k order per output element is that of every other fp32 tile: bit-identical results.
+// Any loader that is pure address math (HAS_PTR: plain rows, the per-heatmap token regroup, the cos/sin maps) can feed the DMA;
+// k order per output element is that of every other fp32 tile: bit-identical results.
 #pragma once
 #include "gemm_f32.h"
 
@@ -17,8 +18,8 @@ struct DmaF32Cfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <class Epi>
-__global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(const float* __restrict__ A, long lda, SegMat W, Epi epi, float* C,
+template <class ALoad, class Epi>
+__global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALoad al, SegMat W, Epi epi, float* C,
                                                                           long ldc, int M, int N, int K, int tiles_m, int tiles_n) {
     using Cfg = DmaF32Cfg;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NS = Cfg::NS, TM = Cfg::TM, TN = Cfg::TN, ROWB = Cfg::ROWB, ELD = Cfg::ELD;
@@ -51,13 +52,14 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(con
     // DMA duty of this wave per slab: 16-row chunks wid and wid + 8 of A and of W.  Lane -> (row lane >> 2 of the chunk, chunk
     // position lane & 3), which holds logical chunk (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ (lane >> 4).
     const int drow = lane >> 2, dchunk = (lane & 3) ^ (lane >> 4);
-    const float *pa0, *pa1, *pb0, *pb1;
+    typename ALoad::Row ra0, ra1;
+    const float *pb0, *pb1;
     int l_tile = 0, l_kt = 0;
     auto set_rows = [&](int i) __attribute__((always_inline)) {
         int tm, tn;
         tile_of(i, tm, tn);
-        pa0 = A + (long)min(tm * BM + wid * 16 + drow, M - 1) * lda + dchunk * 4;
-        pa1 = A + (long)min(tm * BM + (wid + 8) * 16 + drow, M - 1) * lda + dchunk * 4;
+        ra0 = al.row(min(tm * BM + wid * 16 + drow, M - 1));
+        ra1 = al.row(min(tm * BM + (wid + 8) * 16 + drow, M - 1));
         // the segment of W is uniform over a tile (seg % 256 == 0): scalar selects, no indexed (vector) load of W.p[] whose
         // vmcnt wait would drain the DMA pipeline at every tile switch
         const int n0 = tn * BN, sidx = n0 / W.seg;
@@ -78,8 +80,8 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(con
     auto dma = [&](int st) __attribute__((always_inline)) {
         const unsigned sa = lds0 + st * Cfg::STAGE + wid * 1024;
         const int k0 = l_kt * BK;
-        dma1(pa0 + k0, sa);
-        dma1(pa1 + k0, sa + 8 * 1024);
+        dma1(al.ptr(ra0, k0 + dchunk * 4), sa);
+        dma1(al.ptr(ra1, k0 + dchunk * 4), sa + 8 * 1024);
         dma1(pb0 + k0, sa + BM * ROWB);
         dma1(pb1 + k0, sa + BM * ROWB + 8 * 1024);
         if (l_tile < my_n && ++l_kt == KT) {
@@ -200,14 +202,14 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing (dummy) DMAs must not outlive the workgroup's LDS
 }
 
-// A: fp32 [M, K] with row stride lda (multiple of 4 floats), W: fp32 rows (ld multiple of 4)
-template <class Epi>
-static hipError_t gemm_f32_dma_launch(const float* A, long lda, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K,
+// al: a loader with HAS_PTR (16-byte aligned 4-float groups, al.dma_ok()), W: fp32 rows (ld multiple of 4)
+template <class ALoad, class Epi>
+static hipError_t gemm_f32_dma_launch(const ALoad& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K,
                                        int num_cu, hipStream_t stream) {
     using Cfg = DmaF32Cfg;
     if (M <= 0) return hipSuccess;
-    if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0 || lda % 4 != 0 || W.ld % 4 != 0) return hipErrorInvalidValue;
-    auto kern = gemm_f32_dma_kernel<Epi>;
+    if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0 || !al.dma_ok() || W.ld % 4 != 0) return hipErrorInvalidValue;
+    auto kern = gemm_f32_dma_kernel<ALoad, Epi>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
@@ -217,6 +219,6 @@ static hipError_t gemm_f32_dma_launch(const float* A, long lda, const SegMat& W,
     const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < num_cu ? ntiles : num_cu;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, A, lda, W, epi, C, ldc, M, N, K, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, al, W, epi, C, ldc, M, N, K, tiles_m, tiles_n);
     return hipGetLastError();
 }
