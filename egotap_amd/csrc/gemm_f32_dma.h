@@ -103,6 +103,10 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
     const int f0 = l31 * ROWB + ((lh ^ sw) << 4), f1 = l31 * ROWB + (((2 + lh) ^ sw) << 4);
     const int a_base = (wm * (TM * 32)) * ROWB, b_base = (BM + wn * (TN * 32)) * ROWB;
 
+    // Tried and dropped: issuing the epilogue of block q-1 behind the MFMAs of block q in a tile's last slab (to keep the matrix
+    // pipe busy through the epilogue).  As a second, differently ordered copy of the MFMA phase it made the register allocator
+    // shuffle the 128 accumulators between the copies and spill (32 TF); as one block-major sequence for every slab the four
+    // back-to-back MFMAs on one accumulator cost more than the epilogue saves (144 -> 132 TF).
     int c_tile = 0, c_kt = 0;
     auto epilogue = [&]() __attribute__((always_inline)) {
         int tm, tn;
