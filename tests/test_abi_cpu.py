@@ -79,7 +79,8 @@ def test_workspace_grows_with_batch():
     a, b = C.c_size_t(), C.c_size_t()
     lib.egotap_lift_workspace_bytes(h, 1, C.byref(a))
     lib.egotap_lift_workspace_bytes(h, 256, C.byref(b))
-    assert 200 * a.value < b.value < 260 * a.value
+    fixed = 64 << 20                      # split-K partial sums of the small-batch GEMMs: the same 64 MiB at every batch size
+    assert a.value > fixed and 200 * (a.value - fixed) < b.value - fixed < 260 * (a.value - fixed)
     assert b.value < 8 << 30
     lib.egotap_destroy(h)
 
