@@ -130,7 +130,7 @@ struct egotap_handle_s {
     int precision = EGOTAP_PREC_F32;   // arithmetic of the large GEMMs (egotap_set_precision)
     __bf16* wscratch = nullptr;        // scratch for the bf16 copy of a GEMM's weight matrix (plain-bf16 mode), caller-owned
     size_t wscratch_bytes = 0;
-    __bf16* ascratch = nullptr;        // library-owned bf16 copy of a GEMM's activation operand (plain-bf16 mode, gemm_bf16_dma_kernel); grows on demand
+    __bf16* ascratch = nullptr;        // scratch for the bf16 copy of a GEMM's activation operand (plain-bf16 mode, gemm_bf16_dma_kernel), caller-owned
     size_t ascratch_bytes = 0;
     __bf16* conv_pack = nullptr;       // scratch for repacked conv weights (set per egotap_hm_forward call from the workspace)
     // timing
@@ -255,7 +255,6 @@ extern "C" int egotap_create(const egotap_config* cfg, egotap_handle* out) {
 extern "C" void egotap_destroy(egotap_handle h) {
     if (!h) return;
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    if (h->ascratch) (void)hipFree(h->ascratch);
     delete h;
 }
 #endif
@@ -470,19 +469,10 @@ static __global__ __launch_bounds__(256) void f32_to_bf16_rows_kernel(const floa
     const float* p = src + row * lda + (i - row * k8) * 8;
     *(bf16x8*)(dst + i * 8) = bf16_round8(*(const f32x4*)p, *(const f32x4*)(p + 4));
 }
-static __bf16* ensure_ascratch(Handle* h, size_t bytes) {
-    if (bytes <= h->ascratch_bytes) return h->ascratch;
-    if (h->ascratch) (void)hipFree(h->ascratch);          // hipFree waits for the work that still reads it
-    h->ascratch = nullptr; h->ascratch_bytes = 0;
-    const size_t want = bytes + bytes / 4;
-    if (hipMalloc((void**)&h->ascratch, want) != hipSuccess) { (void)hipGetLastError(); h->ascratch = nullptr; return nullptr; }
-    h->ascratch_bytes = want;
-    return h->ascratch;
-}
-
 // plain-bf16 GEMM: W rounded to bf16 into the handle's scratch right before the launch (stream ordered), so the W operand costs
 // half the vector-memory bytes; without a scratch (or if it is too small) the kernel converts fp32 weights on the fly.
-// A plain row-major activation operand is rounded to bf16 the same way (library-owned scratch) and the product runs on the
+// A plain row-major activation operand is rounded to bf16 the same way (egotap_set_act_scratch; skipped when the scratch is
+// absent or too small) and the product runs on the
 // LDS-DMA kernel (gemm_bf16_dma.h): same rounding of both operands, same fp32 accumulation order per output element.
 template <class AL, class Epi>
 static hipError_t gemm_bf16_plain(Handle* h, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K, hipStream_t s) {
@@ -499,7 +489,7 @@ static hipError_t gemm_bf16_plain(Handle* h, const AL& al, const SegMat& W, cons
         static const bool use_dma = []() { const char* v = getenv("EGOTAP_BF16_DMA"); return !(v && v[0] == '0'); }();   // A/B switch for measurements
         if constexpr (std::is_same<AL, ALoadPlain>::value) {
             if (use_dma && K % DmaCfg::BK == 0 && N % DmaCfg::BN == 0 && W.seg % DmaCfg::BN == 0 && al.lda % 4 == 0 && M >= 1024) {
-                __bf16* a = ensure_ascratch(h, (size_t)M * K * 2);
+                __bf16* a = (size_t)M * K * 2 <= h->ascratch_bytes ? h->ascratch : nullptr;
                 if (a) {
                     const long a8 = (long)M * K / 8;
                     hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3((unsigned)((a8 + 255) / 256)), dim3(256), 0, s, al.A, al.lda, a, K / 8, a8);
@@ -625,6 +615,16 @@ extern "C" int egotap_set_weight_scratch(egotap_handle h, void* buf, size_t byte
     EGO_CHECK(((uintptr_t)buf & 15) == 0, "egotap_set_weight_scratch: 16-byte alignment");
     h->wscratch = (__bf16*)buf;
     h->wscratch_bytes = buf ? bytes : 0;
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(0)
+extern "C" int egotap_set_act_scratch(egotap_handle h, void* buf, size_t bytes) {
+    EGO_CHECK(h, "null handle");
+    EGO_CHECK(((uintptr_t)buf & 15) == 0, "egotap_set_act_scratch: 16-byte alignment");
+    h->ascratch = (__bf16*)buf;
+    h->ascratch_bytes = buf ? bytes : 0;
     return EGOTAP_OK;
 }
 #endif

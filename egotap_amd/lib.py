@@ -38,6 +38,7 @@ _PROTOS = {
     "egotap_lift_debug_stop": (C.c_int, [C.c_void_p, C.c_int]),
     "egotap_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "egotap_set_weight_scratch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "egotap_set_act_scratch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "egotap_hm_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "egotap_hm_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),

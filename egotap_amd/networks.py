@@ -138,7 +138,19 @@ class EgoTAPAutoEncoder(nn.Module):
         _lib.check(lib.egotap_lift_workspace_bytes(h, B, C.byref(need)))
         if self._ws is None or self._ws.numel() < need.value or self._ws.device != device:
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+        self._act_scratch(B, device)
         return self._ws
+
+    def _act_scratch(self, B, device):
+        """bf16 mode: scratch for the bf16 copy of a GEMM's activation operand (egotap_set_act_scratch), sized for the ViT MLP's
+        hidden activations [B * seq, 4 * D] and grown with the batch"""
+        if getattr(self, "precision", "f32") != "bf16" or device.type != "cuda":
+            return
+        need = 2 * B * self.preset.seq * 4 * self.preset.vit_dim
+        cur = getattr(self, "_ascratch", None)
+        if cur is None or cur.numel() < need or cur.device != device:
+            self._ascratch = torch.empty(need, dtype=torch.uint8, device=device)
+            _lib.check(_lib.load().egotap_set_act_scratch(self._ensure_handle(), C.c_void_p(self._ascratch.data_ptr()), self._ascratch.numel()))
 
     def set_precision(self, mode: str = "f32"):
         """Arithmetic of the large GEMMs (egotap.h egotap_set_precision): "f32" = exact fp32 MFMA (default),
@@ -154,6 +166,9 @@ class EgoTAPAutoEncoder(nn.Module):
                 self._wscratch = torch.empty(need, dtype=torch.uint8, device=dev)
             if getattr(self, "_wscratch", None) is not None:
                 _lib.check(_lib.load().egotap_set_weight_scratch(self._ensure_handle(), C.c_void_p(self._wscratch.data_ptr()), self._wscratch.numel()))
+        else:                          # the activation scratch is (re)attached by the next forward in bf16 mode (_act_scratch)
+            self._ascratch = None
+            _lib.check(_lib.load().egotap_set_act_scratch(self._ensure_handle(), None, 0))
         return self
 
     def intermediate(self, name: str, B: int):

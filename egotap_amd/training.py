@@ -36,6 +36,7 @@ class LiftTrainFn(torch.autograd.Function):
         # then miss the reference-golden gate (2.6 % of the tensor's typical magnitude against 0.5 %): bf16x3 stays fp32-grade.
         prec = "bf16" if getattr(net, "precision", "f32") == "bf16" else "f32"
         net._bind(dev)
+        net._act_scratch(hm.shape[0], dev)
         B, D, seq, heads, J, T_, hid = hm.shape[0], p.vit_dim, p.seq, p.vit_heads, p.n_joints_hm, p.tokens, p.hidden
         M, BT = B * seq, B * T_
         lib = _lib.load()

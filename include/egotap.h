@@ -108,6 +108,12 @@ int egotap_set_precision(egotap_handle h, int mode);
  * before the launch (stream ordered; nothing is cached, the live fp32 parameters stay the source of truth).  Halves the W operand's
  * vector-memory bytes, which bound that mode.  bytes >= 2 * the largest N*K (67 MB for fc1 of the position encoder); NULL = off. */
 int egotap_set_weight_scratch(egotap_handle h, void* buf, size_t bytes);
+/* EGOTAP_PREC_BF16 only: caller-owned device scratch (16-byte aligned) into which a GEMM's plain row-major activation operand [M, K]
+ * is rounded to bf16 right before the launch; with both operands in bf16 the product runs on the LDS-DMA kernel (gemm_bf16_dma.h,
+ * same rounding and summation order as without it -- bit-identical results, about twice the GEMM rate).  bytes >= 2 * the largest
+ * M*K (tokens x 4096 for the ViT MLP: 1.2 GB at B = 256); a GEMM whose operand does not fit falls back to the register-staged
+ * kernel.  NULL = off. */
+int egotap_set_act_scratch(egotap_handle h, void* buf, size_t bytes);
 
 /* debugging aid for parity tests: 0 = full forward (default); 1 = return after the embeddings;
  * 2+i = return after ViT layer i.  The state is then readable as intermediate "x". */
