@@ -700,10 +700,14 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     EGO_HIP(launch_ln(X, Y, p.lnf_g, p.lnf_b, M, 1e-12f, s));
     // H9-H10: per-heatmap regroup folded into fc1's A loader; fc blocks with folded BatchNorm + LeakyReLU
     auto bn = [](const LiftParams::Fc& f) { return EpiBnLrelu{f.b, f.g, f.beta, f.mean, f.var, 1e-5f, 0.2f}; };
+    // fc1 of the two encoders has few rows (30 / 34 per frame) and a huge K (16384 ... 65536): below 100 tiles of 256 x 256 (UnrealEgo:
+    // B < 107; EgoCap with 128 x 128 heatmaps: B < 95) most CUs would idle, so K is split over them (exact fp32 in every mode)
+    // (the bf16 modes keep their own kernels down to 1024 rows: at 16x the MFMA rate a quarter-filled chip still beats fp32 split-K)
+    const bool skinny_fc1 = BT < SKINNY_ROWS || (h->precision == EGOTAP_PREC_F32 && (long)((BT + 255) / 256) * (2048 / 256) < 100);
     {
         const int K1 = h->ppd * h->ppd * D;
         ALoadTokens al{Y, h->T, D, h->seq, h->side, h->ppd, h->grid};
-        if (BT < SKINNY_ROWS)      // small batch: skinny GEMM, split K over the CUs 
+        if (skinny_fc1)            // few row tiles: split K over the CUs
             EGO_HIP((gemm_f32_splitk_launch<TileA>(al, segmat1(p.pos_fc[0].w, 2048, K1), bn(p.pos_fc[0]), Z1, 2048, SPK, SPLITK_FLOATS, BT, 2048, K1, s)));
         else
             EGO_HIP((gemm_big(h, "pos_fc1", al, segmat1(p.pos_fc[0].w, 2048, K1), bn(p.pos_fc[0]), Z1, 2048, BT, 2048, K1, s)));
@@ -713,7 +717,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     // H11-H12: rotation (cos/sin) heatmaps straight from the input tensor
     {
         ALoadRot al{hm, h->C, J, HW};
-        if (BT < SKINNY_ROWS)
+        if (skinny_fc1)
             EGO_HIP((gemm_f32_splitk_launch<TileA>(al, segmat1(p.rot_fc[0].w, 2048, 2L * HW), bn(p.rot_fc[0]), Z1, 2048, SPK, SPLITK_FLOATS, BT, 2048, 2 * HW, s)));
         else
             EGO_HIP((gemm_big(h, "rot_fc1", al, segmat1(p.rot_fc[0].w, 2048, 2L * HW), bn(p.rot_fc[0]), Z1, 2048, BT, 2048, 2 * HW, s)));
