@@ -187,3 +187,24 @@ def test_lift_forward_on_synthesised_ground_truth_heatmaps():
     torch.cuda.synchronize()
     np.testing.assert_allclose(pose.cpu().numpy(), ref, atol=TOL, rtol=0)
     np.testing.assert_allclose(fast.cpu().numpy(), ref, atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("tag,preset", [("ue", "UnrealEgo"), ("ec", "EgoCap")])
+def test_every_gemm_routing_regime_matches_the_golden(tag, preset):
+    """Batch sizes on both sides of every routing threshold of the forward (split-K for the ViT GEMMs below the tile count that
+    fills the chip, for fc1 below 1024 encoder rows / 100 tiles, DMA-staged persistent kernels above): each frame of each batch
+    equals the reference golden of that frame within the fp32 gate, in the exact and in the bf16x3 mode."""
+    from gpu_util import lift_net
+    net, _, p = lift_net(preset)
+    g = np.load(os.path.join(GOLD, f"lift_fwd_{tag}_b2.npz"))
+    two = torch.from_numpy(synth_input(f"hm_{tag}", (2, p.in_channels, 64, 64))).cuda()
+    try:
+        for mode, gate in (("f32", TOL), ("bf16x3", TOL)):
+            net.set_precision(mode)
+            for B in (1, 3, 7, 30, 31, 34, 35, 36, 63, 106, 107, 108, 129):
+                x = two.repeat((B + 1) // 2, 1, 1, 1)[:B].contiguous()
+                out = net.predict_pose(x).cpu().numpy()
+                ref = np.tile(g["pose"], ((B + 1) // 2, 1, 1))[:B]
+                np.testing.assert_allclose(out, ref, atol=gate, rtol=0, err_msg=f"{preset} {mode} B={B}")
+    finally:
+        net.set_precision("f32")
