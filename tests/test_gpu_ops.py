@@ -130,6 +130,19 @@ def test_linear_persistent_tile_many_shapes(M, N, K):
     assert torch.equal(y, y1)            # same k order as the 128x128 pipelined kernel: bit-identical
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 16), (300, 512, 48), (1153, 768, 1024), (5000, 256, 32), (2304, 1024, 64), (70000, 1024, 256)])
+def test_linear_f32_dma_bit_identical(M, N, K):
+    """gemm_f32_dma_kernel (tile 19: slabs staged global -> LDS by DMA, xor-swizzled unpadded rows, four stages, barrier mid-slab):
+    the k order per output element is that of the register-staged kernels, so the result is bit for bit theirs -- fewer slabs than
+    stages, a single slab per tile, ragged M, tiles < CUs, several tiles per workgroup."""
+    from egotap_amd import lib
+    x, w, b = _rand((M, K), 71), _rand((N, K), 72, -0.1, 0.1), _rand((N,), 73)
+    y = lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=19)
+    assert torch.equal(y, lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=12))
+    if M * N <= 4_000_000:
+        _close(y, x.double() @ w.double().T + b.double(), atol=2e-6 * math.sqrt(K) + 1e-6)
+
+
 # ---- bf16 matrix-core GEMMs with fp32 operands in HBM (gemm_bf16.h): tile 13 = bf16x3 split, tile 14 = plain bf16
 @pytest.mark.parametrize("M,N,K", [(1000, 512, 1024), (300, 256, 16), (257, 256, 48), (2048, 1024, 4096)])
 def test_linear_bf16x3_error_model(M, N, K):
