@@ -143,6 +143,24 @@ def test_linear_f32_dma_bit_identical(M, N, K):
         _close(y, x.double() @ w.double().T + b.double(), atol=2e-6 * math.sqrt(K) + 1e-6)
 
 
+def test_linear_dma_kernels_random_shapes():
+    """seeded sweep over odd row counts and every slab count around the pipeline depth: both DMA-staged GEMMs reproduce their
+    register-staged counterparts bit for bit (fp32: tile 19 vs 12; bf16: tile 17 vs 16)"""
+    from egotap_amd import lib
+    rng = np.random.default_rng(20240607)
+    for trial in range(24):
+        M = int(rng.integers(1, 3000))
+        N = int(rng.choice([256, 512, 768, 1024]))
+        K32 = int(rng.integers(1, 12)) * 32
+        x, w, b = _rand((M, K32), 200 + trial), _rand((N, K32), 300 + trial, -0.2, 0.2), _rand((N,), 400 + trial)
+        xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+        assert torch.equal(lib.linear(xc, wc, bc, tile=19), lib.linear(xc, wc, bc, tile=12)), (M, N, K32)
+        assert torch.equal(lib.linear(xc, wc, bc, tile=17), lib.linear(xc, wc, bc, tile=16)), (M, N, K32)
+        K16 = K32 + 16                                   # fp32 slabs are 16 deep: odd slab counts too
+        x, w = _rand((M, K16), 500 + trial), _rand((N, K16), 600 + trial, -0.2, 0.2)
+        assert torch.equal(lib.linear(x.cuda(), w.cuda(), bc, tile=19), lib.linear(x.cuda(), w.cuda(), bc, tile=12)), (M, N, K16)
+
+
 # ---- bf16 matrix-core GEMMs with fp32 operands in HBM (gemm_bf16.h): tile 13 = bf16x3 split, tile 14 = plain bf16
 @pytest.mark.parametrize("M,N,K", [(1000, 512, 1024), (300, 256, 16), (257, 256, 48), (2048, 1024, 4096)])
 def test_linear_bf16x3_error_model(M, N, K):
