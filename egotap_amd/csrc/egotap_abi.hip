@@ -735,19 +735,18 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     }
     // ... then the two J-step recurrences (layer 0 never reads layer-1 state, so the layers run one after the other)
     EGO_HIP(hipMemsetAsync(C0, 0, (size_t)(w.ZERO - w.C0) + (size_t)B * H * 4, s));   // C0, C1, ZERO are contiguous
-    const dim3 pgrid((B + 31) / 32, H / 32);
     for (int t = 0; t < J; ++t) {
         const float* hprev = t == 0 ? ZERO : HS0 + (size_t)(t - 1) * B * H;
-        hipLaunchKernelGGL(pu_step_kernel, pgrid, dim3(256), 0, s, F0 + (size_t)t * B * NF0, NF0, G0 + (size_t)t * B * 4 * H,
-                           p.h2h0_w, p.h2h0_b, hprev, C0, C0, HS0 + (size_t)t * B * H, nullptr, B, H);
+        pu_step_launch(s, B, H, F0 + (size_t)t * B * NF0, NF0, G0 + (size_t)t * B * 4 * H,
+                           p.h2h0_w, p.h2h0_b, hprev, C0, C0, HS0 + (size_t)t * B * H, nullptr);
     }
     EGO_HIP(hipGetLastError());
     EGO_HIP((gemm<Tile>(h, "pu1_x2f", ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
     EGO_HIP((gemm<Tile>(h, "pu1_x2h", ALoadPlain{HS0, H}, segmat1(p.x2h1_w, 4 * H, H), EpiBias{segvec1(p.x2h1_b, 4 * H)}, G1, 4L * H, JB, 4 * H, H, s)));
     for (int t = 0; t < J; ++t) {
         const float* hprev = t == 0 ? ZERO : HS1 + (size_t)(t - 1) * B * H;
-        hipLaunchKernelGGL(pu_step_kernel, pgrid, dim3(256), 0, s, F1 + (size_t)t * B * H, H, G1 + (size_t)t * B * 4 * H,
-                           p.h2h1_w, p.h2h1_b, hprev, C1, C1, HS1 + (size_t)t * B * H, nullptr, B, H);
+        pu_step_launch(s, B, H, F1 + (size_t)t * B * H, H, G1 + (size_t)t * B * 4 * H,
+                           p.h2h1_w, p.h2h1_b, hprev, C1, C1, HS1 + (size_t)t * B * H, nullptr);
     }
     EGO_HIP(hipGetLastError());
     // H15: per-joint pose head (+ global offset and head joint for UnrealEgo)
@@ -1519,13 +1518,12 @@ extern "C" int egotap_train_pu_fwd(egotap_handle h, const float* posz, const flo
         EGO_HIP((gemm<Tile>(h, "pu0_b2h", bs, segmat1(p.b2h0_w, 4 * H, x), EpiBiasRes{segvec1(p.b2h0_b, 4 * H), G0, 4L * H}, G0, 4L * H, JB, 4 * H, x, s)));
     }
     EGO_HIP(hipMemsetAsync(ZERO, 0, (size_t)B * H * 4, s));
-    const dim3 pgrid((B + 31) / 32, H / 32);
     for (int t = 0; t < J; ++t) {       // G0 holds Gin on entry and the full gate pre-activations on exit (in place)
         const float* hprev = t == 0 ? ZERO : HS0 + (size_t)(t - 1) * B * H;
         const float* cprev = t == 0 ? ZERO : C0 + (size_t)(t - 1) * B * H;
         float* g = G0 + (size_t)t * B * 4 * H;
-        hipLaunchKernelGGL(pu_step_kernel, pgrid, dim3(256), 0, s, F0 + (size_t)t * B * NF0, NF0, g, p.h2h0_w, p.h2h0_b, hprev, cprev,
-                           C0 + (size_t)t * B * H, HS0 + (size_t)t * B * H, g, B, H);
+        pu_step_launch(s, B, H, F0 + (size_t)t * B * NF0, NF0, g, p.h2h0_w, p.h2h0_b, hprev, cprev,
+                           C0 + (size_t)t * B * H, HS0 + (size_t)t * B * H, g);
     }
     EGO_HIP(hipGetLastError());
     EGO_HIP((gemm<Tile>(h, "pu1_x2f", ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
@@ -1534,8 +1532,8 @@ extern "C" int egotap_train_pu_fwd(egotap_handle h, const float* posz, const flo
         const float* hprev = t == 0 ? ZERO : HS1 + (size_t)(t - 1) * B * H;
         const float* cprev = t == 0 ? ZERO : C1 + (size_t)(t - 1) * B * H;
         float* g = G1 + (size_t)t * B * 4 * H;
-        hipLaunchKernelGGL(pu_step_kernel, pgrid, dim3(256), 0, s, F1 + (size_t)t * B * H, H, g, p.h2h1_w, p.h2h1_b, hprev, cprev,
-                           C1 + (size_t)t * B * H, HS1 + (size_t)t * B * H, g, B, H);
+        pu_step_launch(s, B, H, F1 + (size_t)t * B * H, H, g, p.h2h1_w, p.h2h1_b, hprev, cprev,
+                           C1 + (size_t)t * B * H, HS1 + (size_t)t * B * H, g);
     }
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;

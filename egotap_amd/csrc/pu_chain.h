@@ -128,6 +128,86 @@ static __global__ __launch_bounds__(256) void pu_step_kernel(const float* __rest
     }
 }
 
+// The same step on 16 waves: wave = (gate, quarter of K) with one 32 x 32 accumulator, partial sums meet in LDS, and the LSTM
+// pointwise runs one (row, unit) per thread on all 1024 threads.  pu_step_kernel spends its 20-30 us per step on 256 MFMAs per
+// wave at one wave per SIMD (6.9 us), an LDS reduction into a single wave and that wave's 16-row pointwise; here a wave issues 64
+// MFMAs, four waves share a SIMD, and nothing is serial behind one wave.  The k partition (quarters), the order inside a quarter
+// and the order in which the four partial sums are added are those of pu_step_kernel, so the result is bit for bit the same.
+static __global__ __launch_bounds__(1024) void pu_step16_kernel(const float* __restrict__ F_t, int ldf, const float* __restrict__ Gin_t,
+                                                                const float* __restrict__ Whh, const float* __restrict__ bhh,
+                                                                const float* __restrict__ h_prev, const float* c_prev, float* c_out,
+                                                                float* __restrict__ h_out, float* __restrict__ gpre_out, int B, int H) {
+    __shared__ float red[16 * 16 * 64];          // [quarter * 4 + gate][register][lane] (64 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int g = wid & 3, kq4 = wid >> 2;
+    const int r0 = blockIdx.x * 32, u0 = blockIdx.y * 32;
+    const int arow = min(r0 + l31, B - 1);
+    const int kq = H >> 2, k0 = kq4 * kq;
+    // operands of this thread's pointwise element, requested up front
+    const int prow = r0 + (tid >> 5), punit = u0 + (tid & 31);
+    const int prc = min(prow, B - 1);
+    float gin[4], bg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        gin[q] = Gin_t[(long)prc * 4 * H + (long)q * H + punit];
+        bg[q] = bhh[q * H + punit];
+    }
+    const float cpv = c_prev[(long)prc * H + punit];
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* hp = h_prev + (long)arow * H + k0 + 4 * lh;
+    const float* fp = F_t + (long)arow * ldf + k0 + 4 * lh;
+    const float* wp = Whh + (long)g * H * H + (long)(u0 + l31) * H + k0 + 4 * lh;
+#pragma unroll 4
+    for (int k = 0; k < kq; k += 8) {
+        f32x4 a = *(const f32x4*)(hp + k);
+        const f32x4 f = *(const f32x4*)(fp + k);
+        const f32x4 w = *(const f32x4*)(wp + k);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] *= sigmoidf_(f[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], w[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((kq4 * 4 + g) * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (prow < B) {
+        // element (row_local, unit) of a 32 x 32 accumulator: lane = unit + 32 * ((row_local >> 2) & 1), register (row_local & 3) + 4 * (row_local >> 3)
+        const int rl = tid >> 5;
+        const int idx = ((rl & 3) + 4 * (rl >> 3)) * 64 + (tid & 31) + 32 * ((rl >> 2) & 1);
+        float pre[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = red[(0 * 4 + q) * 1024 + idx];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v += red[(w * 4 + q) * 1024 + idx];
+            pre[q] = v + bg[q];
+        }
+        const float pf = pre[0] + gin[0], pi = pre[1] + gin[1], pc = pre[2] + gin[2], po = pre[3] + gin[3];
+        if (gpre_out) {      // training: keep the gate pre-activations for the backward pass
+            float* gp = gpre_out + (long)prow * 4 * H + punit;
+            gp[0] = pf; gp[H] = pi; gp[2 * H] = pc; gp[3 * H] = po;
+        }
+        const float fg = sigmoidf_(pf), ig = sigmoidf_(pi), cg = tanhf(pc), og = sigmoidf_(po);
+        const float cn = cpv * fg + ig * cg;
+        c_out[(long)prow * H + punit] = cn;
+        h_out[(long)prow * H + punit] = og * tanhf(cn);
+    }
+}
+
+// One PU step.  Both kernels give the same bits; measured per step: B = 1: 19.9 us (4 waves, operands requested ahead) against
+// 22.7 (16 waves); B = 256: 30.4 against 28.0 -- neither is bound by its MFMAs (1.7 us on 16 waves), the floor is the chain of
+// dependent memory round trips of a launch that starts cold 30 times per forward.
+static inline void pu_step_launch(hipStream_t s, int B, int H, const float* F_t, int ldf, const float* Gin_t, const float* Whh, const float* bhh,
+                                  const float* h_prev, const float* c_prev, float* c_out, float* h_out, float* gpre_out) {
+    const dim3 grid((B + 31) / 32, H / 32);
+    if (B >= 64) hipLaunchKernelGGL(pu_step16_kernel, grid, dim3(1024), 0, s, F_t, ldf, Gin_t, Whh, bhh, h_prev, c_prev, c_out, h_out, gpre_out, B, H);
+    else hipLaunchKernelGGL(pu_step_kernel, grid, dim3(256), 0, s, F_t, ldf, Gin_t, Whh, bhh, h_prev, c_prev, c_out, h_out, gpre_out, B, H);
+}
+
 // Pose head: one block per sample.
 //   pose_j = Wp . [left_j | right_j | skel_j] + bp  (+ global offset) ; UnrealEgo: head joint = global_mlp[3:6], output LAST.
 // posz: [B*2J, hid] position embeddings (eye-major), hseq: [J, B, H] PU output (time-major).
