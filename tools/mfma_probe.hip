@@ -81,6 +81,16 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ src, f
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                if (MODE == 9) {                    // LDS-DMA through the buffer path: SGPR descriptor + one 32-bit VGPR offset
+                    if (t == 0 || t == 1) {
+                        const int i = t * 4 + u;
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int off = (int)(((long)r0 * 1024 + c4 * 4 + (long)i * 32 * 1024 + (it & 31) * 32) * 4);
+                        const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(smem + 256 * LDK + (wid * 8 + i) * 256);
+                        asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(off), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(la)) : "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 if (MODE == 7) {                    // LDS-DMA: 8 x 1 KiB global_load_lds per 64 MFMAs, issued in groups 0,1
                     if (t == 0 || t == 1) {
                         const int i = t * 4 + u;
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ src, f
 #pragma unroll
             for (int i = 0; i < 8; ++i) g[i] = g2[i];
         }
-        if (MODE == 7) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        if (MODE == 7 || MODE == 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
         else if (MODE >= 2) __syncthreads();
     }
     float s = 0.f;
@@ -145,6 +155,8 @@ int main() {
         run<6>("interleaved  (L2-resident)", blocks, 2000, src, out, 0);
         run<7>("LDS-DMA      (L2-resident)", blocks, 2000, src, out, 0);
         run<8>("buffer_load  (L2-resident)", blocks, 2000, src, out, 0);
+        run<9>("buffer LDS-DMA (L2-resident)", blocks, 2000, src, out, 0);
+        run<9>("buffer LDS-DMA 8x1KiB/64", blocks, 2000, src, out);
     }
     return 0;
 }
