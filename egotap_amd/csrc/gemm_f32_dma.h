@@ -70,7 +70,8 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
     set_rows(0);
     // The DMA goes through inline asm: the compiler's waitcnt pass treats __builtin_amdgcn_global_load_lds as a store to LDS that
     // any later ds_read may alias and drains vmcnt(0) in front of every fragment read, which serialises the pipeline.  vmcnt for
-    // these instructions is counted by hand (constant number in flight, see the loop).
+    // these instructions is counted by hand (constant number in flight, see the loop).  M0 (the LDS base of the DMA) is a reserved
+    // register: the compiler keeps no value in it across statements, so writing it here needs no clobber.
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_dmaf;
     auto dma1 = [&](const float* g, unsigned lds_addr) __attribute__((always_inline)) {
         asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
