@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dv_bf16_kernel(const floa
 
 // ------------------------------------------------------------------------------------------------- dK
 template <int NW, int NP>
-__global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dk_bf16_kernel(const float* __restrict__ QKV, const float* __restrict__ dO,
+__global__ __launch_bounds__(64 * NW, NP == 1 ? 2 : 1) void attn_bwd_dk_bf16_kernel(const float* __restrict__ QKV, const float* __restrict__ dO,
                                                                       const float* __restrict__ LSE, const float* __restrict__ DELTA,
                                                                       float* __restrict__ dQKV, int N, int heads, int kgroups,
                                                                       float scale) {
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dk_bf16_kernel(const floa
     __bf16* Qtr = Qrow + rimg_pair<NP>();
     __bf16* Drow = Qtr + timg_pair<NP>();
     float* Ls = (float*)(Drow + rimg_pair<NP>());     // [32] lse (log2 units), [32] delta
-    __bf16* Vw = (__bf16*)(Ls + 64);                  // per wave: row image of the V rows of its 32 keys (2 x RIMG: also the fp32 output patch)
+    __bf16* Vw = (__bf16*)(Ls + 64);                  // per wave: row image (hi [+ lo]) of the V rows of its 32 keys
     const int bh = blockIdx.x / kgroups, kg = blockIdx.x - bh * kgroups;
     const int b = bh / heads, h = bh - b * heads;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dk_bf16_kernel(const floa
     const int k0 = min(kb * 32, N - 32);
     Frags<NP> kf;
     load_row_frags<NP>(kf, qkv + (long)(k0 + l31) * ld3 + D, lh);
-    __bf16* Vmine = Vw + wid * 2 * RIMG;
+    __bf16* Vmine = Vw + wid * rimg_pair<NP>();
     stage<64, NP>(Vmine, nullptr, qkv + (long)k0 * ld3 + 2 * D, ld3, lane);     // this wave's V rows -> its private row image
     const float c2 = scale * 1.4426950408889634f;
     f32x16 dk[4];
@@ -313,7 +313,9 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dk_bf16_kernel(const floa
         acc_tile_t_x_p<NP>(dk, Qtr, s, lane);                        // dK^T[d][key] += Q^T dS
     }
     __syncthreads();
-    if (valid) store_rows(dk, (float*)Vmine, dQKV + ((long)b * N + k0) * ld3 + D + h * DH, ld3, l31, lh);
+    // every image is dead after the barrier: the fp32 output patches lie over them from the base (plain bf16: 70 KB of images,
+    // 68 KB of patches -- two workgroups per CU instead of one)
+    if (valid) store_rows(dk, (float*)bsm + wid * 32 * OLD, dQKV + ((long)b * N + k0) * ld3 + D + h * DH, ld3, l31, lh);
 }
 
 template <int NP>
@@ -329,8 +331,8 @@ static hipError_t attention_bwd_bf16_launch(const float* QKV, const float* O, co
     constexpr size_t img_q = (size_t)(2 * rimg_pair<NP>() + timg_pair<NP>()) * 2;
     constexpr size_t img_v = (size_t)(rimg_pair<NP>() + timg_pair<NP>()) * 2 + 128;
     constexpr size_t lds_q = img_q > patch ? img_q : patch, lds_v = img_v > patch ? img_v : patch;
-    constexpr size_t lds_k = (size_t)(2 * rimg_pair<NP>() + timg_pair<NP>()) * 2 + 256 + (size_t)NW * 2 * RIMG * 2;
-    static_assert(2 * RIMG * 2 >= 32 * OLD * 4, "the per-wave V image doubles as the fp32 output patch");
+    constexpr size_t img_k = (size_t)(2 * rimg_pair<NP>() + timg_pair<NP>()) * 2 + 256 + (size_t)NW * rimg_pair<NP>() * 2;
+    constexpr size_t lds_k = img_k > patch ? img_k : patch;
     static_assert(lds_k <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
