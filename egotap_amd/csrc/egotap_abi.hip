@@ -1689,7 +1689,7 @@ extern "C" int egotap_train_pose_head_bwd(egotap_handle h, const float* posz, co
     EGO_CHECK(!eh || (dWg && dbg), "egotap_train_pose_head_bwd: global_mlp gradient buffers missing");
     hipLaunchKernelGGL(pose_head_bwd_data_kernel, dim3(B), dim3(256), 0, s, dpose, p.pose_w, p.glob_w, dposz, dhs1, B, J, hid, H, eh);
     const int cols = 2 * hid + H + (eh ? J * H : 0) + 1;
-    hipLaunchKernelGGL(pose_head_bwd_weight_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, dpose, posz, hs1, dWp, dbp, dWg, dbg, B, J, hid,
+    hipLaunchKernelGGL(pose_head_bwd_weight_kernel, dim3((cols + 7) / 8), dim3(256), 0, s, dpose, posz, hs1, dWp, dbp, dWg, dbg, B, J, hid,
                        H, eh, accumulate);
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
