@@ -1595,6 +1595,13 @@ extern "C" int egotap_train_pu_bwd(egotap_handle h, const float* posz, const flo
         hipLaunchKernelGGL(transpose_f32_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, in, WT, R, C, (long)R);
     };
     auto nt = [&](const float* a, int M, int N, int K, float* y, const float* acc_src) -> hipError_t {   // y[M,N] = a[M,K] WT[N,K]^T (+ acc)
+        // the per-step input gradient of the recurrence is [B, H] x K = 4H: 8 tiles of 128 x 128 at B = 256 would walk K = 2048 on 8
+        // CUs (144 us, 32 times per step) -- K is split over the CUs instead, partial sums in the (idle) slab scratch
+        const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+        if (tiles < 128 && K >= 1024 && N % 128 == 0 && K % 32 == 0 && (size_t)2 * M * N * 4 <= part_bytes) {
+            if (acc_src) return gemm_f32_splitk_launch<TileA>(ALoadPlain{a, K}, segmat1(WT, N, K), EpiAccum{acc_src, N}, y, N, part, part_bytes / 4, M, N, K, s);
+            return gemm_f32_splitk_launch<TileA>(ALoadPlain{a, K}, segmat1(WT, N, K), EpiNone{}, y, N, part, part_bytes / 4, M, N, K, s);
+        }
         if (acc_src) return gemm_f32_launch<TileA>(ALoadPlain{a, K}, segmat1(WT, N, K), EpiAccum{acc_src, N}, y, N, M, N, K, s);
         return gemm_f32_launch<TileA>(ALoadPlain{a, K}, segmat1(WT, N, K), EpiNone{}, y, N, M, N, K, s);
     };
