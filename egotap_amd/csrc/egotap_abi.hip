@@ -956,7 +956,7 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
                        p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, F(w.L0), S0);
     EGO_HIP(hipGetLastError());
     // E2: maxpool 3x3/2
-    hipLaunchKernelGGL(maxpool3s2_kernel, dim3(2048), dim3(256), 0, s, F(w.L0), F(w.P0), (long)N2 * 64, S0 / 2);
+    maxpool3s2_launch(F(w.L0), F(w.P0), (long)N2 * 64, S0 / 2, s);
     EGO_HIP(hipGetLastError());
     // E3: four stages of two BasicBlocks
     const float* x = F(w.P0);
@@ -2005,7 +2005,7 @@ extern "C" int egotap_hmtrain_mse(const float* pred, const float* gt, const floa
 #if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_maxpool_fwd(const float* x, float* y, int64_t planes, int HIN, void* stream) {
     EGO_CHECK(x && y && planes > 0 && HIN % 2 == 0, "egotap_hmtrain_maxpool_fwd: bad argument");
-    hipLaunchKernelGGL(maxpool3s2_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, y, (long)planes, HIN);
+    maxpool3s2_launch(x, y, (long)planes, HIN, (hipStream_t)stream);
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }
