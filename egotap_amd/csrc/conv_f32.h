@@ -302,6 +302,122 @@ static __global__ __launch_bounds__(256) void stem_conv7_kernel(const float* __r
     (void)tiles;
 }
 
+// The stem on the matrix cores: implicit GEMM  out[pixel][co] = sum_k patch[pixel][k] * w[co][k],  k = (c, ky, kx) < 147 (one zero
+// column pads K to 148 = 74 MFMA steps of 2).  A workgroup of 8 waves owns 8 output rows x 128 output columns of one image: the
+// 21 x 261 x 3 input patch (zero halo) and the [k][co] weights sit in LDS (104 KB), wave w takes output row w as four 32-pixel
+// MFMA row tiles x two 32-channel column tiles.  An A value is one ds_read_b32 at patch[c][2 row + ky][2 x + kx] (lane = pixel,
+// lane half = k parity), shared by both column tiles; a B value is Ws[k][co] (lane = channel), shared by the four row tiles: 6
+// LDS reads per 8 MFMAs.  Workgroups are persistent over (image, row group, column half) items, the weights are staged once.
+struct StemCfg {
+    static constexpr int RG = 8, XT = 128, PR = 2 * RG + 5, PC = 2 * XT + 5, PLD = 264, KP = 148;
+    static constexpr int XS_FLOATS = 3 * PR * PLD, WS_FLOATS = KP * 64;
+    static constexpr int LDS_BYTES = (XS_FLOATS + WS_FLOATS) * 4;
+    static constexpr int THREADS = 64 * RG;
+};
+static __global__ __launch_bounds__(StemCfg::THREADS, 2) void stem_conv7_mfma_kernel(const float* __restrict__ left, const float* __restrict__ right,
+                                                                                    const float* __restrict__ w, const float* __restrict__ gamma,
+                                                                                    const float* __restrict__ beta, const float* __restrict__ mean,
+                                                                                    const float* __restrict__ var, float* __restrict__ out, int HIN,
+                                                                                    int nimg) {
+    using Cfg = StemCfg;
+    constexpr int RG = Cfg::RG, XT = Cfg::XT, PR = Cfg::PR, PC = Cfg::PC, PLD = Cfg::PLD, KP = Cfg::KP, THREADS = Cfg::THREADS;
+    extern __shared__ __attribute__((aligned(16))) float stem_sm[];
+    float* xs = stem_sm;                          // [3][PR][PLD]
+    float* ws = stem_sm + Cfg::XS_FLOATS;         // [KP][64]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int HO = HIN / 2, xsegs = HO / XT, ygroups = HO / RG;
+    const long items = (long)nimg * ygroups * xsegs;
+    for (int i = tid; i < KP * 64; i += THREADS) {
+        const int k = i >> 6, co = i & 63;
+        ws[i] = k < 147 ? w[co * 147 + k] : 0.f;
+    }
+    // per-lane BatchNorm constants of its two output channels (eval mode); gamma == nullptr: raw convolution output (training)
+    float sc[2] = {1.f, 1.f}, sh[2] = {0.f, 0.f};
+    if (gamma != nullptr) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = nt * 32 + l31;
+            sc[nt] = gamma[co] / sqrtf(var[co] + 1e-5f);
+            sh[nt] = beta[co] - mean[co] * sc[nt];
+        }
+    }
+    for (long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int xseg = (int)(it % xsegs), yg = (int)((it / xsegs) % ygroups);
+        const int n = (int)(it / ((long)xsegs * ygroups));
+        const float* src = ((n & 1) ? right : left) + (long)(n >> 1) * 3 * HIN * HIN;
+        const int iy0 = yg * RG * 2 - 3, ix0 = xseg * XT * 2 - 3;
+        __syncthreads();                          // everyone is done with the previous patch (and the weights are staged)
+        for (int i = tid; i < 3 * PR * PC; i += THREADS) {
+            const int c = i / (PR * PC), rem = i - c * PR * PC, yy = rem / PC, xx = rem - yy * PC;
+            const int y = iy0 + yy, x = ix0 + xx;
+            xs[(c * PR + yy) * PLD + xx] = (y >= 0 && y < HIN && x >= 0 && x < HIN) ? src[((long)c * HIN + y) * HIN + x] : 0.f;
+        }
+        __syncthreads();
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        const float* ap = xs + (2 * wid) * PLD + 2 * l31;        // output row wid, pixel l31 of row tile 0
+        const float* bp = ws + lh * 64 + l31;
+#pragma unroll
+        for (int s2 = 0; s2 < KP / 2; ++s2) {
+            constexpr int dummy = 0; (void)dummy;
+            const int k0 = 2 * s2, k1 = 2 * s2 + 1;              // this lane half multiplies k = k0 + lh
+            const int o0 = ((k0 / 49) * PR + (k0 % 49) / 7) * PLD + (k0 % 7);
+            const int o1 = k1 < 147 ? ((k1 / 49) * PR + (k1 % 49) / 7) * PLD + (k1 % 7) : 0;
+            const int ko = lh ? o1 : o0;
+            float a[4], b[2];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a[mt] = ap[ko + 64 * mt];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) b[nt] = bp[k0 * 64 + nt * 32];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+        const int y = yg * RG + wid;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float* dst = out + ((long)n * 64 + nt * 32 + l31) * HO * HO + (long)y * HO + xseg * XT;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float t = acc[mt][nt][4 * g + c] * sc[nt] + sh[nt];
+                        v[c] = gamma != nullptr ? fmaxf(t, 0.f) : t;
+                    }
+                    *(f32x4*)(dst + mt * 32 + 8 * g + 4 * lh) = v;
+                }
+        }
+    }
+}
+static inline hipError_t stem_conv7_launch(const float* left, const float* right, const float* w, const float* gamma, const float* beta,
+                                           const float* mean, const float* var, float* out, int HIN, int nimg, int num_cu, hipStream_t s) {
+    using Cfg = StemCfg;
+    const int HO = HIN / 2;
+    if (HO % Cfg::XT == 0 && HO % Cfg::RG == 0 && ((uintptr_t)out & 15) == 0) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)stem_conv7_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        const long items = (long)nimg * (HO / Cfg::RG) * (HO / Cfg::XT);
+        const int grid = (int)(items < num_cu ? items : num_cu);
+        hipLaunchKernelGGL(stem_conv7_mfma_kernel, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, left, right, w, gamma, beta, mean, var, out, HIN, nimg);
+    } else {
+        hipLaunchKernelGGL(stem_conv7_kernel, dim3(HO / 16, HO / 16, nimg), dim3(256), 0, s, left, right, w, gamma, beta, mean, var, out, HIN);
+    }
+    return hipGetLastError();
+}
+
 // MaxPool2d(3, stride 2, pad 1) on [N*C] planes of HIN x HIN (torchvision resnet18.maxpool)
 static __global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
                                                          int HIN) {

@@ -952,9 +952,7 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
     const int N2 = 2 * B;
 
     // E1: stem conv7x7/2 + BN + ReLU on image n = 2b + eye (the L/R channel concat of every pyramid level is then a view)
-    hipLaunchKernelGGL(stem_conv7_kernel, dim3(S0 / 32, S0 / 32, N2), dim3(256), 0, s, left, right, p.stem_w, p.stem_bn.g,
-                       p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, F(w.L0), S0);
-    EGO_HIP(hipGetLastError());
+    EGO_HIP(stem_conv7_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, F(w.L0), S0, N2, device_cu_count(), s));
     // E2: maxpool 3x3/2
     maxpool3s2_launch(F(w.L0), F(w.P0), (long)N2 * 64, S0 / 2, s);
     EGO_HIP(hipGetLastError());
@@ -1810,9 +1808,7 @@ extern "C" int egotap_hmtrain_conv_fwd(egotap_handle h, const float* x, const fl
 #if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_stem_fwd(const float* left, const float* right, const float* w, float* z, int B, int S0, void* stream) {
     EGO_CHECK(left && right && w && z && B > 0 && S0 % 32 == 0, "egotap_hmtrain_stem_fwd: bad argument");
-    hipLaunchKernelGGL(stem_conv7_kernel, dim3(S0 / 32, S0 / 32, 2 * B), dim3(256), 0, (hipStream_t)stream, left, right, w, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, z, S0);
-    EGO_HIP(hipGetLastError());
+    EGO_HIP(stem_conv7_launch(left, right, w, nullptr, nullptr, nullptr, nullptr, z, S0, 2 * B, device_cu_count(), (hipStream_t)stream));
     return EGOTAP_OK;
 }
 #endif
