@@ -341,18 +341,38 @@ static __global__ __launch_bounds__(StemCfg::THREADS, 2) void stem_conv7_mfma_ke
             sh[nt] = beta[co] - mean[co] * sc[nt];
         }
     }
+    // the patch of the NEXT item is requested into registers before the MFMAs of the current one and written to LDS behind them
+    constexpr int NPRE = (3 * PR * PC + THREADS - 1) / THREADS;
+    float pre[NPRE];
+    auto request = [&](long item) __attribute__((always_inline)) {
+        const int xseg_ = (int)(item % xsegs), yg_ = (int)((item / xsegs) % ygroups);
+        const int n_ = (int)(item / ((long)xsegs * ygroups));
+        const float* src = ((n_ & 1) ? right : left) + (long)(n_ >> 1) * 3 * HIN * HIN;
+        const int iy0 = yg_ * RG * 2 - 3, ix0 = xseg_ * XT * 2 - 3;
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + j * THREADS;
+            const int c = i / (PR * PC), rem = i - c * PR * PC, yy = rem / PC, xx = rem - yy * PC;
+            const int y = iy0 + yy, x = ix0 + xx;
+            pre[j] = (i < 3 * PR * PC && y >= 0 && y < HIN && x >= 0 && x < HIN) ? src[((long)c * HIN + y) * HIN + x] : 0.f;
+        }
+    };
+    auto publish = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + j * THREADS;
+            const int c = i / (PR * PC), rem = i - c * PR * PC, yy = rem / PC, xx = rem - yy * PC;
+            if (i < 3 * PR * PC) xs[(c * PR + yy) * PLD + xx] = pre[j];
+        }
+    };
+    if ((long)blockIdx.x < items) request(blockIdx.x);
     for (long it = blockIdx.x; it < items; it += gridDim.x) {
         const int xseg = (int)(it % xsegs), yg = (int)((it / xsegs) % ygroups);
         const int n = (int)(it / ((long)xsegs * ygroups));
-        const float* src = ((n & 1) ? right : left) + (long)(n >> 1) * 3 * HIN * HIN;
-        const int iy0 = yg * RG * 2 - 3, ix0 = xseg * XT * 2 - 3;
         __syncthreads();                          // everyone is done with the previous patch (and the weights are staged)
-        for (int i = tid; i < 3 * PR * PC; i += THREADS) {
-            const int c = i / (PR * PC), rem = i - c * PR * PC, yy = rem / PC, xx = rem - yy * PC;
-            const int y = iy0 + yy, x = ix0 + xx;
-            xs[(c * PR + yy) * PLD + xx] = (y >= 0 && y < HIN && x >= 0 && x < HIN) ? src[((long)c * HIN + y) * HIN + x] : 0.f;
-        }
+        publish();
         __syncthreads();
+        if (it + gridDim.x < items) request(it + gridDim.x);
         f32x16 acc[4][2];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
