@@ -81,8 +81,6 @@ extern "C" const char* egotap_gemm_tile_name(int tile) {
         case 15: return "persist256x256x16/8w/bf16x3/interleaved";
         case 16: return "persist256x256x32/8w/bf16/interleaved";
         case 19: return "dma256x256x16/8w (exact fp32, LDS-DMA staging)";
-        case 17: return "dma256x256x32/8w/bf16 (bf16 operand copies + LDS-DMA)";
-        case 18: return "dma256x256x32/8w/bf16 (reusing the copies of the previous tile-17 call)";
         default: return nullptr;
     }
 }
@@ -486,9 +484,8 @@ static hipError_t gemm_bf16_plain(Handle* h, const AL& al, const SegMat& W, cons
             hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, W.p[i], h->wscratch + (size_t)i * W.seg * K, n8);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        static const bool use_dma = []() { const char* v = getenv("EGOTAP_BF16_DMA"); return !(v && v[0] == '0'); }();   // A/B switch for measurements
         if constexpr (std::is_same<AL, ALoadPlain>::value) {
-            if (use_dma && K % DmaCfg::BK == 0 && N % DmaCfg::BN == 0 && W.seg % DmaCfg::BN == 0 && al.lda % 4 == 0 && M >= 1024) {
+            if (K % DmaCfg::BK == 0 && N % DmaCfg::BN == 0 && W.seg % DmaCfg::BN == 0 && al.lda % 4 == 0 && M >= 1024) {
                 __bf16* a = (size_t)M * K * 2 <= h->ascratch_bytes ? h->ascratch : nullptr;
                 if (a) {
                     const long a8 = (long)M * K / 8;
@@ -520,8 +517,7 @@ static hipError_t gemm_big(Handle* h, const char* role, const AL& al, const SegM
     }
     if constexpr (AL::HAS_PTR) {
         // loaders that are pure address math: same tile, same k order (bit-identical), slabs staged global -> LDS by DMA (gemm_f32_dma.h)
-        static const bool use_dma = []() { const char* v = getenv("EGOTAP_F32_DMA"); return !(v && v[0] == '0'); }();   // A/B switch for measurements
-        if (use_dma && N % DmaF32Cfg::BN == 0 && K % DmaF32Cfg::BK == 0 && W.seg % DmaF32Cfg::BN == 0 && W.ld % 4 == 0 && al.dma_ok()) {
+        if (N % DmaF32Cfg::BN == 0 && K % DmaF32Cfg::BK == 0 && W.seg % DmaF32Cfg::BN == 0 && W.ld % 4 == 0 && al.dma_ok()) {
             static const std::string kdma = std::string("gemm_f32_dma_kernel<256x256x16,") + AlName<AL>::v + "," + EpiName<Epi>::v + ">";
             GemmTimer t(h, s, role, kdma.c_str(), 2.0 * M * N * K);
             return gemm_f32_dma_launch(al, W, epi, C, ldc, M, N, K, device_cu_count(), s);
@@ -553,6 +549,8 @@ template <class AL, class Epi>
 static hipError_t fc_gemm(Handle* h, const char* role, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K,
                           float* P, hipStream_t s) {
     if (M >= SKINNY_ROWS || N % 128 != 0 || K % 32 != 0) return gemm<TileA>(h, role, al, W, epi, C, ldc, M, N, K, s);
+    static const std::string kname = std::string("gemm_f32_splitk_kernel<128x128x32,") + AlName<AL>::v + ">+splitk_reduce_kernel<" + EpiName<Epi>::v + ">";
+    GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
     return gemm_f32_splitk_launch<TileA>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s);
 }
 
@@ -1066,35 +1064,29 @@ extern "C" int egotap_linear_f32(const float* x, const float* w, const float* b,
         case 15: e = gemm_bf16_persist_launch<BfCfg<3, 1>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
         case 16: e = gemm_bf16_persist_launch<BfCfg<1, 1>>(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
         case 19: e = gemm_f32_dma_launch(ALoadPlain{x, K}, segmat1(w, N, K), EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s); break;
-        case 17: case 18: {     // development hook (18: reuse the bf16 copies made by the previous call -- times the GEMM alone) for gemm_bf16_dma_kernel: bf16 copies of x and w in a lazily grown scratch
-            static __bf16* scratch = nullptr;
-            static size_t scratch_elems = 0;
-            const size_t need = (size_t)M * K + (size_t)N * K;
-            EGO_CHECK(tile == 17 || need <= scratch_elems, "tile 18: call tile 17 with the same shape first");
-            if (need > scratch_elems) {
-                if (scratch) EGO_HIP(hipFree(scratch));
-                scratch = nullptr; scratch_elems = 0;
-                EGO_HIP(hipMalloc((void**)&scratch, need * 2));
-                scratch_elems = need;
-            }
-            EGO_CHECK(K % 8 == 0, "tile 17: K must be a multiple of 8");
-            const long a8 = (long)M * K / 8, w8 = (long)N * K / 8;
-            if (tile == 17) {
-                hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((a8 + 255) / 256)), dim3(256), 0, s, x, scratch, a8);
-                hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, s, w, scratch + (size_t)M * K, w8);
-            }
-            SegMatB Bm;
-            for (int i = 0; i < 3; ++i) Bm.p[i] = scratch + (size_t)M * K;
-            Bm.seg = N; Bm.ld = K;
-            e = gemm_bf16_dma_launch(scratch, (long)K, Bm, EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), s);
-            break;
-        }
         default: egotap_set_error("unknown tile id %d", tile); return EGOTAP_ERR_INVALID;
     }
     if (e == hipErrorInvalidValue) {
         egotap_set_error("egotap_linear_f32: N=%d / K=%d not a multiple of the tile (%s)", N, K, egotap_gemm_tile_name(tile));
         return EGOTAP_ERR_INVALID;
     }
+    EGO_HIP(e);
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(0)
+// y = x w^T + b on gemm_bf16_dma_kernel with CALLER-OWNED bf16 copies of both operands (x [M,K], w [N,K], row-major) -- the
+// kernel the plain-bf16 mode runs after rounding its operands; exported for the operator tests
+extern "C" int egotap_linear_bf16_dma(const void* x_bf16, const void* w_bf16, const float* b, float* y, int M, int N, int K, void* stream) {
+    EGO_CHECK(x_bf16 && w_bf16 && b && y, "egotap_linear_bf16_dma: null argument");
+    EGO_CHECK(M >= 0 && N > 0 && K > 0 && K % 8 == 0, "egotap_linear_bf16_dma: bad shape (K must be a multiple of 8)");
+    EGO_CHECK((((uintptr_t)x_bf16 | (uintptr_t)w_bf16) & 15) == 0, "egotap_linear_bf16_dma: operands must be 16-byte aligned");
+    SegMatB Bm;
+    for (int i = 0; i < 3; ++i) Bm.p[i] = (const __bf16*)w_bf16;
+    Bm.seg = N; Bm.ld = K;
+    hipError_t e = gemm_bf16_dma_launch((const __bf16*)x_bf16, (long)K, Bm, EpiBias{segvec1(b, N)}, y, N, M, N, K, device_cu_count(), (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) { egotap_set_error("egotap_linear_bf16_dma: N=%d / K=%d not a multiple of the 256 x 256 x 32 tile", N, K); return EGOTAP_ERR_INVALID; }
     EGO_HIP(e);
     return EGOTAP_OK;
 }
@@ -1449,12 +1441,14 @@ extern "C" int egotap_train_pose_loss(egotap_handle h, const float* pred, const 
 #endif
 
 #if EGOTAP_IN(1)
-extern "C" int egotap_train_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                                  float weight_decay, int step, void* stream) {
+extern "C" int egotap_train_adamw(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                                  double weight_decay, int step, void* stream) {
     EGO_CHECK(p && g && m && v && step >= 1, "egotap_train_adamw: bad argument");
-    const float bc1 = 1.0f - powf(beta1, (float)step), bc2s = sqrtf(1.0f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1,
-                       beta2, eps, weight_decay, bc1, bc2s);
+    // bias corrections and step size in double on the host, as torch.optim.AdamW computes them (python floats); the kernel gets
+    // step_size = lr / bc1 and 1 / sqrt(bc2) already rounded once
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2s = sqrt(1.0 - pow(beta2, (double)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, (float)lr,
+                       (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)bc1, (float)bc2s);
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }

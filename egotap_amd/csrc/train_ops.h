@@ -62,11 +62,16 @@ static __global__ __launch_bounds__(64) void pose_loss_kernel(LossArgs a) {
     __syncthreads();
     // gather, fixed order: own distance term + own bone (child side) - bones of the children in index order
     if (t >= off && t < JJ) {
-        float d[3] = {dm[0] + Gb[t][0], dm[1] + Gb[t][1], dm[2] + Gb[t][2]};
+        float d[3] = {Gb[t][0], Gb[t][1], Gb[t][2]};
         for (int ch = 1 + off; ch < JJ; ++ch)
             if (a.parents[ch] == t) { d[0] -= Gb[ch][0]; d[1] -= Gb[ch][1]; d[2] -= Gb[ch][2]; }
+        // plane 0: d loss_pose / d pred, plane 1: d loss_cos_sim / d pred (the caller weighs them with the two upstream gradients)
+        const long plane = (long)a.B * J * 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a.dpred[((long)b * J + t - off) * 3 + c] = d[c];
+        for (int c = 0; c < 3; ++c) {
+            a.dpred[((long)b * J + t - off) * 3 + c] = dm[c];
+            a.dpred[plane + ((long)b * J + t - off) * 3 + c] = d[c];
+        }
     }
     dist = wave_sum(dist);
     cosv = wave_sum(cosv);

@@ -238,3 +238,15 @@ def hm_train_forward(net, left, right):
             net._pack = torch.empty(_lib.load().egotap_hmtrain_pack_bytes(), dtype=torch.uint8, device=left.device)
         _lib.check(_lib.load().egotap_hmtrain_set_pack_buffer(net._ensure_handle(), C.c_void_p(net._pack.data_ptr()), net._pack.numel()))
     return HmTrainFn.apply(net, left, right, *params)
+
+
+def hm_train_forward_nograd(net, left, right):
+    """train-mode forward (batch-statistics BatchNorm2d per eye, running stats updated) with no graph: what the reference's FROZEN
+    estimators compute while the lifting head trains under train.py:91 model.train() (egotap_autoencoder_model.py:179)"""
+    was = net.training
+    net.train()
+    try:
+        with torch.no_grad():
+            return hm_train_forward(net, left, right)
+    finally:
+        net.train(was)

@@ -45,6 +45,7 @@ _PROTOS = {
     "egotap_hm_intermediate": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "egotap_linear_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
     "egotap_gemm_tile_name": (C.c_char_p, [C.c_int]),
+    "egotap_linear_bf16_dma": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "egotap_layernorm_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "egotap_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "egotap_pose_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -79,7 +80,7 @@ _PROTOS = {
     "egotap_train_pose_head_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "egotap_train_pose_head_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "egotap_train_pose_loss": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_float, C.c_float, C.c_void_p]),
-    "egotap_train_adamw": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int, C.c_void_p]),
+    "egotap_train_adamw": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_double] * 5 + [C.c_int, C.c_void_p]),
     # ---- heatmap-estimator training operators
     "egotap_hmtrain_conv_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_int64] * 3 + [C.c_void_p]),
     "egotap_hmtrain_set_pack_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -166,6 +167,19 @@ def linear(x, w, b, epi: str = "bias", residual=None, bn=None, tile: int = 0):
     y = torch.empty((M, N), device=x.device, dtype=torch.float32)
     check(load().egotap_linear_f32(_ptr(x), _ptr(w), _ptr(b), _ptr(y), M, N, K, code, _ptr(residual), _ptr(g), _ptr(beta),
                                    _ptr(mean), _ptr(var), tile, _stream()))
+    return y
+
+
+def linear_bf16_dma(x_bf16, w_bf16, b):
+    """y = x @ w.T + b on the LDS-DMA bf16 kernel; x [M,K], w [N,K] torch.bfloat16 (caller-owned copies), b fp32 -> fp32"""
+    import torch
+    if not (x_bf16.is_cuda and w_bf16.is_cuda and x_bf16.dtype == torch.bfloat16 and w_bf16.dtype == torch.bfloat16
+            and x_bf16.is_contiguous() and w_bf16.is_contiguous()):
+        raise EgotapError("linear_bf16_dma needs contiguous bfloat16 operands on the GPU")
+    _need_cuda_f32(b)
+    (M, K), N = x_bf16.shape, w_bf16.shape[0]
+    y = torch.empty((M, N), device=x_bf16.device, dtype=torch.float32)
+    check(load().egotap_linear_bf16_dma(_ptr(x_bf16), _ptr(w_bf16), _ptr(b), _ptr(y), M, N, K, _stream()))
     return y
 
 

@@ -31,29 +31,6 @@ def create_model(opt):
     return model
 
 
-def batch_procrustes(S1: torch.Tensor, S2: torch.Tensor) -> torch.Tensor:
-    """Similarity-align S1 [B,J,3] onto S2 [B,J,3] (scale, rotation, translation); restates
-    utils/util.py:328-379 (batch_compute_similarity_transform_torch) for the PA-MPJPE metric."""
-    X1, X2 = S1.transpose(1, 2), S2.transpose(1, 2)                  # [B,3,J]
-    mu1, mu2 = X1.mean(dim=-1, keepdim=True), X2.mean(dim=-1, keepdim=True)
-    Y1, Y2 = X1 - mu1, X2 - mu2
-    var1 = (Y1 ** 2).sum(dim=(1, 2))
-    K = Y1 @ Y2.transpose(1, 2)
-    U, _, Vh = torch.linalg.svd(K)
-    V = Vh.transpose(1, 2)
-    Z = torch.eye(3, device=S1.device, dtype=S1.dtype).repeat(S1.shape[0], 1, 1)
-    Z[:, -1, -1] = torch.sign(torch.det(U @ V.transpose(1, 2)))
-    R = V @ Z @ U.transpose(1, 2)
-    scale = torch.diagonal(R @ K, dim1=1, dim2=2).sum(-1) / var1
-    t = mu2 - scale[:, None, None] * (R @ mu1)
-    return (scale[:, None, None] * (R @ X1) + t).transpose(1, 2)
-
-
-def mpjpe(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
-    """LossFuncMPJPE (utils/loss.py:79-85)."""
-    return torch.linalg.norm(gt - pred, dim=-1).mean()
-
-
 class EgoTAPAutoEncoderModel(nn.Module):
     def name(self):
         return "EgoTAP AutoEncoder model"
@@ -82,7 +59,25 @@ class EgoTAPAutoEncoderModel(nn.Module):
         self.optimizers, self.schedulers = [], []
         self.to(self.device)
         self._hm_ws = None
+        # --use_amp (egotap_autoencoder_model.py:21, 219, 317-323: fp16 autocast + GradScaler around the training forward / loss):
+        # mapped to the reduced-precision HIP mode -- bf16 matrix-core arithmetic with fp32 accumulation and fp32 master weights.
+        # bf16 keeps fp32's exponent range, so there is no loss scaling and no scaler state; evaluation stays fp32, as the
+        # reference disables autocast there (options/test_options.py:15, forward(evaluate=True)).
+        self.use_amp = bool(getattr(opt, "use_amp", False)) and self.isTrain
+        self.amp_precision = getattr(opt, "amp_precision", "bf16")
         if self.isTrain:
+            path = getattr(opt, "path_to_trained_heatmap", None)
+            if path is not None:
+                # egotap_autoencoder_model.py:113-126: <dir>_pos/<file> -> net_HeatMap, <dir>_<heatmap_type>/<file> -> net_RotHeatMap
+                d, f = os.path.dirname(path), os.path.basename(path)
+                self.load_networks(net=self.net_HeatMap, path_to_trained_weights=os.path.join(d + "_pos", f))
+                self.load_networks(net=self.net_RotHeatMap,
+                                   path_to_trained_weights=os.path.join(d + "_" + getattr(opt, "heatmap_type", "sin"), f))
+            elif not getattr(opt, "use_gt_heatmap", False):
+                # the reference would train from RGB through never-trained estimators whose parameters are not even in the
+                # optimizer (egotap_autoencoder_model.py:144-148): lifting from noise.  Refuse instead of doing that silently.
+                raise ValueError("training the lifting head from RGB needs --path_to_trained_heatmap (stage-1 checkpoints "
+                                 "<dir>_pos/<file> and <dir>_<heatmap_type>/<file>), or --use_gt_heatmap")
             # heatmap estimators are frozen while the lifting head trains (egotap_autoencoder_model.py:127-129, 144-148)
             for n in (self.net_HeatMap, self.net_RotHeatMap):
                 for prm in n.parameters():
@@ -119,7 +114,7 @@ class EgoTAPAutoEncoderModel(nn.Module):
             self._gt_cat = syn["cat"]
 
     # ---- forward -----------------------------------------------------------------------------------------------
-    def forward_heatmap(self):
+    def forward_heatmap(self, train_bn=False):
         p = self.net_AutoEncoder.preset
         J = p.n_joints_hm
         if getattr(self.opt, "use_gt_heatmap", False):
@@ -133,21 +128,29 @@ class EgoTAPAutoEncoderModel(nn.Module):
             right = self.input_rgb_right.float().contiguous()
             B = left.shape[0]
             cat = torch.empty((B, p.in_channels, p.hm_size, p.hm_size), dtype=torch.float32, device=left.device)
-            ws = self.net_HeatMap._workspace(B, left.device)          # one scratch shared by both estimators
-            self.net_HeatMap.forward_into(left, right, cat, 0, workspace=ws)
-            self.net_RotHeatMap.forward_into(left, right, cat, 2 * J, workspace=ws)
+            if train_bn:
+                from .hm_training import hm_train_forward_nograd
+                cat[:, :2 * J] = hm_train_forward_nograd(self.net_HeatMap, left, right)
+                cat[:, 2 * J:] = hm_train_forward_nograd(self.net_RotHeatMap, left, right)
+            else:
+                ws = self.net_HeatMap._workspace(B, left.device)          # one scratch shared by both estimators
+                self.net_HeatMap.forward_into(left, right, cat, 0, workspace=ws)
+                self.net_RotHeatMap.forward_into(left, right, cat, 2 * J, workspace=ws)
         self.pred_heatmap_cat = cat
         self.pred_heatmap_left, self.pred_heatmap_right = cat[:, :J], cat[:, J:2 * J]
         self.pred_limb_heatmap_left, self.pred_limb_heatmap_right = cat[:, 2 * J:4 * J], cat[:, 4 * J:]
 
     def forward(self, evaluate=False):
-        if getattr(self.opt, "use_amp", False) and not evaluate:
-            raise NotImplementedError("fp16 autocast (--use_amp) is not reproduced; the HIP training path is fp32")
         with torch.no_grad():
             was = (self.net_HeatMap.training, self.net_RotHeatMap.training)
-            # frozen estimators run with folded (eval) BatchNorm: documented deviation from train.py:91
-            self.net_HeatMap.eval(); self.net_RotHeatMap.eval()
-            self.forward_heatmap()
+            # Frozen estimators: the reference's train.py:91 model.train() leaves their BatchNorm2d on batch statistics (and its
+            # running stats drifting) while the head trains.  Default here: folded running-stat BatchNorm (what the checkpoints
+            # were validated with; INTEGRATION.md states the deviation).  opt.frozen_heatmap_bn_train = True reproduces the
+            # reference: train-mode forward of the estimators (batch statistics per eye, running stats updated), no gradient.
+            ref_bn = self.isTrain and not evaluate and getattr(self.opt, "frozen_heatmap_bn_train", False) and was[0]
+            if not ref_bn:
+                self.net_HeatMap.eval(); self.net_RotHeatMap.eval()
+            self.forward_heatmap(train_bn=ref_bn)
             self.net_HeatMap.train(was[0]); self.net_RotHeatMap.train(was[1])
         if self.net_AutoEncoder.training and not evaluate:
             from .training import lift_train_forward
@@ -170,10 +173,13 @@ class EgoTAPAutoEncoderModel(nn.Module):
         self.loss_total = self.loss_total + both.sum()
 
     def optimize_parameters(self):
-        """One step of egotap_autoencoder_model.py:299-323 (fp32): forward, loss, backward, AdamW -- all on HIP kernels."""
+        """One step of egotap_autoencoder_model.py:299-323: forward, loss, backward, AdamW -- all on HIP kernels (fp32, or the
+        bf16 mode under --use_amp; no GradScaler: bf16 has fp32's exponent range)."""
         if not self.isTrain:
             raise RuntimeError("optimize_parameters() needs a model created with opt.isTrain = True")
         self.net_AutoEncoder.train()
+        if self.use_amp and getattr(self.net_AutoEncoder, "precision", "f32") == "f32":
+            self.net_AutoEncoder.set_precision(self.amp_precision)      # --use_amp: reduced-precision training arithmetic
         for o in self.optimizers:
             o.zero_grad()
         self.forward()
@@ -199,7 +205,12 @@ class EgoTAPAutoEncoderModel(nn.Module):
     def evaluate(self, runnning_average_dict):
         self.set_eval_mode()
         with torch.no_grad():
+            prec = getattr(self.net_AutoEncoder, "precision", "f32")
+            if self.use_amp and prec != "f32":
+                self.net_AutoEncoder.set_precision("f32")        # autocast is off in evaluation (forward(evaluate=True))
             self.forward(evaluate=True)
+            if self.use_amp and prec != "f32":
+                self.net_AutoEncoder.set_precision(prec)
             from . import lib as _lib                     # one fused launch: per-sample MPJPE + Procrustes-aligned MPJPE
             err, pa = _lib.pose_metrics(self.pred_pose, self.gt_pose)
             err, pa = (err * self.cm2mm).cpu(), (pa * self.cm2mm).cpu()      # one device->host copy, not one per sample
@@ -242,7 +253,12 @@ class EgoTAPAutoEncoderModel(nn.Module):
 
     def load_networks(self, which_epoch=None, net=None, path_to_trained_weights=None, checkpoint_path=None):
         if path_to_trained_weights is not None:
-            sd = torch.load(path_to_trained_weights, map_location="cpu")
+            # base_model.py:136-146: "./log/" is stripped and the rest joined with opt.log_dir; module. prefixes of a
+            # DataParallel checkpoint are dropped under --distributed (here: always, it is harmless)
+            if "./log" in path_to_trained_weights:
+                path_to_trained_weights = path_to_trained_weights.replace("./log/", "")
+            weight_path = os.path.join(getattr(self.opt, "log_dir", "./log"), path_to_trained_weights)
+            sd = torch.load(weight_path, map_location="cpu")
             sd = OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in sd.items())
             net.load_state_dict(sd)
             return
@@ -278,8 +294,6 @@ class HeatmapSharedModel(nn.Module):
         self.isTrain = getattr(opt, "isTrain", False)
         self.save_dir = os.path.join(getattr(opt, "log_dir", "./log"), getattr(opt, "experiment_name", "experiment"))
         self.device = torch.device("cuda:{}".format(self.gpu_ids[0])) if self.gpu_ids else torch.device("cuda:0")
-        if getattr(opt, "use_amp", False):
-            raise NotImplementedError("fp16 autocast (--use_amp) is not reproduced; the HIP training path is fp32")
         if not getattr(opt, "stereo", True):
             raise NotImplementedError("only the stereo presets are built")
         if opt.num_heatmap > 0 and opt.num_rot_heatmap > 0:
@@ -292,6 +306,12 @@ class HeatmapSharedModel(nn.Module):
         self.net_HeatMap = networks.HeatMap_UnrealEgo_Shared(opt, getattr(opt, "model_name", "resnet18"), 2)
         self.optimizers, self.schedulers = [], []
         self.to(self.device)
+        # --use_amp (heatmap_shared_model.py:17, 99, 111: fp16 autocast + GradScaler): the reduced-precision HIP mode of the
+        # estimator's convolutions (split-bf16 matrix-core products, fp32 accumulate, fp32 master weights; no scaler needed)
+        if self.isTrain and getattr(opt, "use_amp", False):
+            self.net_HeatMap.set_precision(getattr(opt, "amp_precision_heatmap", "bf16x3"))
+        if self.isTrain and getattr(opt, "path_to_trained_heatmap", None) is not None:
+            self.load_networks(net=self.net_HeatMap, path_to_trained_weights=opt.path_to_trained_heatmap)   # heatmap_shared_model.py:60-64
         if self.isTrain:
             if getattr(opt, "weight_decay", 0.0) != 0.0:
                 raise NotImplementedError("torch.optim.Adam's L2 weight decay is not built (the shipped scripts use 0)")

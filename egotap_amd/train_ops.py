@@ -127,9 +127,9 @@ def attention_bwd(qkv, ctx, dctx, lse, B, N, heads, precision="f32"):
 
 
 def pose_loss(h, pred, gt, lambda_mpjpe=0.1, lambda_cos_sim=-0.01):
-    """returns (losses[2] = (loss_pose, loss_cos_sim), d(sum)/d pred)"""
+    """returns (losses[2] = (loss_pose, loss_cos_sim), dpred [2, B, J, 3] = (d loss_pose / d pred, d loss_cos_sim / d pred))"""
     B = pred.shape[0]
-    dpred = torch.empty_like(pred)
+    dpred = torch.empty((2,) + tuple(pred.shape), dtype=torch.float32, device=pred.device)
     out = torch.empty(2, dtype=torch.float32, device=pred.device)
     partial = torch.empty((B, 2), dtype=torch.float32, device=pred.device)
     _lib.check(_lib.load().egotap_train_pose_loss(h, _p(pred), _p(gt), _p(dpred), _p(out), _p(partial), B, lambda_mpjpe, lambda_cos_sim, _s()))

@@ -204,9 +204,8 @@ class PoseLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (dpred,) = ctx.saved_tensors
-        # d(out[0] + out[1]) / d pred is what the kernel produced; both weights are 1 in loss_total = sum(losses)
-        scale = dout[0] if dout is not None else 1.0
-        return None, dpred * scale, None, None, None
+        # the kernel keeps the two terms apart, so any weighting of (loss_pose, loss_cos_sim) downstream gets its exact gradient
+        return None, dpred[0] * dout[0] + dpred[1] * dout[1], None, None, None
 
 
 def lift_train_forward(net, hm):

@@ -127,6 +127,9 @@ int egotap_linear_f32(const float* x, const float* w, const float* b, float* y, 
                       const float* r, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
                       const float* bn_var, int tile, void* stream);
 const char* egotap_gemm_tile_name(int tile);
+/* y = x w^T + b with both operands already bf16 (caller-owned copies x [M,K], w [N,K], 16-byte aligned; N % 256 == 0, K % 32 == 0):
+ * the LDS-DMA kernel of EGOTAP_PREC_BF16 (gemm_bf16_dma.h), fp32 accumulate, fp32 result */
+int egotap_linear_bf16_dma(const void* x_bf16, const void* w_bf16, const float* b, float* y, int M, int N, int K, void* stream);
 /* nn.LayerNorm over the last dim (1024), modeling_vit.py:357-358 */
 int egotap_layernorm_f32(const float* x, float* y, const float* gamma, const float* beta, int rows, int dim, float eps,
                          void* stream);
@@ -193,10 +196,14 @@ int egotap_train_pu_bwd(egotap_handle h, const float* posz, const float* rotz, i
 int egotap_train_pose_head_fwd(egotap_handle h, const float* posz, const float* hs1, int B, float* pose, void* stream);
 int egotap_train_pose_head_bwd(egotap_handle h, const float* posz, const float* hs1, const float* dpose, int B, float* dposz,
                                float* dhs1, float* dWp, float* dbp, float* dWg, float* dbg, int accumulate, void* stream);
+/* out[2] = (loss_pose, loss_cos_sim) as backward_AutoEncoder weighs them; dpred [2, B, J, 3]: plane 0 = d loss_pose / d pred,
+ * plane 1 = d loss_cos_sim / d pred; partial [B, 2] scratch */
 int egotap_train_pose_loss(egotap_handle h, const float* pred, const float* gt, float* dpred, float* out, float* partial,
                            int B, float lambda_mpjpe, float lambda_cos_sim, void* stream);
-int egotap_train_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                       float weight_decay, int step, void* stream);
+/* torch.optim.AdamW update of one tensor; hyper-parameters are doubles (python floats): the bias corrections 1 - beta^step are
+ * computed in double on the host, as torch does */
+int egotap_train_adamw(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                       double weight_decay, int step, void* stream);
 
 /* ---- heatmap-estimator training operators (fp32), called by the autograd glue (egotap_amd/hm_training.py) ----------------
  * One optimisation step of the stage-1 model (model/heatmap_shared_model.py:98-172): HeatMap_UnrealEgo_Shared in train mode

@@ -145,7 +145,7 @@ def test_linear_f32_dma_bit_identical(M, N, K):
 
 def test_linear_dma_kernels_random_shapes():
     """seeded sweep over odd row counts and every slab count around the pipeline depth: both DMA-staged GEMMs reproduce their
-    register-staged counterparts bit for bit (fp32: tile 19 vs 12; bf16: tile 17 vs 16)"""
+    register-staged counterparts bit for bit (fp32: tile 19 vs 12; bf16: egotap_linear_bf16_dma on bf16 copies vs tile 16)"""
     from egotap_amd import lib
     rng = np.random.default_rng(20240607)
     for trial in range(24):
@@ -155,7 +155,7 @@ def test_linear_dma_kernels_random_shapes():
         x, w, b = _rand((M, K32), 200 + trial), _rand((N, K32), 300 + trial, -0.2, 0.2), _rand((N,), 400 + trial)
         xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
         assert torch.equal(lib.linear(xc, wc, bc, tile=19), lib.linear(xc, wc, bc, tile=12)), (M, N, K32)
-        assert torch.equal(lib.linear(xc, wc, bc, tile=17), lib.linear(xc, wc, bc, tile=16)), (M, N, K32)
+        assert torch.equal(lib.linear_bf16_dma(xc.bfloat16(), wc.bfloat16(), bc), lib.linear(xc, wc, bc, tile=16)), (M, N, K32)
         K16 = K32 + 16                                   # fp32 slabs are 16 deep: odd slab counts too
         x, w = _rand((M, K16), 500 + trial), _rand((N, K16), 600 + trial, -0.2, 0.2)
         assert torch.equal(lib.linear(x.cuda(), w.cuda(), bc, tile=19), lib.linear(x.cuda(), w.cuda(), bc, tile=12)), (M, N, K16)
@@ -189,19 +189,20 @@ def test_linear_bf16_plain(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 32), (300, 256, 96), (257, 512, 128), (1153, 768, 1024), (5000, 256, 64), (70000, 1024, 256)])
 def test_linear_bf16_dma(M, N, K):
-    """gemm_bf16_dma_kernel (tile 17: bf16 copies of both operands, global -> LDS DMA, xor-swizzled unpadded rows, 4 stages):
-    equals the float64 product of the bf16-rounded operands to fp32 rounding -- fewer slabs than stages, ragged M, tiles < CUs,
-    several tiles per workgroup (the last shape: 1100 tiles on 256 CUs) -- and bit for bit the register-staged bf16 kernel
-    (tile 16: same operand rounding, same k order per output element)."""
+    """gemm_bf16_dma_kernel (egotap_linear_bf16_dma: caller-owned bf16 copies of both operands, global -> LDS DMA, xor-swizzled
+    unpadded rows, 4 stages): equals the float64 product of the bf16-rounded operands to fp32 rounding -- fewer slabs than stages,
+    ragged M, tiles < CUs, several tiles per workgroup (the last shape: 1100 tiles on 256 CUs) -- and bit for bit the
+    register-staged bf16 kernel (tile 16: same operand rounding (RNE, as torch's .bfloat16()), same k order per output element)."""
     from egotap_amd import lib
     x, w, b = _rand((M, K), 51), _rand((N, K), 52, -1.0, 1.0) / math.sqrt(K), _rand((N,), 53)
-    y = lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=17)
+    xb, wb = x.cuda().bfloat16(), w.cuda().bfloat16()
+    y = lib.linear_bf16_dma(xb, wb, b.cuda())
     if M * N <= 4_000_000:
         ref = x.bfloat16().double() @ w.bfloat16().double().T + b.double()
         _close(y, ref, atol=2e-6 * math.sqrt(K))
     y16 = lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=16)
     assert torch.equal(y, y16)
-    assert torch.equal(y, lib.linear(x.cuda(), w.cuda(), b.cuda(), tile=18))       # reuses the bf16 copies: GEMM alone, reproducible
+    assert torch.equal(y, lib.linear_bf16_dma(xb, wb, b.cuda()))       # run to run reproducible
 
 
 def test_linear_bf16x3_identity_asymmetric_and_ragged_rows():

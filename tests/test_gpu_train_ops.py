@@ -146,10 +146,18 @@ def test_pose_loss(preset):
     pred, gt = _rand((7, J, 3), 41, -20, 20), _rand((7, J, 3), 42, -20, 20)
     pr = pred.double().requires_grad_(True)
     lp, lc = O.loss_mpjpe(pr, gt.double()) * 0.1, O.loss_cos_sim(pr, gt.double(), p) * (-0.01) * 0.1
-    (lp + lc).backward()
+    g_pose, = torch.autograd.grad(lp, pr, retain_graph=True)
+    g_cos, = torch.autograd.grad(lc, pr)
     out, dpred = T.pose_loss(net._ensure_handle(), pred.cuda(), gt.cuda())
     np.testing.assert_allclose(out.cpu().numpy(), [lp.item(), lc.item()], rtol=2e-5, atol=1e-7)
-    _close(dpred, pr.grad, 1e-7, rtol=1e-4)
+    _close(dpred[0], g_pose, 1e-7, rtol=1e-4)          # the two terms are kept apart (PoseLossFn weighs them with the upstream gradients)
+    _close(dpred[1], g_cos, 1e-7, rtol=1e-4)
+    # any weighting of the two returned losses gets its exact gradient through the autograd wrapper
+    from egotap_amd.training import PoseLossFn
+    pc = pred.cuda().requires_grad_(True)
+    both = PoseLossFn.apply(net, pc, gt.cuda(), 0.1, -0.01)
+    (2.0 * both[0] - 3.0 * both[1]).backward()
+    _close(pc.grad, 2.0 * g_pose - 3.0 * g_cos, 1e-7, rtol=1e-4)
 
 
 def test_adamw_matches_torch():
