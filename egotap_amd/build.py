@@ -31,7 +31,7 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-PARTS = (0, 1, 2)      # egotap_abi.hip compiled as three translation units in parallel (-DEGOTAP_PART=n), then linked
+PARTS = (0, 1, 2, 3)   # egotap_abi.hip compiled as four translation units in parallel (-DEGOTAP_PART=n), then linked
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

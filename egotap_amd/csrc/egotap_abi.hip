@@ -23,8 +23,8 @@
 #include "heatmap_synth.h"
 #include "pu_chain.h"
 
-// The library is ONE source compiled as three translation units in parallel (egotap_amd/build.py: -DEGOTAP_PART=0 core and
-// inference, 1 lifting-head training operators, 2 heatmap-estimator training operators); every exported function belongs to one
+// The library is ONE source compiled as four translation units in parallel (egotap_amd/build.py: -DEGOTAP_PART=0 core and
+// inference, 1 lifting-head training operators, 2 heatmap-estimator training operators, 3 bf16-storage operators); every exported function belongs to one
 // part, the static helpers and kernel templates are visible to all.  Without EGOTAP_PART the file is a single translation unit.
 #ifndef EGOTAP_PART
 #define EGOTAP_PART -1
@@ -1171,6 +1171,7 @@ extern "C" int egotap_attention(const float* qkv, float* ctx, int B, int N, int 
 #include "gemm_tn_f32.h"
 #include "gemm_tn_bf16.h"
 #include "train_ops.h"
+#include "gemm_bf16s.h"
 
 using TnBig = TnCfg<256, 256, 16, 4, 2>;     // 8 waves, 64x128 per wave
 using TnSmall = TnCfg<128, 128, 16, 2, 2>;   // 4 waves, 64x64 per wave
@@ -2008,6 +2009,39 @@ extern "C" int egotap_hmtrain_upsample_fwd(const float* x, float* y, int N, int 
     hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, HIN, (long)in_istride,
                        (long)out_istride);
     EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+#endif
+
+
+// ================================================================================================ bf16-storage operators (part 3)
+// EGOTAP_PREC_BF16 with bf16 tensors in HBM: activations are written as bf16 by their producers, weights are rounded once per
+// step; every GEMM reads bf16 through the LDS DMA (gemm_bf16s.h).  Single operators first (tests, tools), the whole step below.
+#if EGOTAP_IN(3)
+extern "C" int egotap_bf16_gemm_nt(const void* x, int64_t ldx, const void* w, const float* bias, int M, int N, int K, int epi, const void* aux,
+                                   void* out0, void* out1, int64_t ldo, void* stream) {
+    EGO_CHECK(x && w && out0, "egotap_bf16_gemm_nt: null argument");
+    EGO_CHECK(M >= 0 && N > 0 && K > 0 && N % 256 == 0 && K % 32 == 0, "egotap_bf16_gemm_nt: N must be a multiple of 256 and K of 32 (N=%d K=%d)", N, K);
+    EGO_CHECK(ldx % 8 == 0 && ldo % 8 == 0 && ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out0 | (uintptr_t)out1 | (uintptr_t)aux)) & 15) == 0,
+              "egotap_bf16_gemm_nt: operands must be 16-byte aligned, leading dimensions multiples of 8");
+    hipStream_t s = (hipStream_t)stream;
+    const XPlain xl{(const __bf16*)x, (long)ldx};
+    const __bf16* wb = (const __bf16*)w;
+    const int cu = device_cu_count();
+    hipError_t e;
+    switch (epi) {
+        case 0: e = gemm_bf16s_launch(xl, wb, (long)K, SEpiBf16{bias, (__bf16*)out0, (long)ldo}, M, N, K, cu, s); break;
+        case 1: EGO_CHECK(bias && aux, "egotap_bf16_gemm_nt: epi 1 needs bias and residual");
+                e = gemm_bf16s_launch(xl, wb, (long)K, SEpiResF32{bias, (const float*)aux, (float*)out0, (long)ldo}, M, N, K, cu, s); break;
+        case 2: EGO_CHECK(bias && out1, "egotap_bf16_gemm_nt: epi 2 needs bias and the second output");
+                e = gemm_bf16s_launch(xl, wb, (long)K, SEpiGeluSave{bias, (__bf16*)out0, (__bf16*)out1, (long)ldo}, M, N, K, cu, s); break;
+        case 3: EGO_CHECK(aux, "egotap_bf16_gemm_nt: epi 3 needs the saved pre-activation");
+                e = gemm_bf16s_launch(xl, wb, (long)K, SEpiGeluGrad{(const __bf16*)aux, (__bf16*)out0, (long)ldo}, M, N, K, cu, s); break;
+        case 4: EGO_CHECK(bias, "egotap_bf16_gemm_nt: epi 4 needs bias");
+                e = gemm_bf16s_launch(xl, wb, (long)K, SEpiF32{bias, (float*)out0, (long)ldo}, M, N, K, cu, s); break;
+        default: egotap_set_error("egotap_bf16_gemm_nt: unknown epilogue %d", epi); return EGOTAP_ERR_INVALID;
+    }
+    EGO_HIP(e);
     return EGOTAP_OK;
 }
 #endif

@@ -1,0 +1,441 @@
+// bf16-STORAGE GEMM for the reduced-precision training / inference mode (EGOTAP_PREC_BF16):
+//     OUT = epi( X[M,K] * W[N,K]^T ),   X, W bf16 in HBM (activations are written as bf16 by their producers, weights are
+// rounded once per step by prep_weights_kernel), fp32 accumulate, OUT bf16 or fp32 -- nn.Linear forward and input gradient
+// (modeling_vit.py:226-230, 271, 319-344; net_architecture.py:366-368, 259-261) without a conversion pass per operand.
+//
+// Structure (256 x 256 tile, 8 waves = 2 groups x 4, one wave of each group per SIMD):
+//   * v_mfma_f32_16x16x32_bf16, MFMA A operand = W rows, B operand = X rows, so a lane's 4 accumulator registers are 4
+//     consecutive n of one row m.  Wave (g, wc) owns rows g*128..+127, columns wc*64..+63: 8 x 4 MFMA tiles, 128 accumulators.
+//   * K is walked in 32-deep K-tiles through a RING of four 32 KB LDS stages ([256 X rows | 256 W rows] x 64 bytes), filled
+//     by global_load_lds_dwordx4 (no staging registers, no ds_write).  A row's four 16-byte chunks are stored at chunk
+//     position c ^ swz(row), swz = (4 - ((row >> 2) & 3)) & 3: the ds_read_b128 of a 16x16x32 fragment (16 rows, chunk
+//     lane >> 4) then touches 16 distinct 16-byte bank groups in each of the instruction's four lane groups.  The swizzle
+//     is applied on the global side (which 16 bytes a lane fetches); the DMA itself writes lane i at base + 16 i.
+//   * Two PHASES per K-tile: phase a multiplies the wave's row half a (4 m-tiles x 4 n-tiles = 16 MFMAs); phase 0 reads the
+//     4 W fragments (kept for phase 1) and 4 X fragments, phase 1 reads 4 X fragments: 12 ds_read_b128 per 32 MFMAs.
+//   * The two wave groups run one barrier apart (group 1 takes one extra barrier up front): while a group's 16 MFMAs own the
+//     SIMD's matrix pipe, the other group's wave on that SIMD issues its DMA, its fragment reads and its waits.  Every
+//     phase is  [DMA of one half stage; fragment reads; vmcnt(8)] barrier [16 MFMAs] barrier.
+//   * Ring schedule (T = K-tile index of this workgroup's slab stream, which runs on across output tiles): phase 2T issues
+//     W(T+3), phase 2T+1 issues X(T+3).  Write-after-read: W(T) is last read in phase 2T, X(T) in 2T+1; with the groups
+//     one barrier apart a region may be refilled two phases after its last read -- exactly W(T+4) at 2T+2, X(T+4) at 2T+3.
+//     Read-after-write: the vmcnt(8) at the end of phase 2T-1 (four newer half stages may stay in flight) retires X(T) and W(T);
+//     the barrier that follows publishes them to the phase-2T readers of both groups.
+//   * Epilogue per wave through a private 4 KB LDS patch (xor-swizzled 16 x 64 fp32): accumulators -> rows -> epilogue
+//     functor on 4 (fp32 out) or 8 (bf16 out) consecutive n -> full-row-segment global stores.  No barrier inside, so the
+//     other group's MFMAs run under it.
+#pragma once
+#include "gemm_bf16.h"
+
+typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+
+struct SCfg {
+    static constexpr int BM = 256, BN = 256, BK = 32, NS = 4, THREADS = 512;
+    static constexpr int ROWB = 64;                       // bytes per LDS row (32 bf16)
+    static constexpr int PART = 256 * ROWB;               // X part or W part of a stage: 16 KiB
+    static constexpr int STAGE = 2 * PART;                // 32 KiB
+    static constexpr int EPATCH = 16 * 64 * 4;            // per-wave epilogue patch: 16 rows x 64 fp32
+    static constexpr int LDS_BYTES = NS * STAGE + (THREADS / 64) * EPATCH;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// ---------------------------------------------------------------------------------------------------- X-operand loaders (bf16)
+// ptr(row, k0, ko): address of the 8 consecutive k (16 bytes) k0 + ko .. of logical row `row`; k0 = first k of a 32-deep K-tile
+// (wave-uniform: the index arithmetic on it stays on the scalar unit), ko = 0, 8, 16 or 24
+struct XPlain {
+    const __bf16* A;
+    long lda;
+    struct Row { const __bf16* p; };
+    __device__ __forceinline__ Row row(int m) const { return Row{A + (long)m * lda}; }
+    __device__ __forceinline__ const __bf16* ptr(const Row& r, int k0, int ko) const { return r.p + k0 + ko; }
+};
+// fc1 of the position encoder: row (b, i) = the ppd x ppd patch tokens of heatmap i (net_architecture.py:388-406), tokens bf16 [B*seq, D]
+struct XTokens {
+    const __bf16* Y;
+    int T, D, seq, side, ppd, grid;
+    struct Row { const __bf16* p; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int b = m / T, i = m - b * T;
+        return Row{Y + ((long)b * seq + (long)(ppd * (i / grid)) * side + ppd * (i % grid)) * D};
+    }
+    __device__ __forceinline__ const __bf16* ptr(const Row& r, int k0, int ko) const {      // D % 32 == 0: a K-tile stays inside one patch token
+        const int s = k0 / D, c = k0 - s * D;
+        const int prl = s / ppd, pcl = s - prl * ppd;
+        return r.p + (long)(prl * side + pcl) * D + c + ko;
+    }
+};
+// fc1 of the rotation encoder: row (b, eye*J + j) = [cos map | sin map] of limb j (net_architecture.py:690-694), hm bf16 [B, C, HW]
+struct XRot {
+    const __bf16* hm;
+    int C, J, HW;
+    struct Row { const __bf16* p; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int T = 2 * J;
+        const int b = m / T, t = m - b * T;
+        const int eye = t / J, j = t - eye * J;
+        return Row{hm + (long)(b * C + 2 * J + eye * 2 * J + j) * HW};
+    }
+    __device__ __forceinline__ const __bf16* ptr(const Row& r, int k0, int ko) const {      // HW % 32 == 0
+        const int cs = k0 / HW;
+        return r.p + (long)cs * J * HW + (k0 - cs * HW) + ko;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------- epilogues
+// W = elements per lane and call: 4 for fp32 outputs (16 lanes cover a 256-byte row segment), 8 for bf16 outputs (8 lanes cover
+// 128 bytes).  col(n): per-column constants of the lane's W columns (loaded once per tile); fetch(m, n): per-element operands from
+// memory (residual, saved pre-activation), requested one 16-row block ahead of their use; emit(v, col, aux, m, n): v[0..W) =
+// accumulators of row m, columns n..n+W-1 (m < M guaranteed) -> exactly STORES global store instructions (the main loop counts
+// them: vmcnt is one in-order counter for DMA, loads and stores).
+struct SNoAux {};
+// "use" of a loaded value outside any lane predicate: the compiler then waits for the load HERE.  Without it a value whose only
+// uses sit under `if (m < M)` counts as possibly pending at the loop's back edge, and the waitcnt pass protects the registers it
+// lands in with vmcnt(0) waits in the middle of the main loop (they are reused as fragment registers there).
+__device__ __forceinline__ void s_keep(const SNoAux&) {}
+__device__ __forceinline__ void s_keep(const f32x4& v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void s_keep(const __bf16 __attribute__((ext_vector_type(8))) & v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void store_bf16x8(__bf16* p, const float* v) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+    *(bf16x8*)p = o;
+}
+struct SBias8 { f32x4 b0, b1; };
+__device__ __forceinline__ void s_keep(const SBias8& b) { asm volatile("" ::"v"(b.b0), "v"(b.b1)); }
+__device__ __forceinline__ SBias8 load_bias8(const float* bias, int n) {
+    if (bias == nullptr) return SBias8{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    return SBias8{*(const f32x4*)(bias + n), *(const f32x4*)(bias + n + 4)};
+}
+struct SEpiBf16 {            // out bf16 = acc (+ bias)
+    static constexpr int W = 8, STORES = 1;
+    const float* bias;       // may be null
+    __bf16* out;
+    long ld;
+    typedef SBias8 Col;
+    typedef SNoAux Aux;
+    __device__ __forceinline__ Col col(int n) const { return load_bias8(bias, n); }
+    __device__ __forceinline__ Aux fetch(int m, int n) const { return Aux{}; }
+    __device__ __forceinline__ void emit(float* v, const Col& c, const Aux&, int m, int n) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] += c.b0[i]; v[4 + i] += c.b1[i]; }
+        store_bf16x8(out + (long)m * ld + n, v);
+    }
+};
+struct SEpiResF32 {          // out f32 = acc + bias + R   (R may alias out)
+    static constexpr int W = 4, STORES = 1;
+    const float* bias;
+    const float* R;
+    float* out;
+    long ld;
+    typedef f32x4 Col;
+    typedef f32x4 Aux;
+    __device__ __forceinline__ Col col(int n) const { return *(const f32x4*)(bias + n); }
+    __device__ __forceinline__ Aux fetch(int m, int n) const { return *(const f32x4*)(R + (long)m * ld + n); }
+    __device__ __forceinline__ void emit(float* v, const Col& c, const Aux& r, int m, int n) const {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = v[i] + c[i] + r[i];
+        *(f32x4*)(out + (long)m * ld + n) = o;
+    }
+};
+struct SEpiF32 {             // out f32 = acc + bias  (fc1: the BatchNorm statistics need the fp32 pre-activation)
+    static constexpr int W = 4, STORES = 1;
+    const float* bias;
+    float* out;
+    long ld;
+    typedef f32x4 Col;
+    typedef SNoAux Aux;
+    __device__ __forceinline__ Col col(int n) const { return *(const f32x4*)(bias + n); }
+    __device__ __forceinline__ Aux fetch(int m, int n) const { return Aux{}; }
+    __device__ __forceinline__ void emit(float* v, const Col& c, const Aux&, int m, int n) const {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = v[i] + c[i];
+        *(f32x4*)(out + (long)m * ld + n) = o;
+    }
+};
+struct SEpiGeluSave {        // z = acc + bias -> Z (bf16, kept for the backward); H = GELU(z) (bf16)
+    static constexpr int W = 8, STORES = 2;
+    const float* bias;
+    __bf16 *Z, *H;
+    long ld;
+    typedef SBias8 Col;
+    typedef SNoAux Aux;
+    __device__ __forceinline__ Col col(int n) const { return load_bias8(bias, n); }
+    __device__ __forceinline__ Aux fetch(int m, int n) const { return Aux{}; }
+    __device__ __forceinline__ void emit(float* v, const Col& c, const Aux&, int m, int n) const {
+        float g[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] += c.b0[i]; v[4 + i] += c.b1[i]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = gelu_erf(v[i]);
+        store_bf16x8(Z + (long)m * ld + n, v);
+        store_bf16x8(H + (long)m * ld + n, g);
+    }
+};
+struct SEpiGeluGrad {        // out bf16 = acc * GELU'(Z)   (Z bf16: the saved pre-activation)
+    static constexpr int W = 8, STORES = 1;
+    const __bf16* Z;
+    __bf16* out;
+    long ld;
+    typedef SNoAux Col;
+    typedef bf16x8 Aux;
+    __device__ __forceinline__ Col col(int n) const { return Col{}; }
+    __device__ __forceinline__ Aux fetch(int m, int n) const { return *(const bf16x8*)(Z + (long)m * ld + n); }
+    __device__ __forceinline__ void emit(float* v, const Col&, const Aux& z, int m, int n) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= dgelu_erf((float)z[i]);
+        store_bf16x8(out + (long)m * ld + n, v);
+    }
+};
+// input gradient of fc1 of the position encoder, scattered back to token order: row (b, i), column (s, c) -> token
+// (b, patch s of heatmap i), channel c.  The gather of XTokens is a bijection onto the non-dummy tokens (dummy rows stay zero:
+// the caller clears the buffer once).  out bf16 [B*seq, D]
+struct SEpiScatterTokens {
+    static constexpr int W = 8, STORES = 1;
+    __bf16* out;
+    int T, D, seq, side, ppd, grid;
+    typedef SNoAux Col;
+    typedef SNoAux Aux;
+    __device__ __forceinline__ Col col(int n) const { return Col{}; }
+    __device__ __forceinline__ Aux fetch(int m, int n) const { return Aux{}; }
+    __device__ __forceinline__ void emit(float* v, const Col&, const Aux&, int m, int n) const {
+        const int b = m / T, i = m - b * T;
+        const int s = n / D, c = n - s * D;
+        const int prl = s / ppd, pcl = s - prl * ppd;
+        const long tok = (long)b * seq + (long)(ppd * (i / grid) + prl) * side + ppd * (i % grid) + pcl;
+        store_bf16x8(out + tok * D + c, v);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------- kernel
+template <class XL, class Epi>
+__global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, const __bf16* __restrict__ Wb, long ldw, Epi epi, int M, int N, int K,
+                                                                       int tiles_m, int tiles_n) {
+    using Cfg = SCfg;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NS = Cfg::NS, ROWB = Cfg::ROWB, PART = Cfg::PART, STAGE = Cfg::STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem_s[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2, wc = wid & 3;
+    float* Es = (float*)(smem_s + NS * STAGE + wid * Cfg::EPATCH);
+
+    // tiles of this workgroup: XCD-aware chunk of the grouped tile order (as gemm_f32_persist_kernel)
+    const int ntiles = tiles_m * tiles_n, nb = gridDim.x, x8 = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int nbx = (nb >> 3) + (x8 < (nb & 7) ? 1 : 0);
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int lo_t = x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8;
+    const int cnt = q8 + (x8 < r8 ? 1 : 0);
+    const int my_n = cnt > jb ? (cnt - jb + nbx - 1) / nbx : 0;
+    const int KT = K / BK;
+    const int total = my_n * KT;                     // K-tiles of this workgroup's stream
+    if (total == 0) return;
+    auto tile_of = [&](int i, int& tm, int& tn) __attribute__((always_inline)) {
+        const int lin = lo_t + jb + i * nbx;
+        const int per_group = 8 * tiles_n;
+        const int g = lin / per_group, first = g * 8;
+        const int gsz = min(tiles_m - first, 8);
+        const int in = lin - g * per_group;
+        tm = first + in % gsz;
+        tn = in / gsz;
+    };
+
+    // ---- DMA duty of this wave per part: 16-row blocks wid and wid + 8.  Lane -> row lane >> 2 of the block, chunk position
+    // lane & 3, which holds logical chunk (lane & 3) ^ swz(row), swz(row) = (4 - ((row >> 2) & 3)) & 3 and (row >> 2) & 3 = lane >> 4.
+    const int drow = lane >> 2, dchunk = (lane & 3) ^ ((4 - (lane >> 4)) & 3);
+    typename XL::Row xr0, xr1;
+    const __bf16 *pw0, *pw1;
+    int lx_tile = 0, lx_kt = 0, lw_tile = 0, lw_kt = 0;       // position of the X / W issue streams (the W stream runs one phase ahead)
+    auto set_x = [&](int i) __attribute__((always_inline)) {
+        int tm, tn;
+        tile_of(i, tm, tn);
+        xr0 = xl.row(min(tm * BM + wid * 16 + drow, M - 1));
+        xr1 = xl.row(min(tm * BM + (wid + 8) * 16 + drow, M - 1));
+    };
+    auto set_w = [&](int i) __attribute__((always_inline)) {
+        int tm, tn;
+        tile_of(i, tm, tn);
+        pw0 = Wb + (long)(tn * BN + wid * 16 + drow) * ldw + dchunk * 8;
+        pw1 = Wb + (long)(tn * BN + (wid + 8) * 16 + drow) * ldw + dchunk * 8;
+    };
+    set_x(0);
+    set_w(0);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_s;
+    // inline asm: the compiler's waitcnt pass would drain vmcnt(0) before every LDS read after __builtin_amdgcn_global_load_lds;
+    // the waits are counted by hand below (a constant number of DMA instructions per phase, unconditionally)
+    auto dma1 = [&](const __bf16* g, unsigned lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+    };
+    auto issue_w = [&](int st) __attribute__((always_inline)) {        // W part of the next K-tile of the W stream -> stage st
+        const unsigned sa = lds0 + st * STAGE + PART + wid * 1024;
+        const int k0 = lw_kt * BK;
+        dma1(pw0 + k0, sa);
+        dma1(pw1 + k0, sa + 8 * 1024);
+        if (lw_tile < my_n && ++lw_kt == KT) {
+            lw_kt = 0;
+            if (++lw_tile < my_n) set_w(lw_tile);
+            else lw_kt = KT - 1;                 // stream exhausted: keep re-reading the last K-tile into a stage nobody reads
+        }
+    };
+    auto issue_x = [&](int st) __attribute__((always_inline)) {
+        const unsigned sa = lds0 + st * STAGE + wid * 1024;
+        const int k0 = lx_kt * BK;
+        dma1(xl.ptr(xr0, k0, dchunk * 8), sa);
+        dma1(xl.ptr(xr1, k0, dchunk * 8), sa + 8 * 1024);
+        if (lx_tile < my_n && ++lx_kt == KT) {
+            lx_kt = 0;
+            if (++lx_tile < my_n) set_x(lx_tile);
+            else lx_kt = KT - 1;
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment byte offset of this lane inside a 16-row block: row lane & 15, logical chunk lane >> 4
+    const int l15 = lane & 15;
+    const int foff = l15 * ROWB + (((lane >> 4) ^ ((4 - (l15 >> 2)) & 3)) << 4);
+    const int x_base = (grp * 128) * ROWB + foff;             // + mi * 16 * ROWB
+    const int w_base = PART + (wc * 64) * ROWB + foff;        // + ni * 16 * ROWB
+
+    int c_tile = 0, c_kt = 0;
+    // number of K-tiles (from the start of a tile) whose waits must leave the previous epilogue's stores in flight: vmcnt is ONE
+    // in-order counter, so a wait that retires a DMA also waits for every older store; the epilogue's NST stores are younger than
+    // the (up to) four half stages in flight and older than the ones issued after it, so for the first two K-tiles (four phases)
+    // of the next tile the allowance is 8 + NST, by which time the stores have had ~2 us to drain.  Only after a FULL tile (every
+    // lane active in every store: the count is exact); after a ragged tile the plain allowance makes the first wait drain them.
+    constexpr int IT = Epi::W == 4 ? 4 : 2, NST = 8 * IT * Epi::STORES;
+    static_assert(8 + NST <= 63, "vmcnt is a 6-bit counter");
+    int slack_kt = 0;
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        int tm, tn;
+        tile_of(c_tile, tm, tn);
+        const int m_wave = tm * BM + grp * 128, n_wave = tn * BN + wc * 64;
+        const int q = lane >> 4;
+        // lane -> (row of the 16-row block, first column) of its IT pieces
+        const int er = Epi::W == 4 ? q : (lane >> 3), en = n_wave + (Epi::W == 4 ? l15 * 4 : (lane & 7) * 8);
+        const typename Epi::Col cc = epi.col(en);
+        typename Epi::Aux ax[IT], an[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) ax[it] = epi.fetch(min(m_wave + (16 / IT) * it + er, M - 1), en);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            if (mi + 1 < 8) {
+#pragma unroll
+                for (int it = 0; it < IT; ++it) an[it] = epi.fetch(min(m_wave + (mi + 1) * 16 + (16 / IT) * it + er, M - 1), en);
+            }
+            // accumulators -> patch[16 m][64 n] (fp32), 16-byte chunk ch of row r at position ch ^ r
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                *(f32x4*)(Es + l15 * 64 + (((4 * ni + q) ^ l15) << 2)) = acc[mi][ni];
+                acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const int m0 = m_wave + mi * 16;
+            if (mi == 0) s_keep(cc);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int r = (16 / IT) * it + er;
+                s_keep(ax[it]);
+                if constexpr (Epi::W == 4) {
+                    const f32x4 v = *(const f32x4*)(Es + r * 64 + ((l15 ^ r) << 2));
+                    float vv[4] = {v[0], v[1], v[2], v[3]};
+                    if (m0 + r < M) epi.emit(vv, cc, ax[it], m0 + r, en);
+                } else {
+                    const int c2 = lane & 7;
+                    const f32x4 v0 = *(const f32x4*)(Es + r * 64 + (((2 * c2) ^ r) << 2));
+                    const f32x4 v1 = *(const f32x4*)(Es + r * 64 + (((2 * c2 + 1) ^ r) << 2));
+                    float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (m0 + r < M) epi.emit(vv, cc, ax[it], m0 + r, en);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) ax[it] = an[it];
+        }
+        slack_kt = ((tm + 1) * BM <= M && KT >= 4) ? 2 : 0;
+    };
+
+    // ---- prologue: K-tiles 0, 1, 2 complete (W then X each), then the steady-state issues of phases 0.. pick up W(3), X(3)
+    issue_w(0); issue_x(0);
+    issue_w(1); issue_x(1);
+    issue_w(2); issue_x(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // K-tile 0 has landed (K-tiles 1, 2 may be in flight) ...
+    __builtin_amdgcn_s_barrier();                          // ... for every wave: phase 0 may read it
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
+
+    bf16x8 wf[4], xf[4];
+    int st = 0;
+    for (int T = 0; T < total; ++T) {
+        const char* sa = smem_s + st * STAGE;
+        const int st3 = (st + 3) & 3;
+        // ---------------- phase 2T: row half 0
+        issue_w(st3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(sa + w_base + j * 16 * ROWB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(sa + x_base + i * 16 * ROWB);
+        __builtin_amdgcn_sched_barrier(0);
+        // retire the half stage issued four phases ago (this phase's and the three before it may stay in flight): it is read from
+        // the next phase on.  The wait sits behind this phase's own DMA and fragment reads, which do not depend on it.
+        if (slack_kt > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- phase 2T + 1: row half 1
+        issue_x(st3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(sa + x_base + (4 + i) * 16 * ROWB);
+        __builtin_amdgcn_sched_barrier(0);
+        if (slack_kt > 0) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST) : "memory"); --slack_kt; }
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        st = (st + 1) & 3;
+        if (++c_kt == KT) {
+            epilogue();
+            c_kt = 0;
+            ++c_tile;
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();          // matches group 1's extra barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing (dummy) DMAs must not outlive the workgroup's LDS
+}
+
+template <class XL, class Epi>
+static hipError_t gemm_bf16s_launch(const XL& xl, const __bf16* Wb, long ldw, const Epi& epi, int M, int N, int K, int num_cu, hipStream_t stream) {
+    using Cfg = SCfg;
+    if (M <= 0) return hipSuccess;
+    if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || ldw % 8 != 0) return hipErrorInvalidValue;
+    auto kern = gemm_bf16s_kernel<XL, Epi>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
+    const int ntiles = tiles_m * tiles_n;
+    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xl, Wb, ldw, epi, M, N, K, tiles_m, tiles_n);
+    return hipGetLastError();
+}

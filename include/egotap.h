@@ -243,6 +243,15 @@ int egotap_hmtrain_upsample_fwd(const float* x, float* y, int N, int C, int HIN,
 int egotap_hmtrain_mse(const float* pred, const float* gt, const float* plen, float* dpred, float* loss, int B, int Cn, int HW, float lambda,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* ---- bf16-storage operators (EGOTAP_PREC_BF16 with bf16 tensors in HBM; gemm_bf16s.h) -----------------------------------------
+ * nn.Linear forward / input gradient on bf16 operands:  OUT = epi(x[M,K] w[N,K]^T), x row stride ldx, outputs row stride ldo
+ * (elements).  N % 256 == 0, K % 32 == 0, 16-byte aligned pointers.  epi:
+ *   0  out0 bf16 = acc (+ bias if not NULL)                    1  out0 f32 = acc + bias + aux (aux: f32 residual, may alias out0)
+ *   2  out0 bf16 = z = acc + bias (may be NULL), out1 bf16 = GELU(z)      3  out0 bf16 = acc * GELU'(aux), aux: bf16 z
+ *   4  out0 f32 = acc + bias */
+int egotap_bf16_gemm_nt(const void* x, int64_t ldx, const void* w, const float* bias, int M, int N, int K, int epi, const void* aux,
+                        void* out0, void* out1, int64_t ldo, void* stream);
+
 /* ---- measurement hooks (bench.py roofline) ---- */
 /* when enabled, every GEMM launch of the handle is bracketed by HIP events on the caller's stream */
 int egotap_timing_enable(egotap_handle h, int enable);

@@ -1,0 +1,299 @@
+"""GPU tests of the BASELINE.json configurations that are not the headline:
+  config 3  UnrealEgo training step (fwd + bwd + AdamW), bf16, batch 1024, one GPU        -> create_model(opt) under --use_amp
+  config 4  the same step data-parallel                                                    -> two ranks sharing this one GPU (gloo)
+  config 5  EgoCap preset, 512x512 RGB = 128x128 heatmaps, bf16                            -> forward in plain bf16 + one train step
+All of them go through the reference-shaped wrapper (egotap_amd.models.create_model) and the C ABI.  The checker is the float64
+oracle (oracle/lift_ref.py, pinned by the reference's golden vectors), never the HIP fp32 path.
+
+bf16 error model used for the gates: an operand rounded to bf16 carries a relative error of at most 2^-9 (round to nearest even,
+8 significant bits), products are exact in the fp32 accumulator, so a length-K dot product of rounded operands has a relative error
+of about 2^-9 * sqrt(2) on a random-sign sum, independent of K; through the head's ~20 dependent rounded layers the loss and the
+large gradient tensors stay within a few 1e-2 (measured: loss 1e-3, gradient cosine >= 0.99).  The gates below are 1e-2 on the
+loss, cosine > 0.98 and relative L2 < 0.2 on every large gradient tensor against float64.
+"""
+import os
+import shlex
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from egotap_amd.synthetic import synth_input, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# flags of the reference's own stage-2 training script (scripts/train/PoseEstimator/unrealego.sh:4-30), verbatim
+UNREALEGO_TRAIN_FLAGS = """
+    --project_name UnrealEgoPose --experiment_name egotap_unrealego --model egotap_autoencoder
+    --use_amp --init_ImageNet --optimizer_type AdamW --lr_policy cos_anneal_warmup --lr 1e-3
+    --gpu_ids 0 --lambda_mpjpe 0.1 --lambda_rot 1.0 --lambda_indep_pos 0.1 --lambda_heatmap 1.0 --lambda_rot_heatmap 1.0
+    --lambda_cos_sim -0.01 --lambda_heatmap_rec 0.0 --lambda_rot_heatmap_rec 0.0 --skel_layer PU --ae_hidden_size 128
+    --patched_heatmap_ae --niter 1 --niter_decay 15 --batch_size 32 --num_rot_heatmap 15 --num_heatmap 15 --heatmap_type sin
+    --path_to_trained_heatmap ./log/unrealego_heatmap_shared/best_net_HeatMap.pth
+"""
+
+
+def _data(B, p, seed="cfg", gt_range=20.0):
+    J = p.n_joints_hm
+    hm = torch.from_numpy(synth_input(f"hm_{seed}", (min(B, 8), p.in_channels, p.hm_size, p.hm_size)))
+    hm = hm.repeat((B + hm.shape[0] - 1) // hm.shape[0], 1, 1, 1)[:B].contiguous()
+    gt = torch.from_numpy(synth_input(f"gt_{seed}", (B, p.out_joints, 3), -gt_range, gt_range))
+    data = {"input_rgb_left": torch.zeros(1, 3, 4, 4), "input_rgb_right": torch.zeros(1, 3, 4, 4), "gt_heatmap_left": hm[:, :J],
+            "gt_heatmap_right": hm[:, J:2 * J], "gt_limb_heatmap_left": hm[:, 2 * J:4 * J], "gt_limb_heatmap_right": hm[:, 4 * J:],
+            "gt_local_pose": gt}
+    return data, hm, gt
+
+
+def _model(preset="UnrealEgo", hm=64, **over):
+    from egotap_amd import models, spec
+    from egotap_amd.options import preset_defaults
+    opt = preset_defaults(preset, hm)
+    opt.isTrain, opt.use_gt_heatmap, opt.lr, opt.opt_eps, opt.weight_decay = True, True, 1e-3, 1e-4, 0.0
+    for k, v in over.items():
+        setattr(opt, k, v)
+    m = models.create_model(opt)
+    p = spec.lift_preset(preset, hm)
+    m.net_AutoEncoder.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
+    return m, p
+
+
+def _oracle_step(hm, gt, p, dtype=torch.float64):
+    from egotap_amd import spec
+    from oracle import lift_ref as O
+    sd = O.to_torch_sd(synth_state_dict(spec.lift_state_spec(p)), dtype)
+    return O.train_step(hm.to(dtype), gt.to(dtype), sd, p)
+
+
+def _grad_gates(net, ref_grads, cos_min, rel_max, min_numel=65536):
+    worst = (1.0, 0.0)
+    for k, v in net.named_parameters():
+        g = ref_grads.get(k)
+        if g is None:
+            assert v.grad is None, k
+            continue
+        assert v.grad is not None and torch.isfinite(v.grad).all(), k
+        if v.numel() < min_numel:
+            continue
+        a, b = v.grad.double().reshape(-1).cpu(), g.double().reshape(-1)
+        if float(b.norm()) < 1e-9:
+            continue
+        cos = float(a @ b / (a.norm() * b.norm()))
+        rel = float((a - b).norm() / b.norm())
+        assert cos > cos_min and rel < rel_max, f"{k}: cos {cos:.5f} rel {rel:.3e}"
+        worst = (min(worst[0], cos), max(worst[1], rel))
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------------------ --use_amp / flags
+def test_create_model_with_the_reference_training_flags(tmp_path):
+    """create_model(opt) with the exact flag set of scripts/train/PoseEstimator/unrealego.sh: --use_amp maps to the bf16 mode (no
+    GradScaler), --path_to_trained_heatmap loads <dir>_pos/<file> and <dir>_sin/<file> into the two frozen estimators
+    (egotap_autoencoder_model.py:113-129), the optimizer is AdamW with cos_anneal_warmup; one optimize_parameters() from RGB runs."""
+    from egotap_amd import models, options, spec
+    from egotap_amd.synthetic import synth_hm_state_dict
+    opt = options.parse_train(shlex.split(UNREALEGO_TRAIN_FLAGS))
+    assert opt.use_amp and opt.isTrain and opt.optimizer_type == "AdamW" and opt.lr_policy == "cos_anneal_warmup"
+    opt.log_dir = str(tmp_path)
+    opt.epoch_iter_cnt = 4
+    with pytest.raises(FileNotFoundError):
+        models.create_model(opt)                                   # the stage-1 checkpoints are required, as in the reference
+    sd_pos = {k: torch.from_numpy(v) for k, v in synth_hm_state_dict(15, "hm_pos.").items()}
+    sd_rot = {k: torch.from_numpy(v) for k, v in synth_hm_state_dict(30, "hm_rot.").items()}
+    for sub, sd in (("unrealego_heatmap_shared_pos", sd_pos), ("unrealego_heatmap_shared_sin", sd_rot)):
+        os.makedirs(tmp_path / sub)
+        torch.save(sd, tmp_path / sub / "best_net_HeatMap.pth")
+    m = models.create_model(opt)
+    for k, v in m.net_HeatMap.state_dict().items():
+        assert torch.equal(v.cpu(), sd_pos[k]), k
+    for k, v in m.net_RotHeatMap.state_dict().items():
+        assert torch.equal(v.cpu(), sd_rot[k]), k
+    assert not any(q.requires_grad for q in m.net_HeatMap.parameters()) and not any(q.requires_grad for q in m.net_RotHeatMap.parameters())
+    p = spec.lift_preset("UnrealEgo")
+    m.net_AutoEncoder.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
+    B = 2
+    data = {"input_rgb_left": torch.from_numpy(synth_input("rgb_l", (B, 3, 256, 256), -2.0, 2.0)),
+            "input_rgb_right": torch.from_numpy(synth_input("rgb_r", (B, 3, 256, 256), -2.0, 2.0)),
+            "gt_local_pose": torch.from_numpy(synth_input("gt_flags", (B, 16, 3), -20.0, 20.0))}
+    m.set_input(data)
+    m.update_learning_rate()                                       # warm-up starts at lr 0: take one scheduler step first
+    before = {k: v.detach().clone() for k, v in m.net_AutoEncoder.named_parameters()}
+    m.optimize_parameters()
+    assert m.net_AutoEncoder.precision == "bf16"                   # --use_amp -> reduced-precision HIP mode
+    errs = m.get_current_errors()
+    assert set(errs) == {"pose", "cos_sim"} and all(np.isfinite(v) for v in errs.values())
+    moved = sum(int(not torch.equal(before[k], v.detach())) for k, v in m.net_AutoEncoder.named_parameters())
+    assert moved >= 90                                             # every trained tensor moved; cls_token / pooler did not
+    # evaluation runs in fp32 whatever --use_amp says (options/test_options.py:15)
+    from egotap_amd.training import EgotapAdamW
+    assert isinstance(m.optimizers[0], EgotapAdamW)
+    class Avg(dict):
+        def update(self, d):
+            for k, v in d.items():
+                self.setdefault(k, []).append(float(v))
+    avg = Avg()
+    m.evaluate(avg)
+    assert len(avg["mpjpe"]) == B and m.net_AutoEncoder.precision == "bf16"
+
+    opt2 = options.parse_train(shlex.split(UNREALEGO_TRAIN_FLAGS.replace("--path_to_trained_heatmap ./log/unrealego_heatmap_shared/best_net_HeatMap.pth", "")))
+    with pytest.raises(ValueError):
+        models.create_model(opt2)                                  # training from RGB without trained estimators is refused
+
+
+# ------------------------------------------------------------------------------------------------------------ config 3
+def test_config3_bf16_step_b2_against_float64_oracle():
+    """one bf16 optimisation step at B = 2 against ONE STEP OF THE FLOAT64 ORACLE (not against the HIP fp32 step)"""
+    m, p = _model(use_amp=True)
+    data, hm, gt = _data(2, p, "c3", gt_range=1.0)
+    m.set_input(data)
+    m.optimize_parameters()
+    assert m.net_AutoEncoder.precision == "bf16"
+    ref = _oracle_step(hm, gt, p)
+    errs = m.get_current_errors()
+    np.testing.assert_allclose(errs["pose"], float(ref["loss_pose"]), rtol=1e-2)
+    np.testing.assert_allclose(errs["cos_sim"], float(ref["loss_cos_sim"]), rtol=5e-2, atol=1e-5)
+    pose = m.pred_pose.detach().double().cpu()
+    assert float((pose - ref["pose"]).abs().max()) < 3e-2 * float(ref["pose"].abs().max())
+    cos, rel = _grad_gates(m.net_AutoEncoder, ref["grads"], 0.98, 0.2)
+    print(f"bf16 step vs float64 oracle: worst gradient cosine {cos:.5f}, worst relative L2 {rel:.3e}")
+
+
+def test_config3_bf16_train_step_b1024_through_the_wrapper():
+    """BASELINE config 3 as stated: UnrealEgo, batch 1024, bf16, fwd + bwd + AdamW on one GPU, through create_model(opt).
+    Finite losses; a second model stepped on the same batch ends bit-identical (fixed-order reductions); peak memory bounded;
+    eval rows of the B = 1024 batch equal the same rows evaluated as a batch of 2 (samples are independent in eval)."""
+    B = 1024
+    finals, peaks, losses = [], [], []
+    for rep in range(2):
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        m, p = _model(use_amp=True)
+        data, hm, gt = _data(B, p, "c3big")
+        m.set_input(data)
+        m.optimize_parameters()
+        torch.cuda.synchronize()
+        peaks.append(torch.cuda.max_memory_allocated() / 2 ** 30)
+        e = m.get_current_errors()
+        losses.append((e["pose"], e["cos_sim"]))
+        assert np.isfinite(e["pose"]) and np.isfinite(e["cos_sim"]) and 0.0 < e["pose"] < 10.0
+        finals.append({k: v.detach().clone() for k, v in m.net_AutoEncoder.named_parameters()})
+        if rep == 1:
+            m.net_AutoEncoder.eval()
+            with torch.no_grad():
+                big = m.net_AutoEncoder.predict_pose(m.pred_heatmap_cat)
+                small = m.net_AutoEncoder.predict_pose(m.pred_heatmap_cat[510:512].contiguous())
+            assert torch.isfinite(big).all()
+            # bf16 rounding of operands is per element, so a row does not depend on its batch; the small batch takes the split-K
+            # fp32 path for its few-tile GEMMs, hence a tolerance (bf16-sized) instead of bit equality
+            assert float((big[510:512] - small).abs().max()) < 3e-2 * float(small.abs().max())
+        del m, data, hm, gt
+    assert losses[0] == losses[1]
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+    print(f"config 3 peak HBM {peaks[0]:.1f} GiB")
+    assert peaks[0] < float(os.environ.get("EGOTAP_C3_PEAK_GIB", "160"))
+
+
+# ------------------------------------------------------------------------------------------------------------ config 5
+def test_config5_egocap_hm128_forward_bf16_against_oracle():
+    """EgoCap, 128x128 heatmaps (512x512 RGB): 2304 tokens, fc1 K = 65536 / 32768 -- forward in PLAIN bf16 against the float64 oracle"""
+    from gpu_util import lift_net
+    from oracle import lift_ref as O
+    net, sd_np, p = lift_net("EgoCap", 128)
+    hm = torch.from_numpy(synth_input("hm_c5", (2, p.in_channels, 128, 128)))
+    with torch.no_grad():
+        ref = O.lift_forward(hm.double(), O.to_torch_sd(sd_np, torch.float64), p)
+    try:
+        net.set_precision("bf16")
+        got = net.predict_pose(hm.cuda()).double().cpu()
+    finally:
+        net.set_precision("f32")
+    f32 = net.predict_pose(hm.cuda()).double().cpu()
+    assert float((f32 - ref).abs().max()) < 1e-4                               # the exact mode: north-star tolerance
+    assert float((got - ref).abs().max()) < 3e-2 * float(ref.abs().max())       # bf16 operands: 2^-9 per rounding
+
+
+def test_config5_egocap_hm128_train_step_against_oracle():
+    """one fp32 optimisation step of the EgoCap head at 128x128 heatmaps against oracle.train_step (float64): loss, every gradient
+    tensor (5e-3 of its typical magnitude, as the UnrealEgo golden gate), parameters after AdamW"""
+    m, p = _model("EgoCap", 128)
+    data, hm, gt = _data(2, p, "c5t", gt_range=1.0)
+    m.set_input(data)
+    m.optimize_parameters()
+    ref = _oracle_step(hm, gt, p)
+    errs = m.get_current_errors()
+    np.testing.assert_allclose(errs["pose"], float(ref["loss_pose"]), rtol=1e-4)
+    np.testing.assert_allclose(errs["cos_sim"], float(ref["loss_cos_sim"]), rtol=2e-3, atol=1e-7)
+    params = dict(m.net_AutoEncoder.named_parameters())
+    for k, g in ref["grads"].items():
+        if g is None:
+            assert params[k].grad is None, k
+            continue
+        got = params[k].grad.double().cpu()
+        scale = max(float(g.norm()) / np.sqrt(g.numel()), 1e-12)
+        err = float((got - g).abs().max())
+        # gradients that vanish by symmetry (|g| ~ 1e-12: the final LayerNorm's bias here) are rounding noise of fp32 sums over
+        # 2304-token rows: floor 5e-8 (UnrealEgo at 576 tokens: 5e-9)
+        assert err <= 5e-3 * scale + 5e-8, f"{k}: err {err:.3e} vs typical magnitude {scale:.3e}"
+        np.testing.assert_allclose(params[k].detach().double().cpu().numpy(), ref["new_params"][k].numpy(), atol=3e-5, err_msg=k)
+    # and the same step in the bf16 mode tracks it (cosine / relative L2 against float64)
+    m2, _ = _model("EgoCap", 128, use_amp=True)
+    m2.set_input(data)
+    m2.optimize_parameters()
+    np.testing.assert_allclose(m2.get_current_errors()["pose"], float(ref["loss_pose"]), rtol=1e-2)
+    _grad_gates(m2.net_AutoEncoder, ref["grads"], 0.98, 0.2)
+
+
+# ------------------------------------------------------------------------------------------------------------ config 4 (2 ranks)
+def _ddp_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from egotap_amd import parallel
+    torch.cuda.set_device(0)
+    parallel.init_from_env("gloo", torch.device("cuda", 0))       # two ranks share the one GPU of the box: gloo, not RCCL
+    m, p = _model()
+    data, hm, gt = _data(2, p, f"ddp_rank{rank}", gt_range=1.0)
+    m.set_input(data)
+    m.optimize_parameters()                                        # forward, loss, backward, gradient averaging, AdamW
+    torch.cuda.synchronize()
+    out = {k: v.grad.detach().cpu() for k, v in m.net_AutoEncoder.named_parameters() if v.grad is not None}
+    out.update({"p:" + k: v.detach().cpu() for k, v in m.net_AutoEncoder.named_parameters()})
+    torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_config4_two_rank_wrapper_step_on_one_gpu(tmp_path):
+    """SURVEY 8(e) parity: two ranks, each the real wrapper on its own shard -> the averaged gradients every rank holds equal the
+    gradients of the MEAN of the per-rank losses (BatchNorm statistics stay per rank), i.e. the mean of the two single-process
+    gradients; parameters after AdamW are identical on both ranks."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
+    # the same two shards, one process, no collective
+    singles = []
+    for r in range(2):
+        m, p = _model()
+        data, hm, gt = _data(2, p, f"ddp_rank{r}", gt_range=1.0)
+        m.set_input(data)
+        m.net_AutoEncoder.train()
+        m.forward()
+        m.loss_total = 0.0
+        m.backward_AutoEncoder()
+        m.loss_total.backward()
+        singles.append({k: v.grad.detach().cpu() for k, v in m.net_AutoEncoder.named_parameters() if v.grad is not None})
+        del m
+    for k in singles[0]:
+        mean = (singles[0][k].double() + singles[1][k].double()) / 2
+        for r in range(2):
+            a = got[r][k].double()
+            tol = 1e-6 * float(mean.abs().max()) + 1e-12
+            assert float((a - mean).abs().max()) <= tol, (k, r, float((a - mean).abs().max()), tol)
+    for k in got[0]:
+        assert torch.equal(got[0][k], got[1][k]), k                 # ranks stay in lock step (grads and parameters)

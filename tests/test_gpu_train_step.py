@@ -139,25 +139,28 @@ def test_train_step_bf16x3_mode_matches_reference_golden():
     _check_against_golden(net, g, losses, abs_floor=3e-8)
 
 
-def test_train_step_bf16_mode_tracks_fp32():
-    """BASELINE configs 3-4 arithmetic (bf16 MFMA, fp32 accumulate, fp32 master weights): loss within 1 %, every large
-    gradient tensor within 20 % relative L2 and cosine > 0.98 of the exact-fp32 step (bf16 keeps 8 significant bits per
-    operand; the deepest gradient, the position embeddings behind three transformer layers, sits at cos 0.992 / 13 %)."""
-    ref, pose32, l32 = _one_step("f32")
+def test_train_step_bf16_mode_against_float64_oracle():
+    """BASELINE configs 3-4 arithmetic (bf16 MFMA, fp32 accumulate, fp32 master weights) against ONE STEP OF THE FLOAT64 ORACLE on
+    the golden's inputs: loss within 1 %, every large gradient tensor within 20 % relative L2 and cosine > 0.98 (bf16 keeps 8
+    significant bits per operand; the deepest gradient, the position embeddings behind three transformer layers, is the worst).
+    The wrapper-level version of this test (create_model under --use_amp) is tests/test_gpu_configs.py."""
+    from egotap_amd import spec
+    from oracle import lift_ref as O
     net, pose16, l16 = _one_step("bf16")
-    np.testing.assert_allclose(l16[0], l32[0], rtol=1e-2)
-    assert float((pose16 - pose32).abs().max()) < 5e-2 * float(pose32.abs().max())
-    gref = {k: v.grad for k, v in ref.named_parameters() if v.grad is not None}
-    worst_cos, worst_rel = 1.0, 0.0
+    p = spec.lift_preset("UnrealEgo")
+    hm = torch.from_numpy(synth_input("hm_train", (2, 90, 64, 64))).double()
+    gt = torch.from_numpy(synth_input("gt_train", (2, 16, 3), -1.0, 1.0)).double()
+    ref = O.train_step(hm, gt, O.to_torch_sd(synth_state_dict(spec.lift_state_spec(p)), torch.float64), p)
+    np.testing.assert_allclose(l16[0], float(ref["loss_pose"]), rtol=1e-2)
+    assert float((pose16.double().cpu() - ref["pose"]).abs().max()) < 5e-2 * float(ref["pose"].abs().max())
     for k, v in net.named_parameters():
         if v.grad is None or v.numel() < 65536:
             continue
-        a, b = v.grad.double().reshape(-1), gref[k].double().reshape(-1)
+        a, b = v.grad.double().reshape(-1).cpu(), ref["grads"][k].double().reshape(-1)
         if float(b.norm()) < 1e-9:
             continue
         cos = float(a @ b / (a.norm() * b.norm()))
         rel = float((a - b).norm() / b.norm())
-        worst_cos, worst_rel = min(worst_cos, cos), max(worst_rel, rel)
         assert cos > 0.98 and rel < 0.2, f"{k}: cos {cos:.5f} rel {rel:.3e}"
 
 
