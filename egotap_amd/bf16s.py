@@ -40,3 +40,105 @@ def gemm_nt(x, w, bias, epi="bf16", aux=None, out=None, out1=None):
     _lib.check(_lib.load().egotap_bf16_gemm_nt(_p(x), x.stride(0), _p(w), _p(bias), M, N, K, EPI[epi], _p(aux), _p(out), _p(out1),
                                                out.stride(0), _s()))
     return (out, out1) if epi == "gelu_save" else out
+
+
+_zero_pages = {}
+
+
+def zero_page(device):
+    """a small all-zero device buffer (the TN kernel fetches rows past M from it)"""
+    key = str(device)
+    if key not in _zero_pages:
+        _zero_pages[key] = torch.zeros(4096, dtype=torch.uint8, device=device)
+    return _zero_pages[key]
+
+
+def gemm_tn(dy, x, dw, accumulate=False):
+    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]; dy, x bf16, dw fp32"""
+    from .train_ops import _scratch
+    _bf(dy, "dy"); _bf(x, "x")
+    M, N = dy.shape
+    K = x.shape[1]
+    ws = _scratch.get(max(64 << 20, 4 * N * K * 8), dy.device)
+    _lib.check(_lib.load().egotap_bf16_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), M, N, K, int(accumulate), _p(zero_page(dy.device)),
+                                               _p(ws), ws.numel(), _s()))
+    return dw
+
+
+def _ws(nbytes, device):
+    from .train_ops import _scratch
+    return _scratch.get(nbytes, device)
+
+
+def layernorm_fwd(x, g, b, eps=1e-12, want_stats=True):
+    """x fp32 [rows, 1024] -> (y bf16, mean, rstd)"""
+    rows = x.shape[0]
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty_like(mean) if want_stats else None
+    _lib.check(_lib.load().egotap_bf16_layernorm_fwd(_p(x), _p(y), _p(g), _p(b), _p(mean), _p(rstd), rows, eps, _s()))
+    return y, mean, rstd
+
+
+def layernorm_bwd(x, dy, g, mean, rstd, dgamma, dbeta, dres=None, dcolsum=None, want_bf16=True, accumulate=False):
+    """returns (dx fp32, dx bf16 or None); dcolsum (+)= column sums of dx"""
+    rows = x.shape[0]
+    dx = torch.empty_like(x)
+    dxb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    nb = (rows + 63) // 64
+    ws = _ws((3 * nb + 3 + 3 * ((nb + 63) // 64)) * 4096 + 4096, x.device)
+    _lib.check(_lib.load().egotap_bf16_layernorm_bwd(_p(x), _p(dy), _p(g), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dxb), _p(dgamma), _p(dbeta),
+                                                     _p(dcolsum), rows, int(accumulate), _p(ws), ws.numel(), _s()))
+    return dx, dxb
+
+
+def colsum(y, out, accumulate=False):
+    M, N = y.shape
+    ws = _ws(64 << 20, y.device)
+    _lib.check(_lib.load().egotap_bf16_colsum(_p(y), y.stride(0), _p(out), M, N, int(accumulate), _p(ws), ws.numel(), _s()))
+    return out
+
+
+def prep_weight(w, wb, wt=None):
+    """w fp32 [N, K] -> wb bf16 [N, K] (and wt bf16 [K, N], which may be a column slice of a wider matrix)"""
+    N, K = w.shape[0], w.numel() // w.shape[0]
+    _lib.check(_lib.load().egotap_bf16_prep_weight(_p(w), _p(wb), _p(wt), N, K, wt.stride(0) if wt is not None else N, _s()))
+
+
+def from_f32(src, dst=None):
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    _lib.check(_lib.load().egotap_bf16_from_f32(_p(src), _p(dst), src.numel(), _s()))
+    return dst
+
+
+def attention_fwd(qkv, B, N, heads, want_lse=True):
+    ctx = torch.empty((B * N, heads * 128), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(B * heads * N, dtype=torch.float32, device=qkv.device) if want_lse else None
+    _lib.check(_lib.load().egotap_bf16_attention_fwd(_p(qkv), _p(ctx), _p(lse), B, N, heads, _s()))
+    return ctx, lse
+
+
+def attention_bwd(qkv, ctx, dctx, lse, B, N, heads):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    _lib.check(_lib.load().egotap_bf16_attention_bwd(_p(qkv), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), B, N, heads, _s()))
+    return dqkv
+
+
+def fc1_fwd(h, which, src, w, bias, B, T):
+    z = torch.empty((B * T, 2048), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().egotap_bf16_fc1_fwd(h, which, _p(src), _p(w), _p(bias), _p(z), B, _s()))
+    return z
+
+
+def fc1_wgrad(h, which, dz, src, dw, B):
+    ws = _ws(max(64 << 20, 4 * dw.numel() * 2), dz.device)
+    _lib.check(_lib.load().egotap_bf16_fc1_wgrad(h, which, _p(dz), _p(src), _p(dw), B, _p(zero_page(dz.device)), _p(ws), ws.numel(), _s()))
+    return dw
+
+
+def fc1_dgrad_tokens(h, dz, wt, B, seq, D):
+    dtok = torch.empty((B * seq, D), dtype=torch.bfloat16, device=dz.device)
+    _lib.check(_lib.load().egotap_bf16_fc1_dgrad_tokens(h, _p(dz), _p(wt), _p(dtok), B, _s()))
+    return dtok

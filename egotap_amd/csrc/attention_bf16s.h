@@ -1,0 +1,285 @@
+// Fused softmax attention with bf16 tensors in HBM (bf16-storage training mode, EGOTAP_PREC_BF16):
+//   forward   ctx = softmax(Q K^T / sqrt(128)) V                                   (model/modeling_vit.py:226-252)
+//   backward  flash style, P recomputed from Q, K and the forward's log-sum-exp:
+//             dV = P^T dO,  dP = dO V^T,  dS = P * (dP - delta) / sqrt(dh),  dQ = dS K,  dK = dS^T Q,  delta = rowsum(dO * O)
+// q | k | v are read in place from the fused bf16 [B*N, 3*heads*128] buffer and the three gradients are written in place into a
+// bf16 buffer of the same layout (the operand of the QKV weight-gradient / input-gradient GEMMs).
+// Same operand maps as attention_bf16.h / attention_bwd_bf16.h (v_mfma_f32_32x32x16_bf16; scores with the key on the accumulator
+// row; probability accumulators used as the next product's B operand where they stand; transposed tiles through
+// ds_read_b64_tr_b16) -- what changes: no conversion pass (tiles are staged as they lie, 16-byte loads, half the bytes), and the
+// backward is TWO kernels instead of three:
+//   attn_bwd_dq_bf16s_kernel   per 32-query block: S, dP, dQ (3 products) + delta
+//   attn_bwd_dkv_bf16s_kernel  per 32-key block:   S, dV, dP, dK (4 products): S and dP are shared by the two gradient sums, the
+//                              block's K rows stay in registers and its V rows in a per-wave LDS image, each gradient owns its accumulator (no float atomics,
+//                              fixed summation order: bitwise reproducible).  7 products per tile pair instead of 8.
+#pragma once
+#include "attention_bwd_bf16.h"
+
+namespace attns {
+using namespace attnbf;
+
+// stage a 32 x 128 bf16 tile (row stride ld elements) into a row image and / or a transposed-read image
+template <int THREADS>
+__device__ __forceinline__ void stage(__bf16* rowimg, __bf16* trimg, const __bf16* src, long ld, int tid) {
+    constexpr int PER = KT * (DH / 8) / THREADS;          // 16-byte chunks per thread
+    bf16x8 st[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int idx = tid + i * THREADS, row = idx >> 4, c8 = idx & 15;
+        st[i] = *(const bf16x8*)(src + (long)row * ld + c8 * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int idx = tid + i * THREADS, row = idx >> 4, c8 = idx & 15;
+        if (rowimg) *(bf16x8*)(rowimg + row * RSTR + c8 * 8) = st[i];
+        if (trimg) *(bf16x8*)(trimg + row * TSTR + c8 * 8) = st[i];
+    }
+}
+
+// one 128-element bf16 row as 8 k-step fragments: lane half h of step s holds d = 16 s + 8 h + j
+__device__ __forceinline__ void load_row_frags(Frags<1>& fr, const __bf16* rowp, int lh) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) fr.f[0][s] = *(const bf16x8*)(rowp + 16 * s + 8 * lh);
+}
+
+// a wave's [4][32 d x 32 lane-rows] accumulators (times mul) as 32 rows of 128 bf16 (row stride ld) through an fp32 LDS patch
+__device__ __forceinline__ void store_rows_bf16(const f32x16 (&o)[4], float mul, float* patch, __bf16* out, long ld, int lane) {
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = o[dt][4 * g + c] * mul;
+            *(f32x4*)(patch + l31 * OLD + dt * 32 + 8 * g + 4 * lh) = v;
+        }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4), c8 = lane & 15;
+        const f32x4 a = *(const f32x4*)(patch + row * OLD + c8 * 8), b = *(const f32x4*)(patch + row * OLD + c8 * 8 + 4);
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        store_bf16x8(out + (long)row * ld + c8 * 8, v);
+    }
+}
+}  // namespace attns
+
+// ------------------------------------------------------------------------------------------------- forward
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attention_bf16s_kernel(const __bf16* __restrict__ QKV, __bf16* __restrict__ CTX, int N, int heads,
+                                                                    int qgroups, float scale_log2e, float* __restrict__ LSE) {
+    using namespace attns;
+    constexpr int THREADS = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) __bf16 simg_s[];
+    __bf16* Kimg = simg_s;                     // [32][RSTR]
+    __bf16* Vimg = simg_s + RIMG;              // [32][TSTR]
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, x8 = bid & 7;
+    const int lin = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (bid >> 3);
+    const int bh = lin / qgroups, qg = lin - bh * qgroups;
+    const int b = bh / heads, h = bh - b * heads;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int D = heads * DH;
+    const long ld = 3L * D;
+    const __bf16* base = QKV + (long)b * N * ld + h * DH;
+    const int qb = qg * NW + wid;
+    const bool valid = qb * 32 < N;            // invalid waves run on clamped rows (EXEC all ones around the transposing reads) and skip the store
+    const int q0 = min(qb * 32, N - 32);
+    Frags<1> qf;
+    load_row_frags(qf, base + (long)(q0 + l31) * ld, lh);
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int kt = 0; kt < N / KT; ++kt) {
+        __syncthreads();
+        stage<THREADS>(Kimg, nullptr, base + (long)(kt * KT) * ld + D, ld, tid);
+        stage<THREADS>(nullptr, Vimg, base + (long)(kt * KT) * ld + 2 * D, ld, tid);
+        __syncthreads();
+        f32x16 s = tile_x_frags<1>(Kimg, qf, l31, lh);                 // S^T[key][q]
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f((m_run - m_new) * scale_log2e);
+        const float mneg = -m_new * scale_log2e;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = exp2f(fmaf(s[r], scale_log2e, mneg));
+            psum += s[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        acc_tile_t_x_p<1>(o, Vimg, s, lane);                           // O^T[d][q] += V^T P^T
+    }
+    __syncthreads();
+    if (valid) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        if (LSE != nullptr && lh == 0) LSE[(long)bh * N + q0 + l31] = m_run * (scale_log2e * 0.6931471805599453f) + logf(l_tot);
+        store_rows_bf16(o, 1.0f / l_tot, (float*)simg_s + wid * 32 * OLD, CTX + ((long)b * N + q0) * D + h * DH, D, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- dQ (+ delta)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_bf16s_kernel(const __bf16* __restrict__ QKV, const __bf16* __restrict__ O,
+                                                                      const __bf16* __restrict__ dO, const float* __restrict__ LSE,
+                                                                      __bf16* __restrict__ dQKV, float* __restrict__ DELTA, int N, int heads,
+                                                                      int qgroups, float scale) {
+    using namespace attns;
+    constexpr int THREADS = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) __bf16 bsm_s[];
+    __bf16* Krow = bsm_s;
+    __bf16* Ktr = Krow + RIMG;
+    __bf16* Vrow = Ktr + TIMG;
+    const int bh = blockIdx.x / qgroups, qg = blockIdx.x - bh * qgroups;
+    const int b = bh / heads, h = bh - b * heads;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int D = heads * DH;
+    const long ld3 = 3L * D;
+    const __bf16* qkv = QKV + (long)b * N * ld3 + h * DH;
+    const int qb = qg * NW + wid;
+    const bool valid = qb * 32 < N;
+    const int q0 = min(qb * 32, N - 32);
+    const long orow = ((long)b * N + q0 + l31) * D + h * DH;
+    Frags<1> qf, dof;
+    load_row_frags(qf, qkv + (long)(q0 + l31) * ld3, lh);
+    load_row_frags(dof, dO + orow, lh);
+    float delta = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const bf16x8 o8 = *(const bf16x8*)(O + orow + 16 * s + 8 * lh);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) delta += (float)o8[u] * (float)dof.f[0][s][u];
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const float lse = LSE[(long)bh * N + q0 + l31];
+    if (valid && lh == 0) DELTA[(long)bh * N + q0 + l31] = delta;
+    const float c2 = scale * 1.4426950408889634f, lse2 = lse * 1.4426950408889634f;
+    f32x16 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    for (int kt = 0; kt < N / KT; ++kt) {
+        __syncthreads();
+        stage<THREADS>(Krow, Ktr, qkv + (long)(kt * KT) * ld3 + D, ld3, tid);
+        stage<THREADS>(Vrow, nullptr, qkv + (long)(kt * KT) * ld3 + 2 * D, ld3, tid);
+        __syncthreads();
+        f32x16 s = tile_x_frags<1>(Krow, qf, l31, lh);             // S^T[key][q]
+        const f32x16 dp = tile_x_frags<1>(Vrow, dof, l31, lh);     // dP^T[key][q]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = exp2f(fmaf(s[r], c2, -lse2)) * (dp[r] - delta) * scale;   // dS^T
+        acc_tile_t_x_p<1>(dq, Ktr, s, lane);                       // dQ^T[d][q] += K^T dS^T
+    }
+    __syncthreads();
+    if (valid) store_rows_bf16(dq, 1.0f, (float*)bsm_s + wid * 32 * OLD, dQKV + ((long)b * N + q0) * ld3 + h * DH, ld3, lane);
+}
+
+// ------------------------------------------------------------------------------------------------- dK and dV
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_bf16s_kernel(const __bf16* __restrict__ QKV, const __bf16* __restrict__ dO,
+                                                                       const float* __restrict__ LSE, const float* __restrict__ DELTA,
+                                                                       __bf16* __restrict__ dQKV, int N, int heads, int kgroups, float scale) {
+    using namespace attns;
+    constexpr int THREADS = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) __bf16 bsm_s[];
+    __bf16* Qrow = bsm_s;
+    __bf16* Qtr = Qrow + RIMG;
+    __bf16* Drow = Qtr + TIMG;
+    __bf16* Dtr = Drow + RIMG;
+    float* Ls = (float*)(Dtr + TIMG);          // [32] lse (log2 units), [32] delta
+    __bf16* Vw = (__bf16*)(Ls + 64);           // per wave: row image of the V rows of its 32 keys (registers hold K, dK, dV)
+    const int bh = blockIdx.x / kgroups, kg = blockIdx.x - bh * kgroups;
+    const int b = bh / heads, h = bh - b * heads;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int D = heads * DH;
+    const long ld3 = 3L * D;
+    const __bf16* qkv = QKV + (long)b * N * ld3 + h * DH;
+    const int kb = kg * NW + wid;
+    const bool valid = kb * 32 < N;
+    const int k0 = min(kb * 32, N - 32);
+    Frags<1> kf;
+    load_row_frags(kf, qkv + (long)(k0 + l31) * ld3 + D, lh);
+    __bf16* Vmine = Vw + wid * RIMG;
+    stage<64>(Vmine, nullptr, qkv + (long)k0 * ld3 + 2 * D, ld3, lane);
+    const float c2 = scale * 1.4426950408889634f;
+    f32x16 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
+    for (int qt = 0; qt < N / KT; ++qt) {
+        __syncthreads();
+        stage<THREADS>(Qrow, Qtr, qkv + (long)(qt * KT) * ld3, ld3, tid);
+        stage<THREADS>(Drow, Dtr, dO + ((long)b * N + qt * KT) * D + h * DH, D, tid);
+        if (tid < 32) Ls[tid] = LSE[(long)bh * N + qt * KT + tid] * 1.4426950408889634f;
+        else if (tid < 64) Ls[tid] = DELTA[(long)bh * N + qt * KT + tid - 32];
+        __syncthreads();
+        f32x16 p = tile_x_frags<1>(Qrow, kf, l31, lh);               // S[q][key]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = exp2f(fmaf(p[r], c2, -Ls[(r & 3) + 8 * (r >> 2) + 4 * lh]));
+        acc_tile_t_x_p<1>(dv, Dtr, p, lane);                         // dV^T[d][key] += dO^T P
+        const f32x16 dp = tile_x_tile<1>(Drow, Vmine, l31, lh);      // dP[q][key] = dO V^T
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = p[r] * (dp[r] - Ls[32 + (r & 3) + 8 * (r >> 2) + 4 * lh]) * scale;   // dS[q][key]
+        acc_tile_t_x_p<1>(dk, Qtr, p, lane);                         // dK^T[d][key] += Q^T dS
+    }
+    __syncthreads();
+    if (valid) {
+        float* patch = (float*)bsm_s + wid * 32 * OLD;
+        __bf16* dst = dQKV + ((long)b * N + k0) * ld3 + h * DH;
+        store_rows_bf16(dk, 1.0f, patch, dst + D, ld3, lane);
+        store_rows_bf16(dv, 1.0f, patch, dst + 2 * D, ld3, lane);    // same wave, same patch: program order
+    }
+}
+
+static hipError_t attention_bf16s_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream) {
+    using namespace attns;
+    constexpr int NW = 4;
+    if (B <= 0) return hipSuccess;
+    if (N % 32 != 0) return hipErrorInvalidValue;
+    constexpr size_t img = (size_t)(RIMG + TIMG) * 2, patch = (size_t)NW * 32 * OLD * 4;
+    constexpr size_t lds = img > patch ? img : patch;
+    auto kern = attention_bf16s_kernel<NW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int qgroups = (N / 32 + NW - 1) / NW;
+    hipLaunchKernelGGL(kern, dim3(B * heads * qgroups), dim3(64 * NW), lds, stream, QKV, CTX, N, heads, qgroups, 1.4426950408889634f / sqrtf(128.0f), LSE);
+    return hipGetLastError();
+}
+
+static hipError_t attention_bf16s_bwd_launch(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
+                                             int heads, hipStream_t stream) {
+    using namespace attns;
+    constexpr int NW = 4;
+    if (B <= 0) return hipSuccess;
+    if (N % 32 != 0) return hipErrorInvalidValue;
+    const float scale = 1.0f / sqrtf((float)DH);
+    const int groups = (N / 32 + NW - 1) / NW;
+    constexpr size_t patch = (size_t)NW * 32 * OLD * 4;
+    constexpr size_t img_q = (size_t)(2 * RIMG + TIMG) * 2, img_kv = (size_t)(2 * RIMG + 2 * TIMG) * 2 + 256 + (size_t)NW * RIMG * 2;
+    constexpr size_t lds_q = img_q > patch ? img_q : patch, lds_kv = img_kv > patch ? img_kv : patch;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_bf16s_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_bf16s_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_dq_bf16s_kernel<NW>), dim3(B * heads * groups), dim3(64 * NW), lds_q, stream, QKV, O, dO, LSE, dQKV, DELTA, N, heads, groups, scale);
+    hipLaunchKernelGGL((attn_bwd_dkv_bf16s_kernel<NW>), dim3(B * heads * groups), dim3(64 * NW), lds_kv, stream, QKV, dO, LSE, DELTA, dQKV, N, heads, groups, scale);
+    return hipGetLastError();
+}

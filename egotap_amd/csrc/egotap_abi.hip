@@ -1172,6 +1172,9 @@ extern "C" int egotap_attention(const float* qkv, float* ctx, int B, int N, int 
 #include "gemm_tn_bf16.h"
 #include "train_ops.h"
 #include "gemm_bf16s.h"
+#include "gemm_tn_bf16s.h"
+#include "bf16s_ops.h"
+#include "attention_bf16s.h"
 
 using TnBig = TnCfg<256, 256, 16, 4, 2>;     // 8 waves, 64x128 per wave
 using TnSmall = TnCfg<128, 128, 16, 2, 2>;   // 4 waves, 64x64 per wave
@@ -2042,6 +2045,148 @@ extern "C" int egotap_bf16_gemm_nt(const void* x, int64_t ldx, const void* w, co
         default: egotap_set_error("egotap_bf16_gemm_nt: unknown epilogue %d", epi); return EGOTAP_ERR_INVALID;
     }
     EGO_HIP(e);
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(3)
+extern "C" int egotap_bf16_gemm_tn(const void* dy, int64_t ldy, const void* x, int64_t ldx, float* dw, int M, int N, int K, int accumulate,
+                                   const void* zeros, void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(dy && x && dw && zeros, "egotap_bf16_gemm_tn: null argument");
+    EGO_CHECK(M > 0 && N % 256 == 0 && K % 256 == 0, "egotap_bf16_gemm_tn: N and K must be multiples of 256 (N=%d K=%d)", N, K);
+    EGO_CHECK(ldy % 8 == 0 && ldx % 8 == 0 && ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw | (uintptr_t)zeros | (uintptr_t)ws)) & 15) == 0,
+              "egotap_bf16_gemm_tn: operands must be 16-byte aligned, leading dimensions multiples of 8");
+    hipError_t e = gemm_tn_bf16s_launch((const __bf16*)dy, (long)ldy, TXPlain{(const __bf16*)x, (long)ldx}, (const __bf16*)zeros, dw, (float*)ws, ws_bytes, M, N, K,
+                                        device_cu_count(), accumulate, (hipStream_t)stream);
+    if (e == hipErrorOutOfMemory) { egotap_set_error("egotap_bf16_gemm_tn: workspace too small for one partial slab (%zu bytes given)", ws_bytes); return EGOTAP_ERR_WORKSPACE; }
+    EGO_HIP(e);
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(3)
+extern "C" int egotap_bf16_layernorm_fwd(const float* x, void* y, const float* g, const float* b, float* mean, float* rstd, int rows, float eps, void* stream) {
+    EGO_CHECK(x && y && g && b, "egotap_bf16_layernorm_fwd: null argument");
+    if (rows <= 0) return EGOTAP_OK;
+    hipLaunchKernelGGL(ln_fwd_bf16_kernel<1024>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y, g, b, mean, rstd, rows, eps);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(3)
+// ws >= (3 * blocks + 3 + 3 * ceil(blocks / 64)) * 1024 floats, blocks = ceil(rows / 64)
+extern "C" int egotap_bf16_layernorm_bwd(const float* x, const void* dy, const float* g, const float* mean, const float* rstd, const float* dres, float* dx,
+                                         void* dxb, float* dgamma, float* dbeta, float* dcolsum, int rows, int accumulate, void* ws, size_t ws_bytes,
+                                         void* stream) {
+    EGO_CHECK(x && dy && g && mean && rstd && dx && dgamma && dbeta && ws, "egotap_bf16_layernorm_bwd: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int rows_per_wave = 16, blocks = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
+    const int gy = (blocks + 63) / 64;
+    EGO_CHECK(ws_bytes >= ((size_t)blocks * 3072 + 3072 + (size_t)gy * 3072) * 4, "egotap_bf16_layernorm_bwd: workspace too small");
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(ln_bwd_bf16_kernel<1024>, dim3(blocks), dim3(256), 0, s, x, (const __bf16*)dy, g, mean, rstd, dres, dx, (__bf16*)dxb, part, rows, rows_per_wave);
+    EGO_HIP(hipGetLastError());
+    float* tmp = part + (size_t)blocks * 3072;
+    float* part2 = tmp + 3072;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(3072 / 4 / 64, gy), dim3(256), 0, s, (const float*)part, 3072L, part2, blocks, 3072, 64);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(3), dim3(256), 0, s, (const float*)part2, tmp, 3072L, gy, 0);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, tmp, dgamma, 1024L, 1, accumulate);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, tmp + 1024, dbeta, 1024L, 1, accumulate);
+    if (dcolsum) hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, s, tmp + 2048, dcolsum, 1024L, 1, accumulate);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(3)
+extern "C" int egotap_bf16_colsum(const void* y, int64_t ldy, float* out, int M, int N, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(y && out && ws && N % 8 == 0 && ldy % 8 == 0, "egotap_bf16_colsum: bad argument");
+    hipError_t e = colsum_bf16_launch((const __bf16*)y, (long)ldy, out, M, N, accumulate, (float*)ws, ws_bytes, (hipStream_t)stream);
+    if (e == hipErrorOutOfMemory) { egotap_set_error("egotap_bf16_colsum: workspace too small"); return EGOTAP_ERR_WORKSPACE; }
+    EGO_HIP(e);
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(3)
+extern "C" int egotap_bf16_prep_weight(const float* w, void* wb, void* wt, int N, int K, int64_t ldt, void* stream) {
+    EGO_CHECK(w && wb && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0, "egotap_bf16_prep_weight: bad argument (N, K multiples of 8)");
+    EGO_CHECK(wt == nullptr || (ldt >= N && ldt % 8 == 0), "egotap_bf16_prep_weight: ldt must be >= N and a multiple of 8");
+    hipLaunchKernelGGL(prep_weight_kernel, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)wb, (__bf16*)wt, N, K, (long)ldt);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(3)
+extern "C" int egotap_bf16_from_f32(const float* src, void* dst, int64_t n, void* stream) {
+    EGO_CHECK(src && dst && n % 8 == 0, "egotap_bf16_from_f32: n must be a multiple of 8");
+    if (n == 0) return EGOTAP_OK;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, (long)(n / 8));
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(3)
+extern "C" int egotap_bf16_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int N, int heads, void* stream) {
+    EGO_CHECK(qkv && ctx, "egotap_bf16_attention_fwd: null argument");
+    hipError_t e = attention_bf16s_fwd_launch((const __bf16*)qkv, (__bf16*)ctx, lse, B, N, heads, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) { egotap_set_error("egotap_bf16_attention_fwd: sequence length %d is not a multiple of 32", N); return EGOTAP_ERR_INVALID; }
+    EGO_HIP(e);
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(3)
+extern "C" int egotap_bf16_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv, int B, int N, int heads,
+                                         void* stream) {
+    EGO_CHECK(qkv && ctx && dctx && lse && delta && dqkv, "egotap_bf16_attention_bwd: null argument");
+    hipError_t e = attention_bf16s_bwd_launch((const __bf16*)qkv, (const __bf16*)ctx, (const __bf16*)dctx, lse, delta, (__bf16*)dqkv, B, N, heads, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) { egotap_set_error("egotap_bf16_attention_bwd: sequence length %d is not a multiple of 32", N); return EGOTAP_ERR_INVALID; }
+    EGO_HIP(e);
+    return EGOTAP_OK;
+}
+#endif
+
+// fc1 of the two heatmap encoders on bf16 operands, the gathers folded into the loaders (net_architecture.py:388-406, 690-694):
+//   which 0: rows = per-heatmap patch tokens gathered from tokens bf16 [B*seq, D];  1: rows = [cos | sin] maps from hm bf16 [B, C, S, S]
+#if EGOTAP_IN(3)
+extern "C" int egotap_bf16_fc1_fwd(egotap_handle h, int which, const void* src, const void* w, const float* bias, float* z, int B, void* stream) {
+    EGO_CHECK(h && src && w && bias && z && (which == 0 || which == 1), "egotap_bf16_fc1_fwd: bad argument");
+    const int BT = B * h->T, S = h->cfg.hm_size, K = which == 0 ? h->ppd * h->ppd * h->D : 2 * S * S;
+    hipError_t e;
+    if (which == 0) e = gemm_bf16s_launch(XTokens{(const __bf16*)src, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, (const __bf16*)w, (long)K, SEpiF32{bias, z, 2048L}, BT, 2048, K, device_cu_count(), (hipStream_t)stream);
+    else e = gemm_bf16s_launch(XRot{(const __bf16*)src, h->C, h->J, S * S}, (const __bf16*)w, (long)K, SEpiF32{bias, z, 2048L}, BT, 2048, K, device_cu_count(), (hipStream_t)stream);
+    EGO_HIP(e);
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(3)
+extern "C" int egotap_bf16_fc1_wgrad(egotap_handle h, int which, const void* dz, const void* src, float* dw, int B, const void* zeros, void* ws,
+                                     size_t ws_bytes, void* stream) {
+    EGO_CHECK(h && dz && src && dw && zeros && ws && (which == 0 || which == 1), "egotap_bf16_fc1_wgrad: bad argument");
+    const int BT = B * h->T, S = h->cfg.hm_size, K = which == 0 ? h->ppd * h->ppd * h->D : 2 * S * S;
+    hipError_t e;
+    if (which == 0) e = gemm_tn_bf16s_launch((const __bf16*)dz, 2048L, TXTokens{(const __bf16*)src, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, (const __bf16*)zeros, dw, (float*)ws, ws_bytes, BT, 2048, K, device_cu_count(), 0, (hipStream_t)stream);
+    else e = gemm_tn_bf16s_launch((const __bf16*)dz, 2048L, TXRot{(const __bf16*)src, h->C, h->J, S * S}, (const __bf16*)zeros, dw, (float*)ws, ws_bytes, BT, 2048, K, device_cu_count(), 0, (hipStream_t)stream);
+    if (e == hipErrorOutOfMemory) { egotap_set_error("egotap_bf16_fc1_wgrad: workspace too small"); return EGOTAP_ERR_WORKSPACE; }
+    EGO_HIP(e);
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(3)
+// input gradient of fc1 of the position encoder, scattered back to token order: dtok bf16 [B*seq, D] (cleared here: dummy cells get zero)
+extern "C" int egotap_bf16_fc1_dgrad_tokens(egotap_handle h, const void* dz, const void* wt, void* dtok, int B, void* stream) {
+    EGO_CHECK(h && dz && wt && dtok, "egotap_bf16_fc1_dgrad_tokens: null argument");
+    const int BT = B * h->T, K1 = h->ppd * h->ppd * h->D;
+    hipStream_t s = (hipStream_t)stream;
+    EGO_HIP(hipMemsetAsync(dtok, 0, (size_t)B * h->seq * h->D * 2, s));
+    EGO_HIP(gemm_bf16s_launch(XPlain{(const __bf16*)dz, 2048L}, (const __bf16*)wt, 2048L, SEpiScatterTokens{(__bf16*)dtok, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, BT, K1, 2048,
+                              device_cu_count(), s));
     return EGOTAP_OK;
 }
 #endif

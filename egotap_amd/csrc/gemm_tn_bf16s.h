@@ -1,0 +1,226 @@
+// bf16-STORAGE weight-gradient GEMM ("TN"):  dW[N,K] (+)= sum_m dY[m,n] * X[m,k],  dY, X bf16 in HBM, fp32 accumulate, dW fp32
+// (nn.Linear's weight gradient of the reduced-precision training step; model/egotap_autoencoder_model.py:299-323).
+//
+// Same skeleton as gemm_bf16s.h -- 256 x 256 output tile, 8 waves = 2 groups x 4 one barrier apart, ring of four 32 KB LDS
+// stages filled by global_load_lds_dwordx4, v_mfma_f32_16x16x32_bf16, two phases of 16 MFMAs per 32-deep step -- with the
+// CONTRACTED index m being the memory row of both operands:
+//   * a stage = [32 rows of dY | 32 rows of X] x 256 columns (512-byte rows), staged exactly as the rows lie in memory;
+//   * MFMA A operand = X^T (row = k of dW), B operand = dY (column = n): a lane's 4 accumulator registers are 4 consecutive k of
+//     one n, i.e. 16 contiguous bytes of dW[n][k..k+3] -- the partial tile is stored without a transpose;
+//   * both fragments need 8 consecutive m for one column per lane: two ds_read_b64_tr_b16 each (4 x 16 block transpose,
+//     cdna_hip_programming.md T10).  A 32-lane half of that instruction reads 8 row segments of 32 bytes: rows 8g + q (g = 16-lane
+//     group, q = 0..3) of one 16-column block.  Chunk pair cb (32 bytes) of row r is stored at pair position
+//     cb ^ f(r), f(r) = (r & 3) | (((r >> 3) & 1) << 2): the 8 segments then fall in 8 distinct 32-byte bank groups.  The swizzle is
+//     applied on the global side of the DMA (which 16 bytes a lane fetches).
+//   * M is split over workgroups (grid = tiles x splits); each split accumulates a whole number of 32-row steps and writes a
+//     partial fp32 slab, reduce_slabs_kernel adds the slabs in a fixed order (bitwise reproducible, no float atomics).  Rows past M
+//     are fetched from a caller-supplied page of zeros.
+#pragma once
+#include "gemm_bf16s.h"
+#include "gemm_tn_bf16.h"
+
+struct TnSCfg {
+    static constexpr int BN = 256, BK = 256, BKM = 32, NS = 4, THREADS = 512;
+    static constexpr int ROWB = 512;                      // bytes per LDS row (256 bf16)
+    static constexpr int PART = BKM * ROWB;               // dY part or X part of a stage: 16 KiB
+    static constexpr int STAGE = 2 * PART;
+    static constexpr int LDS_BYTES = NS * STAGE;
+};
+
+// X-operand loaders for the TN kernel: address of 8 consecutive columns (16 bytes) k .. k+7 of row m
+struct TXPlain {
+    const __bf16* A;
+    long lda;
+    __device__ __forceinline__ const __bf16* ptr(int m, int k) const { return A + (long)m * lda + k; }
+};
+struct TXTokens {            // rows gathered as XTokens (fc1 of the position encoder)
+    const __bf16* Y;
+    int T, D, seq, side, ppd, grid;
+    __device__ __forceinline__ const __bf16* ptr(int m, int k) const {
+        const int b = m / T, i = m - b * T;
+        const int s = k / D, c = k - s * D;
+        const int prl = s / ppd, pcl = s - prl * ppd;
+        return Y + ((long)b * seq + (long)(ppd * (i / grid) + prl) * side + ppd * (i % grid) + pcl) * D + c;
+    }
+};
+struct TXRot {               // rows gathered as XRot (fc1 of the rotation encoder)
+    const __bf16* hm;
+    int C, J, HW;
+    __device__ __forceinline__ const __bf16* ptr(int m, int k) const {
+        const int T = 2 * J;
+        const int b = m / T, t = m - b * T;
+        const int eye = t / J, j = t - eye * J;
+        const int cs = k / HW;
+        return hm + (long)(b * C + 2 * J + eye * 2 * J + j) * HW + (long)cs * J * HW + (k - cs * HW);
+    }
+};
+
+template <class XL>
+__global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const __bf16* __restrict__ dY, long ldy, XL xl, const __bf16* __restrict__ zeros,
+                                                                            float* __restrict__ slabs, int M, int N, int K, int tiles_n, int splits,
+                                                                            int rows_per) {
+    using Cfg = TnSCfg;
+    constexpr int BN = Cfg::BN, BK = Cfg::BK, BKM = Cfg::BKM, ROWB = Cfg::ROWB, PART = Cfg::PART, STAGE = Cfg::STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem_t[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2, wc = wid & 3;
+    const int l15 = lane & 15;
+
+    const int bid = blockIdx.x;
+    const int split = bid % splits, tile = bid / splits;
+    const int tn = tile % tiles_n, tk = tile / tiles_n;
+    const int n0 = tn * BN, k0 = tk * BK;
+    const int m_lo = split * rows_per, m_hi = min(M, m_lo + rows_per);
+    const int total = m_hi > m_lo ? (m_hi - m_lo + BKM - 1) / BKM : 0;      // 32-row steps of this split
+    float* out = slabs + (long)split * N * K;
+
+    // ---- DMA duty per part: 2-row blocks wid and wid + 8 (a wave instruction = 1024 bytes = two 512-byte rows).  Lane -> row
+    // lane >> 5 of the block, chunk position lane & 31, holding logical chunk pos ^ (2 f(row)).
+    const int r0 = 2 * wid + (lane >> 5), r1 = r0 + 16;
+    auto fsw = [](int r) { return 2 * ((r & 3) | (((r >> 3) & 1) << 2)); };
+    const int c0 = (lane & 31) ^ fsw(r0), c1 = (lane & 31) ^ fsw(r1);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_t;
+    auto dma1 = [&](const __bf16* g, unsigned lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+    };
+    int ly = 0, lx = 0;            // next step of the dY / X issue streams; past the end they keep re-reading the zero page
+    auto issue_y = [&](int st) __attribute__((always_inline)) {
+        const unsigned sa = lds0 + st * STAGE + wid * 1024;
+        const int mb = m_lo + ly * BKM;
+        const bool in = ly < total;
+        const int ma = mb + r0, mc = mb + r1;
+        dma1(in && ma < m_hi ? dY + (long)ma * ldy + n0 + c0 * 8 : zeros + c0 * 8, sa);
+        dma1(in && mc < m_hi ? dY + (long)mc * ldy + n0 + c1 * 8 : zeros + c1 * 8, sa + 8 * 1024);
+        ++ly;
+    };
+    auto issue_x = [&](int st) __attribute__((always_inline)) {
+        const unsigned sa = lds0 + st * STAGE + PART + wid * 1024;
+        const int mb = m_lo + lx * BKM;
+        const bool in = lx < total;
+        const int ma = mb + r0, mc = mb + r1;
+        dma1(in && ma < m_hi ? xl.ptr(ma, k0 + c0 * 8) : zeros + c0 * 8, sa);
+        dma1(in && mc < m_hi ? xl.ptr(mc, k0 + c1 * 8) : zeros + c1 * 8, sa + 8 * 1024);
+        ++lx;
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read address of this lane for a 16-column block cb: rows 8 g4 + q' (first read) and + 4 (second read),
+    // 8 bytes at chunk 2 cb + (p >> 1), half p & 1; the swizzle term f depends on (q', g4 & 1) only, identical for both reads
+    const int g4 = lane >> 4, qp = l15 >> 2, pp = l15 & 3;
+    const int fr = qp | ((g4 & 1) << 2);
+    const int t_row = (8 * g4 + qp) * ROWB + (pp & 1) * 8;
+    auto frag = [&](const char* part, int cb) __attribute__((always_inline)) {
+        const char* p = part + t_row + (((2 * cb + (pp >> 1)) ^ (2 * fr)) << 4);
+        const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
+        const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + 4 * ROWB));
+        bf16x8 f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[e] = a[e];
+            f[4 + e] = b[e];
+        }
+        return f;
+    };
+
+    if (total > 0) {
+        issue_y(0); issue_x(0);
+        issue_y(1); issue_x(1);
+        issue_y(2); issue_x(2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+
+        bf16x8 yf[4], xf[4];
+        int st = 0;
+        for (int T = 0; T < total; ++T) {
+            const char* sa = smem_t + st * STAGE;
+            const int st3 = (st + 3) & 3;
+            // ---------------- phase 2T: k half 0 of this wave
+            issue_y(st3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yf[j] = frag(sa, wc * 4 + j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = frag(sa + PART, grp * 8 + i);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- phase 2T + 1: k half 1
+            issue_x(st3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = frag(sa + PART, grp * 8 + 4 + i);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[j], acc[4 + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            st = (st + 1) & 3;
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // partial tile: acc[i][j] = D[k = 16 i' + 4 q + r][n = 16 j' + l15]  ->  out[n][k .. k+3]
+    const int q = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + l15, kk = k0 + grp * 128 + i * 16 + 4 * q;
+            *(f32x4*)(out + (long)n * K + kk) = acc[i][j];
+        }
+}
+
+// dY bf16 [M, N] (row stride ldy), X through xl, zeros: >= 512 bytes of zeros (16-byte aligned), dW fp32 [N, K]
+template <class XL>
+static hipError_t gemm_tn_bf16s_launch(const __bf16* dY, long ldy, const XL& xl, const __bf16* zeros, float* dW, float* slabs, size_t slab_bytes,
+                                       int M, int N, int K, int num_cu, int accumulate, hipStream_t stream) {
+    using Cfg = TnSCfg;
+    if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || ldy % 8 != 0 || M <= 0) return hipErrorInvalidValue;
+    const int tiles_n = N / Cfg::BN, tiles_k = K / Cfg::BK;
+    const int tiles = tiles_n * tiles_k;
+    int splits = (num_cu + tiles - 1) / tiles;                   // one 512-thread workgroup per CU (128 KB of LDS each)
+    const int max_by_rows = (M + 8 * Cfg::BKM - 1) / (8 * Cfg::BKM);
+    if (splits > max_by_rows) splits = max_by_rows;
+    if (splits < 1) splits = 1;
+    while ((size_t)splits * N * K * 4 > slab_bytes && splits > 1) --splits;
+    const bool direct = splits == 1 && !accumulate;              // a single slab that is not added to anything IS the gradient
+    if (!direct && (size_t)splits * N * K * 4 > slab_bytes) return hipErrorOutOfMemory;
+    const int rows_per = ((M + splits - 1) / splits + Cfg::BKM - 1) / Cfg::BKM * Cfg::BKM;
+    auto kern = gemm_tn_bf16s_kernel<XL>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, dY, ldy, xl, zeros, direct ? dW : slabs, M, N, K,
+                       tiles_n, splits, rows_per);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || direct) return e;
+    const long n = (long)N * K;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, slabs, dW, n, splits, accumulate);
+    return hipGetLastError();
+}

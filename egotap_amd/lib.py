@@ -84,6 +84,18 @@ _PROTOS = {
     # ---- bf16-storage operators
     "egotap_bf16_gemm_nt": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "egotap_bf16_gemm_tn": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_bf16_layernorm_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_float, C.c_void_p]),
+    "egotap_bf16_layernorm_bwd": (C.c_int, [C.c_void_p] * 11 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_bf16_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_bf16_prep_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "egotap_bf16_from_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "egotap_bf16_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "egotap_bf16_attention_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "egotap_bf16_fc1_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "egotap_bf16_fc1_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_bf16_fc1_dgrad_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     # ---- heatmap-estimator training operators
     "egotap_hmtrain_conv_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_int64] * 3 + [C.c_void_p]),
     "egotap_hmtrain_set_pack_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -252,6 +252,37 @@ int egotap_hmtrain_mse(const float* pred, const float* gt, const float* plen, fl
 int egotap_bf16_gemm_nt(const void* x, int64_t ldx, const void* w, const float* bias, int M, int N, int K, int epi, const void* aux,
                         void* out0, void* out1, int64_t ldo, void* stream);
 
+/* nn.Linear weight gradient on bf16 operands: dw[N,K] (+)= dy[M,N]^T x[M,K] (fp32 result).  N, K % 256 == 0.  zeros: >= 512 bytes of
+ * zeros (rows past M are fetched from it); ws: scratch for the split-M partial slabs (>= 4*N*K bytes per split, up to 256 splits are
+ * used when it allows; fixed-order reduction: bitwise reproducible) */
+int egotap_bf16_gemm_tn(const void* dy, int64_t ldy, const void* x, int64_t ldx, float* dw, int M, int N, int K, int accumulate,
+                        const void* zeros, void* ws, size_t ws_bytes, void* stream);
+
+/* LayerNorm(1024) with a bf16 output (the next GEMM's operand) and its backward: dy bf16, dx fp32 (+ dxb: a bf16 copy when not NULL),
+ * dgamma / dbeta, and dcolsum (not NULL): column sums of dx = the bias gradient of the Linear layer whose output gradient dx is.
+ * ws >= (3 * ceil(rows / 64) + 3 + 3 * ceil(ceil(rows / 64) / 64)) * 4096 bytes */
+int egotap_bf16_layernorm_fwd(const float* x, void* y, const float* g, const float* b, float* mean, float* rstd, int rows, float eps, void* stream);
+int egotap_bf16_layernorm_bwd(const float* x, const void* dy, const float* g, const float* mean, const float* rstd, const float* dres, float* dx,
+                              void* dxb, float* dgamma, float* dbeta, float* dcolsum, int rows, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* out[N] (+)= column sums of a bf16 matrix y[M, N] (row stride ldy): bias gradients */
+int egotap_bf16_colsum(const void* y, int64_t ldy, float* out, int M, int N, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* per-step weight preparation: w fp32 [N, K] (the live master weights) -> wb bf16 [N, K] and, when wt != NULL, wt bf16 [K, N] with row
+ * stride ldt (so three projections can share one transposed [K, 3N] matrix) */
+int egotap_bf16_prep_weight(const float* w, void* wb, void* wt, int N, int K, int64_t ldt, void* stream);
+int egotap_bf16_from_f32(const float* src, void* dst, int64_t n, void* stream);
+/* ViTSelfAttention core on bf16 tensors (modeling_vit.py:233-252): qkv bf16 [B*N, 3*heads*128] -> ctx bf16 [B*N, heads*128], lse fp32
+ * [B*heads*N]; backward: dqkv bf16 (same layout as qkv), delta fp32 [B*heads*N] scratch.  Two backward kernels (dQ; dK + dV). */
+int egotap_bf16_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int N, int heads, void* stream);
+int egotap_bf16_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv, int B, int N, int heads,
+                              void* stream);
+/* fc1 of the two heatmap encoders on bf16 operands (which 0: position encoder, src = final-LayerNorm tokens bf16 [B*seq, D];
+ * 1: rotation encoder, src = the head's input heatmaps as bf16 [B, 6J, S, S]); z fp32 [B*T, 2048] = x w^T + bias.
+ * wgrad: dw fp32 [2048, K1] = dz^T x;  dgrad_tokens (position encoder): dtok bf16 [B*seq, D] = scatter(dz wt^T), wt bf16 [K1, 2048] */
+int egotap_bf16_fc1_fwd(egotap_handle h, int which, const void* src, const void* w, const float* bias, float* z, int B, void* stream);
+int egotap_bf16_fc1_wgrad(egotap_handle h, int which, const void* dz, const void* src, float* dw, int B, const void* zeros, void* ws, size_t ws_bytes,
+                          void* stream);
+int egotap_bf16_fc1_dgrad_tokens(egotap_handle h, const void* dz, const void* wt, void* dtok, int B, void* stream);
+
 /* ---- measurement hooks (bench.py roofline) ---- */
 /* when enabled, every GEMM launch of the handle is bracketed by HIP events on the caller's stream */
 int egotap_timing_enable(egotap_handle h, int enable);

@@ -97,3 +97,100 @@ def test_gemm_nt_f32_out():
     out = bf16s.gemm_nt(x.cuda(), w.cuda(), b.cuda(), epi="f32")
     ref = x.double() @ w.double().T + b.double()
     assert out.dtype == torch.float32 and float((out.double().cpu() - ref).abs().max()) < 2e-6 * math.sqrt(K) + 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 256, 256), (100, 256, 512), (1000, 512, 256), (4096, 1024, 1024), (36864, 1024, 256), (9001, 256, 1024)])
+def test_gemm_tn(M, N, K):
+    """dw = dy^T x (fp32) from bf16 operands: ragged M (zero-page rows), one step, fewer steps than ring stages, many splits; an
+    asymmetric pair catches swapped operands / transposed fragments; accumulate adds onto dw; run to run bit-identical"""
+    from egotap_amd import bf16s
+    dy, x = _rand((M, N), 41).bfloat16(), _rand((M, K), 42).bfloat16()
+    ref = dy.double().T @ x.double()
+    dw = torch.full((N, K), 3.0, device="cuda")
+    bf16s.gemm_tn(dy.cuda(), x.cuda(), dw)
+    tol = 3e-6 * math.sqrt(M) * 1.0 + 1e-5
+    assert float((dw.double().cpu() - ref).abs().max()) < tol, (float((dw.double().cpu() - ref).abs().max()), tol)
+    again = torch.empty_like(dw)
+    bf16s.gemm_tn(dy.cuda(), x.cuda(), again)
+    assert torch.equal(dw, again)
+    bf16s.gemm_tn(dy.cuda(), x.cuda(), again, accumulate=True)
+    assert float((again.double().cpu() - 2 * ref).abs().max()) < 2 * tol
+
+
+def test_gemm_tn_strided_dy():
+    """dy as a column slice of a wider matrix (the fused q|k|v gradient: three weight gradients from one [M, 3D] buffer)"""
+    from egotap_amd import bf16s
+    M, N, K = 2304, 256, 512
+    big, x = _rand((M, 3 * N), 51).bfloat16(), _rand((M, K), 52).bfloat16()
+    bc = big.cuda()
+    for sidx in range(3):
+        dw = torch.empty((N, K), device="cuda")
+        bf16s.gemm_tn(bc[:, sidx * N:(sidx + 1) * N], x.cuda(), dw)
+        ref = big[:, sidx * N:(sidx + 1) * N].double().T @ x.double()
+        assert float((dw.double().cpu() - ref).abs().max()) < 3e-6 * math.sqrt(M) + 1e-5
+
+
+def test_layernorm_fwd_bwd_bf16():
+    """LayerNorm(1024, eps 1e-12) with a bf16 output, and its backward from a bf16 dy: dx (fp32 + bf16 copy), dgamma, dbeta and
+    the column sums of dx, against float64 autograd on the same (rounded) dy"""
+    from egotap_amd import bf16s
+    rows, D = 777, 1024
+    x, g, b = _rand((rows, D), 61, -3, 3), _rand((D,), 62, 0.5, 1.5), _rand((D,), 63)
+    dy, dres = _rand((rows, D), 64).bfloat16(), _rand((rows, D), 65)
+    y, mean, rstd = bf16s.layernorm_fwd(x.cuda(), g.cuda(), b.cuda())
+    xd = x.double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xd, (D,), gd, bd, 1e-12)
+    _close_bf16(y, yr.detach(), "layernorm y")
+    yr.backward(dy.double())
+    dgam, dbet, dcs = (torch.empty(D, device="cuda") for _ in range(3))
+    dx, dxb = bf16s.layernorm_bwd(x.cuda(), dy.cuda(), g.cuda(), mean, rstd, dgam, dbet, dres=dres.cuda(), dcolsum=dcs)
+    ref_dx = xd.grad + dres.double()
+    assert float((dx.double().cpu() - ref_dx).abs().max()) < 2e-5
+    _close_bf16(dxb, ref_dx, "dx bf16")
+    assert float((dgam.double().cpu() - gd.grad).abs().max()) < 2e-4 and float((dbet.double().cpu() - bd.grad).abs().max()) < 2e-4
+    assert float((dcs.double().cpu() - ref_dx.sum(0)).abs().max()) < 2e-4
+
+
+def test_colsum_and_prep_weight():
+    from egotap_amd import bf16s
+    y = _rand((5003, 3072), 71).bfloat16()
+    out = torch.zeros(1024, device="cuda")
+    bf16s.colsum(y.cuda()[:, 1024:2048], out)                         # a column slice (fused q|k|v gradient)
+    assert float((out.double().cpu() - y[:, 1024:2048].double().sum(0)).abs().max()) < 2e-3
+    w = _rand((1000, 520), 72)
+    wb, wt = torch.empty((1000, 520), dtype=torch.bfloat16, device="cuda"), torch.empty((520, 1000), dtype=torch.bfloat16, device="cuda")
+    bf16s.prep_weight(w.cuda(), wb, wt)
+    assert torch.equal(wb.cpu(), w.bfloat16()) and torch.equal(wt.cpu(), w.bfloat16().T.contiguous())
+    assert torch.equal(bf16s.from_f32(w.cuda()).cpu(), w.bfloat16())
+
+
+@pytest.mark.parametrize("B,N", [(2, 576), (1, 2304), (3, 96)])
+def test_attention_fwd_bwd_bf16(B, N):
+    """softmax attention on bf16 q|k|v: ctx, log-sum-exp and the three gradients (two backward kernels) against float64 autograd
+    on the same rounded inputs; a structured V (value = key index) catches permuted keys"""
+    from egotap_amd import bf16s
+    heads, dh = 8, 128
+    D = heads * dh
+    qkv = _rand((B * N, 3 * D), 81, -2, 2).bfloat16()
+    qkv[:, 2 * D:2 * D + 4] = (torch.arange(B * N) % N).to(torch.bfloat16)[:, None] / 64.0
+    dctx = _rand((B * N, D), 82).bfloat16()
+    ctx, lse = bf16s.attention_fwd(qkv.cuda(), B, N, heads)
+    t = qkv.double().requires_grad_(True)
+    q, k, v = (t[:, i * D:(i + 1) * D].view(B, N, heads, dh).transpose(1, 2) for i in range(3))
+    sc = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * N, D)
+    _close_bf16(ctx, ref.detach(), "ctx", abs_=2e-3)
+    assert float((lse.double().cpu() - torch.logsumexp(sc, -1).reshape(-1).detach()).abs().max()) < 2e-3
+    # backward from the bf16 ctx the forward stored (what the training step does)
+    ref.backward(dctx.double())
+    dqkv = bf16s.attention_bwd(qkv.cuda(), ctx, dctx.cuda(), lse, B, N, heads)
+    err = (dqkv.double().cpu() - t.grad).abs()
+    scale = t.grad.abs().mean()
+    assert float(err.max()) < 0.1 * float(t.grad.abs().max()) and float(err.mean()) < 0.02 * float(scale), (float(err.max()), float(err.mean()), float(scale))
+    for i, name in enumerate(("dq", "dk", "dv")):
+        a, r = dqkv[:, i * D:(i + 1) * D].double().cpu().reshape(-1), t.grad[:, i * D:(i + 1) * D].reshape(-1)
+        cos = float(a @ r / (a.norm() * r.norm()))
+        assert cos > 0.999, (name, cos)
+    again = bf16s.attention_bwd(qkv.cuda(), ctx, dctx.cuda(), lse, B, N, heads)
+    assert torch.equal(dqkv, again)
