@@ -36,6 +36,27 @@ __device__ __forceinline__ void stage(__bf16* rowimg, __bf16* trimg, const __bf1
     }
 }
 
+// the same in two halves, so that the next tile's global loads are in flight during the current tile's MFMAs
+template <int THREADS>
+struct TileRegs { bf16x8 v[KT * (DH / 8) / THREADS]; };
+template <int THREADS>
+__device__ __forceinline__ void tile_load(TileRegs<THREADS>& t, const __bf16* src, long ld, int tid) {
+#pragma unroll
+    for (int i = 0; i < KT * (DH / 8) / THREADS; ++i) {
+        const int idx = tid + i * THREADS, row = idx >> 4, c8 = idx & 15;
+        t.v[i] = *(const bf16x8*)(src + (long)row * ld + c8 * 8);
+    }
+}
+template <int THREADS>
+__device__ __forceinline__ void tile_store(const TileRegs<THREADS>& t, __bf16* rowimg, __bf16* trimg, int tid) {
+#pragma unroll
+    for (int i = 0; i < KT * (DH / 8) / THREADS; ++i) {
+        const int idx = tid + i * THREADS, row = idx >> 4, c8 = idx & 15;
+        if (rowimg) *(bf16x8*)(rowimg + row * RSTR + c8 * 8) = t.v[i];
+        if (trimg) *(bf16x8*)(trimg + row * TSTR + c8 * 8) = t.v[i];
+    }
+}
+
 // one 128-element bf16 row as 8 k-step fragments: lane half h of step s holds d = 16 s + 8 h + j
 __device__ __forceinline__ void load_row_frags(Frags<1>& fr, const __bf16* rowp, int lh) {
 #pragma unroll
@@ -93,11 +114,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16s_kernel(const __bf1
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    for (int kt = 0; kt < N / KT; ++kt) {
+    TileRegs<THREADS> tk, tv;
+    tile_load(tk, base + D, ld, tid);
+    tile_load(tv, base + 2 * D, ld, tid);
+    const int ntiles = N / KT;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();                       // every wave is done with the previous tile's images
+        tile_store(tk, Kimg, nullptr, tid);
+        tile_store(tv, nullptr, Vimg, tid);
         __syncthreads();
-        stage<THREADS>(Kimg, nullptr, base + (long)(kt * KT) * ld + D, ld, tid);
-        stage<THREADS>(nullptr, Vimg, base + (long)(kt * KT) * ld + 2 * D, ld, tid);
-        __syncthreads();
+        if (kt + 1 < ntiles) {                 // next tile's loads fly during this tile's MFMAs
+            tile_load(tk, base + (long)((kt + 1) * KT) * ld + D, ld, tid);
+            tile_load(tv, base + (long)((kt + 1) * KT) * ld + 2 * D, ld, tid);
+        }
         f32x16 s = tile_x_frags<1>(Kimg, qf, l31, lh);                 // S^T[key][q]
         float mx = s[0];
 #pragma unroll
@@ -169,11 +198,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_bf16s_kernel(const __b
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-    for (int kt = 0; kt < N / KT; ++kt) {
+    TileRegs<THREADS> tk, tv;
+    tile_load(tk, qkv + D, ld3, tid);
+    tile_load(tv, qkv + 2 * D, ld3, tid);
+    const int ntiles = N / KT;
+    for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        stage<THREADS>(Krow, Ktr, qkv + (long)(kt * KT) * ld3 + D, ld3, tid);
-        stage<THREADS>(Vrow, nullptr, qkv + (long)(kt * KT) * ld3 + 2 * D, ld3, tid);
+        tile_store(tk, Krow, Ktr, tid);
+        tile_store(tv, Vrow, nullptr, tid);
         __syncthreads();
+        if (kt + 1 < ntiles) {
+            tile_load(tk, qkv + (long)((kt + 1) * KT) * ld3 + D, ld3, tid);
+            tile_load(tv, qkv + (long)((kt + 1) * KT) * ld3 + 2 * D, ld3, tid);
+        }
         f32x16 s = tile_x_frags<1>(Krow, qf, l31, lh);             // S^T[key][q]
         const f32x16 dp = tile_x_frags<1>(Vrow, dof, l31, lh);     // dP^T[key][q]
 #pragma unroll
@@ -217,13 +254,26 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_bf16s_kernel(const __
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
-    for (int qt = 0; qt < N / KT; ++qt) {
+    TileRegs<THREADS> tq, td;
+    const __bf16* dob = dO + (long)b * N * D + h * DH;
+    tile_load(tq, qkv, ld3, tid);
+    tile_load(td, dob, D, tid);
+    float lsv = 0.f;                               // threads 0..31: lse of the tile's queries (log2 units), 32..63: delta
+    if (tid < 32) lsv = LSE[(long)bh * N + tid] * 1.4426950408889634f;
+    else if (tid < 64) lsv = DELTA[(long)bh * N + tid - 32];
+    const int ntiles = N / KT;
+    for (int qt = 0; qt < ntiles; ++qt) {
         __syncthreads();
-        stage<THREADS>(Qrow, Qtr, qkv + (long)(qt * KT) * ld3, ld3, tid);
-        stage<THREADS>(Drow, Dtr, dO + ((long)b * N + qt * KT) * D + h * DH, D, tid);
-        if (tid < 32) Ls[tid] = LSE[(long)bh * N + qt * KT + tid] * 1.4426950408889634f;
-        else if (tid < 64) Ls[tid] = DELTA[(long)bh * N + qt * KT + tid - 32];
+        tile_store(tq, Qrow, Qtr, tid);
+        tile_store(td, Drow, Dtr, tid);
+        if (tid < 64) Ls[tid] = lsv;
         __syncthreads();
+        if (qt + 1 < ntiles) {
+            tile_load(tq, qkv + (long)((qt + 1) * KT) * ld3, ld3, tid);
+            tile_load(td, dob + (long)((qt + 1) * KT) * D, D, tid);
+            if (tid < 32) lsv = LSE[(long)bh * N + (qt + 1) * KT + tid] * 1.4426950408889634f;
+            else if (tid < 64) lsv = DELTA[(long)bh * N + (qt + 1) * KT + tid - 32];
+        }
         f32x16 p = tile_x_frags<1>(Qrow, kf, l31, lh);               // S[q][key]
 #pragma unroll
         for (int r = 0; r < 16; ++r) p[r] = exp2f(fmaf(p[r], c2, -Ls[(r & 3) + 8 * (r >> 2) + 4 * lh]));

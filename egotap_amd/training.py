@@ -6,7 +6,8 @@ through the backward operators and hands every parameter gradient back to autogr
 ``optimizer.step()`` in the wrapper read exactly like the reference (model/egotap_autoencoder_model.py:299-323).
 ``PoseLossFn`` is the loss (utils/loss.py:54-85), ``EgotapAdamW`` the optimizer (model/network.py:72-78) -- both HIP.
 
-The fp32 path only (the reference's optional fp16 autocast is not reproduced).
+``LiftTrainFn`` runs the fp32 / bf16x3 arithmetic on fp32 tensors; ``LiftTrainBf16Fn`` is the reduced-precision mode (bf16
+activations in HBM, fp32 master weights and accumulation) behind the wrapper's --use_amp.
 """
 from __future__ import annotations
 
@@ -192,6 +193,209 @@ class LiftTrainFn(torch.autograd.Function):
         return (None, None) + tuple(G[k] for k in keys)
 
 
+class LiftTrainBf16Fn(torch.autograd.Function):
+    """The training step of the head in the bf16-STORAGE mode (EGOTAP_PREC_BF16; BASELINE configs 3-5, the wrapper's --use_amp):
+    the ViT's activations live in HBM as bf16 (written by their producers: LayerNorm, the GEMM epilogues, attention), the fp32 master
+    weights are rounded once per step (bf16 copy + transposed bf16 copy for the input-gradient GEMMs), every large product reads bf16
+    operands through the LDS DMA (csrc/gemm_bf16s.h, gemm_tn_bf16s.h) with fp32 accumulation; the residual stream, LayerNorm / BatchNorm
+    statistics, the small FC layers, the propagation units, the pose head, all gradients and the optimizer state stay fp32.
+    Same autograd contract as LiftTrainFn (model/egotap_autoencoder_model.py:299-323 drives it unchanged)."""
+
+    @staticmethod
+    def _prep(net, P, dev):
+        """per-step bf16 copies of the GEMM weights in a persistent arena on the module"""
+        from . import bf16s as S
+        p = net.preset
+        D = p.vit_dim
+        ar = getattr(net, "_bf16_arena", None)
+        if ar is None or ar["dev"] != dev:
+            bf = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=dev)      # noqa: E731
+            K1p, K1r = p.ppd * p.ppd * D, 2 * p.hm_size * p.hm_size
+            ar = dict(dev=dev, layers=[dict(qkv=bf(3 * D, D), qkv_t=bf(D, 3 * D), o=bf(D, D), o_t=bf(D, D), up=bf(4 * D, D), up_t=bf(D, 4 * D),
+                                            dn=bf(D, 4 * D), dn_t=bf(4 * D, D)) for _ in range(p.vit_layers)],
+                      fc1p=bf(2048, K1p), fc1p_t=bf(K1p, 2048), fc1r=bf(2048, K1r))
+            net._bf16_arena = ar
+        v = "pos_heatmap_encoder.vit."
+        for i, L in enumerate(ar["layers"]):
+            l = f"{v}encoder.layer.{i}."
+            for sidx, nme in enumerate(("query", "key", "value")):
+                S.prep_weight(P[l + "attention.attention." + nme + ".weight"], L["qkv"][sidx * D:(sidx + 1) * D], L["qkv_t"][:, sidx * D:(sidx + 1) * D])
+            S.prep_weight(P[l + "attention.output.dense.weight"], L["o"], L["o_t"])
+            S.prep_weight(P[l + "intermediate.dense.weight"], L["up"], L["up_t"])
+            S.prep_weight(P[l + "output.dense.weight"], L["dn"], L["dn_t"])
+        S.prep_weight(P["pos_heatmap_encoder.fc1.fc.weight"], ar["fc1p"], ar["fc1p_t"])
+        S.prep_weight(P["rot_heatmap_encoder.fc1.fc.weight"], ar["fc1r"])
+        return ar
+
+    @staticmethod
+    def forward(ctx, net, hm, *params):
+        from . import bf16s as S
+        p = net.preset
+        keys = _param_order(p)
+        P = dict(zip(keys, params))
+        dev = hm.device
+        h = net._ensure_handle()
+        net._bind(dev)
+        B, D, seq, heads, J, T_, hid = hm.shape[0], p.vit_dim, p.seq, p.vit_heads, p.n_joints_hm, p.tokens, p.hidden
+        M, BT = B * seq, B * T_
+        lib = _lib.load()
+        st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)      # noqa: E731
+        v = "pos_heatmap_encoder.vit."
+        hm = hm.detach().float().contiguous()
+        W = LiftTrainBf16Fn._prep(net, P, dev)
+        hm_b = S.from_f32(hm)                                       # bf16 copy of the input heatmaps: the rotation encoder's fc1 operand
+        saved = {"hm": hm, "hm_b": hm_b}
+        x = torch.empty((M, D), dtype=torch.float32, device=dev)
+        _lib.check(lib.egotap_train_patch_fwd(h, T._p(hm), B, T._p(P[v + "embeddings.patch_embeddings.projection.weight"]),
+                                              T._p(P[v + "embeddings.patch_embeddings.projection.bias"]), T._p(P[v + "embeddings.mask_token"]),
+                                              T._p(P[v + "embeddings.position_embeddings"]), T._p(x), st()))
+        layers = []
+        for i in range(p.vit_layers):
+            l = f"{v}encoder.layer.{i}."
+            a = l + "attention.attention."
+            Wl = W["layers"][i]
+            y1, m1, r1 = S.layernorm_fwd(x, P[l + "layernorm_before.weight"], P[l + "layernorm_before.bias"])
+            bqkv = torch.cat((P[a + "query.bias"], P[a + "key.bias"], P[a + "value.bias"]))
+            qkv = S.gemm_nt(y1, Wl["qkv"], bqkv)
+            ctx_, lse = S.attention_fwd(qkv, B, seq, heads)
+            xm = S.gemm_nt(ctx_, Wl["o"], P[l + "attention.output.dense.bias"], epi="residual", aux=x)
+            y2, m2, r2 = S.layernorm_fwd(xm, P[l + "layernorm_after.weight"], P[l + "layernorm_after.bias"])
+            z, hid_ = S.gemm_nt(y2, Wl["up"], P[l + "intermediate.dense.bias"], epi="gelu_save")
+            xo = S.gemm_nt(hid_, Wl["dn"], P[l + "output.dense.bias"], epi="residual", aux=xm)
+            layers.append(dict(x=x, m1=m1, r1=r1, y1=y1, qkv=qkv, ctx=ctx_, lse=lse, xm=xm, m2=m2, r2=r2, y2=y2, z=z, hid=hid_))
+            x = xo
+        tokens, mf, rf = S.layernorm_fwd(x, P[v + "layernorm.weight"], P[v + "layernorm.bias"])
+        saved.update(layers=layers, xf=x, mf=mf, rf=rf, tokens=tokens)
+        bufs = dict(net.named_buffers())
+
+        def encoder(name, which, src, wb):
+            acts = []
+            a_in = None
+            for j, n_out in enumerate((2048, 512, hid), start=1):
+                f = f"{name}.fc{j}"
+                if j == 1:
+                    zz = S.fc1_fwd(h, which, src, wb, P[f + ".fc.bias"], B, T_)
+                    K = wb.shape[1]
+                else:
+                    K = a_in.shape[1]
+                    zz = T.gemm_nt(h, a_in, P[f + ".fc.weight"], P[f + ".fc.bias"], BT, n_out, K, epi=T.TE_BIAS)
+                yy, mean, rstd = T.bn_lrelu_fwd(zz, P[f + ".bn.weight"], P[f + ".bn.bias"], bufs[f + ".bn.running_mean"], bufs[f + ".bn.running_var"])
+                bufs[f + ".bn.num_batches_tracked"].add_(1)
+                acts.append(dict(a_in=a_in, z=zz, y=yy, mean=mean, rstd=rstd, K=K, N=n_out, name=f))
+                a_in = yy
+            return acts
+
+        pos_acts = encoder("pos_heatmap_encoder", 0, tokens, W["fc1p"])
+        rot_acts = encoder("rot_heatmap_encoder", 1, hm_b, W["fc1r"])
+        posz, rotz = pos_acts[-1]["y"], rot_acts[-1]["y"]
+        nb, off = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.egotap_train_pu_saved_bytes(h, B, C.byref(nb), C.byref(off)))
+        pu_saved = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+        _lib.check(lib.egotap_train_pu_fwd(h, T._p(posz), T._p(rotz), B, T._p(pu_saved), pu_saved.numel(), st()))
+        hs1 = pu_saved[off.value: off.value + 4 * J * B * p.pu_hidden].view(torch.float32)
+        pose = torch.empty((B, p.out_joints, 3), dtype=torch.float32, device=dev)
+        _lib.check(lib.egotap_train_pose_head_fwd(h, T._p(posz), T._p(hs1), B, T._p(pose), st()))
+        saved.update(pos_acts=pos_acts, rot_acts=rot_acts, pu_saved=pu_saved, hs1=hs1, P=P, keys=keys, net=net, B=B, W=W)
+        ctx.egotap = saved
+        return pose
+
+    @staticmethod
+    def backward(ctx, dpose):
+        from . import bf16s as S
+        Sv = ctx.egotap
+        net, P, keys, B, W = Sv["net"], Sv["P"], Sv["keys"], Sv["B"], Sv["W"]
+        p = net.preset
+        h = net._ensure_handle()
+        dev = dpose.device
+        D, seq, heads, J, T_, hid, H = p.vit_dim, p.seq, p.vit_heads, p.n_joints_hm, p.tokens, p.hidden, p.pu_hidden
+        M, BT = B * seq, B * T_
+        lib = _lib.load()
+        st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)      # noqa: E731
+        G = {k: torch.empty_like(P[k]) for k in keys}          # every entry is fully overwritten below
+        dpose = dpose.detach().float().contiguous()
+        v = "pos_heatmap_encoder.vit."
+        posz, rotz, hs1 = Sv["pos_acts"][-1]["y"], Sv["rot_acts"][-1]["y"], Sv["hs1"]
+        # pose head + propagation units (fp32, as in every mode)
+        dposz, drotz = torch.empty_like(posz), torch.empty_like(rotz)
+        dhs1 = torch.empty(J * B * H, dtype=torch.float32, device=dev)
+        gw, gb = G.get("global_mlp.pose_fcs.0.weight"), G.get("global_mlp.pose_fcs.0.bias")
+        _lib.check(lib.egotap_train_pose_head_bwd(h, T._p(posz), T._p(hs1), T._p(dpose), B, T._p(dposz), T._p(dhs1),
+                                                  T._p(G["pose_mlp.pose_fcs.0.weight"]), T._p(G["pose_mlp.pose_fcs.0.bias"]), T._p(gw), T._p(gb), 0, st()))
+        wsb = C.c_size_t()
+        _lib.check(lib.egotap_train_pu_bwd_ws_bytes(h, B, C.byref(wsb)))
+        ws = torch.empty(wsb.value, dtype=torch.uint8, device=dev)
+        ptrs = (C.c_void_p * 14)()
+        c = "skel_sequential_layer.lstm_custom.layers."
+        for i, nme in enumerate(("0.x2f", "0.x2h", "0.b2h", "0.h2h", "1.x2f", "1.x2h", "1.h2h")):
+            ptrs[2 * i] = G[c + nme + ".weight"].data_ptr()
+            ptrs[2 * i + 1] = G[c + nme + ".bias"].data_ptr()
+        _lib.check(lib.egotap_train_pu_bwd(h, T._p(posz), T._p(rotz), B, T._p(Sv["pu_saved"]), T._p(dhs1), T._p(dposz), T._p(drotz), ptrs, 0,
+                                           T._p(ws), ws.numel(), st()))
+        del ws
+
+        def encoder_bwd(acts, dy, which, src, wt):
+            """fc3, fc2 in fp32 (small); fc1 on the bf16 kernels.  Returns the token gradient (position encoder) or None"""
+            for j in (2, 1, 0):
+                a = acts[j]
+                f = a["name"]
+                dz = T.bn_lrelu_bwd(a["z"], a["y"], dy, P[f + ".bn.weight"], a["mean"], a["rstd"], G[f + ".bn.weight"], G[f + ".bn.bias"])
+                T.colsum(dz, G[f + ".fc.bias"], BT, a["N"])
+                if j > 0:
+                    T.gemm_tn(h, dz, a["a_in"], G[f + ".fc.weight"], BT, a["N"], a["K"])
+                    dy = T.gemm_nt(h, dz, T.transpose(P[f + ".fc.weight"]), None, BT, a["K"], a["N"], epi=T.TE_NONE)
+                else:
+                    dzb = S.from_f32(dz)
+                    S.fc1_wgrad(h, which, dzb, src, G[f + ".fc.weight"], B)
+                    return S.fc1_dgrad_tokens(h, dzb, wt, B, seq, D) if wt is not None else None
+
+        encoder_bwd(Sv["rot_acts"], drotz, 1, Sv["hm_b"], None)
+        dtok = encoder_bwd(Sv["pos_acts"], dposz, 0, Sv["tokens"], W["fc1p_t"])       # bf16 [M, D], token order
+        nl = p.vit_layers
+        last = f"{v}encoder.layer.{nl - 1}."
+        dx, dxb = S.layernorm_bwd(Sv["xf"], dtok, P[v + "layernorm.weight"], Sv["mf"], Sv["rf"], G[v + "layernorm.weight"], G[v + "layernorm.bias"],
+                                  dcolsum=G[last + "output.dense.bias"])
+        del dtok
+        for i in reversed(range(nl)):
+            L = Sv["layers"][i]
+            Wl = W["layers"][i]
+            l = f"{v}encoder.layer.{i}."
+            a = l + "attention.attention."
+            # MLP: dx is the output gradient of output.dense (its bias gradient came with the LayerNorm backward that produced dx)
+            S.gemm_tn(dxb, L["hid"], G[l + "output.dense.weight"])
+            dz = S.gemm_nt(dxb, Wl["dn_t"], None, epi="gelu_grad", aux=L["z"])
+            del dxb
+            S.gemm_tn(dz, L["y2"], G[l + "intermediate.dense.weight"])
+            S.colsum(dz, G[l + "intermediate.dense.bias"])
+            dy2 = S.gemm_nt(dz, Wl["up_t"], None)
+            del dz
+            dxm, dxmb = S.layernorm_bwd(L["xm"], dy2, P[l + "layernorm_after.weight"], L["m2"], L["r2"], G[l + "layernorm_after.weight"],
+                                        G[l + "layernorm_after.bias"], dres=dx, dcolsum=G[l + "attention.output.dense.bias"])
+            del dy2, dx
+            # attention
+            S.gemm_tn(dxmb, L["ctx"], G[l + "attention.output.dense.weight"])
+            dctx = S.gemm_nt(dxmb, Wl["o_t"], None)
+            del dxmb
+            dqkv = S.attention_bwd(L["qkv"], L["ctx"], dctx, L["lse"], B, seq, heads)
+            del dctx
+            for sidx, nme in enumerate(("query", "key", "value")):
+                S.gemm_tn(dqkv[:, sidx * D:(sidx + 1) * D], L["y1"], G[a + nme + ".weight"])
+                S.colsum(dqkv[:, sidx * D:(sidx + 1) * D], G[a + nme + ".bias"])
+            dy1 = S.gemm_nt(dqkv, Wl["qkv_t"], None)
+            del dqkv
+            prev_bias = G[f"{v}encoder.layer.{i - 1}.output.dense.bias"] if i > 0 else None
+            dx, dxb = S.layernorm_bwd(L["x"], dy1, P[l + "layernorm_before.weight"], L["m1"], L["r1"], G[l + "layernorm_before.weight"],
+                                      G[l + "layernorm_before.bias"], dres=dxm, dcolsum=prev_bias, want_bf16=i > 0)
+            del dy1, dxm
+        # patch embedding (fp32 operands: the input heatmaps): weight, position embeddings, bias / mask token
+        T.gemm_tn(h, dx, Sv["hm"], G[v + "embeddings.patch_embeddings.projection.weight"], M, D, 256, loader=T.LD_PATCH)
+        dpos = G[v + "embeddings.position_embeddings"]
+        T.colsum(dx, dpos, B, seq * D)
+        _lib.check(lib.egotap_train_patch_split(h, T._p(dpos), T._p(G[v + "embeddings.patch_embeddings.projection.bias"]),
+                                                T._p(G[v + "embeddings.mask_token"]), 0, st()))
+        ctx.egotap = None
+        return (None, None) + tuple(G[k] for k in keys)
+
+
 class PoseLossFn(torch.autograd.Function):
     """returns a tensor [2] = (loss_pose, loss_cos_sim) exactly as backward_AutoEncoder weighs them"""
 
@@ -211,7 +415,9 @@ class PoseLossFn(torch.autograd.Function):
 def lift_train_forward(net, hm):
     """training-mode forward of EgoTAPAutoEncoder through the HIP operators, differentiable w.r.t. net.parameters()"""
     params = dict(net.named_parameters())
-    return LiftTrainFn.apply(net, hm, *[params[k] for k in _param_order(net.preset)])
+    # net.bf16_storage = False keeps fp32 tensors in HBM under the bf16 arithmetic (round 1's path: operands converted per launch)
+    fn = LiftTrainBf16Fn if getattr(net, "precision", "f32") == "bf16" and net.preset.vit_dim == 1024 and getattr(net, "bf16_storage", True) else LiftTrainFn
+    return fn.apply(net, hm, *[params[k] for k in _param_order(net.preset)])
 
 
 class EgotapAdamW(torch.optim.Optimizer):

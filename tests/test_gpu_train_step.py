@@ -22,7 +22,9 @@ def _fresh_net():
     return net.cuda(), p
 
 
-def _check_against_golden(net, g, losses, abs_floor=5e-9):
+def _check_against_golden(net, g, losses, abs_floor=1e-8):
+    # abs_floor: gradients that vanish by symmetry in the reference (|g| ~ 5e-10: the final LayerNorm's bias) are rounding noise of
+    # fp32 sums; its size depends on the order of the additions (the two loss terms' gradients are added outside the kernel now)
     norms = dict(zip(g["grad_keys"], g["grad_norms"]))
     params = dict(net.named_parameters())
     assert sorted(k for k, v in params.items() if v.grad is not None) == sorted(g["grad_keys"])
@@ -153,15 +155,8 @@ def test_train_step_bf16_mode_against_float64_oracle():
     ref = O.train_step(hm, gt, O.to_torch_sd(synth_state_dict(spec.lift_state_spec(p)), torch.float64), p)
     np.testing.assert_allclose(l16[0], float(ref["loss_pose"]), rtol=1e-2)
     assert float((pose16.double().cpu() - ref["pose"]).abs().max()) < 5e-2 * float(ref["pose"].abs().max())
-    for k, v in net.named_parameters():
-        if v.grad is None or v.numel() < 65536:
-            continue
-        a, b = v.grad.double().reshape(-1).cpu(), ref["grads"][k].double().reshape(-1)
-        if float(b.norm()) < 1e-9:
-            continue
-        cos = float(a @ b / (a.norm() * b.norm()))
-        rel = float((a - b).norm() / b.norm())
-        assert cos > 0.98 and rel < 0.2, f"{k}: cos {cos:.5f} rel {rel:.3e}"
+    from test_gpu_configs import _grad_gates          # one definition of the bf16 gradient gates (incl. the small-by-cancellation rule)
+    _grad_gates(net, ref["grads"], 0.98, 0.2)
 
 
 def test_wrapper_checkpoint_roundtrip_and_scheduler(tmp_path):
