@@ -26,7 +26,9 @@ __device__ __forceinline__ void stage(__bf16* rowimg, __bf16* trimg, const __bf1
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int idx = tid + i * THREADS, row = idx >> 4, c8 = idx & 15;
-        st[i] = *(const bf16x8*)(src + (long)row * ld + c8 * 8);
+        // wave-uniform base + 32-bit lane offset (global_load saddr form): a hoisted 64-bit pointer per lane and chunk spills in the
+        // register-bound backward kernels, and a spill reload in the tile loop is a vmcnt-ordered memory operation
+        st[i] = *(const bf16x8*)(src + (size_t)(unsigned)(row * (int)ld + c8 * 8));
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -36,21 +38,22 @@ __device__ __forceinline__ void stage(__bf16* rowimg, __bf16* trimg, const __bf1
     }
 }
 
-// the same in two halves, so that the next tile's global loads are in flight during the current tile's MFMAs
-template <int THREADS>
-struct TileRegs { bf16x8 v[KT * (DH / 8) / THREADS]; };
-template <int THREADS>
-__device__ __forceinline__ void tile_load(TileRegs<THREADS>& t, const __bf16* src, long ld, int tid) {
+// a ROWS x 128 bf16 tile in two steps (global -> registers, registers -> LDS images), so that the next tile's global loads are in
+// flight during the current tile's MFMAs.  ROWS = 32 * SUB: SUB sub-tiles of 32 rows are staged per barrier pair.
+template <int THREADS, int ROWS>
+struct TileRegs { bf16x8 v[ROWS * (DH / 8) / THREADS]; };
+template <int THREADS, int ROWS>
+__device__ __forceinline__ void tile_load(TileRegs<THREADS, ROWS>& t, const __bf16* src, long ld, int tid) {
 #pragma unroll
-    for (int i = 0; i < KT * (DH / 8) / THREADS; ++i) {
+    for (int i = 0; i < ROWS * (DH / 8) / THREADS; ++i) {
         const int idx = tid + i * THREADS, row = idx >> 4, c8 = idx & 15;
-        t.v[i] = *(const bf16x8*)(src + (long)row * ld + c8 * 8);
+        t.v[i] = *(const bf16x8*)(src + (size_t)(unsigned)(row * (int)ld + c8 * 8));
     }
 }
-template <int THREADS>
-__device__ __forceinline__ void tile_store(const TileRegs<THREADS>& t, __bf16* rowimg, __bf16* trimg, int tid) {
+template <int THREADS, int ROWS>
+__device__ __forceinline__ void tile_store(const TileRegs<THREADS, ROWS>& t, __bf16* rowimg, __bf16* trimg, int tid) {
 #pragma unroll
-    for (int i = 0; i < KT * (DH / 8) / THREADS; ++i) {
+    for (int i = 0; i < ROWS * (DH / 8) / THREADS; ++i) {
         const int idx = tid + i * THREADS, row = idx >> 4, c8 = idx & 15;
         if (rowimg) *(bf16x8*)(rowimg + row * RSTR + c8 * 8) = t.v[i];
         if (trimg) *(bf16x8*)(trimg + row * TSTR + c8 * 8) = t.v[i];
@@ -86,14 +89,18 @@ __device__ __forceinline__ void store_rows_bf16(const f32x16 (&o)[4], float mul,
 }  // namespace attns
 
 // ------------------------------------------------------------------------------------------------- forward
-template <int NW>
+// SUB sub-tiles of 32 keys per barrier pair.  The running maximum is only raised (and the output accumulators rescaled) when a
+// query's scores exceed it by more than 2^RESC in the softmax's base-2 units (cdna_hip_programming.md T13): probabilities then
+// stay below 2^RESC, harmless in fp32 sums and bf16 operands, and the 64 multiplies per sub-tile disappear from almost every tile.
+template <int NW, int SUB>
 __global__ __launch_bounds__(64 * NW, 2) void attention_bf16s_kernel(const __bf16* __restrict__ QKV, __bf16* __restrict__ CTX, int N, int heads,
                                                                     int qgroups, float scale_log2e, float* __restrict__ LSE) {
     using namespace attns;
-    constexpr int THREADS = 64 * NW;
+    constexpr int THREADS = 64 * NW, ROWS = 32 * SUB;
+    constexpr float RESC = 6.0f;
     extern __shared__ __attribute__((aligned(16))) __bf16 simg_s[];
-    __bf16* Kimg = simg_s;                     // [32][RSTR]
-    __bf16* Vimg = simg_s + RIMG;              // [32][TSTR]
+    __bf16* Kimg = simg_s;                     // [ROWS][RSTR]
+    __bf16* Vimg = simg_s + SUB * RIMG;        // [ROWS][TSTR]
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int q8 = nblk >> 3, r8 = nblk & 7, x8 = bid & 7;
     const int lin = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (bid >> 3);
@@ -113,52 +120,58 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16s_kernel(const __bf1
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    TileRegs<THREADS> tk, tv;
+    float m_run = -INFINITY, l_run = 0.f;      // m_run in base-2 units (score * scale_log2e)
+    TileRegs<THREADS, ROWS> tk, tv;
     tile_load(tk, base + D, ld, tid);
     tile_load(tv, base + 2 * D, ld, tid);
-    const int ntiles = N / KT;
+    const int ntiles = N / ROWS;
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();                       // every wave is done with the previous tile's images
         tile_store(tk, Kimg, nullptr, tid);
         tile_store(tv, nullptr, Vimg, tid);
         __syncthreads();
         if (kt + 1 < ntiles) {                 // next tile's loads fly during this tile's MFMAs
-            tile_load(tk, base + (long)((kt + 1) * KT) * ld + D, ld, tid);
-            tile_load(tv, base + (long)((kt + 1) * KT) * ld + 2 * D, ld, tid);
+            tile_load(tk, base + (long)((kt + 1) * ROWS) * ld + D, ld, tid);
+            tile_load(tv, base + (long)((kt + 1) * ROWS) * ld + 2 * D, ld, tid);
         }
-        f32x16 s = tile_x_frags<1>(Kimg, qf, l31, lh);                 // S^T[key][q]
-        float mx = s[0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * scale_log2e);
-        const float mneg = -m_new * scale_log2e;
-        float psum = 0.f;
+        for (int sub = 0; sub < SUB; ++sub) {
+            f32x16 s = tile_x_frags<1>(Kimg + sub * RIMG, qf, l31, lh);     // S^T[key][q]
+            float mx = s[0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = exp2f(fmaf(s[r], scale_log2e, mneg));
-            psum += s[r];
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
+            const bool raise = mx > m_run + RESC;
+            if (__builtin_amdgcn_ballot_w64(raise) != 0) {                   // rare after the first tile: wave-uniform branch
+                const float m_new = raise ? mx : m_run;
+                const float alpha = exp2f(m_run - m_new);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = exp2f(fmaf(s[r], scale_log2e, -m_run));
+                psum += s[r];
+            }
+            l_run += psum;
+            acc_tile_t_x_p<1>(o, Vimg + sub * TIMG, s, lane);                // O^T[d][q] += V^T P^T
         }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-        acc_tile_t_x_p<1>(o, Vimg, s, lane);                           // O^T[d][q] += V^T P^T
     }
     __syncthreads();
     if (valid) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        if (LSE != nullptr && lh == 0) LSE[(long)bh * N + q0 + l31] = m_run * (scale_log2e * 0.6931471805599453f) + logf(l_tot);
+        if (LSE != nullptr && lh == 0) LSE[(long)bh * N + q0 + l31] = m_run * 0.6931471805599453f + logf(l_tot);
         store_rows_bf16(o, 1.0f / l_tot, (float*)simg_s + wid * 32 * OLD, CTX + ((long)b * N + q0) * D + h * DH, D, lane);
     }
 }
 
 // ------------------------------------------------------------------------------------------------- dQ (+ delta)
-template <int NW>
+template <int NW, int SUB>
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_bf16s_kernel(const __bf16* __restrict__ QKV, const __bf16* __restrict__ O,
                                                                       const __bf16* __restrict__ dO, const float* __restrict__ LSE,
                                                                       __bf16* __restrict__ dQKV, float* __restrict__ DELTA, int N, int heads,
@@ -166,9 +179,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_bf16s_kernel(const __b
     using namespace attns;
     constexpr int THREADS = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) __bf16 bsm_s[];
+    constexpr int ROWS = 32 * SUB;
     __bf16* Krow = bsm_s;
-    __bf16* Ktr = Krow + RIMG;
-    __bf16* Vrow = Ktr + TIMG;
+    __bf16* Ktr = Krow + SUB * RIMG;
+    __bf16* Vrow = Ktr + SUB * TIMG;
     const int bh = blockIdx.x / qgroups, qg = blockIdx.x - bh * qgroups;
     const int b = bh / heads, h = bh - b * heads;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -198,43 +212,47 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_bf16s_kernel(const __b
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-    TileRegs<THREADS> tk, tv;
+    TileRegs<THREADS, ROWS> tk, tv;
     tile_load(tk, qkv + D, ld3, tid);
     tile_load(tv, qkv + 2 * D, ld3, tid);
-    const int ntiles = N / KT;
+    const int ntiles = N / ROWS;
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
         tile_store(tk, Krow, Ktr, tid);
         tile_store(tv, Vrow, nullptr, tid);
         __syncthreads();
         if (kt + 1 < ntiles) {
-            tile_load(tk, qkv + (long)((kt + 1) * KT) * ld3 + D, ld3, tid);
-            tile_load(tv, qkv + (long)((kt + 1) * KT) * ld3 + 2 * D, ld3, tid);
+            tile_load(tk, qkv + (long)((kt + 1) * ROWS) * ld3 + D, ld3, tid);
+            tile_load(tv, qkv + (long)((kt + 1) * ROWS) * ld3 + 2 * D, ld3, tid);
         }
-        f32x16 s = tile_x_frags<1>(Krow, qf, l31, lh);             // S^T[key][q]
-        const f32x16 dp = tile_x_frags<1>(Vrow, dof, l31, lh);     // dP^T[key][q]
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = exp2f(fmaf(s[r], c2, -lse2)) * (dp[r] - delta) * scale;   // dS^T
-        acc_tile_t_x_p<1>(dq, Ktr, s, lane);                       // dQ^T[d][q] += K^T dS^T
+        for (int sub = 0; sub < SUB; ++sub) {
+            f32x16 s = tile_x_frags<1>(Krow + sub * RIMG, qf, l31, lh);             // S^T[key][q]
+            const f32x16 dp = tile_x_frags<1>(Vrow + sub * RIMG, dof, l31, lh);     // dP^T[key][q]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = exp2f(fmaf(s[r], c2, -lse2)) * (dp[r] - delta) * scale;   // dS^T
+            acc_tile_t_x_p<1>(dq, Ktr + sub * TIMG, s, lane);                       // dQ^T[d][q] += K^T dS^T
+        }
     }
     __syncthreads();
     if (valid) store_rows_bf16(dq, 1.0f, (float*)bsm_s + wid * 32 * OLD, dQKV + ((long)b * N + q0) * ld3 + h * DH, ld3, lane);
 }
 
 // ------------------------------------------------------------------------------------------------- dK and dV
-template <int NW>
+template <int NW, int SUB>
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_bf16s_kernel(const __bf16* __restrict__ QKV, const __bf16* __restrict__ dO,
                                                                        const float* __restrict__ LSE, const float* __restrict__ DELTA,
                                                                        __bf16* __restrict__ dQKV, int N, int heads, int kgroups, float scale) {
     using namespace attns;
     constexpr int THREADS = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) __bf16 bsm_s[];
+    constexpr int ROWS = 32 * SUB;
     __bf16* Qrow = bsm_s;
-    __bf16* Qtr = Qrow + RIMG;
-    __bf16* Drow = Qtr + TIMG;
-    __bf16* Dtr = Drow + RIMG;
-    float* Ls = (float*)(Dtr + TIMG);          // [32] lse (log2 units), [32] delta
-    __bf16* Vw = (__bf16*)(Ls + 64);           // per wave: row image of the V rows of its 32 keys (registers hold K, dK, dV)
+    __bf16* Qtr = Qrow + SUB * RIMG;
+    __bf16* Drow = Qtr + SUB * TIMG;
+    __bf16* Dtr = Drow + SUB * RIMG;
+    float* Ls = (float*)(Dtr + SUB * TIMG);    // [ROWS] lse (log2 units), [ROWS] delta
+    __bf16* Vw = (__bf16*)(Ls + 2 * ROWS);     // per wave: row image of the V rows of its 32 keys (registers hold K, dK, dV)
     const int bh = blockIdx.x / kgroups, kg = blockIdx.x - bh * kgroups;
     const int b = bh / heads, h = bh - b * heads;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -254,34 +272,35 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_bf16s_kernel(const __
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
-    TileRegs<THREADS> tq, td;
+    // no register prefetch of the next tile here: dK + dV hold 128 accumulators, the K fragments 32 more, and 16 staging registers
+    // on top spill in the tile loop (measured 5.3 -> 7.2 ms); the CU's second workgroup covers the load latency instead
     const __bf16* dob = dO + (long)b * N * D + h * DH;
-    tile_load(tq, qkv, ld3, tid);
-    tile_load(td, dob, D, tid);
-    float lsv = 0.f;                               // threads 0..31: lse of the tile's queries (log2 units), 32..63: delta
-    if (tid < 32) lsv = LSE[(long)bh * N + tid] * 1.4426950408889634f;
-    else if (tid < 64) lsv = DELTA[(long)bh * N + tid - 32];
-    const int ntiles = N / KT;
+    const int ntiles = N / ROWS;
     for (int qt = 0; qt < ntiles; ++qt) {
         __syncthreads();
-        tile_store(tq, Qrow, Qtr, tid);
-        tile_store(td, Drow, Dtr, tid);
-        if (tid < 64) Ls[tid] = lsv;
-        __syncthreads();
-        if (qt + 1 < ntiles) {
-            tile_load(tq, qkv + (long)((qt + 1) * KT) * ld3, ld3, tid);
-            tile_load(td, dob + (long)((qt + 1) * KT) * D, D, tid);
-            if (tid < 32) lsv = LSE[(long)bh * N + (qt + 1) * KT + tid] * 1.4426950408889634f;
-            else if (tid < 64) lsv = DELTA[(long)bh * N + (qt + 1) * KT + tid - 32];
+#pragma unroll
+        for (int sub = 0; sub < SUB; ++sub) {
+            stage<THREADS>(Qrow + sub * RIMG, Qtr + sub * TIMG, qkv + (long)(qt * ROWS + 32 * sub) * ld3, ld3, tid);
+            stage<THREADS>(Drow + sub * RIMG, Dtr + sub * TIMG, dob + (long)(qt * ROWS + 32 * sub) * D, D, tid);
         }
-        f32x16 p = tile_x_frags<1>(Qrow, kf, l31, lh);               // S[q][key]
+        {
+            const float* lp = LSE + (long)bh * N + qt * ROWS;
+            const float* dp_ = DELTA + (long)bh * N + qt * ROWS;
+            if (tid < ROWS) Ls[tid] = lp[(unsigned)tid] * 1.4426950408889634f;
+            else if (tid < 2 * ROWS) Ls[tid] = dp_[(unsigned)(tid - ROWS)];
+        }
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) p[r] = exp2f(fmaf(p[r], c2, -Ls[(r & 3) + 8 * (r >> 2) + 4 * lh]));
-        acc_tile_t_x_p<1>(dv, Dtr, p, lane);                         // dV^T[d][key] += dO^T P
-        const f32x16 dp = tile_x_tile<1>(Drow, Vmine, l31, lh);      // dP[q][key] = dO V^T
+        for (int sub = 0; sub < SUB; ++sub) {
+            f32x16 p = tile_x_frags<1>(Qrow + sub * RIMG, kf, l31, lh);              // S[q][key]
 #pragma unroll
-        for (int r = 0; r < 16; ++r) p[r] = p[r] * (dp[r] - Ls[32 + (r & 3) + 8 * (r >> 2) + 4 * lh]) * scale;   // dS[q][key]
-        acc_tile_t_x_p<1>(dk, Qtr, p, lane);                         // dK^T[d][key] += Q^T dS
+            for (int r = 0; r < 16; ++r) p[r] = exp2f(fmaf(p[r], c2, -Ls[32 * sub + (r & 3) + 8 * (r >> 2) + 4 * lh]));
+            acc_tile_t_x_p<1>(dv, Dtr + sub * TIMG, p, lane);                        // dV^T[d][key] += dO^T P
+            const f32x16 dp = tile_x_tile<1>(Drow + sub * RIMG, Vmine, l31, lh);     // dP[q][key] = dO V^T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = p[r] * (dp[r] - Ls[ROWS + 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * lh]) * scale;   // dS[q][key]
+            acc_tile_t_x_p<1>(dk, Qtr + sub * TIMG, p, lane);                        // dK^T[d][key] += Q^T dS
+        }
     }
     __syncthreads();
     if (valid) {
@@ -292,14 +311,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_bf16s_kernel(const __
     }
 }
 
-static hipError_t attention_bf16s_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream) {
+template <int SUB>
+static hipError_t attention_bf16s_fwd_launch_t(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream) {
     using namespace attns;
     constexpr int NW = 4;
-    if (B <= 0) return hipSuccess;
-    if (N % 32 != 0) return hipErrorInvalidValue;
-    constexpr size_t img = (size_t)(RIMG + TIMG) * 2, patch = (size_t)NW * 32 * OLD * 4;
+    constexpr size_t img = (size_t)SUB * (RIMG + TIMG) * 2, patch = (size_t)NW * 32 * OLD * 4;
     constexpr size_t lds = img > patch ? img : patch;
-    auto kern = attention_bf16s_kernel<NW>;
+    auto kern = attention_bf16s_kernel<NW, SUB>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -310,26 +328,39 @@ static hipError_t attention_bf16s_fwd_launch(const __bf16* QKV, __bf16* CTX, flo
     hipLaunchKernelGGL(kern, dim3(B * heads * qgroups), dim3(64 * NW), lds, stream, QKV, CTX, N, heads, qgroups, 1.4426950408889634f / sqrtf(128.0f), LSE);
     return hipGetLastError();
 }
-
-static hipError_t attention_bf16s_bwd_launch(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
-                                             int heads, hipStream_t stream) {
-    using namespace attns;
-    constexpr int NW = 4;
+static hipError_t attention_bf16s_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream) {
     if (B <= 0) return hipSuccess;
     if (N % 32 != 0) return hipErrorInvalidValue;
+    return N % 64 == 0 ? attention_bf16s_fwd_launch_t<2>(QKV, CTX, LSE, B, N, heads, stream) : attention_bf16s_fwd_launch_t<1>(QKV, CTX, LSE, B, N, heads, stream);
+}
+
+template <int SUB>
+static hipError_t attention_bf16s_bwd_launch_t(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
+                                               int heads, hipStream_t stream) {
+    using namespace attns;
+    constexpr int NW = 4;
     const float scale = 1.0f / sqrtf((float)DH);
     const int groups = (N / 32 + NW - 1) / NW;
     constexpr size_t patch = (size_t)NW * 32 * OLD * 4;
-    constexpr size_t img_q = (size_t)(2 * RIMG + TIMG) * 2, img_kv = (size_t)(2 * RIMG + 2 * TIMG) * 2 + 256 + (size_t)NW * RIMG * 2;
+    constexpr int SKV = 1;       // the dK + dV kernel keeps four images + a per-wave V image: 64-row tiles would leave one workgroup per CU
+    constexpr size_t img_q = (size_t)SUB * (2 * RIMG + TIMG) * 2, img_kv = (size_t)SKV * (2 * RIMG + 2 * TIMG) * 2 + SKV * 256 + (size_t)NW * RIMG * 2;
     constexpr size_t lds_q = img_q > patch ? img_q : patch, lds_kv = img_kv > patch ? img_kv : patch;
+    static_assert(2 * lds_kv <= 160 * 1024 && 2 * lds_q <= 160 * 1024, "two workgroups per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_bf16s_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_bf16s_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_bf16s_kernel<NW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_bf16s_kernel<NW, SKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((attn_bwd_dq_bf16s_kernel<NW>), dim3(B * heads * groups), dim3(64 * NW), lds_q, stream, QKV, O, dO, LSE, dQKV, DELTA, N, heads, groups, scale);
-    hipLaunchKernelGGL((attn_bwd_dkv_bf16s_kernel<NW>), dim3(B * heads * groups), dim3(64 * NW), lds_kv, stream, QKV, dO, LSE, DELTA, dQKV, N, heads, groups, scale);
+    hipLaunchKernelGGL((attn_bwd_dq_bf16s_kernel<NW, SUB>), dim3(B * heads * groups), dim3(64 * NW), lds_q, stream, QKV, O, dO, LSE, dQKV, DELTA, N, heads, groups, scale);
+    hipLaunchKernelGGL((attn_bwd_dkv_bf16s_kernel<NW, SKV>), dim3(B * heads * groups), dim3(64 * NW), lds_kv, stream, QKV, dO, LSE, DELTA, dQKV, N, heads, groups, scale);
     return hipGetLastError();
+}
+static hipError_t attention_bf16s_bwd_launch(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
+                                             int heads, hipStream_t stream) {
+    if (B <= 0) return hipSuccess;
+    if (N % 32 != 0) return hipErrorInvalidValue;
+    return N % 64 == 0 ? attention_bf16s_bwd_launch_t<2>(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream)
+                       : attention_bf16s_bwd_launch_t<1>(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream);
 }

@@ -412,7 +412,13 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
         __builtin_amdgcn_sched_barrier(0);
         st = (st + 1) & 3;
         if (++c_kt == KT) {
+            // One extra barrier per tile and group lets the two groups' epilogues run side by side: group 0 waits here for group 1's
+            // last MFMA phase (256 cycles idle), then both store their tiles concurrently; without it each group sits at a barrier
+            // through most of the other's epilogue (they are latency-bound: LDS round trips, residual loads, store issue).
+            if (grp == 0) __builtin_amdgcn_s_barrier();
             epilogue();
+            if (grp == 1) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
             c_kt = 0;
             ++c_tile;
         }

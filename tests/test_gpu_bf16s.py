@@ -180,7 +180,8 @@ def test_attention_fwd_bwd_bf16(B, N):
     q, k, v = (t[:, i * D:(i + 1) * D].view(B, N, heads, dh).transpose(1, 2) for i in range(3))
     sc = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
     ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * N, D)
-    _close_bf16(ctx, ref.detach(), "ctx", abs_=2e-3)
+    # probabilities and V are bf16 operands (2^-9 each) of a 576-term sum with |v| <= 2: absolute noise of a few 1e-3
+    _close_bf16(ctx, ref.detach(), "ctx", abs_=4e-3)
     assert float((lse.double().cpu() - torch.logsumexp(sc, -1).reshape(-1).detach()).abs().max()) < 2e-3
     # backward from the bf16 ctx the forward stored (what the training step does)
     ref.backward(dctx.double())

@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""GPU probe: lifting-head training step in a precision mode at batch B (bench.py's bench_train leg alone).
-EGOTAP_BF16_DMA=0 in the environment switches the plain-bf16 GEMMs back to the register-staged kernel (A/B)."""
+"""GPU probe: lifting-head training step in a precision mode at batch B (bench.py's bench_train leg alone)."""
 import sys, os, json, argparse
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -13,5 +12,5 @@ args = argparse.Namespace(preset="UnrealEgo", train_steps=2, train_batch=B)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 r = bench.bench_train(args, spec.lift_preset("UnrealEgo"), dev, 0, 1, lambda: torch.cuda.synchronize(dev), mode=mode, batch=B)
-print(json.dumps({"dma": os.environ.get("EGOTAP_BF16_DMA", "1"), "B": B, "mode": mode, "frames_per_s": r["value"], "ms_per_step": r["ms_per_step"],
-                  "loss_pose": r["loss_pose"]}))
+print(json.dumps({"B": B, "mode": mode, "frames_per_s": r["value"], "ms_per_step": r["ms_per_step"],
+                  "loss_pose": r["loss_pose"], "peak_hbm_gib": r["peak_hbm_gib"], "tflops": r["end_to_end_tflops_per_gpu"]}))
