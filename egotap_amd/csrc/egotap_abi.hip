@@ -459,6 +459,20 @@ static int device_cu_count() {
     return n;
 }
 
+// stream-ordered zero fill as a KERNEL: a hipMemsetAsync captured into a HIP graph did not re-execute on replay (ROCm 7.2: the
+// propagation units' cell state then carried over from one replay to the next), a kernel node does
+static __global__ __launch_bounds__(256) void zero_fill_kernel(f32x4* __restrict__ p, long n16) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) p[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+static hipError_t zero_fill(void* p, size_t bytes, hipStream_t s) {       // p 16-byte aligned, bytes a multiple of 16
+    if (bytes == 0) return hipSuccess;
+    if ((((uintptr_t)p) | bytes) & 15) return hipErrorInvalidValue;
+    const long n16 = (long)(bytes / 16);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (f32x4*)p, n16);
+    return hipGetLastError();
+}
+
 // rows of an fp32 matrix (row stride lda) -> dense bf16 [M, K]
 static __global__ __launch_bounds__(256) void f32_to_bf16_rows_kernel(const float* __restrict__ src, long lda, __bf16* __restrict__ dst, int k8, long n8) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -732,7 +746,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
         EGO_HIP((gemm<Tile>(h, "pu0_b2h", bs, segmat1(p.b2h0_w, 4 * H, x), EpiBiasRes{segvec1(p.b2h0_b, 4 * H), G0, 4L * H}, G0, 4L * H, JB, 4 * H, x, s)));
     }
     // ... then the two J-step recurrences (layer 0 never reads layer-1 state, so the layers run one after the other)
-    EGO_HIP(hipMemsetAsync(C0, 0, (size_t)(w.ZERO - w.C0) + (size_t)B * H * 4, s));   // C0, C1, ZERO are contiguous
+    EGO_HIP(zero_fill(C0, (size_t)(w.ZERO - w.C0) + al256((size_t)B * H * 4), s));   // C0, C1, ZERO are contiguous (256-byte aligned slices)
     for (int t = 0; t < J; ++t) {
         const float* hprev = t == 0 ? ZERO : HS0 + (size_t)(t - 1) * B * H;
         pu_step_launch(s, B, H, F0 + (size_t)t * B * NF0, NF0, G0 + (size_t)t * B * 4 * H,
@@ -1459,6 +1473,18 @@ extern "C" int egotap_train_adamw(float* p, const float* g, float* m, float* v, 
 #endif
 
 #if EGOTAP_IN(1)
+extern "C" int egotap_train_adamw_multi(const void* table, int nseg, const float* g, float* m, float* v, int64_t span, double lr, double beta1,
+                                        double beta2, double eps, double weight_decay, int step, void* stream) {
+    EGO_CHECK(table && g && m && v && nseg >= 1 && span >= 1 && step >= 1, "egotap_train_adamw_multi: bad argument");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2s = sqrt(1.0 - pow(beta2, (double)step));
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const long*)table, nseg, g, m, v,
+                       (long)span, (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)bc1, (float)bc2s);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(1)
 extern "C" int egotap_train_add_inplace(float* out, const float* in, int64_t n, void* stream) {
     EGO_CHECK(out && in && n % 4 == 0, "egotap_train_add_inplace: bad argument");
     hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, in, (long)(n / 4));
@@ -1513,7 +1539,7 @@ extern "C" int egotap_train_pu_fwd(egotap_handle h, const float* posz, const flo
         ALoadStereoGated bs{ALoadStereo{rotz, B, J, hid}, F0, NF0, H};
         EGO_HIP((gemm<Tile>(h, "pu0_b2h", bs, segmat1(p.b2h0_w, 4 * H, x), EpiBiasRes{segvec1(p.b2h0_b, 4 * H), G0, 4L * H}, G0, 4L * H, JB, 4 * H, x, s)));
     }
-    EGO_HIP(hipMemsetAsync(ZERO, 0, (size_t)B * H * 4, s));
+    EGO_HIP(zero_fill(ZERO, (size_t)B * H * 4, s));
     for (int t = 0; t < J; ++t) {       // G0 holds Gin on entry and the full gate pre-activations on exit (in place)
         const float* hprev = t == 0 ? ZERO : HS0 + (size_t)(t - 1) * B * H;
         const float* cprev = t == 0 ? ZERO : C0 + (size_t)(t - 1) * B * H;
@@ -2184,7 +2210,7 @@ extern "C" int egotap_bf16_fc1_dgrad_tokens(egotap_handle h, const void* dz, con
     EGO_CHECK(h && dz && wt && dtok, "egotap_bf16_fc1_dgrad_tokens: null argument");
     const int BT = B * h->T, K1 = h->ppd * h->ppd * h->D;
     hipStream_t s = (hipStream_t)stream;
-    EGO_HIP(hipMemsetAsync(dtok, 0, (size_t)B * h->seq * h->D * 2, s));
+    EGO_HIP(zero_fill(dtok, (size_t)B * h->seq * h->D * 2, s));
     EGO_HIP(gemm_bf16s_launch(XPlain{(const __bf16*)dz, 2048L}, (const __bf16*)wt, 2048L, SEpiScatterTokens{(__bf16*)dtok, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, BT, K1, 2048,
                               device_cu_count(), s));
     return EGOTAP_OK;

@@ -185,10 +185,8 @@ class EgoTAPAutoEncoderModel(nn.Module):
         self.forward()
         self.loss_total = 0.0
         self.backward_AutoEncoder()
-        self.loss_total.backward()
-        from . import parallel                              # data parallel: average gradients over the ranks (RCCL); no-op for one rank
-        parallel.allreduce_gradients(list(self.net_AutoEncoder.parameters()))
-        for o in self.optimizers:
+        self.loss_total.backward()          # data parallel: the gradient all-reduce runs INSIDE the backward, bucket by bucket, overlapped
+        for o in self.optimizers:          # with it (parallel.GradReducer on the flat gradient arena); the gradients arrive averaged
             o.step()
 
     def set_precision(self, mode: str = "f32"):

@@ -152,6 +152,13 @@ class EgoTAPAutoEncoder(nn.Module):
             self._ascratch = torch.empty(need, dtype=torch.uint8, device=device)
             _lib.check(_lib.load().egotap_set_act_scratch(self._ensure_handle(), C.c_void_p(self._ascratch.data_ptr()), self._ascratch.numel()))
 
+    def _reducer(self):
+        """the overlapped gradient reducer of this module's training Function (egotap_amd.parallel.GradReducer; a no-op for one rank)"""
+        if getattr(self, "_grad_reducer", None) is None:
+            from .parallel import GradReducer
+            self._grad_reducer = GradReducer()
+        return self._grad_reducer
+
     def set_precision(self, mode: str = "f32"):
         """Arithmetic of the large GEMMs (egotap.h egotap_set_precision): "f32" = exact fp32 MFMA (default),
         "bf16x3" = fp32 operands split into hi + lo bf16, three bf16 MFMAs per product, fp32 accumulate (opt-in fast mode)."""

@@ -100,3 +100,57 @@ def allreduce_gradients(params, bucket_bytes: int = 64 << 20):
             g.copy_(flat[off:off + n].view_as(g))
             off += n
     return len(buckets)
+
+
+class GradReducer:
+    """Gradient averaging OVERLAPPED with the backward: the head's gradients live in one flat fp32 arena laid out
+    in the order the backward finishes them (head + encoders first, then ViT layers last to first, patch embedding last); as soon as
+    a bucket's kernels are enqueued the training Function calls ``bucket_ready(lo, hi)`` and the bucket's all-reduce starts on the
+    process group's own stream (RCCL: torch orders it behind the compute stream's current point) while the backward goes on.
+    ``finish()`` waits for the outstanding buckets, scales by 1 / world in place and reports how long the compute stream had to wait
+    (the EXPOSED all-reduce time).  In place on arena slices: no torch.cat pack, no copy-back.  No-op for one rank."""
+
+    def __init__(self):
+        self.pending = []
+        self.exposed_ms = 0.0
+        self.steps = 0
+        self._ev = None
+
+    @staticmethod
+    def active():
+        return dist.is_initialized() and dist.get_world_size() > 1
+
+    def begin(self, arena):
+        self.arena = arena
+        self.pending = []
+
+    def bucket_ready(self, lo, hi):
+        if not self.active() or hi <= lo:
+            return
+        self.pending.append((dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi))
+
+    def finish(self):
+        if not self.active():
+            return 0.0
+        world = dist.get_world_size()
+        cuda = self.arena.is_cuda
+        if cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for work, lo, hi in self.pending:
+            work.wait()
+        if cuda:
+            e1.record()
+            self._ev = (e0, e1)
+        for _, lo, hi in self.pending:
+            self.arena[lo:hi].mul_(1.0 / world)
+        self.pending = []
+        self.steps += 1
+        return 0.0
+
+    def read_exposed_ms(self):
+        """exposed wait of the LAST finish() in milliseconds (synchronises)"""
+        if self._ev is None:
+            return 0.0
+        self._ev[1].synchronize()
+        return float(self._ev[0].elapsed_time(self._ev[1]))

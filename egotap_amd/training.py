@@ -24,6 +24,62 @@ def _param_order(p):
     return [k for k, _ in _spec.lift_state_spec(p) if not _spec.is_buffer(k) and k not in _spec.LIFT_DEAD_KEYS]
 
 
+def _arena_layout(p):
+    """Order of the trained tensors in the flat gradient arena = the order in which the backward FINISHES them, cut into buckets:
+    bucket 0 (head, propagation units, both FC encoders, the final LayerNorm, the last layer's output.dense.bias) is complete after
+    the final LayerNorm's backward; bucket 1 + j (ViT layer L-1-j, plus the output.dense.bias of the layer below, whose gradient comes
+    out of this layer's first LayerNorm backward) after that layer; the last bucket (patch embedding) at the end.
+    Returns (keys in arena order, [bucket end index into keys])."""
+    keys = _param_order(p)
+    v = "pos_heatmap_encoder.vit."
+    L = p.vit_layers
+    layer_of = {}
+    for k in keys:
+        if k.startswith(v + "encoder.layer."):
+            i = int(k[len(v + "encoder.layer."):].split(".")[0])
+            layer_of[k] = i + 1 if k.endswith("output.dense.bias") and ".attention." not in k else i
+    order, ends = [], []
+    order += [k for k in keys if not k.startswith(v)] + [v + "layernorm.weight", v + "layernorm.bias"]
+    order += [k for k in keys if layer_of.get(k) == L]
+    ends.append(len(order))
+    for i in reversed(range(L)):
+        order += [k for k in keys if layer_of.get(k) == i]
+        ends.append(len(order))
+    order += [k for k in keys if k.startswith(v + "embeddings.")]
+    ends.append(len(order))
+    assert sorted(order) == sorted(keys) and len(set(order)) == len(order)
+    return order, ends
+
+
+def _grad_arena(net, P):
+    """views of the flat gradient arena, one per trained tensor (allocated once per module and device)"""
+    dev = next(iter(P.values())).device
+    ga = getattr(net, "_grad_arena", None)
+    if ga is None or ga["flat"].device != dev:
+        order, ends = _arena_layout(net.preset)
+        offs, o = {}, 0
+        for k in order:
+            offs[k] = o
+            o += (P[k].numel() + 63) // 64 * 64                  # 256-byte aligned slices
+        flat = torch.empty(o, dtype=torch.float32, device=dev)
+        bounds = [0] + [offs[order[e]] if e < len(order) else o for e in ends]
+        ga = dict(flat=flat, offs=offs, order=order, bounds=bounds)
+        net._grad_arena = ga
+    G = {k: ga["flat"][ga["offs"][k]: ga["offs"][k] + P[k].numel()].view(P[k].shape) for k in P}
+    return ga, G
+
+
+def _publish_grads(P, G):
+    """hand the arena views to the parameters directly (.grad), instead of returning them through autograd's accumulation (which
+    would copy 384 MB unless it can steal the buffers): the optimizer and the gradient reducer then work in place on the arena.
+    A parameter that already holds a gradient (a second backward before zero_grad) accumulates."""
+    for k, prm in P.items():
+        if prm.grad is None:
+            prm.grad = G[k]
+        elif prm.grad.data_ptr() != G[k].data_ptr():
+            prm.grad.add_(G[k])
+
+
 class LiftTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, hm, *params):
@@ -110,7 +166,9 @@ class LiftTrainFn(torch.autograd.Function):
         M, BT = B * seq, B * T_
         lib = _lib.load()
         st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        G = {k: torch.empty_like(P[k]) for k in keys}          # every entry is fully overwritten below
+        ga, G = _grad_arena(net, P)                            # every entry is fully overwritten below
+        red = net._reducer()
+        red.begin(ga["flat"])
         dpose = dpose.detach().float().contiguous()
         v = "pos_heatmap_encoder.vit."
         posz, rotz, hs1 = S["pos_acts"][-1]["y"], S["rot_acts"][-1]["y"], S["hs1"]
@@ -155,12 +213,15 @@ class LiftTrainFn(torch.autograd.Function):
         dx = T.layernorm_bwd(S["xf"], dtok, P[v + "layernorm.weight"], S["mf"], S["rf"], G[v + "layernorm.weight"], G[v + "layernorm.bias"])
         del dtok
         for i in reversed(range(p.vit_layers)):
+            # the bias gradient of output.dense of layer i belongs to the bucket that closes after layer i + 1 (arena layout shared
+            # with the bf16 path, where it comes out of a LayerNorm backward): compute it first, then close that bucket
+            T.colsum(dx, G[f"{v}encoder.layer.{i}.output.dense.bias"], M, D)
+            red.bucket_ready(ga["bounds"][p.vit_layers - 1 - i], ga["bounds"][p.vit_layers - i])
             L = S["layers"][i]
             l = f"{v}encoder.layer.{i}."
             a = l + "attention.attention."
             # MLP
             T.gemm_tn(h, dx, L["hid"], G[l + "output.dense.weight"], M, D, 4 * D)
-            T.colsum(dx, G[l + "output.dense.bias"], M, D)
             dz = T.gemm_nt(h, dx, T.transpose(P[l + "output.dense.weight"]), None, M, 4 * D, D, epi=T.TE_GELU_GRAD, r=L["z"])
             T.gemm_tn(h, dz, L["y2"], G[l + "intermediate.dense.weight"], M, 4 * D, D)
             T.colsum(dz, G[l + "intermediate.dense.bias"], M, 4 * D)
@@ -189,8 +250,13 @@ class LiftTrainFn(torch.autograd.Function):
         T.colsum(dx, dpos, B, seq * D)                                    # sum over the batch: dx viewed as [B, seq*D]
         _lib.check(lib.egotap_train_patch_split(h, T._p(dpos), T._p(G[v + "embeddings.patch_embeddings.projection.bias"]),
                                                 T._p(G[v + "embeddings.mask_token"]), 0, st()))
+        nb = len(ga["bounds"])
+        red.bucket_ready(ga["bounds"][nb - 3], ga["bounds"][nb - 2])
+        red.bucket_ready(ga["bounds"][nb - 2], ga["bounds"][nb - 1])
+        red.finish()
+        _publish_grads(P, G)
         ctx.egotap = None
-        return (None, None) + tuple(G[k] for k in keys)
+        return (None, None) + (None,) * len(keys)
 
 
 class LiftTrainBf16Fn(torch.autograd.Function):
@@ -311,7 +377,9 @@ class LiftTrainBf16Fn(torch.autograd.Function):
         M, BT = B * seq, B * T_
         lib = _lib.load()
         st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)      # noqa: E731
-        G = {k: torch.empty_like(P[k]) for k in keys}          # every entry is fully overwritten below
+        ga, G = _grad_arena(net, P)                            # every entry is fully overwritten below
+        red = net._reducer()
+        red.begin(ga["flat"])
         dpose = dpose.detach().float().contiguous()
         v = "pos_heatmap_encoder.vit."
         posz, rotz, hs1 = Sv["pos_acts"][-1]["y"], Sv["rot_acts"][-1]["y"], Sv["hs1"]
@@ -356,6 +424,7 @@ class LiftTrainBf16Fn(torch.autograd.Function):
                                   dcolsum=G[last + "output.dense.bias"])
         del dtok
         for i in reversed(range(nl)):
+            red.bucket_ready(ga["bounds"][nl - 1 - i], ga["bounds"][nl - i])      # everything above layer i is final: start its all-reduce
             L = Sv["layers"][i]
             Wl = W["layers"][i]
             l = f"{v}encoder.layer.{i}."
@@ -392,8 +461,13 @@ class LiftTrainBf16Fn(torch.autograd.Function):
         T.colsum(dx, dpos, B, seq * D)
         _lib.check(lib.egotap_train_patch_split(h, T._p(dpos), T._p(G[v + "embeddings.patch_embeddings.projection.bias"]),
                                                 T._p(G[v + "embeddings.mask_token"]), 0, st()))
+        nb = len(ga["bounds"])
+        red.bucket_ready(ga["bounds"][nb - 3], ga["bounds"][nb - 2])
+        red.bucket_ready(ga["bounds"][nb - 2], ga["bounds"][nb - 1])
+        red.finish()
+        _publish_grads(P, G)
         ctx.egotap = None
-        return (None, None) + tuple(G[k] for k in keys)
+        return (None, None) + (None,) * len(keys)
 
 
 class PoseLossFn(torch.autograd.Function):
@@ -421,15 +495,66 @@ def lift_train_forward(net, hm):
 
 
 class EgotapAdamW(torch.optim.Optimizer):
-    """torch.optim.AdamW semantics (decoupled weight decay, bias correction) with the update done by the HIP kernel."""
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction) with the update done by the HIP kernels.
+    When the gradients of a group are views of ONE flat arena (the lifting head's training Functions publish them that way) the
+    whole group is updated by a single launch (egotap_train_adamw_multi): the moment buffers become views of two flat arenas with the
+    gradient arena's layout; otherwise one launch per tensor.  state_dict() keeps torch.optim.AdamW's format either way."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._flat = {}
+
+    def _flat_plan(self, gi, group):
+        """(table, g_base, m_flat, v_flat, span, segs) if every gradient of the group lies in one allocation, else None"""
+        ps = [p for p in group["params"] if p.grad is not None]
+        if len(ps) < 2 or not all(p.grad.is_cuda and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.is_contiguous() for p in ps):
+            return None
+        base = min(p.grad.untyped_storage().data_ptr() for p in ps)
+        if any(p.grad.untyped_storage().data_ptr() != base for p in ps):
+            return None
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
+        plan = self._flat.get(gi)
+        if plan is not None and plan["sig"] == sig:
+            return plan
+        segs = sorted(((p.grad.data_ptr() - base) // 4, p.numel(), p) for p in ps)
+        span = segs[-1][0] + segs[-1][1]
+        dev = ps[0].device
+        old = plan
+        m_flat = torch.zeros(span, dtype=torch.float32, device=dev)
+        v_flat = torch.zeros(span, dtype=torch.float32, device=dev)
+        table = torch.tensor([[o, n, p.data_ptr()] for o, n, p in segs], dtype=torch.int64, device=dev)
+        g_flat = torch.empty(0, dtype=torch.float32, device=dev).set_(ps[0].grad.untyped_storage(), 0, (span,))
+        plan = dict(sig=sig, segs=segs, span=span, m=m_flat, v=v_flat, table=table, g=g_flat)
+        self._flat[gi] = plan
+        return plan
 
     @torch.no_grad()
     def step(self, closure=None):
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
+            plan = self._flat_plan(gi, group)
+            if plan is not None:
+                steps = set()
+                for o, n, p in plan["segs"]:
+                    st = self.state[p]
+                    mv, vv = plan["m"][o:o + n].view(p.shape), plan["v"][o:o + n].view(p.shape)
+                    if not st:
+                        st["step"] = 0
+                    else:                                   # state from a checkpoint or from per-tensor steps: move it into the arenas
+                        if st["exp_avg"].data_ptr() != mv.data_ptr():
+                            mv.copy_(st["exp_avg"])
+                            vv.copy_(st["exp_avg_sq"])
+                    st["exp_avg"], st["exp_avg_sq"] = mv, vv
+                    st["step"] = int(st["step"]) + 1
+                    steps.add(st["step"])
+                if len(steps) == 1:
+                    _lib.check(_lib.load().egotap_train_adamw_multi(T._p(plan["table"]), len(plan["segs"]), T._p(plan["g"]), T._p(plan["m"]), T._p(plan["v"]),
+                                                                    plan["span"], group["lr"], b1, b2, group["eps"], group["weight_decay"], steps.pop(), T._s()))
+                    continue
+                for o, n, p in plan["segs"]:                # tensors at different step counts (partial checkpoints): per tensor
+                    st = self.state[p]
+                    T.adamw(p, p.grad, st["exp_avg"], st["exp_avg_sq"], group["lr"], st["step"], b1, b2, group["eps"], group["weight_decay"])
+                continue
             for p in group["params"]:
                 if p.grad is None:
                     continue                        # cls_token / pooler: never receive a gradient, never move

@@ -204,6 +204,11 @@ int egotap_train_pose_loss(egotap_handle h, const float* pred, const float* gt, 
  * computed in double on the host, as torch does */
 int egotap_train_adamw(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                        double weight_decay, int step, void* stream);
+/* the same update for every tensor of a network in ONE launch (the optimizer step of egotap_autoencoder_model.py:313-314): gradients
+ * and the two moment buffers are flat arenas of `span` floats with one layout, table = device int64 [nseg][3] = {arena offset, numel,
+ * parameter pointer} sorted by offset (segments may be separated by padding) */
+int egotap_train_adamw_multi(const void* table, int nseg, const float* g, float* m, float* v, int64_t span, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, int step, void* stream);
 
 /* ---- heatmap-estimator training operators (fp32), called by the autograd glue (egotap_amd/hm_training.py) ----------------
  * One optimisation step of the stage-1 model (model/heatmap_shared_model.py:98-172): HeatMap_UnrealEgo_Shared in train mode

@@ -200,7 +200,7 @@ def test_config3_bf16_train_step_b1024_through_the_wrapper():
     for k in finals[0]:
         assert torch.equal(finals[0][k], finals[1][k]), k
     print(f"config 3 peak HBM {peaks[0]:.1f} GiB")
-    assert peaks[0] < float(os.environ.get("EGOTAP_C3_PEAK_GIB", "160"))
+    assert peaks[0] < 90.0                  # bf16 activation storage: 79.6 GiB measured (fp32 storage in round 1: 146.7 GiB)
 
 
 # ------------------------------------------------------------------------------------------------------------ config 5

@@ -208,3 +208,29 @@ def test_every_gemm_routing_regime_matches_the_golden(tag, preset):
                 np.testing.assert_allclose(out, ref, atol=gate, rtol=0, err_msg=f"{preset} {mode} B={B}")
     finally:
         net.set_precision("f32")
+
+
+def test_lift_forward_graph_capture_replays_bit_identically():
+    """the header's contract "no device allocation, no synchronisation, all work on the caller's stream: graph-capture safe": capture
+    egotap_lift_forward (B = 5: split-K small-batch path and the 30 propagation-unit launches included) in a HIP graph on a side
+    stream, replay it on fresh inputs, and compare bit for bit with the eager call"""
+    from gpu_util import lift_net
+    net, sd_np, p = lift_net("UnrealEgo")
+    B = 5
+    hm_a = torch.from_numpy(synth_input("hm_graph_a", (B, p.in_channels, 64, 64))).cuda()
+    hm_b = torch.from_numpy(synth_input("hm_graph_b", (B, p.in_channels, 64, 64))).cuda()
+    eager_a, eager_b = net.predict_pose(hm_a).clone(), net.predict_pose(hm_b).clone()      # also warms up lazy attribute calls
+    static_in = hm_a.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        net.predict_pose(static_in)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        static_out = net.predict_pose(static_in)
+    for src, ref in ((hm_a, eager_a), (hm_b, eager_b), (hm_a, eager_a)):
+        static_in.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_out, ref)
