@@ -316,14 +316,17 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None):
     fps = world * B * args.train_steps / elapsed
     flops = 3.0 * lift_flops_per_frame(p)        # algorithmic: backward = 2 x forward (dgrad + wgrad)
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    exposed = m.net_AutoEncoder._reducer().read_exposed_ms() if world > 1 else 0.0
     del m, hm, gt, data
     torch.cuda.empty_cache()
     return {"value": round(fps, 1), "unit": "stereo frames/s (training step)", "ms_per_step": round(1e3 * elapsed / args.train_steps, 2),
             "steps": args.train_steps, "batch_per_gpu": B, "dtype": mode, "flops_per_frame": flops,
             "end_to_end_tflops_per_gpu": round(fps * flops / world / 1e12, 2), **frac_fields(mode, fps * flops / world / 1e12),
             "loss_pose": errs.get("pose"), "loss_cos_sim": errs.get("cos_sim"), "peak_hbm_gib": round(peak_gb, 1),
-            "note": "heatmap estimators frozen and fed from resident heatmaps (use_gt_heatmap); attention backward recomputes "
-                    "S three times (8 MFMA products instead of 5), not counted in flops_per_frame"}
+            "allreduce_exposed_ms_last_step": round(exposed, 3),
+            "note": "heatmap estimators frozen and fed from resident heatmaps (use_gt_heatmap); gradient all-reduce (N > 1) overlapped with the "
+                    "backward, bucket by bucket, in place on a flat arena; the attention backward recomputes the scores (f32 / bf16x3: three "
+                    "kernels, 8 MFMA products; bf16: two kernels, 7 products), not counted in flops_per_frame"}
 
 
 def bench_stage1(args, p, dev, rank, world, barrier, mode="f32"):
@@ -507,6 +510,24 @@ def main():
             fast["gemm_frac_of_bf16_mfma_peak"] = round(3 * t3[2] / (t3[1] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
             fast["gemm_share_of_step_time"] = round(t3[1] * 1e-3 / el3, 4)
 
+    # reduced-precision inference: bf16 activations in HBM, LDS-DMA bf16 GEMMs, bf16 attention (EGOTAP_PREC_BF16; the wrapper's --use_amp
+    # arithmetic).  Not an fp32 result (bf16 keeps 8 significant bits per operand): reported beside the headline, never in `value`.
+    fast16 = None
+    if not args.no_fast_mode:
+        net.set_precision("bf16")
+        try:
+            el16, pose16, _ = timed_lift(net, hm, args.steps, args.warmup, lib, L, h, barrier, dev, False, world)
+        finally:
+            net.set_precision("f32")
+        fps16 = world * B * args.steps / el16
+        tf16 = fps16 * lift_flops_per_frame(p) / world / 1e12
+        fast16 = {"value": round(fps16, 1), "unit": "stereo frames/s", "ms_per_step": round(1e3 * el16 / args.steps, 3),
+                  "dtype": "bf16 (bf16 activations in HBM, bf16 MFMA with fp32 accumulation, fp32 residual stream / LayerNorm statistics / "
+                           "small FC layers / PU chain / pose head)",
+                  "end_to_end_tflops_per_gpu": round(tf16, 2), **frac_fields("bf16", tf16),
+                  "max_abs_diff_vs_f32_mode": float((pose16 - pose).abs().max()),
+                  "speedup_vs_f32_mode": round(fps16 / (world * B * args.steps / elapsed), 3)}
+
     def leg(fn, *a, **k):
         """secondary measurements never take the headline line down with them"""
         try:
@@ -558,6 +579,11 @@ def main():
             net.set_precision("bf16x3")
             fast["max_abs_diff_vs_oracle"] = float((net.predict_pose(hm_c).cpu() - ref).abs().max())
             net.set_precision("f32")
+        if fast16 is not None:
+            net.set_precision("bf16")
+            fast16["max_abs_diff_vs_oracle"] = float((net.predict_pose(hm_c).cpu() - ref).abs().max())
+            fast16["oracle_pose_scale"] = float(ref.abs().max())
+            net.set_precision("f32")
 
     if rank == 0:
         frames = world * B * args.steps
@@ -575,7 +601,7 @@ def main():
             "end_to_end_tflops_per_gpu": round(fps * flops_frame / world / 1e12, 2),
             "end_to_end_frac_of_f32_mfma_peak": round(fps * flops_frame / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "roofline": roof, "cpu_baseline": cpu, "max_abs_diff_vs_oracle": gpu_vs_oracle,
-            "fast_mode_bf16x3": fast, "full_pipeline_from_rgb": full, "config5_geometry_egocap_hm128": config5,
+            "fast_mode_bf16x3": fast, "fast_mode_bf16": fast16, "full_pipeline_from_rgb": full, "config5_geometry_egocap_hm128": config5,
             "train_step_lifting_head": train, "small_batch_latency": latency,
         }
         print(json.dumps(line), flush=True)

@@ -22,6 +22,12 @@
 #include "metrics.h"
 #include "heatmap_synth.h"
 #include "pu_chain.h"
+#include "gemm_tn_bf16.h"
+#include "train_ops.h"
+#include "gemm_bf16s.h"
+#include "gemm_tn_bf16s.h"
+#include "bf16s_ops.h"
+#include "attention_bf16s.h"
 
 // The library is ONE source compiled as four translation units in parallel (egotap_amd/build.py: -DEGOTAP_PART=0 core and
 // inference, 1 lifting-head training operators, 2 heatmap-estimator training operators, 3 bf16-storage operators); every exported function belongs to one
@@ -473,6 +479,13 @@ static hipError_t zero_fill(void* p, size_t bytes, hipStream_t s) {       // p 1
     return hipGetLastError();
 }
 
+// out[0:n | n:2n | 2n:3n] = a | b | c  (the fused q|k|v bias of the bf16-storage forward)
+static __global__ __launch_bounds__(256) void concat3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                             float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { out[i] = a[i]; out[n + i] = b[i]; out[2 * n + i] = c[i]; }
+}
+
 // rows of an fp32 matrix (row stride lda) -> dense bf16 [M, K]
 static __global__ __launch_bounds__(256) void f32_to_bf16_rows_kernel(const float* __restrict__ src, long lda, __bf16* __restrict__ dst, int k8, long n8) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -691,6 +704,59 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
         EGO_HIP((gemm_small(h, "patch_embed", al, segmat1(p.patch_w, D, 256), ep, X, D, M, D, 256, SPK, s)));
     }
     if (h->debug_stop == 1) return EGOTAP_OK;
+    // EGOTAP_PREC_BF16 at a batch that fills the chip: bf16 ACTIVATION STORAGE (the same workspace slices hold bf16): LayerNorm, the
+    // GEMM epilogues and attention write bf16, every GEMM reads bf16 operands through the LDS DMA (gemm_bf16s.h); weights are rounded
+    // into the caller's weight scratch right before each launch (nothing cached: the fp32 parameters stay the source of truth)
+    const bool bf16s = h->precision == EGOTAP_PREC_BF16 && D == 1024 && M >= 4096 && h->wscratch != nullptr &&
+                       h->wscratch_bytes >= (size_t)2 * 2048 * (size_t)(h->ppd * h->ppd * D);
+    if (bf16s) {
+        __bf16 *Yb = (__bf16*)Y, *QKVb = (__bf16*)QKV, *CTXb = (__bf16*)CTX, *HIDb = (__bf16*)HID, *Wb = h->wscratch;
+        float* bias3 = SPK;
+        const int cu = device_cu_count();
+        auto prep = [&](const float* wsrc, __bf16* dst, int n, int k) {
+            hipLaunchKernelGGL(prep_weight_kernel, dim3((k + 63) / 64, (n + 63) / 64), dim3(256), 0, s, wsrc, dst, (__bf16*)nullptr, n, k, (long)n);
+        };
+        auto ln = [&](const float* gg, const float* bb) {
+            hipLaunchKernelGGL(ln_fwd_bf16_kernel<1024>, dim3((M + 3) / 4), dim3(256), 0, s, (const float*)X, Yb, gg, bb, (float*)nullptr, (float*)nullptr, M, 1e-12f);
+        };
+        for (int i = 0; i < h->cfg.vit_layers; ++i) {
+            const auto& L = p.layer[i];
+            ln(L.ln1_g, L.ln1_b);
+            prep(L.q_w, Wb, D, D); prep(L.k_w, Wb + (size_t)D * D, D, D); prep(L.v_w, Wb + (size_t)2 * D * D, D, D);
+            hipLaunchKernelGGL(concat3_kernel, dim3((D + 255) / 256), dim3(256), 0, s, L.q_b, L.k_b, L.v_b, bias3, D);
+            EGO_HIP(hipGetLastError());
+            EGO_HIP(gemm_bf16s_launch(XPlain{Yb, (long)D}, Wb, (long)D, SEpiBf16{bias3, QKVb, 3L * D}, M, 3 * D, D, cu, s));
+            EGO_HIP(attention_bf16s_fwd_launch(QKVb, CTXb, nullptr, B, h->seq, h->cfg.vit_heads, s));
+            prep(L.o_w, Wb, D, D);
+            EGO_HIP(gemm_bf16s_launch(XPlain{CTXb, (long)D}, Wb, (long)D, SEpiResF32{L.o_b, X, X, (long)D}, M, D, D, cu, s));
+            ln(L.ln2_g, L.ln2_b);
+            prep(L.up_w, Wb, 4 * D, D);
+            EGO_HIP(gemm_bf16s_launch(XPlain{Yb, (long)D}, Wb, (long)D, SEpiGelu{L.up_b, HIDb, 4L * D}, M, 4 * D, D, cu, s));
+            prep(L.dn_w, Wb, D, 4 * D);
+            EGO_HIP(gemm_bf16s_launch(XPlain{HIDb, 4L * D}, Wb, 4L * D, SEpiResF32{L.dn_b, X, X, (long)D}, M, D, 4 * D, cu, s));
+            if (h->debug_stop == 2 + i) return EGOTAP_OK;
+        }
+        ln(p.lnf_g, p.lnf_b);                               // tokens (bf16) -> fc1's gathering loader
+        auto bnf = [](const LiftParams::Fc& f, float* out) { return SEpiBnLreluF32{f.b, f.g, f.beta, f.mean, f.var, 1e-5f, 0.2f, out, 2048L}; };
+        auto bn = [](const LiftParams::Fc& f) { return EpiBnLrelu{f.b, f.g, f.beta, f.mean, f.var, 1e-5f, 0.2f}; };
+        {
+            const int K1 = h->ppd * h->ppd * D;
+            prep(p.pos_fc[0].w, Wb, 2048, K1);
+            EGO_HIP(gemm_bf16s_launch(XTokens{Yb, h->T, D, h->seq, h->side, h->ppd, h->grid}, Wb, (long)K1, bnf(p.pos_fc[0], Z1), BT, 2048, K1, cu, s));
+            EGO_HIP((fc_gemm(h, "pos_fc2", ALoadPlain{Z1, 2048}, segmat1(p.pos_fc[1].w, 512, 2048), bn(p.pos_fc[1]), Z2, 512, BT, 512, 2048, SPK, s)));
+            EGO_HIP((fc_gemm(h, "pos_fc3", ALoadPlain{Z2, 512}, segmat1(p.pos_fc[2].w, hid, 512), bn(p.pos_fc[2]), POSZ, hid, BT, hid, 512, SPK, s)));
+        }
+        {
+            __bf16* hmb = HIDb;                             // the MLP's hidden buffer is free now: bf16 copy of the input heatmaps
+            const long n8 = (long)B * h->C * HW / 8;
+            hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, hm, hmb, n8);
+            prep(p.rot_fc[0].w, Wb, 2048, 2 * HW);
+            EGO_HIP(hipGetLastError());
+            EGO_HIP(gemm_bf16s_launch(XRot{hmb, h->C, J, HW}, Wb, 2L * HW, bnf(p.rot_fc[0], Z1), BT, 2048, 2 * HW, cu, s));
+            EGO_HIP((fc_gemm(h, "rot_fc2", ALoadPlain{Z1, 2048}, segmat1(p.rot_fc[1].w, 512, 2048), bn(p.rot_fc[1]), Z2, 512, BT, 512, 2048, SPK, s)));
+            EGO_HIP((fc_gemm(h, "rot_fc3", ALoadPlain{Z2, 512}, segmat1(p.rot_fc[2].w, hid, 512), bn(p.rot_fc[2]), ROTZ, hid, BT, hid, 512, SPK, s)));
+        }
+    } else {
     // H3-H8: pre-LN transformer layers
     for (int i = 0; i < h->cfg.vit_layers; ++i) {
         const auto& L = p.layer[i];
@@ -736,6 +802,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
         EGO_HIP((fc_gemm(h, "rot_fc2", ALoadPlain{Z1, 2048}, segmat1(p.rot_fc[1].w, 512, 2048), bn(p.rot_fc[1]), Z2, 512, BT, 512, 2048, SPK, s)));
         EGO_HIP((fc_gemm(h, "rot_fc3", ALoadPlain{Z2, 512}, segmat1(p.rot_fc[2].w, hid, 512), bn(p.rot_fc[2]), ROTZ, hid, BT, hid, 512, SPK, s)));
     }
+    }       // fp32 tensors in HBM
     // H13-H14: propagation units.  State-independent projections of all J steps as GEMMs (rows time-major t*B+b) ...
     const int x = 2 * hid, NF0 = H + x;
     ALoadStereo xs{POSZ, B, J, hid};
@@ -1185,10 +1252,6 @@ extern "C" int egotap_attention(const float* qkv, float* ctx, int B, int N, int 
 #include "gemm_tn_f32.h"
 #include "gemm_tn_bf16.h"
 #include "train_ops.h"
-#include "gemm_bf16s.h"
-#include "gemm_tn_bf16s.h"
-#include "bf16s_ops.h"
-#include "attention_bf16s.h"
 
 using TnBig = TnCfg<256, 256, 16, 4, 2>;     // 8 waves, 64x128 per wave
 using TnSmall = TnCfg<128, 128, 16, 2, 2>;   // 4 waves, 64x64 per wave

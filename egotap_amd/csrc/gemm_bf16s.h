@@ -173,6 +173,50 @@ struct SEpiGeluSave {        // z = acc + bias -> Z (bf16, kept for the backward
         store_bf16x8(H + (long)m * ld + n, g);
     }
 };
+struct SEpiGelu {            // out bf16 = GELU(acc + bias)   (inference: the pre-activation is not kept)
+    static constexpr int W = 8, STORES = 1;
+    const float* bias;
+    __bf16* H;
+    long ld;
+    typedef SBias8 Col;
+    typedef SNoAux Aux;
+    __device__ __forceinline__ Col col(int n) const { return load_bias8(bias, n); }
+    __device__ __forceinline__ Aux fetch(int m, int n) const { return Aux{}; }
+    __device__ __forceinline__ void emit(float* v, const Col& c, const Aux&, int m, int n) const {
+        float g[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { g[i] = gelu_erf(v[i] + c.b0[i]); g[4 + i] = gelu_erf(v[4 + i] + c.b1[i]); }
+        store_bf16x8(H + (long)m * ld + n, g);
+    }
+};
+struct SBn4 { f32x4 b, mu, sc, sh; };
+__device__ __forceinline__ void s_keep(const SBn4& c) { asm volatile("" ::"v"(c.b), "v"(c.mu), "v"(c.sc), "v"(c.sh)); }
+struct SEpiBnLreluF32 {      // out f32 = LeakyReLU_0.2(BatchNorm1d_eval(acc + bias))   (network_utils.py:123-142, eval mode)
+    static constexpr int W = 4, STORES = 1;
+    const float *bias, *gamma, *beta, *mean, *var;
+    float eps, slope;
+    float* out;
+    long ld;
+    typedef SBn4 Col;
+    typedef SNoAux Aux;
+    __device__ __forceinline__ Col col(int n) const {
+        const f32x4 g = *(const f32x4*)(gamma + n), vv = *(const f32x4*)(var + n);
+        f32x4 sc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sc[i] = g[i] / sqrtf(vv[i] + eps);
+        return Col{*(const f32x4*)(bias + n), *(const f32x4*)(mean + n), sc, *(const f32x4*)(beta + n)};
+    }
+    __device__ __forceinline__ Aux fetch(int m, int n) const { return Aux{}; }
+    __device__ __forceinline__ void emit(float* v, const Col& c, const Aux&, int m, int n) const {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float y = (v[i] + c.b[i] - c.mu[i]) * c.sc[i] + c.sh[i];
+            o[i] = y > 0.f ? y : slope * y;
+        }
+        *(f32x4*)(out + (long)m * ld + n) = o;
+    }
+};
 struct SEpiGeluGrad {        // out bf16 = acc * GELU'(Z)   (Z bf16: the saved pre-activation)
     static constexpr int W = 8, STORES = 1;
     const __bf16* Z;

@@ -146,6 +146,8 @@ class EgoTAPAutoEncoder(nn.Module):
         hidden activations [B * seq, 4 * D] and grown with the batch"""
         if getattr(self, "precision", "f32") != "bf16" or device.type != "cuda":
             return
+        if B * self.preset.seq >= 4096:      # the bf16-storage forward (egotap_lift_forward at batches that fill the chip) converts nothing
+            return
         need = 2 * B * self.preset.seq * 4 * self.preset.vit_dim
         cur = getattr(self, "_ascratch", None)
         if cur is None or cur.numel() < need or cur.device != device:

@@ -234,3 +234,28 @@ def test_lift_forward_graph_capture_replays_bit_identically():
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(static_out, ref)
+
+
+@pytest.mark.parametrize("preset,B", [("UnrealEgo", 17), ("EgoCap", 9)])
+def test_lift_forward_bf16_storage_mode_against_oracle(preset, B):
+    """EGOTAP_PREC_BF16 at a batch that takes the bf16-storage forward (B * 576 >= 4096: bf16 activations in the workspace, LDS-DMA
+    GEMMs, bf16 attention; ragged last tile row): first and last frames against the float64 oracle within bf16's error (2^-9 per
+    rounded operand through ~20 layers: a few 1e-2 of the pose scale), bit-reproducible run to run, and switching back restores fp32"""
+    from gpu_util import lift_net
+    from oracle import lift_ref as O
+    net, sd_np, p = lift_net(preset)
+    hm = torch.from_numpy(synth_input(f"hm_bf16s_{preset}", (B, p.in_channels, 64, 64)))
+    rows = [0, 1, B - 1]
+    with torch.no_grad():
+        ref = O.lift_forward(hm[rows].double(), O.to_torch_sd(sd_np, torch.float64), p)
+    exact = net.predict_pose(hm.cuda()).clone()
+    try:
+        net.set_precision("bf16")
+        low = net.predict_pose(hm.cuda()).clone()
+        again = net.predict_pose(hm.cuda()).clone()
+    finally:
+        net.set_precision("f32")
+    back = net.predict_pose(hm.cuda())
+    assert torch.equal(low, again) and torch.equal(back, exact) and not torch.equal(low, exact)
+    assert float((exact[rows].double().cpu() - ref).abs().max()) < 1e-4
+    assert float((low[rows].double().cpu() - ref).abs().max()) < 3e-2 * float(ref.abs().max())
