@@ -97,6 +97,13 @@ static inline SegMat segmat1(const float* p, int n, long ld) {
     return v;
 }
 
+// blocks are dealt round-robin over the 8 XCDs: give every XCD a contiguous chunk of the linear work order (bijective for any grid;
+// placement affects speed only)
+__device__ __forceinline__ int xcd_lin(int bid, int nblk) {
+    const int q8 = nblk >> 3, r8 = nblk & 7, x8 = bid & 7;
+    return (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (bid >> 3);
+}
+
 // XCD-aware block -> tile map.  Blocks are dealt round-robin over the 8 XCDs
 // (blockIdx % 8 labels the group that shares an L2), so give every group a
 // contiguous chunk of a grouped tile order: inside a group of GM tile-rows

@@ -66,8 +66,12 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
     const int grp = wid >> 2, wc = wid & 3;
     const int l15 = lane & 15;
 
-    const int bid = blockIdx.x;
-    const int split = bid % splits, tile = bid / splits;
+    // XCD-aware order: an XCD takes a contiguous range of (split, tile) pairs with the tile index fastest, so the tiles_n x tiles_k tiles
+    // of one split -- which read the same 32-row steps of dY and X -- share them in one L2 instead of fetching them once per XCD
+    // (measured before: 6.9 GB of L2-side reads per launch against 3.6 GB algorithmic)
+    const int tiles = tiles_n * (K / BK);
+    const int bid = xcd_lin(blockIdx.x, gridDim.x);
+    const int split = bid / tiles, tile = bid - split * tiles;
     const int tn = tile % tiles_n, tk = tile / tiles_n;
     const int n0 = tn * BN, k0 = tk * BK;
     const int m_lo = split * rows_per, m_hi = min(M, m_lo + rows_per);

@@ -15,8 +15,9 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "gpurun_out", "prof")
-HEADLINE_CMD = "python3 bench.py --steps 5 --warmup 2 --lift-only --no-fast-mode --no-cpu-baseline"
-ALL_CMD = "python3 bench.py --steps 2 --warmup 1 --full-steps 1 --train-steps 1 --train-batch-bf16 256 --no-cpu-baseline"
+HEADLINE_CMD = "python3 bench.py --steps 5 --warmup 2 --lift-only --no-fast-mode --no-cpu-baseline --no-kernel-timing"
+CONFIG3_CMD = "python3 tools/train_bf16_probe.py 1024 bf16"
+ALL_CMD = "python3 bench.py --steps 2 --warmup 1 --full-steps 1 --train-steps 1 --no-cpu-baseline --no-kernel-timing"
 
 
 def newest(pat):
@@ -45,15 +46,20 @@ def short(name):
 
 def main():
     """profiles/<tag>_*: the HEADLINE command (what bench.py times: fp32 lifting head at B = 256 alone; per-launch HBM bytes are
-    meaningful because every launch of a kernel has the same shape); profiles/<tag>_all_legs_*: every secondary leg as well
-    (durations / MFMA busy only: launches of one kernel mix batch sizes there)."""
+    meaningful because every launch of a kernel has the same shape); profiles/<tag>_config3_*: one bf16 training step at B = 1024
+    (BASELINE config 3) alone; profiles/<tag>_all_legs_*: every secondary leg as well (launches of one kernel mix batch sizes there)."""
     global SRC
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    one(tag, HEADLINE_CMD, "B = 256; the timed workload of bench.py alone: fp32 lifting head forward")
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    if os.path.isdir(SRC):
+        one(tag, HEADLINE_CMD, "B = 256; the timed workload of bench.py alone: fp32 lifting head forward")
+    SRC = os.path.join(REPO, "gpurun_out", "prof_c3")
+    if os.path.isdir(SRC):
+        one(tag + "_config3", CONFIG3_CMD, "BASELINE config 3: UnrealEgo training step (forward + backward + AdamW), bf16 storage, batch 1024, 1 warm-up + 2 "
+            "timed steps; per-launch HBM bytes are meaningful (one batch size)")
     SRC = os.path.join(REPO, "gpurun_out", "prof_all")
     if os.path.isdir(SRC):
-        one(tag + "_all_legs", ALL_CMD, "every leg: fp32 headline, bf16x3 fast mode, full pipeline in both modes, EgoCap / 128x128 geometry, "
-            "training steps in f32 / bf16x3 / bf16, stage-1 training, small-batch latency -- launches of one kernel mix batch sizes, "
+        one(tag + "_all_legs", ALL_CMD, "every leg: fp32 headline, bf16x3 / bf16 fast modes, full pipeline in both modes, EgoCap / 128x128 geometry, "
+            "training steps in f32 / bf16x3 / bf16 (B = 1024), stage-1 training, small-batch latency -- launches of one kernel mix batch sizes, "
             "so the per-launch averages here are not comparable with the headline table", traffic_json=False)
 
 
