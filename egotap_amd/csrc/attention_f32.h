@@ -63,39 +63,40 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
+    // K / V tiles go global -> registers -> LDS in two steps (cdna_hip_programming.md T14): the NEXT tile's loads are issued right
+    // after this tile's score MFMAs and fly during its softmax and its P V MFMAs; the registers are written to LDS after the barrier
+    // that retires this tile's reads.  Before: both loads of a tile were waited for on the spot, two exposed round trips per tile
+    // with the workgroup's MFMAs idle (MFMA busy 0.77).
+    constexpr int PER = KT * (DH / 4) / THREADS;
+    f32x4 stk[PER], stv[PER];
+    auto tile_load = [&](int kt) __attribute__((always_inline)) {
+        const float* kp = base + (long)(kt * KT) * ld + D;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
+            stk[i] = *(const f32x4*)(kp + (size_t)(unsigned)(row * (int)ld + c4 * 4));
+            stv[i] = *(const f32x4*)(kp + D + (size_t)(unsigned)(row * (int)ld + c4 * 4));
+        }
+    };
     const int ntiles = N / KT;
+    tile_load(0);
+    // The running maximum is raised (and the output rescaled) only when a query's scores exceed it by more than 2^RESC in the
+    // softmax's base-2 units (T13): probabilities stay below 2^RESC -- harmless in fp32 -- and the 64 multiplies per tile vanish
+    // from almost every tile.
+    constexpr float RESC = 8.0f;
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();   // every wave is done with the previous tile
-        {   // K then V through registers (two short phases keep the staging at 16 float4 per lane)
-            const float* kp = base + (long)(kt * KT) * ld + D;
-            constexpr int PER = KT * (DH / 4) / THREADS;
-            f32x4 st[PER];
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
-                st[i] = *(const f32x4*)(kp + (long)row * ld + c4 * 4);
-            }
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
-                *(f32x4*)(Ks + row * KLD + c4 * 4) = st[i];
-            }
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
-                st[i] = *(const f32x4*)(kp + (long)row * ld + D + c4 * 4);
-            }
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
-                *(f32x4*)(Vs + row * DH + c4 * 4) = st[i];
-            }
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
+            *(f32x4*)(Ks + row * KLD + c4 * 4) = stk[i];
+            *(f32x4*)(Vs + row * DH + c4 * 4) = stv[i];
         }
         __syncthreads();
-        if (valid) {
-            f32x16 s;
+        f32x16 s;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        if (valid) {
             const float* kf = Ks + l31 * KLD + 4 * lh;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -103,26 +104,32 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
 #pragma unroll
                 for (int u = 0; u < 4; ++u) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], qreg[4 * t + u], s, 0, 0, 0);
             }
+        }
+        if (kt + 1 < ntiles) tile_load(kt + 1);
+        if (valid) {
             // online softmax; the 32 keys of this tile sit in 16 registers x 2 lane halves
             float mx = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = exp2f((m_run - m_new) * scale_log2e);
-            const float mneg = -m_new * scale_log2e;
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
+            const bool raise = mx > m_run + RESC;
+            if (__builtin_amdgcn_ballot_w64(raise) != 0) {
+                const float m_new = raise ? mx : m_run;
+                const float alpha = exp2f(m_run - m_new);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
             float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = exp2f(fmaf(s[r], scale_log2e, mneg));
+                s[r] = exp2f(fmaf(s[r], scale_log2e, -m_run));
                 psum += s[r];
             }
-            l_run = l_run * alpha + psum;     // per lane-half partial sum; halves are added at the end
-            m_run = m_new;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            l_run += psum;                   // per lane-half partial sum; halves are added at the end
             // O^T += V^T P^T : step r contracts keys key(r,0), key(r,1)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
         // training: log-sum-exp of the scaled scores (natural log) per query row, for the flash-style backward
-        if (LSE != nullptr && lh == 0) LSE[((long)b * heads + h) * N + qb * 32 + l31] = m_run * (scale_log2e * 0.6931471805599453f) + logf(l_tot);
+        if (LSE != nullptr && lh == 0) LSE[((long)b * heads + h) * N + qb * 32 + l31] = m_run * 0.6931471805599453f + logf(l_tot);      // m_run is in base-2 units
         float* Os = smem + wid * 32 * KLD;     // [32 q][132]
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
