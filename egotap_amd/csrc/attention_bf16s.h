@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16s_kernel(const __bf1
             float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = exp2f(fmaf(s[r], scale_log2e, -m_run));
+                s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_run));
                 psum += s[r];
             }
             l_run += psum;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_bf16s_kernel(const __b
             f32x16 s = tile_x_frags<1>(Krow + sub * RIMG, qf, l31, lh);             // S^T[key][q]
             const f32x16 dp = tile_x_frags<1>(Vrow + sub * RIMG, dof, l31, lh);     // dP^T[key][q]
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = exp2f(fmaf(s[r], c2, -lse2)) * (dp[r] - delta) * scale;   // dS^T
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse2)) * (dp[r] - delta) * scale;   // dS^T
             acc_tile_t_x_p<1>(dq, Ktr + sub * TIMG, s, lane);                       // dQ^T[d][q] += K^T dS^T
         }
     }
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_bf16s_kernel(const __
         for (int sub = 0; sub < SUB; ++sub) {
             f32x16 p = tile_x_frags<1>(Qrow + sub * RIMG, kf, l31, lh);              // S[q][key]
 #pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = exp2f(fmaf(p[r], c2, -Ls[32 * sub + (r & 3) + 8 * (r >> 2) + 4 * lh]));
+            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(fmaf(p[r], c2, -Ls[32 * sub + (r & 3) + 8 * (r >> 2) + 4 * lh]));
             acc_tile_t_x_p<1>(dv, Dtr + sub * TIMG, p, lane);                        // dV^T[d][key] += dO^T P
             const f32x16 dp = tile_x_tile<1>(Drow + sub * RIMG, Vmine, l31, lh);     // dP[q][key] = dO V^T
 #pragma unroll
