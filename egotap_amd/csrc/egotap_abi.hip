@@ -131,6 +131,7 @@ struct egotap_handle_s {
     bool hm_resolved[EGOTAP_NET_COUNT] = {false, false, false};
     HmParams hp[EGOTAP_NET_COUNT];
     int debug_stop = 0;
+    int pu_resident[2] = {-1, -1};     // workgroups of pu_chain_kernel<1> / <2> the device keeps resident (-1: not asked yet)
     int precision = EGOTAP_PREC_F32;   // arithmetic of the large GEMMs (egotap_set_precision)
     __bf16* wscratch = nullptr;        // scratch for the bf16 copy of a GEMM's weight matrix (plain-bf16 mode), caller-owned
     size_t wscratch_bytes = 0;
@@ -582,8 +583,16 @@ static hipError_t fc_gemm(Handle* h, const char* role, const AL& al, const SegMa
 }
 
 // ------------------------------------------------------------------------------------------------ workspace
+// asks the device once how many workgroups of the one-launch PU chain it keeps resident (pu_chain.h)
+static void pu_chain_probe(Handle* h) {
+    if (h->pu_resident[0] < 0) {
+        h->pu_resident[0] = pu_chain_resident<1>();
+        h->pu_resident[1] = pu_chain_resident<2>();
+    }
+}
+
 struct LiftWs {
-    size_t X, Y, QKV, CTX, HID, Z1, Z2, POSZ, ROTZ, F0, G0, HS0, F1, G1, HS1, C0, C1, ZERO, SPLITK, total;
+    size_t X, Y, QKV, CTX, HID, Z1, Z2, POSZ, ROTZ, F0, G0, HS0, F1, G1, HS1, C0, C1, ZERO, HPA, HPB, FLAGS, SPLITK, total;
 };
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static LiftWs lift_ws(const Handle* h, int B) {
@@ -596,6 +605,8 @@ static LiftWs lift_ws(const Handle* h, int B) {
     w.F0 = take(JB * (H + 2 * h->hid)); w.G0 = take(JB * 4 * H); w.HS0 = take(JB * H);
     w.F1 = take(JB * H); w.G1 = take(JB * 4 * H); w.HS1 = take(JB * H);
     w.C0 = take((size_t)B * H); w.C1 = take((size_t)B * H); w.ZERO = take((size_t)B * H);
+    w.HPA = take((size_t)B * H); w.HPB = take((size_t)B * H);      // the propagation units' gated state, ping-pong
+    w.FLAGS = take((size_t)((B + 15) / 16) * PU_FLAG_STRIDE);      // step flags of the one-launch PU chain
     w.SPLITK = take(SPLITK_FLOATS);       // split-K partial sums of the small-batch GEMMs (gemm_small)
     w.total = o;
     return w;
@@ -692,7 +703,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     float* SPK = F(w.SPLITK);
     float *Z1 = F(w.Z1), *Z2 = F(w.Z2), *POSZ = F(w.POSZ), *ROTZ = F(w.ROTZ);
     float *F0 = F(w.F0), *G0 = F(w.G0), *HS0 = F(w.HS0), *F1 = F(w.F1), *G1 = F(w.G1), *HS1 = F(w.HS1);
-    float *C0 = F(w.C0), *C1 = F(w.C1), *ZERO = F(w.ZERO);
+    float *C0 = F(w.C0), *C1 = F(w.C1), *ZERO = F(w.ZERO), *HPA = F(w.HPA), *HPB = F(w.HPB);
     const int D = h->D, M = B * h->seq, BT = B * h->T, J = h->J, H = h->H, hid = h->hid, JB = J * B;
     const int S = h->cfg.hm_size, HW = S * S;
     using Tile = TileA;
@@ -814,18 +825,24 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     }
     // ... then the two J-step recurrences (layer 0 never reads layer-1 state, so the layers run one after the other)
     EGO_HIP(zero_fill(C0, (size_t)(w.ZERO - w.C0) + al256((size_t)B * H * 4), s));   // C0, C1, ZERO are contiguous (256-byte aligned slices)
-    for (int t = 0; t < J; ++t) {
-        const float* hprev = t == 0 ? ZERO : HS0 + (size_t)(t - 1) * B * H;
-        pu_step_launch(s, B, H, F0 + (size_t)t * B * NF0, NF0, G0 + (size_t)t * B * 4 * H,
-                           p.h2h0_w, p.h2h0_b, hprev, C0, C0, HS0 + (size_t)t * B * H, nullptr);
+    pu_chain_probe(h);
+    unsigned* FLAGS = (unsigned*)F(w.FLAGS);
+    const PuChain ch0{F0, (long)B * NF0, NF0, G0, (long)B * 4 * H, p.h2h0_w, p.h2h0_b, nullptr, 0, HS0, (long)B * H, HPA, (long)(HPB - HPA), FLAGS, B, H, J, 0};
+    if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch0, B))
+    for (int t = 0; t < J; ++t) {       // the gated state of step t + 1 comes out of step t (ping-pong buffers; zeros at t = 0)
+        const float* hp_in = t == 0 ? ZERO : ((t & 1) ? HPA : HPB);
+        pu_step_launch(s, B, H, hp_in, G0 + (size_t)t * B * 4 * H, p.h2h0_w, p.h2h0_b, C0, C0, HS0 + (size_t)t * B * H,
+                       t + 1 < J ? F0 + (size_t)(t + 1) * B * NF0 : nullptr, NF0, (t & 1) ? HPB : HPA, nullptr);
     }
     EGO_HIP(hipGetLastError());
     EGO_HIP((gemm<Tile>(h, "pu1_x2f", ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
     EGO_HIP((gemm<Tile>(h, "pu1_x2h", ALoadPlain{HS0, H}, segmat1(p.x2h1_w, 4 * H, H), EpiBias{segvec1(p.x2h1_b, 4 * H)}, G1, 4L * H, JB, 4 * H, H, s)));
+    const PuChain ch1{F1, (long)B * H, H, G1, (long)B * 4 * H, p.h2h1_w, p.h2h1_b, nullptr, 0, HS1, (long)B * H, HPA, (long)(HPB - HPA), FLAGS, B, H, J, 0};
+    if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch1, B))
     for (int t = 0; t < J; ++t) {
-        const float* hprev = t == 0 ? ZERO : HS1 + (size_t)(t - 1) * B * H;
-        pu_step_launch(s, B, H, F1 + (size_t)t * B * H, H, G1 + (size_t)t * B * 4 * H,
-                           p.h2h1_w, p.h2h1_b, hprev, C1, C1, HS1 + (size_t)t * B * H, nullptr);
+        const float* hp_in = t == 0 ? ZERO : ((t & 1) ? HPA : HPB);
+        pu_step_launch(s, B, H, hp_in, G1 + (size_t)t * B * 4 * H, p.h2h1_w, p.h2h1_b, C1, C1, HS1 + (size_t)t * B * H,
+                       t + 1 < J ? F1 + (size_t)(t + 1) * B * H : nullptr, H, (t & 1) ? HPB : HPA, nullptr);
     }
     EGO_HIP(hipGetLastError());
     // H15: per-joint pose head (+ global offset and head joint for UnrealEgo)
@@ -1557,7 +1574,7 @@ extern "C" int egotap_train_add_inplace(float* out, const float* in, int64_t n, 
 #endif
 
 // ------------------------------------------------------------------------------------------------ PU chain + pose head (training)
-struct PuSaved { size_t F0, G0, HS0, C0, F1, G1, HS1, C1, ZERO, total; };
+struct PuSaved { size_t F0, G0, HS0, C0, F1, G1, HS1, C1, ZERO, HPA, HPB, FLAGS, total; };
 static PuSaved pu_saved(const Handle* h, int B) {
     PuSaved w;
     const size_t JB = (size_t)h->J * B, H = h->H, NF0 = H + 2 * h->hid;
@@ -1566,6 +1583,8 @@ static PuSaved pu_saved(const Handle* h, int B) {
     w.F0 = take(JB * NF0); w.G0 = take(JB * 4 * H); w.HS0 = take(JB * H); w.C0 = take(JB * H);
     w.F1 = take(JB * H); w.G1 = take(JB * 4 * H); w.HS1 = take(JB * H); w.C1 = take(JB * H);
     w.ZERO = take((size_t)B * H);
+    w.HPA = take((size_t)B * H); w.HPB = take((size_t)B * H);
+    w.FLAGS = take((size_t)((B + 15) / 16) * PU_FLAG_STRIDE);
     w.total = o;
     return w;
 }
@@ -1593,6 +1612,7 @@ extern "C" int egotap_train_pu_fwd(egotap_handle h, const float* posz, const flo
     char* base = (char*)saved;
     auto F = [&](size_t off) { return (float*)(base + off); };
     float *F0 = F(w.F0), *G0 = F(w.G0), *HS0 = F(w.HS0), *C0 = F(w.C0), *F1 = F(w.F1), *G1 = F(w.G1), *HS1 = F(w.HS1), *C1 = F(w.C1), *ZERO = F(w.ZERO);
+    float *HPA = F(w.HPA), *HPB = F(w.HPB);
     const int J = h->J, H = h->H, hid = h->hid, JB = J * B, x = 2 * hid, NF0 = H + x;
     using Tile = TileA;
     ALoadStereo xs{posz, B, J, hid};
@@ -1603,22 +1623,29 @@ extern "C" int egotap_train_pu_fwd(egotap_handle h, const float* posz, const flo
         EGO_HIP((gemm<Tile>(h, "pu0_b2h", bs, segmat1(p.b2h0_w, 4 * H, x), EpiBiasRes{segvec1(p.b2h0_b, 4 * H), G0, 4L * H}, G0, 4L * H, JB, 4 * H, x, s)));
     }
     EGO_HIP(zero_fill(ZERO, (size_t)B * H * 4, s));
-    for (int t = 0; t < J; ++t) {       // G0 holds Gin on entry and the full gate pre-activations on exit (in place)
-        const float* hprev = t == 0 ? ZERO : HS0 + (size_t)(t - 1) * B * H;
+    pu_chain_probe(h);
+    unsigned* FLAGS = (unsigned*)F(w.FLAGS);
+    // G0 / G1 hold Gin on entry and the full gate pre-activations on exit (in place); C0 / C1 keep the cell state of every step
+    const PuChain ch0{F0, (long)B * NF0, NF0, G0, (long)B * 4 * H, p.h2h0_w, p.h2h0_b, C0, (long)B * H, HS0, (long)B * H, HPA, (long)(HPB - HPA), FLAGS, B, H, J, 1};
+    if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch0, B))
+    for (int t = 0; t < J; ++t) {
+        const float* hp_in = t == 0 ? ZERO : ((t & 1) ? HPA : HPB);
         const float* cprev = t == 0 ? ZERO : C0 + (size_t)(t - 1) * B * H;
         float* g = G0 + (size_t)t * B * 4 * H;
-        pu_step_launch(s, B, H, F0 + (size_t)t * B * NF0, NF0, g, p.h2h0_w, p.h2h0_b, hprev, cprev,
-                           C0 + (size_t)t * B * H, HS0 + (size_t)t * B * H, g);
+        pu_step_launch(s, B, H, hp_in, g, p.h2h0_w, p.h2h0_b, cprev, C0 + (size_t)t * B * H, HS0 + (size_t)t * B * H,
+                       t + 1 < J ? F0 + (size_t)(t + 1) * B * NF0 : nullptr, NF0, (t & 1) ? HPB : HPA, g);
     }
     EGO_HIP(hipGetLastError());
     EGO_HIP((gemm<Tile>(h, "pu1_x2f", ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
     EGO_HIP((gemm<Tile>(h, "pu1_x2h", ALoadPlain{HS0, H}, segmat1(p.x2h1_w, 4 * H, H), EpiBias{segvec1(p.x2h1_b, 4 * H)}, G1, 4L * H, JB, 4 * H, H, s)));
+    const PuChain ch1{F1, (long)B * H, H, G1, (long)B * 4 * H, p.h2h1_w, p.h2h1_b, C1, (long)B * H, HS1, (long)B * H, HPA, (long)(HPB - HPA), FLAGS, B, H, J, 1};
+    if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch1, B))
     for (int t = 0; t < J; ++t) {
-        const float* hprev = t == 0 ? ZERO : HS1 + (size_t)(t - 1) * B * H;
+        const float* hp_in = t == 0 ? ZERO : ((t & 1) ? HPA : HPB);
         const float* cprev = t == 0 ? ZERO : C1 + (size_t)(t - 1) * B * H;
         float* g = G1 + (size_t)t * B * 4 * H;
-        pu_step_launch(s, B, H, F1 + (size_t)t * B * H, H, g, p.h2h1_w, p.h2h1_b, hprev, cprev,
-                           C1 + (size_t)t * B * H, HS1 + (size_t)t * B * H, g);
+        pu_step_launch(s, B, H, hp_in, g, p.h2h1_w, p.h2h1_b, cprev, C1 + (size_t)t * B * H, HS1 + (size_t)t * B * H,
+                       t + 1 < J ? F1 + (size_t)(t + 1) * B * H : nullptr, H, (t & 1) ? HPB : HPA, g);
     }
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;

@@ -8,182 +8,88 @@
 //     hp    = sigmoid(F_t[:, 0:H]) * h_{t-1}
 //     gates = Gin_t + hp * Whh^T + bhh                       (gate order: forget, input, cell, output)
 //     c_t   = c_{t-1} * sig(f) + sig(i) * tanh(g) ;  h_t = sig(o) * tanh(c_t)
-// which pu_step_kernel does in one launch: a block owns 32 batch rows x 32 hidden units (all four
-// gates of those units, so the LSTM pointwise runs on the MFMA accumulators), its 4 waves split
-// K = H, partials meet in LDS.  Latency-bound by construction (30 dependent steps per forward).
+// which pu_step_r16_kernel does in one launch per step (30 dependent steps per forward).
 #pragma once
 #include "common.h"
 #include "layernorm.h"   // wave_sum
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-static __global__ __launch_bounds__(256) void pu_step_kernel(const float* __restrict__ F_t, int ldf,
-                                                      const float* __restrict__ Gin_t,
-                                                      const float* __restrict__ Whh,
-                                                      const float* __restrict__ bhh,
-                                                      const float* __restrict__ h_prev, const float* c_prev,
-                                                      float* c_out, float* __restrict__ h_out,
-                                                      float* __restrict__ gpre_out, int B, int H) {
-    __shared__ float red[3 * 4 * 16 * 64];   // partial accumulators of waves 1..3 (48 KiB)
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int r0 = blockIdx.x * 32, u0 = blockIdx.y * 32;
-    const int arow = min(r0 + l31, B - 1);
-    const int kq = H >> 2, k0 = wid * kq;
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-
-    // operands of the LSTM pointwise (wave 0 finishes the step): requested before the k loop, so their latency is hidden by it
-    // instead of being paid row by row behind the reduction (c_out may alias c_prev: every element is read here, once, by the
-    // thread that later writes it)
-    const int unit = u0 + l31;
-    float gin[16][4], cpv[16], bg[4];
-    if (wid == 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bg[g] = bhh[g * H + unit];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = min(r0 + (r & 3) + 8 * (r >> 2) + 4 * lh, B - 1);
-            const float* gi = Gin_t + (long)row * 4 * H + unit;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gin[r][g] = gi[(long)g * H];
-            cpv[r] = c_prev[(long)row * H + unit];
-        }
-    }
-    const float* hp = h_prev + (long)arow * H + k0 + 4 * lh;
-    const float* fp = F_t + (long)arow * ldf + k0 + 4 * lh;
-    const float* wp = Whh + (long)(u0 + l31) * H + k0 + 4 * lh;
-    // The step is one of 30 dependent launches: a chunk of 32 k (4 k-steps x 6 float4 per lane) is requested ahead of the chunk
-    // being multiplied so that no k-step waits for its own loads.  Measured: 32.7 -> 30.4 us per step at B = 256 (18.6 -> 19.9 at
-    // B = 1): the loads were not the bulk of it -- 256 MFMAs per wave on one wave per SIMD (6.9 us), the LDS reduction and the
-    // pointwise on a single wave are; the next step would be 16 waves per block (gate x k split).
-    constexpr int CH = 4;                        // k-steps of 8 per chunk
-    f32x4 xa[2][CH], xf[2][CH], xw[2][CH][4];
-    auto request = [&](int buf, int kc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int k = min(kc + 8 * c, kq - 8);   // kq % 32 != 0: the tail re-reads the last k-step (discarded by the guard below)
-            xa[buf][c] = *(const f32x4*)(hp + k);
-            xf[buf][c] = *(const f32x4*)(fp + k);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) xw[buf][c][g] = *(const f32x4*)(wp + (long)g * H * H + k);
-        }
-    };
-    auto multiply = [&](int buf, int kc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if (kc + 8 * c < kq) {
-                f32x4 a = xa[buf][c];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) a[u] *= sigmoidf_(xf[buf][c][u]);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], xw[buf][c][g][u], acc[g], 0, 0, 0);
-            }
-        }
-    };
-    request(0, 0);
-    for (int k = 0; k < kq; k += 16 * CH) {
-        request(1, k + 8 * CH);
-        multiply(0, k);
-        request(0, k + 16 * CH);
-        multiply(1, k + 8 * CH);
-    }
-    if (wid > 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[(((wid - 1) * 4 + g) * 16 + r) * 64 + lane] = acc[g][r];
-    }
-    __syncthreads();
-    if (wid == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float pre[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v = acc[g][r];
-#pragma unroll
-                for (int w = 0; w < 3; ++w) v += red[((w * 4 + g) * 16 + r) * 64 + lane];
-                pre[g] = v + bg[g];
-            }
-            if (row < B) {
-                const float pf = pre[0] + gin[r][0], pi = pre[1] + gin[r][1], pc = pre[2] + gin[r][2], po = pre[3] + gin[r][3];
-                if (gpre_out) {      // training: keep the gate pre-activations for the backward pass
-                    float* gp = gpre_out + (long)row * 4 * H + unit;
-                    gp[0] = pf; gp[H] = pi; gp[2 * H] = pc; gp[3 * H] = po;
-                }
-                const float fg = sigmoidf_(pf), ig = sigmoidf_(pi), cg = tanhf(pc), og = sigmoidf_(po);
-                const float cn = cpv[r] * fg + ig * cg;
-                c_out[(long)row * H + unit] = cn;
-                h_out[(long)row * H + unit] = og * tanhf(cn);
-            }
-        }
-    }
+static __global__ void zero_fill_u32_kernel(unsigned* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
 }
 
-// The same step on 16 waves: wave = (gate, quarter of K) with one 32 x 32 accumulator, partial sums meet in LDS, and the LSTM
-// pointwise runs one (row, unit) per thread on all 1024 threads.  pu_step_kernel spends its 20-30 us per step on 256 MFMAs per
-// wave at one wave per SIMD (6.9 us), an LDS reduction into a single wave and that wave's 16-row pointwise; here a wave issues 64
-// MFMAs, four waves share a SIMD, and nothing is serial behind one wave.  The k partition (quarters), the order inside a quarter
-// and the order in which the four partial sums are added are those of pu_step_kernel, so the result is bit for bit the same.
-static __global__ __launch_bounds__(1024) void pu_step16_kernel(const float* __restrict__ F_t, int ldf, const float* __restrict__ Gin_t,
-                                                                const float* __restrict__ Whh, const float* __restrict__ bhh,
-                                                                const float* __restrict__ h_prev, const float* c_prev, float* c_out,
-                                                                float* __restrict__ h_out, float* __restrict__ gpre_out, int B, int H) {
-    __shared__ float red[16 * 16 * 64];          // [quarter * 4 + gate][register][lane] (64 KiB)
+// One recurrent step of a PU layer.  The gated state hp_t = sigmoid(F_t[:, 0:H]) * h_{t-1} is produced by the PREVIOUS step's pointwise
+// stage (which owns h_{t-1} element by element and knows F_t, a state-independent GEMM output): one sigmoid per element and step
+// instead of one per element, gate wave and unit block (64 x redundant when every GEMM wave gated its own operand slice: 7-8k VALU
+// cycles per wave in front of 2k cycles of MFMA -- that, not the matrix pipe, was the 28 us step).
+// A block owns 16 batch rows (v_mfma_f32_16x16x4_f32) x 32 units x 4 gates, so B = 256 is 256 workgroups; wave = (gate, quarter of K),
+// every operand of a wave's 64 MFMAs is requested up front in two rounds, partial sums meet in LDS, pointwise on 512 threads.
+// k order inside a quarter: MFMA (i, u) contracts k = 16 i + 4 g + u over the four lane groups g; the quarters are added in the
+// order 0..3.  One kernel for every batch size: a row's result does not depend on the batch it is in.
+static __global__ __launch_bounds__(1024) void pu_step_r16_kernel(const float* __restrict__ hp_in, const float* __restrict__ Gin_t,
+                                                                  const float* __restrict__ Whh, const float* __restrict__ bhh,
+                                                                  const float* c_prev, float* c_out, float* __restrict__ h_out,
+                                                                  const float* __restrict__ F_next, int ldf_next, float* __restrict__ hp_out,
+                                                                  float* __restrict__ gpre_out, int B, int H) {
+    __shared__ f32x4 red[4 * 4 * 2 * 64];        // [quarter][gate][unit tile][lane] (32 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
+    const int l15 = lane & 15, lg = lane >> 4;
     const int g = wid & 3, kq4 = wid >> 2;
-    const int r0 = blockIdx.x * 32, u0 = blockIdx.y * 32;
-    const int arow = min(r0 + l31, B - 1);
-    const int kq = H >> 2, k0 = kq4 * kq;
-    // operands of this thread's pointwise element, requested up front
+    // workgroups go round-robin over the 8 XCDs: XCD x gets the unit blocks {2x, 2x + 1} of every row block, so each L2 holds one
+    // eighth of Whh (512 KiB, resident from step to step) instead of all 4 MiB
+    const int lin = blockIdx.x;
+    const int r0 = (lin >> 4) * 16, u0 = (((lin & 7) << 1) | ((lin >> 3) & 1)) * 32;
+    const int arow = min(r0 + l15, B - 1);
+    const int k0 = kq4 * 128;                    // H = 512 (checked by the launcher): a quarter of K is 128
+    // operands of this thread's pointwise element (threads 0..511: row tid >> 5, unit tid & 31), requested up front
     const int prow = r0 + (tid >> 5), punit = u0 + (tid & 31);
     const int prc = min(prow, B - 1);
-    float gin[4], bg[4];
+    const bool pw = tid < 512;
+    float gin[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f}, cpv = 0.f, fnext = 0.f;
+    if (pw) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        gin[q] = Gin_t[(long)prc * 4 * H + (long)q * H + punit];
-        bg[q] = bhh[q * H + punit];
+        for (int q = 0; q < 4; ++q) {
+            gin[q] = Gin_t[(long)prc * 4 * H + (long)q * H + punit];
+            bg[q] = bhh[q * H + punit];
+        }
+        cpv = c_prev[(long)prc * H + punit];
+        if (F_next) fnext = F_next[(long)prc * ldf_next + punit];
     }
-    const float cpv = c_prev[(long)prc * H + punit];
-
-    f32x16 acc;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const float* hp = hp_in + (long)arow * H + k0 + 4 * lg;
+    const float* wp = Whh + (long)g * H * H + (long)(u0 + l15) * H + k0 + 4 * lg;
+    // H = 512: 8 iterations of 16 k; every operand of the wave is in flight before its first MFMA
+    f32x4 a[8], w0[8], w1[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* hp = h_prev + (long)arow * H + k0 + 4 * lh;
-    const float* fp = F_t + (long)arow * ldf + k0 + 4 * lh;
-    const float* wp = Whh + (long)g * H * H + (long)(u0 + l31) * H + k0 + 4 * lh;
-#pragma unroll 4
-    for (int k = 0; k < kq; k += 8) {
-        f32x4 a = *(const f32x4*)(hp + k);
-        const f32x4 f = *(const f32x4*)(fp + k);
-        const f32x4 w = *(const f32x4*)(wp + k);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] *= sigmoidf_(f[u]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], w[u], acc, 0, 0, 0);
+    for (int i = 0; i < 8; ++i) {
+        a[i] = *(const f32x4*)(hp + 16 * i);
+        w0[i] = *(const f32x4*)(wp + 16 * i);
+        w1[i] = *(const f32x4*)(wp + (long)16 * H + 16 * i);
     }
+    __builtin_amdgcn_sched_barrier(0);           // keep the 24 requests ahead of the MFMAs (the scheduler would pair them up)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[((kq4 * 4 + g) * 16 + r) * 64 + lane] = acc[r];
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][u], w0[i][u], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][u], w1[i][u], acc[1], 0, 0, 0);
+        }
+    }
+    red[((kq4 * 4 + g) * 2 + 0) * 64 + lane] = acc[0];
+    red[((kq4 * 4 + g) * 2 + 1) * 64 + lane] = acc[1];
     __syncthreads();
-    if (prow < B) {
-        // element (row_local, unit) of a 32 x 32 accumulator: lane = unit + 32 * ((row_local >> 2) & 1), register (row_local & 3) + 4 * (row_local >> 3)
-        const int rl = tid >> 5;
-        const int idx = ((rl & 3) + 4 * (rl >> 3)) * 64 + (tid & 31) + 32 * ((rl >> 2) & 1);
+    if (pw && prow < B) {
+        // element (row_local, unit_local) of the 16 x 16 accumulator tiles: tile unit_local >> 4, lane (unit_local & 15) + 16 * (row_local >> 2), register row_local & 3
+        const int rl = tid >> 5, ul = tid & 31;
+        const int idx = (ul >> 4) * 64 + (ul & 15) + 16 * (rl >> 2), reg = rl & 3;
         float pre[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float v = red[(0 * 4 + q) * 1024 + idx];
+            float v = red[(0 * 4 + q) * 128 + idx][reg];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) v += red[(w * 4 + q) * 1024 + idx];
+            for (int w = 1; w < 4; ++w) v += red[(w * 4 + q) * 128 + idx][reg];
             pre[q] = v + bg[q];
         }
         const float pf = pre[0] + gin[0], pi = pre[1] + gin[1], pc = pre[2] + gin[2], po = pre[3] + gin[3];
@@ -193,19 +99,199 @@ static __global__ __launch_bounds__(1024) void pu_step16_kernel(const float* __r
         }
         const float fg = sigmoidf_(pf), ig = sigmoidf_(pi), cg = tanhf(pc), og = sigmoidf_(po);
         const float cn = cpv * fg + ig * cg;
+        const float hn = og * tanhf(cn);
         c_out[(long)prow * H + punit] = cn;
-        h_out[(long)prow * H + punit] = og * tanhf(cn);
+        h_out[(long)prow * H + punit] = hn;
+        if (hp_out) hp_out[(long)prow * H + punit] = sigmoidf_(fnext) * hn;      // the next step's gated state
     }
 }
 
-// One PU step.  Both kernels give the same bits; measured per step: B = 1: 19.9 us (4 waves, operands requested ahead) against
-// 22.7 (16 waves); B = 256: 30.4 against 28.0 -- neither is bound by its MFMAs (1.7 us on 16 waves), the floor is the chain of
-// dependent memory round trips of a launch that starts cold 30 times per forward.
-static inline void pu_step_launch(hipStream_t s, int B, int H, const float* F_t, int ldf, const float* Gin_t, const float* Whh, const float* bhh,
-                                  const float* h_prev, const float* c_prev, float* c_out, float* h_out, float* gpre_out) {
-    const dim3 grid((B + 31) / 32, H / 32);
-    if (B >= 64) hipLaunchKernelGGL(pu_step16_kernel, grid, dim3(1024), 0, s, F_t, ldf, Gin_t, Whh, bhh, h_prev, c_prev, c_out, h_out, gpre_out, B, H);
-    else hipLaunchKernelGGL(pu_step_kernel, grid, dim3(256), 0, s, F_t, ldf, Gin_t, Whh, bhh, h_prev, c_prev, c_out, h_out, gpre_out, B, H);
+// One PU step: hp_in = gated state of this step (zeros at t = 0), F_next = the next step's gate logits F_{t+1}[:, 0:H] (row stride
+// ldf_next) or nullptr at the last step, hp_out = where the next step's gated state goes (not hp_in: blocks finish at different times).
+static inline void pu_step_launch(hipStream_t s, int B, int H, const float* hp_in, const float* Gin_t, const float* Whh, const float* bhh,
+                                  const float* c_prev, float* c_out, float* h_out, const float* F_next, int ldf_next, float* hp_out,
+                                  float* gpre_out) {
+    hipLaunchKernelGGL(pu_step_r16_kernel, dim3(((B + 15) / 16) * 16), dim3(1024), 0, s, hp_in, Gin_t, Whh, bhh, c_prev, c_out, h_out, F_next,
+                       ldf_next, hp_out, gpre_out, B, H);
+}
+
+// The whole J-step recurrence of one PU layer in ONE launch.  What a step kernel re-reads every step -- its 256 KiB slice of Whh, at the
+// 66-73 GB/s per CU an XCD's L2 serves (4 us of a 14 us step, 8 us as measured with half-used lines) -- lives in the waves' registers
+// here (64 VGPRs per lane for UT = 2), and the launch boundary becomes a flag wait among the workgroups that share a row block:
+// the only cross-workgroup dependence of step t is on the gated state hp_t of the SAME 16 rows, all H units (H / (16 UT) workgroups).
+//   hp is stored write-through (agent-scope atomic stores) and read with sc1 loads, so no L2 write-back / invalidate is needed:
+//   __syncthreads (stores acknowledged), publish this workgroup's step flag, bounded spin on the row block's flags, __syncthreads, hp loads.
+// Workgroups of a row block must be co-resident (they wait for each other): the launcher sizes the grid from the occupancy query and
+// walks larger batches in row chunks; the spin is bounded so that a wave always reaches its exit.
+// Arithmetic, k order and reduction order are those of pu_step_r16_kernel (bit-identical results).
+constexpr int PU_FLAG_STRIDE = 64;              // unsigned per row block: 256 B, so that row blocks do not share a line / channel
+struct PuChain {
+    const float* F; long f_step; int ldf;       // gate logits: F + t * f_step + row * ldf + unit  (sigmoid gates h_{t-1})
+    float* G; long g_step;                      // Gin_t [rows, 4H] at G + t * g_step; keep_gates: overwritten with the gate pre-activations
+    const float* Whh; const float* bhh;
+    float* C; long c_step;                      // c_t of every step (training) or nullptr
+    float* HS; long hs_step;                    // h_t at HS + t * hs_step
+    float* HP; long hp_stride;                  // gated state, two buffers
+    unsigned* cnt;                              // PU_FLAG_STRIDE step flags per row block (one per workgroup), zero on entry
+    int rows, H, J, keep_gates;
+};
+
+template <int UT>
+static __global__ __launch_bounds__(1024) void pu_chain_kernel(const PuChain p) {
+    constexpr int NBG = 32 / UT;                 // workgroups per row block (H = 512)
+    constexpr int PW = 256 * UT;                 // pointwise threads: 16 rows x 16 UT units
+    __shared__ f32x4 red[4 * 4 * UT * 64];       // [quarter][gate][unit tile][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int g = wid & 3, kq4 = wid >> 2;
+    const int H = p.H;
+    const int rb = blockIdx.x / NBG, r0 = rb * 16, u0 = (blockIdx.x % NBG) * (16 * UT);
+    const int arow = min(r0 + l15, p.rows - 1);
+    const int k0 = kq4 * 128;
+    const int rl = tid / (16 * UT), ul = tid % (16 * UT);
+    const int prow = r0 + rl, punit = u0 + ul;
+    const int prc = min(prow, p.rows - 1);
+    const bool pw = tid < PW;
+    const int idx = (ul >> 4) * 64 + (ul & 15) + 16 * ((rl & 15) >> 2), reg = rl & 3;
+    // this wave's slice of Whh: rows u0 + 16 tile + l15 of gate g, k = k0 + 16 i + 4 lg + (0..3)
+    f32x4 w[UT][8];
+    {
+        const float* wp = p.Whh + (long)g * H * H + (long)(u0 + l15) * H + k0 + 4 * lg;
+#pragma unroll
+        for (int tl = 0; tl < UT; ++tl)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[tl][i] = *(const f32x4*)(wp + (long)tl * 16 * H + 16 * i);
+    }
+    float bg[4] = {0.f, 0.f, 0.f, 0.f}, c = 0.f;
+    if (pw) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bg[q] = p.bhh[q * H + punit];
+    }
+    unsigned* flags = p.cnt + (long)rb * PU_FLAG_STRIDE;
+    bool dead = false;                           // wave 0: a wait ran out (the group is not co-resident); stop waiting, finish
+    // what does not depend on the state is requested one step ahead, before the wait
+    float gin[4] = {0.f, 0.f, 0.f, 0.f}, fnext = 0.f;
+    auto fetch = [&](int t) {
+        if (pw) {
+            const float* gt = p.G + (long)t * p.g_step + (long)prc * 4 * H + punit;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gin[q] = gt[(long)q * H];
+            fnext = t + 1 < p.J ? p.F[(long)(t + 1) * p.f_step + (long)prc * p.ldf + punit] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int t = 0; t < p.J; ++t) {
+        f32x4 acc[UT];
+#pragma unroll
+        for (int tl = 0; tl < UT; ++tl) acc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {                             // hp_0 = 0: the recurrent product of the first step is the bias alone
+            const float* hp = p.HP + (long)((t - 1) & 1) * p.hp_stride + (long)arow * H + k0 + 4 * lg;
+            f32x4 a[8];
+            // agent-coherent reads (sc1): served from memory / the Infinity Cache, never from a line this XCD cached a step ago
+            asm volatile(
+                "global_load_dwordx4 %0, %8, off sc1\n\t"
+                "global_load_dwordx4 %1, %8, off offset:64 sc1\n\t"
+                "global_load_dwordx4 %2, %8, off offset:128 sc1\n\t"
+                "global_load_dwordx4 %3, %8, off offset:192 sc1\n\t"
+                "global_load_dwordx4 %4, %8, off offset:256 sc1\n\t"
+                "global_load_dwordx4 %5, %8, off offset:320 sc1\n\t"
+                "global_load_dwordx4 %6, %8, off offset:384 sc1\n\t"
+                "global_load_dwordx4 %7, %8, off offset:448 sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
+                : "v"(hp)
+                : "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int tl = 0; tl < UT; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][u], w[tl][i][u], acc[tl], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int tl = 0; tl < UT; ++tl) red[((kq4 * 4 + g) * UT + tl) * 64 + lane] = acc[tl];
+        __syncthreads();
+        if (pw && prow < p.rows) {
+            float pre[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = red[(0 * 4 + q) * (UT * 64) + idx][reg];
+#pragma unroll
+                for (int wq = 1; wq < 4; ++wq) v += red[(wq * 4 + q) * (UT * 64) + idx][reg];
+                pre[q] = v + bg[q];
+            }
+            const float pf = pre[0] + gin[0], pi = pre[1] + gin[1], pc = pre[2] + gin[2], po = pre[3] + gin[3];
+            if (p.keep_gates) {
+                float* gt = p.G + (long)t * p.g_step + (long)prow * 4 * H + punit;
+                gt[0] = pf; gt[H] = pi; gt[2L * H] = pc; gt[3L * H] = po;
+            }
+            const float fg = sigmoidf_(pf), ig = sigmoidf_(pi), cg = tanhf(pc), og = sigmoidf_(po);
+            c = c * fg + ig * cg;
+            const float hn = og * tanhf(c);
+            if (p.C) p.C[(long)t * p.c_step + (long)prow * H + punit] = c;
+            p.HS[(long)t * p.hs_step + (long)prow * H + punit] = hn;
+            // written through to memory (agent scope): no L2 write-back needed before the other XCDs may read it
+            if (t + 1 < p.J)
+                __hip_atomic_store(p.HP + (long)(t & 1) * p.hp_stride + (long)prow * H + punit, sigmoidf_(fnext) * hn, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (t + 1 < p.J) {
+            fetch(t + 1);
+            // workgroup barrier: every wave's hp stores are acknowledged (vmcnt) and every read of red is done; then one thread
+            // counts the workgroup in and waits for the other workgroups of the row block.  No cache maintenance: hp moves with
+            // write-through stores and sc1 loads, everything else a workgroup reads back is its own.
+            __syncthreads();
+            if (wid == 0) {
+                // one flag per workgroup (no read-modify-write, no shared counter for 16 XCD-crossing adders to queue on): the
+                // workgroup publishes the step it has finished, lanes 0..NBG-1 watch the row block's NBG flags (one line)
+                if (lane == 0) __hip_atomic_store(flags + (blockIdx.x % NBG), (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!dead) {
+                    int spins = 0;
+                    for (;;) {
+                        const unsigned f = lane < NBG ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                        if (__builtin_amdgcn_ballot_w64(f < (unsigned)(t + 1)) == 0) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1 << 18)) { dead = true; break; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Workgroups of pu_chain_kernel<UT> the device keeps resident at once (0: the chain kernel cannot be used).
+template <int UT>
+static inline int pu_chain_resident() {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pu_chain_kernel<UT>, 1024, 0) != hipSuccess) return 0;
+    return per_cu * prop.multiProcessorCount;
+}
+
+// One PU layer over all J steps of B rows.  cnt: PU_FLAG_STRIDE * ((B + 15) / 16) flags, zeroed here.  resident1/resident2: pu_chain_resident<1/2>().
+// Returns false when the chain kernel cannot run here (the caller then walks the steps with pu_step_launch).
+static inline bool pu_chain_launch(hipStream_t s, int resident1, int resident2, PuChain p, int B) {
+    const int nrb = (B + 15) / 16;
+    const bool small = nrb * 32 <= resident1 && nrb <= 8;      // few rows: 16 units per workgroup, twice the workgroups
+    const int nbg = small ? 32 : 16, resident = small ? resident1 : resident2;
+    const int chunk_rb = resident / nbg;
+    if (chunk_rb < 1) return false;
+    hipLaunchKernelGGL(zero_fill_u32_kernel, dim3((nrb * PU_FLAG_STRIDE + 255) / 256), dim3(256), 0, s, p.cnt, nrb * PU_FLAG_STRIDE);
+    for (int rb0 = 0; rb0 < nrb; rb0 += chunk_rb) {
+        const int nb = min(chunk_rb, nrb - rb0), row0 = rb0 * 16;
+        PuChain q = p;
+        q.F = p.F + (long)row0 * p.ldf; q.G = p.G + (long)row0 * 4 * p.H; q.HS = p.HS + (long)row0 * p.H; q.HP = p.HP + (long)row0 * p.H;
+        if (p.C) q.C = p.C + (long)row0 * p.H;
+        q.cnt = p.cnt + (long)rb0 * PU_FLAG_STRIDE;
+        q.rows = min(B - row0, nb * 16);
+        if (small) hipLaunchKernelGGL(pu_chain_kernel<1>, dim3(nb * nbg), dim3(1024), 0, s, q);
+        else hipLaunchKernelGGL(pu_chain_kernel<2>, dim3(nb * nbg), dim3(1024), 0, s, q);
+    }
+    return true;
 }
 
 // Pose head: one block per sample.

@@ -8,7 +8,8 @@
  *   - plain pointers and sizes only; every pointer marked "device" is a HIP device pointer owned
  *     by the caller (PyTorch allocates params, activations, workspace); the library borrows them.
  *   - no device allocation, no synchronisation, no internal streams: all work is enqueued on the
- *     caller's stream (pass torch.cuda.current_stream().cuda_stream as a void*).  Graph-capture safe.
+ *     caller's stream (pass torch.cuda.current_stream().cuda_stream as a void*).  Graph-capture safe
+ *     after one eager call per handle (the first forward asks the device for its occupancy figures).
  *   - every function returns 0 on success, an EGOTAP_ERR_* code otherwise; the message is in
  *     egotap_last_error() (thread local).  No C++ exception crosses the ABI.
  *   - a handle is not thread-safe; data parallelism = one process + one handle per GPU.

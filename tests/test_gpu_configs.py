@@ -176,12 +176,13 @@ def test_config3_bf16_train_step_b1024_through_the_wrapper():
     for rep in range(2):
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
+        held = torch.cuda.memory_allocated()        # what earlier tests of this process still hold (cached nets, workspaces)
         m, p = _model(use_amp=True)
         data, hm, gt = _data(B, p, "c3big")
         m.set_input(data)
         m.optimize_parameters()
         torch.cuda.synchronize()
-        peaks.append(torch.cuda.max_memory_allocated() / 2 ** 30)
+        peaks.append((torch.cuda.max_memory_allocated() - held) / 2 ** 30)
         e = m.get_current_errors()
         losses.append((e["pose"], e["cos_sim"]))
         assert np.isfinite(e["pose"]) and np.isfinite(e["cos_sim"]) and 0.0 < e["pose"] < 10.0
