@@ -128,6 +128,9 @@ struct egotap_handle_s {
     std::unordered_map<std::string, Param> bound[EGOTAP_NET_COUNT];
     bool lift_resolved = false;
     LiftParams lp;
+    std::unordered_map<std::string, Param> bound_grad;                   // egotap_bind_grad: where egotap_lift_backward writes
+    bool grad_resolved = false;
+    LiftParams lg;                                                       // the same tensors' gradient buffers (running stats unused)
     bool hm_resolved[EGOTAP_NET_COUNT] = {false, false, false};
     HmParams hp[EGOTAP_NET_COUNT];
     int debug_stop = 0;
@@ -297,21 +300,21 @@ extern "C" int egotap_unbound_count(egotap_handle h, int net, int* count) {
 }
 #endif
 
-static const float* P(Handle* h, int net, const std::string& key, bool& ok) {
-    auto it = h->bound[net].find(key);
-    if (it == h->bound[net].end()) {
-        if (ok) egotap_set_error("parameter '%s' is not bound", key.c_str());
+typedef std::unordered_map<std::string, Param> ParamMap;
+static const float* P(Handle*, const ParamMap& m, const std::string& key, bool& ok) {
+    auto it = m.find(key);
+    if (it == m.end()) {
+        if (ok) egotap_set_error("'%s' is not bound", key.c_str());
         ok = false;
         return nullptr;
     }
     return (const float*)it->second.ptr;
 }
+static const float* P(Handle* h, int net, const std::string& key, bool& ok) { return P(h, h->bound[net], key, ok); }
 
-static int lift_resolve(Handle* h) {
-    if (h->lift_resolved) return EGOTAP_OK;
+// fills a LiftParams from a key -> pointer map: the parameters (with_stats: and the BatchNorm running statistics) or their gradients
+static int lift_resolve_into(Handle* h, const ParamMap& N, LiftParams& p, bool with_stats) {
     bool ok = true;
-    const int N = EGOTAP_NET_LIFT;
-    LiftParams& p = h->lp;
     const std::string v = "pos_heatmap_encoder.vit.";
     p.mask_tok = P(h, N, v + "embeddings.mask_token", ok);
     p.pos_emb = P(h, N, v + "embeddings.position_embeddings", ok);
@@ -338,7 +341,8 @@ static int lift_resolve(Handle* h) {
             LiftParams::Fc& fc = e == 0 ? p.pos_fc[i] : p.rot_fc[i];
             fc.w = P(h, N, f + ".fc.weight", ok);        fc.b = P(h, N, f + ".fc.bias", ok);
             fc.g = P(h, N, f + ".bn.weight", ok);        fc.beta = P(h, N, f + ".bn.bias", ok);
-            fc.mean = P(h, N, f + ".bn.running_mean", ok); fc.var = P(h, N, f + ".bn.running_var", ok);
+            fc.mean = fc.var = nullptr;
+            if (with_stats) { fc.mean = P(h, N, f + ".bn.running_mean", ok); fc.var = P(h, N, f + ".bn.running_var", ok); }
         }
     const std::string c = "skel_sequential_layer.lstm_custom.layers.";
     p.x2f0_w = P(h, N, c + "0.x2f.weight", ok); p.x2f0_b = P(h, N, c + "0.x2f.bias", ok);
@@ -354,7 +358,13 @@ static int lift_resolve(Handle* h) {
         p.glob_w = P(h, N, "global_mlp.pose_fcs.0.weight", ok);
         p.glob_b = P(h, N, "global_mlp.pose_fcs.0.bias", ok);
     }
-    if (!ok) return EGOTAP_ERR_UNBOUND;
+    return ok ? EGOTAP_OK : EGOTAP_ERR_UNBOUND;
+}
+
+static int lift_resolve(Handle* h) {
+    if (h->lift_resolved) return EGOTAP_OK;
+    const int rc = lift_resolve_into(h, h->bound[EGOTAP_NET_LIFT], h->lp, true);
+    if (rc != EGOTAP_OK) return rc;
     h->lift_resolved = true;
     return EGOTAP_OK;
 }
@@ -2303,6 +2313,254 @@ extern "C" int egotap_bf16_fc1_dgrad_tokens(egotap_handle h, const void* dz, con
     EGO_HIP(zero_fill(dtok, (size_t)B * h->seq * h->D * 2, s));
     EGO_HIP(gemm_bf16s_launch(XPlain{(const __bf16*)dz, 2048L}, (const __bf16*)wt, 2048L, SEpiScatterTokens{(__bf16*)dtok, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, BT, K1, 2048,
                               device_cu_count(), s));
+    return EGOTAP_OK;
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------ one-call training step
+// egotap_lift_forward_train + egotap_lift_backward: the lifting head's training-mode forward (activations kept in `saved`) and its
+// whole backward as ONE call each (egotap_lift_forward(…, saved, …) / egotap_lift_backward; reference:
+// egotap_autoencoder_model.py:284-311 loss.backward()).  They compose the granular training operators above in the order
+// egotap_amd/training.py used to (the per-operator tests keep calling those), read the parameters bound with egotap_bind_param
+// and write the gradients into the buffers bound with egotap_bind_grad.  fp32 tensors; arithmetic of the large GEMMs follows
+// egotap_set_precision (f32 / bf16x3; bf16 here means bf16 operand copies, the bf16-STORAGE step is egotap_amd/training.py's
+// LiftTrainBf16Fn).  Everything is enqueued on the caller's stream; no allocation, no synchronisation.
+#if EGOTAP_IN(0)
+struct LiftTrainPlan {      // byte offsets into `saved`
+    size_t X[9];            // X[i]: input of ViT layer i (X[0] = embeddings), X[L]: input of the final LayerNorm
+    struct Layer { size_t m1, r1, y1, qkv, ctx, lse, xm, m2, r2, y2, z, hid; } layer[8];
+    size_t mf, rf, tokens;
+    struct Fc { size_t z, y, mean, rstd; } pos[3], rot[3];
+    size_t pu, pu_hs1, pu_bytes, total;
+};
+struct LiftBwdPlan {        // byte offsets into the backward workspace
+    size_t R[3], A4, A3, WT, E[2], dposz, drotz, dhs1, delta, pu, pu_bytes, scr, scr_bytes, total;
+};
+static const int FC_OUT[2] = {2048, 512};
+
+static int lift_train_plan(Handle* h, int B, LiftTrainPlan& t, LiftBwdPlan& w) {
+    const size_t M = (size_t)B * h->seq, D = h->D, BT = (size_t)B * h->T, heads = h->cfg.vit_heads, L = h->cfg.vit_layers;
+    size_t o = 0;
+    auto take = [&](size_t floats) { size_t r = o; o = al256(o + floats * 4); return r; };
+    for (size_t i = 0; i <= L; ++i) t.X[i] = take(M * D);
+    for (size_t i = 0; i < L; ++i) {
+        auto& l = t.layer[i];
+        l.m1 = take(M); l.r1 = take(M); l.y1 = take(M * D); l.qkv = take(M * 3 * D); l.ctx = take(M * D); l.lse = take((size_t)B * heads * h->seq);
+        l.xm = take(M * D); l.m2 = take(M); l.r2 = take(M); l.y2 = take(M * D); l.z = take(M * 4 * D); l.hid = take(M * 4 * D);
+    }
+    t.mf = take(M); t.rf = take(M); t.tokens = take(M * D);
+    for (int e = 0; e < 2; ++e)
+        for (int j = 0; j < 3; ++j) {
+            const size_t n = j < 2 ? (size_t)FC_OUT[j] : (size_t)h->hid;
+            LiftTrainPlan::Fc& f = e == 0 ? t.pos[j] : t.rot[j];
+            f.z = take(BT * n); f.y = take(BT * n); f.mean = take(n); f.rstd = take(n);
+        }
+    size_t pub = 0, hs1 = 0;
+    int rc = egotap_train_pu_saved_bytes(h, B, &pub, &hs1);
+    if (rc != EGOTAP_OK) return rc;
+    t.pu = take(pub / 4 + 1); t.pu_hs1 = hs1; t.pu_bytes = pub;
+    t.total = o;
+
+    o = 0;
+    const size_t K1 = (size_t)h->ppd * h->ppd * D, K1r = 2 * (size_t)h->cfg.hm_size * h->cfg.hm_size;
+    for (int i = 0; i < 3; ++i) w.R[i] = take(M * D);
+    w.A4 = take(M * 4 * D); w.A3 = take(M * 3 * D);
+    w.WT = take(std::max((size_t)4 * D * D, K1 * 2048));
+    w.E[0] = take(BT * 2048); w.E[1] = take(BT * 2048);
+    w.dposz = take(BT * h->hid); w.drotz = take(BT * h->hid); w.dhs1 = take((size_t)h->J * B * h->H);
+    w.delta = take((size_t)B * heads * h->seq);
+    size_t pwb = 0;
+    rc = egotap_train_pu_bwd_ws_bytes(h, B, &pwb);
+    if (rc != EGOTAP_OK) return rc;
+    w.pu = take(pwb / 4 + 1); w.pu_bytes = pwb;
+    // split-M slabs of the weight-gradient GEMMs (8 slabs of the largest [N, K]) / column-sum partials / LayerNorm partials
+    w.scr_bytes = std::max((size_t)64 << 20, (size_t)4 * 2048 * std::max(K1, K1r) * 8);
+    w.scr = take(w.scr_bytes / 4);
+    w.total = o;
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_lift_train_bytes(egotap_handle h, int B, size_t* saved_bytes, size_t* ws_bytes) {
+    EGO_CHECK(h && saved_bytes && ws_bytes && B > 0, "egotap_lift_train_bytes: bad argument");
+    LiftTrainPlan t; LiftBwdPlan w;
+    const int rc = lift_train_plan(h, B, t, w);
+    if (rc != EGOTAP_OK) return rc;
+    *saved_bytes = t.total;
+    *ws_bytes = w.total;
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_bind_grad(egotap_handle h, const char* key, void* dev_ptr, int64_t numel) {
+    EGO_CHECK(h && key && dev_ptr, "egotap_bind_grad: null argument");
+    auto it = h->bound[EGOTAP_NET_LIFT].find(key);
+    EGO_CHECK(it != h->bound[EGOTAP_NET_LIFT].end(), "egotap_bind_grad(%s): bind the parameter first", key);
+    EGO_CHECK(it->second.numel == numel, "egotap_bind_grad(%s): %lld elements, the parameter has %lld", key, (long long)numel, (long long)it->second.numel);
+    EGO_CHECK(((uintptr_t)dev_ptr & 15) == 0, "egotap_bind_grad(%s): pointer must be 16-byte aligned", key);
+    Param p;
+    p.ptr = dev_ptr; p.numel = numel; p.dtype = EGOTAP_F32;
+    h->bound_grad[key] = p;
+    h->grad_resolved = false;
+    return EGOTAP_OK;
+}
+
+#define EGO_RC(call) do { const int rc_ = (call); if (rc_ != EGOTAP_OK) return rc_; } while (0)
+
+extern "C" int egotap_lift_forward_train(egotap_handle h, const float* hm, int B, float* pose, void* saved, size_t saved_bytes, void* ws,
+                                         size_t ws_bytes, void* stream) {
+    EGO_CHECK(h && hm && pose && saved && ws && B > 0, "egotap_lift_forward_train: bad argument");
+    EGO_RC(lift_resolve(h));
+    LiftTrainPlan t; LiftBwdPlan w;
+    EGO_RC(lift_train_plan(h, B, t, w));
+    EGO_CHECK(saved_bytes >= t.total, "egotap_lift_forward_train: saved buffer too small (%zu < %zu)", saved_bytes, t.total);
+    EGO_CHECK(ws_bytes >= w.total, "egotap_lift_forward_train: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    const LiftParams& p = h->lp;
+    char* sb = (char*)saved;
+    auto S = [&](size_t off) { return (float*)(sb + off); };
+    void* scr = (char*)ws + w.scr;
+    const int M = B * h->seq, D = h->D, BT = B * h->T, heads = h->cfg.vit_heads, L = h->cfg.vit_layers;
+    const int prec = h->precision == EGOTAP_PREC_BF16 ? EGOTAP_PREC_BF16 : EGOTAP_PREC_F32;   // attention: exact unless the whole step is bf16
+    EGO_RC(egotap_train_patch_fwd(h, hm, B, p.patch_w, p.patch_b, p.mask_tok, p.pos_emb, S(t.X[0]), stream));
+    for (int i = 0; i < L; ++i) {
+        const auto& P_ = p.layer[i];
+        const auto& l = t.layer[i];
+        float* x = S(t.X[i]);
+        EGO_RC(egotap_train_layernorm_fwd(x, S(l.y1), P_.ln1_g, P_.ln1_b, S(l.m1), S(l.r1), M, 1e-12f, stream));
+        EGO_RC(egotap_train_qkv_fwd(h, S(l.y1), P_.q_w, P_.q_b, P_.k_w, P_.k_b, P_.v_w, P_.v_b, S(l.qkv), M, D, stream));
+        EGO_RC(egotap_train_attention_fwd(S(l.qkv), S(l.ctx), S(l.lse), B, h->seq, heads, prec, stream));
+        EGO_RC(egotap_train_gemm_nt(h, 0, S(l.ctx), 0, nullptr, P_.o_w, P_.o_b, S(l.xm), M, D, D, 2, x, nullptr, 0, stream));
+        EGO_RC(egotap_train_layernorm_fwd(S(l.xm), S(l.y2), P_.ln2_g, P_.ln2_b, S(l.m2), S(l.r2), M, 1e-12f, stream));
+        EGO_RC(egotap_train_gemm_nt(h, 0, S(l.y2), 0, nullptr, P_.up_w, P_.up_b, S(l.hid), M, 4 * D, D, 3, nullptr, S(l.z), 0, stream));
+        EGO_RC(egotap_train_gemm_nt(h, 0, S(l.hid), 0, nullptr, P_.dn_w, P_.dn_b, S(t.X[i + 1]), M, D, 4 * D, 2, S(l.xm), nullptr, 0, stream));
+    }
+    EGO_RC(egotap_train_layernorm_fwd(S(t.X[L]), S(t.tokens), p.lnf_g, p.lnf_b, S(t.mf), S(t.rf), M, 1e-12f, stream));
+    for (int e = 0; e < 2; ++e) {
+        const float* a_in = e == 0 ? S(t.tokens) : hm;
+        int loader = e == 0 ? 2 : 3, K = e == 0 ? h->ppd * h->ppd * D : 2 * h->cfg.hm_size * h->cfg.hm_size;
+        for (int j = 0; j < 3; ++j) {
+            const int n = j < 2 ? FC_OUT[j] : h->hid;
+            const LiftParams::Fc& fc = e == 0 ? p.pos_fc[j] : p.rot_fc[j];
+            const LiftTrainPlan::Fc& f = e == 0 ? t.pos[j] : t.rot[j];
+            EGO_RC(egotap_train_gemm_nt(h, loader, a_in, 0, nullptr, fc.w, fc.b, S(f.z), BT, n, K, 1, nullptr, nullptr, 0, stream));
+            // train-mode BatchNorm1d: batch statistics, running statistics updated in the bound buffers (momentum 0.1, unbiased variance)
+            EGO_RC(egotap_train_bn_lrelu_fwd(S(f.z), S(f.y), fc.g, fc.beta, S(f.mean), S(f.rstd), (float*)fc.mean, (float*)fc.var, BT, n, 1e-5f,
+                                             0.1f, scr, w.scr_bytes, stream));
+            a_in = S(f.y); loader = 0; K = n;
+        }
+    }
+    EGO_RC(egotap_train_pu_fwd(h, S(t.pos[2].y), S(t.rot[2].y), B, sb + t.pu, t.pu_bytes, stream));
+    EGO_RC(egotap_train_pose_head_fwd(h, S(t.pos[2].y), (const float*)(sb + t.pu + t.pu_hs1), B, pose, stream));
+    return EGOTAP_OK;
+}
+
+extern "C" int egotap_lift_backward(egotap_handle h, const float* hm, const float* dpose, int B, const void* saved, size_t saved_bytes,
+                                    void* ws, size_t ws_bytes, void* const* bucket_events, int n_events, void* stream) {
+    EGO_CHECK(h && hm && dpose && saved && ws && B > 0, "egotap_lift_backward: bad argument");
+    EGO_RC(lift_resolve(h));
+    if (!h->grad_resolved) {
+        EGO_RC(lift_resolve_into(h, h->bound_grad, h->lg, false));
+        h->grad_resolved = true;
+    }
+    LiftTrainPlan t; LiftBwdPlan w;
+    EGO_RC(lift_train_plan(h, B, t, w));
+    EGO_CHECK(saved_bytes >= t.total, "egotap_lift_backward: saved buffer too small (%zu < %zu)", saved_bytes, t.total);
+    EGO_CHECK(ws_bytes >= w.total, "egotap_lift_backward: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    const int L = h->cfg.vit_layers;
+    EGO_CHECK(n_events == 0 || (bucket_events && n_events == L + 2), "egotap_lift_backward: %d bucket events, the arena has %d buckets", n_events, L + 2);
+    const LiftParams& p = h->lp;
+    const LiftParams& g = h->lg;
+    auto G = [](const float* q) { return (float*)q; };
+    const char* sb = (const char*)saved;
+    auto S = [&](size_t off) { return (const float*)(sb + off); };
+    char* wb = (char*)ws;
+    auto W = [&](size_t off) { return (float*)(wb + off); };
+    void* scr = wb + w.scr;
+    const size_t scrb = w.scr_bytes;
+    hipStream_t s = (hipStream_t)stream;
+    const int M = B * h->seq, D = h->D, BT = B * h->T, heads = h->cfg.vit_heads;
+    const int prec = h->precision == EGOTAP_PREC_BF16 ? EGOTAP_PREC_BF16 : EGOTAP_PREC_F32;
+    int bucket = 0;
+    auto bucket_done = [&]() -> int {     // every gradient of the next bucket (arena order, egotap_amd/training.py _arena_layout) is final
+        if (n_events) EGO_HIP(hipEventRecord((hipEvent_t)bucket_events[bucket], s));
+        ++bucket;
+        return EGOTAP_OK;
+    };
+    const float *posz = S(t.pos[2].y), *rotz = S(t.rot[2].y), *hs1 = (const float*)(sb + t.pu + t.pu_hs1);
+    // pose head + propagation units
+    EGO_RC(egotap_train_pose_head_bwd(h, posz, hs1, dpose, B, W(w.dposz), W(w.dhs1), G(g.pose_w), G(g.pose_b), G(g.glob_w), G(g.glob_b), 0, stream));
+    float* pug[14] = {G(g.x2f0_w), G(g.x2f0_b), G(g.x2h0_w), G(g.x2h0_b), G(g.b2h0_w), G(g.b2h0_b), G(g.h2h0_w), G(g.h2h0_b),
+                      G(g.x2f1_w), G(g.x2f1_b), G(g.x2h1_w), G(g.x2h1_b), G(g.h2h1_w), G(g.h2h1_b)};
+    EGO_RC(egotap_train_pu_bwd(h, posz, rotz, B, sb + t.pu, W(w.dhs1), W(w.dposz), W(w.drotz), pug, 0, wb + w.pu, w.pu_bytes, stream));
+    // the two FC encoders, last block first; returns in *dA the gradient w.r.t. the gathered fc1 rows (position encoder only)
+    auto encoder_bwd = [&](int e, const float* dy, float** dA) -> int {
+        for (int j = 2; j >= 0; --j) {
+            const int n = j < 2 ? FC_OUT[j] : h->hid;
+            const int K = j > 0 ? FC_OUT[j - 1] : (e == 0 ? h->ppd * h->ppd * D : 2 * h->cfg.hm_size * h->cfg.hm_size);
+            const int loader = j > 0 ? 0 : (e == 0 ? 2 : 3);
+            const LiftParams::Fc& fc = e == 0 ? p.pos_fc[j] : p.rot_fc[j];
+            const LiftParams::Fc& gc = e == 0 ? g.pos_fc[j] : g.rot_fc[j];
+            const LiftTrainPlan::Fc& f = e == 0 ? t.pos[j] : t.rot[j];
+            const float* a_in = j > 0 ? S((e == 0 ? t.pos[j - 1] : t.rot[j - 1]).y) : (e == 0 ? S(t.tokens) : hm);
+            float* dz = W(w.E[0]);
+            EGO_RC(egotap_train_bn_lrelu_bwd(S(f.z), S(f.y), dy, fc.g, S(f.mean), S(f.rstd), dz, G(gc.g), G(gc.beta), BT, n, 0, scr, scrb, stream));
+            EGO_RC(egotap_train_gemm_tn(h, loader, dz, 0, a_in, nullptr, G(gc.w), BT, n, K, 0, 0, scr, scrb, stream));
+            EGO_RC(egotap_train_colsum(dz, 0, G(gc.b), BT, n, 0, scr, scrb, stream));
+            if (j == 0 && e == 1) return EGOTAP_OK;                          // the rotation encoder's input is data
+            EGO_RC(egotap_train_transpose(fc.w, W(w.WT), n, K, 0, stream));  // [K, n]
+            float* dnext = j == 0 ? W(w.R[1]) : W(w.E[1]);
+            EGO_RC(egotap_train_gemm_nt(h, 0, dz, 0, nullptr, W(w.WT), nullptr, dnext, BT, K, n, 0, nullptr, nullptr, 0, stream));
+            dy = dnext;
+            if (j == 0) *dA = dnext;
+        }
+        return EGOTAP_OK;
+    };
+    float* dA = nullptr;
+    EGO_RC(encoder_bwd(1, W(w.drotz), nullptr));
+    EGO_RC(encoder_bwd(0, W(w.dposz), &dA));
+    float *R0 = W(w.R[0]), *R1 = W(w.R[1]), *R2 = W(w.R[2]), *A4 = W(w.A4), *A3 = W(w.A3), *WT = W(w.WT);
+    EGO_RC(egotap_train_tokens_scatter(h, dA, R0, B, stream));                                                   // dtok
+    EGO_RC(egotap_train_layernorm_bwd(S(t.X[L]), R0, p.lnf_g, S(t.mf), S(t.rf), nullptr, R1, G(g.lnf_g), G(g.lnf_b), M, 0, scr, scrb, stream));
+    float* dx = R1;
+    for (int i = L - 1; i >= 0; --i) {
+        const auto& P_ = p.layer[i];
+        const auto& G_ = g.layer[i];
+        const auto& l = t.layer[i];
+        // output.dense.bias of layer i closes the bucket of layer i + 1 (or of the head, for the last layer)
+        EGO_RC(egotap_train_colsum(dx, 0, G(G_.dn_b), M, D, 0, scr, scrb, stream));
+        EGO_RC(bucket_done());
+        // MLP
+        EGO_RC(egotap_train_gemm_tn(h, 0, dx, 0, S(l.hid), nullptr, G(G_.dn_w), M, D, 4 * D, 0, 0, scr, scrb, stream));
+        EGO_RC(egotap_train_transpose(P_.dn_w, WT, D, 4 * D, 0, stream));
+        EGO_RC(egotap_train_gemm_nt(h, 0, dx, 0, nullptr, WT, nullptr, A4, M, 4 * D, D, 5, S(l.z), nullptr, 0, stream));          // dz
+        EGO_RC(egotap_train_gemm_tn(h, 0, A4, 0, S(l.y2), nullptr, G(G_.up_w), M, 4 * D, D, 0, 0, scr, scrb, stream));
+        EGO_RC(egotap_train_colsum(A4, 0, G(G_.up_b), M, 4 * D, 0, scr, scrb, stream));
+        EGO_RC(egotap_train_transpose(P_.up_w, WT, 4 * D, D, 0, stream));
+        EGO_RC(egotap_train_gemm_nt(h, 0, A4, 0, nullptr, WT, nullptr, R0, M, D, 4 * D, 0, nullptr, nullptr, 0, stream));          // dy2
+        EGO_RC(egotap_train_layernorm_bwd(S(l.xm), R0, P_.ln2_g, S(l.m2), S(l.r2), dx, R2, G(G_.ln2_g), G(G_.ln2_b), M, 0, scr, scrb, stream));
+        float* dxm = R2;
+        // attention
+        EGO_RC(egotap_train_gemm_tn(h, 0, dxm, 0, S(l.ctx), nullptr, G(G_.o_w), M, D, D, 0, 0, scr, scrb, stream));
+        EGO_RC(egotap_train_colsum(dxm, 0, G(G_.o_b), M, D, 0, scr, scrb, stream));
+        EGO_RC(egotap_train_transpose(P_.o_w, WT, D, D, 0, stream));
+        EGO_RC(egotap_train_gemm_nt(h, 0, dxm, 0, nullptr, WT, nullptr, R0, M, D, D, 0, nullptr, nullptr, 0, stream));             // dctx
+        EGO_RC(egotap_train_attention_bwd(S(l.qkv), S(l.ctx), R0, S(l.lse), W(w.delta), A3, B, h->seq, heads, prec, stream));   // dqkv
+        const float* pw[3] = {P_.q_w, P_.k_w, P_.v_w};
+        float* gw[3] = {G(G_.q_w), G(G_.k_w), G(G_.v_w)};
+        float* gb[3] = {G(G_.q_b), G(G_.k_b), G(G_.v_b)};
+        for (int q = 0; q < 3; ++q) {
+            EGO_RC(egotap_train_gemm_tn(h, 0, A3 + (size_t)q * D, 3 * D, S(l.y1), nullptr, gw[q], M, D, D, 0, 0, scr, scrb, stream));
+            EGO_RC(egotap_train_colsum(A3 + (size_t)q * D, 3 * D, gb[q], M, D, 0, scr, scrb, stream));
+            EGO_RC(egotap_train_transpose(pw[q], WT + (size_t)q * D, D, D, 3 * D, stream));                                         // [Wq^T | Wk^T | Wv^T]
+        }
+        EGO_RC(egotap_train_gemm_nt(h, 0, A3, 0, nullptr, WT, nullptr, R0, M, D, 3 * D, 0, nullptr, nullptr, 0, stream));          // dy1
+        EGO_RC(egotap_train_layernorm_bwd(S(t.X[i]), R0, P_.ln1_g, S(l.m1), S(l.r1), dxm, R1, G(G_.ln1_g), G(G_.ln1_b), M, 0, scr, scrb, stream));
+        dx = R1;
+    }
+    // patch embedding: weight, position embeddings (sum over the batch: dx viewed as [B, seq * D]), bias / mask token
+    EGO_RC(egotap_train_gemm_tn(h, 1, dx, 0, hm, nullptr, G(g.patch_w), M, D, 256, 0, 0, scr, scrb, stream));
+    EGO_RC(egotap_train_colsum(dx, 0, G(g.pos_emb), B, h->seq * D, 0, scr, scrb, stream));
+    EGO_RC(egotap_train_patch_split(h, g.pos_emb, G(g.patch_b), G(g.mask_tok), 0, stream));
+    EGO_RC(bucket_done());
+    EGO_RC(bucket_done());
     return EGOTAP_OK;
 }
 #endif

@@ -242,6 +242,7 @@ static __global__ __launch_bounds__(1024) void pu_chain_kernel(const PuChain p) 
             // workgroup barrier: every wave's hp stores are acknowledged (vmcnt) and every read of red is done; then one thread
             // counts the workgroup in and waits for the other workgroups of the row block.  No cache maintenance: hp moves with
             // write-through stores and sc1 loads, everything else a workgroup reads back is its own.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores itself
             __syncthreads();
             if (wid == 0) {
                 // one flag per workgroup (no read-modify-write, no shared counter for 16 XCD-crossing adders to queue on): the

@@ -97,6 +97,11 @@ _PROTOS = {
     "egotap_bf16_fc1_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "egotap_bf16_fc1_dgrad_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "egotap_train_adamw_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_double] * 5 + [C.c_int, C.c_void_p]),
+    "egotap_bind_grad": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "egotap_lift_train_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "egotap_lift_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "egotap_lift_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                      C.c_void_p, C.c_int, C.c_void_p]),
     # ---- heatmap-estimator training operators
     "egotap_hmtrain_conv_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_int64] * 3 + [C.c_void_p]),
     "egotap_hmtrain_set_pack_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -124,10 +124,27 @@ class GradReducer:
         self.arena = arena
         self.pending = []
 
-    def bucket_ready(self, lo, hi):
+    def events(self, n):
+        """n reusable events for egotap_lift_backward's bucket hand-off (created by a first record: the raw handle exists afterwards)"""
+        if len(getattr(self, "_bucket_events", ())) != n:
+            self._bucket_events = [torch.cuda.Event() for _ in range(n)]
+            for e in self._bucket_events:
+                e.record()
+        return self._bucket_events
+
+    def bucket_ready(self, lo, hi, after=None):
+        """start the all-reduce of arena[lo:hi]: behind the current point of the compute stream, or (one-call backward: the whole
+        backward is already enqueued) behind the event the library recorded when the bucket became final"""
         if not self.active() or hi <= lo:
             return
-        self.pending.append((dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi))
+        if after is None or not self.arena.is_cuda:
+            self.pending.append((dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi))
+            return
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(after)
+            self.pending.append((dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi))
 
     def finish(self):
         if not self.active():

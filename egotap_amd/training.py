@@ -80,7 +80,80 @@ def _publish_grads(P, G):
             prm.grad.add_(G[k])
 
 
+_train_ws = T.Scratch()
+
+
+def _bind_grads(net, h, ga, G):
+    """egotap_bind_grad for every trained tensor, once per arena"""
+    sig = ga["flat"].data_ptr()
+    if getattr(net, "_grads_bound", None) != sig:
+        lib = _lib.load()
+        for k, g in G.items():
+            _lib.check(lib.egotap_bind_grad(h, k.encode(), C.c_void_p(g.data_ptr()), g.numel()))
+        net._grads_bound = sig
+
+
+class LiftTrainOneCallFn(torch.autograd.Function):
+    """The fp32 / bf16x3 training step on the one-call ABI: egotap_lift_forward_train keeps the activations in one caller-owned buffer,
+    egotap_lift_backward writes every gradient into the flat arena (bound once with egotap_bind_grad) and records one event per arena
+    bucket, behind which the bucket's all-reduce starts on a side stream while the rest of the backward runs (parallel.GradReducer)."""
+
+    @staticmethod
+    def forward(ctx, net, hm, *params):
+        p = net.preset
+        keys = _param_order(p)
+        P = dict(zip(keys, params))
+        dev = hm.device
+        h = net._ensure_handle()
+        net._bind(dev)
+        B = hm.shape[0]
+        net._act_scratch(B, dev)
+        lib = _lib.load()
+        hm = hm.detach().float().contiguous()
+        sb, wb = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.egotap_lift_train_bytes(h, B, C.byref(sb), C.byref(wb)))
+        saved = torch.empty(sb.value, dtype=torch.uint8, device=dev)
+        ws = _train_ws.get(wb.value, dev)
+        pose = torch.empty((B, p.out_joints, 3), dtype=torch.float32, device=dev)
+        _lib.check(lib.egotap_lift_forward_train(h, T._p(hm), B, T._p(pose), T._p(saved), saved.numel(), T._p(ws), ws.numel(), T._s()))
+        for k, b in net.named_buffers():
+            if k.endswith("num_batches_tracked"):
+                b.add_(1)
+        ctx.egotap = dict(net=net, P=P, keys=keys, B=B, hm=hm, saved=saved, wb=wb.value)
+        return pose
+
+    @staticmethod
+    def backward(ctx, dpose):
+        S = ctx.egotap
+        net, P, keys, B = S["net"], S["P"], S["keys"], S["B"]
+        h = net._ensure_handle()
+        lib = _lib.load()
+        dev = dpose.device
+        ga, G = _grad_arena(net, P)
+        _bind_grads(net, h, ga, G)
+        red = net._reducer()
+        red.begin(ga["flat"])
+        nb = len(ga["bounds"]) - 1
+        events, evp = [], None
+        if red.active():
+            events = red.events(nb)
+            evp = (C.c_void_p * nb)(*[e.cuda_event for e in events])
+        ws = _train_ws.get(S["wb"], dev)
+        dpose = dpose.detach().float().contiguous()
+        _lib.check(lib.egotap_lift_backward(h, T._p(S["hm"]), T._p(dpose), B, T._p(S["saved"]), S["saved"].numel(), T._p(ws), ws.numel(),
+                                            evp, len(events), T._s()))
+        for k, e in enumerate(events):
+            red.bucket_ready(ga["bounds"][k], ga["bounds"][k + 1], after=e)
+        red.finish()
+        _publish_grads(P, G)
+        ctx.egotap = None
+        return (None, None) + (None,) * len(keys)
+
+
 class LiftTrainFn(torch.autograd.Function):
+    """The same step composed operator by operator from Python (what the one-call ABI does inside the library): kept as the
+    reference composition for tests/test_gpu_train_step.py (bit-identical gradients) and for `net.one_call_training = False`."""
+
     @staticmethod
     def forward(ctx, net, hm, *params):
         p = net.preset
@@ -490,7 +563,10 @@ def lift_train_forward(net, hm):
     """training-mode forward of EgoTAPAutoEncoder through the HIP operators, differentiable w.r.t. net.parameters()"""
     params = dict(net.named_parameters())
     # net.bf16_storage = False keeps fp32 tensors in HBM under the bf16 arithmetic (round 1's path: operands converted per launch)
-    fn = LiftTrainBf16Fn if getattr(net, "precision", "f32") == "bf16" and net.preset.vit_dim == 1024 and getattr(net, "bf16_storage", True) else LiftTrainFn
+    if getattr(net, "precision", "f32") == "bf16" and net.preset.vit_dim == 1024 and getattr(net, "bf16_storage", True):
+        fn = LiftTrainBf16Fn
+    else:
+        fn = LiftTrainOneCallFn if getattr(net, "one_call_training", True) else LiftTrainFn
     return fn.apply(net, hm, *[params[k] for k in _param_order(net.preset)])
 
 

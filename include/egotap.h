@@ -211,6 +211,26 @@ int egotap_train_adamw(float* p, const float* g, float* m, float* v, int64_t n, 
 int egotap_train_adamw_multi(const void* table, int nseg, const float* g, float* m, float* v, int64_t span, double lr, double beta1,
                              double beta2, double eps, double weight_decay, int step, void* stream);
 
+/* ---- the lifting head's training step as one call per direction (reference: the autograd graph behind
+ * egotap_autoencoder_model.py:284-311 forward() + loss.backward()) -----------------------------------------------------------
+ * egotap_lift_forward_train = egotap_lift_forward in train mode (BatchNorm1d on batch statistics, running statistics updated in
+ * the bound buffers; num_batches_tracked is the caller's bookkeeping) keeping every activation the backward needs in `saved`;
+ * egotap_lift_backward walks the layers in reverse and OVERWRITES the gradient buffers bound with egotap_bind_grad (same keys as
+ * egotap_bind_param; every trained tensor must have one).  Both compose the granular operators above, in a fixed order, on the
+ * caller's stream.  fp32 tensors; the large GEMMs follow egotap_set_precision (f32 / bf16x3 / bf16 operand copies).
+ *   hm        device f32 [B, 6J, S, S]          pose    device f32 [B, out_joints, 3]        dpose  device f32 [B, out_joints, 3]
+ *   saved     device, egotap_lift_train_bytes   ws      device scratch, egotap_lift_train_bytes (shared by both calls)
+ *   bucket_events  NULL / n_events = 0, or vit_layers + 2 hipEvent_t: event k is recorded on `stream` when every gradient of
+ *             bucket k is final -- bucket 0: pose head, propagation units, both FC encoders, final LayerNorm and the last ViT layer's
+ *             output.dense.bias; bucket 1 + j: ViT layer L-1-j plus the output.dense.bias of the layer below; last: embeddings --
+ *             so that a data-parallel caller starts each bucket's all-reduce behind its event while the backward goes on. */
+int egotap_bind_grad(egotap_handle h, const char* key, void* dev_ptr, int64_t numel);
+int egotap_lift_train_bytes(egotap_handle h, int B, size_t* saved_bytes, size_t* ws_bytes);
+int egotap_lift_forward_train(egotap_handle h, const float* hm, int B, float* pose, void* saved, size_t saved_bytes, void* ws,
+                              size_t ws_bytes, void* stream);
+int egotap_lift_backward(egotap_handle h, const float* hm, const float* dpose, int B, const void* saved, size_t saved_bytes, void* ws,
+                         size_t ws_bytes, void* const* bucket_events, int n_events, void* stream);
+
 /* ---- heatmap-estimator training operators (fp32), called by the autograd glue (egotap_amd/hm_training.py) ----------------
  * One optimisation step of the stage-1 model (model/heatmap_shared_model.py:98-172): HeatMap_UnrealEgo_Shared in train mode
  * (model/net_architecture.py:25-173: BatchNorm2d on batch statistics), MSE / limb-length-normalised MSE losses, Adam.

@@ -208,3 +208,36 @@ def test_wrapper_checkpoint_roundtrip_and_scheduler(tmp_path):
     ref_opt.step()
     b.optimizers[0].load_state_dict(ref_opt.state_dict())
     b.optimize_parameters()
+
+
+@pytest.mark.parametrize("preset,B", [("UnrealEgo", 3), ("EgoCap", 2)])
+def test_one_call_training_abi_equals_the_operator_composition(preset, B):
+    """egotap_lift_forward_train + egotap_lift_backward (the one-call ABI the wrapper trains through) against the same step composed
+    operator by operator from Python (net.one_call_training = False): pose, every gradient and the BatchNorm running statistics are
+    bit-identical -- the library composes the same launches in the same order -- and num_batches_tracked advances"""
+    from egotap_amd import networks, spec
+    from egotap_amd.options import preset_defaults
+    from egotap_amd.training import PoseLossFn
+    p = spec.lift_preset(preset)
+    hm = torch.from_numpy(synth_input(f"hm_onecall_{preset}", (B, p.in_channels, 64, 64))).cuda()
+    gt = torch.from_numpy(synth_input(f"gt_onecall_{preset}", (B, p.out_joints, 3), -1.0, 1.0)).cuda()
+    out = []
+    for one_call in (True, False):
+        net = networks.EgoTAPAutoEncoder(preset_defaults(preset), input_channel_scale=2)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
+        net = net.cuda().train()
+        net.one_call_training = one_call
+        pose = net(hm)[0]
+        PoseLossFn.apply(net, pose, gt, 0.1, -0.01).sum().backward()
+        torch.cuda.synchronize()
+        grads = {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None}
+        bufs = {k: v.clone() for k, v in net.named_buffers()}
+        out.append((pose.detach().clone(), grads, bufs))
+    (pose_a, g_a, b_a), (pose_b, g_b, b_b) = out
+    assert torch.equal(pose_a, pose_b)
+    assert sorted(g_a) == sorted(g_b) and len(g_a) > 50
+    for k in g_a:
+        assert torch.equal(g_a[k], g_b[k]), k
+    for k in b_a:
+        assert torch.equal(b_a[k], b_b[k]), k
+    assert int(b_a["pos_heatmap_encoder.fc1.bn.num_batches_tracked"]) == 1
