@@ -3,12 +3,11 @@
 //   dV = P^T dO,  dP = dO V^T,  dS = P * (dP - delta) / sqrt(dh),  delta_q = sum_d dO[q,d] O[q,d],
 //   dQ = dS K,    dK = dS^T Q.
 // dQ needs a sum over keys per query and dK / dV sums over queries per key; instead of float atomics (slow, and not
-// reproducible) each gradient gets its own kernel that owns its accumulator: 8 MFMA products instead of 5
-// (+60 % on the attention backward = +4 % of a training step), every sum in a fixed order.
-//   attn_bwd_dq_kernel : wave = 32 queries on the lanes, streams key tiles   (S^T, dP^T, dQ^T; also writes delta)
-//   attn_bwd_dv_kernel : wave = 32 keys on the lanes,    streams query tiles (S, dV^T)
-//   attn_bwd_dk_kernel : wave = 32 keys on the lanes,    streams query tiles (S, dP, dK^T); V of the wave's keys in LDS
-// All three use the forward kernel's tricks: the score tile's accumulator registers are, as they stand, the B operand
+// reproducible) the query side and the key side each get a kernel that owns its accumulators: 7 MFMA products instead of 5,
+// every sum in a fixed order.
+//   attn_bwd_dq_kernel  : wave = 32 queries on the lanes, streams key tiles   (S^T, dP^T, dQ^T; also writes delta)
+//   attn_bwd_dkv_kernel : wave = 32 keys on the lanes,    streams query tiles (S, dP, dV^T, dK^T); V of the wave's keys in LDS
+// Both use the forward kernel's tricks: the score tile's accumulator registers are, as they stand, the B operand
 // of the next product; the fixed operand lives in 64 registers (k-permuted float4 loads); tiles are padded to 132
 // floats for conflict-free ds_read_b128 fragments; results leave through an LDS transpose as whole 512-byte rows.
 // Gradients are written in the fused [B*N, 3*D] q|k|v layout the QKV input-gradient GEMM reads directly.
@@ -147,57 +146,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const float* __
     if (valid) store_rows(dq, 1.0f, smem + wid * 32 * LD, dQKV + ((long)b * N + q0) * ld3 + h * DH, ld3, l31, lh);
 }
 
-// ------------------------------------------------------------------------------------------------- dV
+// ------------------------------------------------------------------------------------------------- dK + dV
+// One kernel owns both key-side gradients: S and P are computed once for the two of them (4 products: S, dP, dV, dK; with the
+// dQ kernel's 3 that is 7 instead of the 8 of three separate kernels).  The next query tile (Q, dO rows) is requested into
+// registers before the products of the current one and written to LDS after them, so the global latency is under the MFMAs.
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dv_kernel(const float* __restrict__ QKV, const float* __restrict__ dO,
-                                                                 const float* __restrict__ LSE, float* __restrict__ dQKV, int N,
-                                                                 int heads, int kgroups, float scale) {
+__global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dkv_kernel(const float* __restrict__ QKV, const float* __restrict__ dO,
+                                                                  const float* __restrict__ LSE, const float* __restrict__ DELTA,
+                                                                  float* __restrict__ dQKV, int N, int heads, int kgroups,
+                                                                  float scale) {
     using namespace attnbwd;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Qs = smem;                       // [32][132]
-    float* Ds = smem + KT * LD;             // dO tile [32][132]
-    float* Ls = smem + 2 * KT * LD;         // lse of the tile's 32 queries (log2 units)
-    const int bh = blockIdx.x / kgroups, kg = blockIdx.x - bh * kgroups;
-    const int b = bh / heads, h = bh - b * heads;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int D = heads * DH;
-    const long ld3 = 3L * D;
-    const float* qkv = QKV + (long)b * N * ld3 + h * DH;
-    const int kb = kg * NW + wid;
-    const bool valid = kb * 32 < N;
-    const int k0 = min(kb * 32, N - 32);
-    float kreg[64];
-    load_row_regs(kreg, qkv + (long)(k0 + l31) * ld3 + D, lh);
-    const float c2 = scale * 1.4426950408889634f;
-    f32x16 dv[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dv[dt][r] = 0.f;
-    for (int qt = 0; qt < N / KT; ++qt) {
-        __syncthreads();
-        stage_tile<64 * NW>(Qs, qkv + (long)(qt * KT) * ld3, ld3, tid);
-        stage_tile<64 * NW>(Ds, dO + ((long)b * N + qt * KT) * D + h * DH, D, tid);
-        if (tid < 32) Ls[tid] = LSE[(long)bh * N + qt * KT + tid] * 1.4426950408889634f;
-        __syncthreads();
-        if (valid) {
-            f32x16 p = tile_x_regs(Qs, kreg, l31, lh);          // S[q][key]
-#pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = exp2f(fmaf(p[r], c2, -Ls[(r & 3) + 8 * (r >> 2) + 4 * lh]));
-            acc_tile_t_x_p(dv, Ds, p, l31, lh);                 // dV^T[d][key] += dO^T P
-        }
-    }
-    __syncthreads();
-    if (valid) store_rows(dv, 1.0f, smem + wid * 32 * LD, dQKV + ((long)b * N + k0) * ld3 + 2 * D + h * DH, ld3, l31, lh);
-}
-
-// ------------------------------------------------------------------------------------------------- dK
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dk_kernel(const float* __restrict__ QKV, const float* __restrict__ dO,
-                                                                 const float* __restrict__ LSE, const float* __restrict__ DELTA,
-                                                                 float* __restrict__ dQKV, int N, int heads, int kgroups,
-                                                                 float scale) {
-    using namespace attnbwd;
+    constexpr int THREADS = 64 * NW, PER = KT * (DH / 4) / THREADS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;                              // [32][132]
     float* Ds = smem + KT * LD;                    // dO tile
@@ -209,6 +168,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dk_kernel(const float* __
     const int D = heads * DH;
     const long ld3 = 3L * D;
     const float* qkv = QKV + (long)b * N * ld3 + h * DH;
+    const float* dop = dO + (long)b * N * D + h * DH;
     const int kb = kg * NW + wid;
     const bool valid = kb * 32 < N;
     const int k0 = min(kb * 32, N - 32);
@@ -224,18 +184,36 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dk_kernel(const float* __
         }
     }
     const float c2 = scale * 1.4426950408889634f;
-    f32x16 dk[4];
+    f32x16 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dk[dt][r] = 0.f;
-    for (int qt = 0; qt < N / KT; ++qt) {
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    f32x4 stq[PER], std_[PER];
+    float stl = 0.f;
+    auto request = [&](int qt) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
+            stq[i] = *(const f32x4*)(qkv + (long)(qt * KT + row) * ld3 + c4 * 4);
+            std_[i] = *(const f32x4*)(dop + (long)(qt * KT + row) * D + c4 * 4);
+        }
+        if (tid < 32) stl = LSE[(long)bh * N + qt * KT + tid] * 1.4426950408889634f;
+        else if (tid < 64) stl = DELTA[(long)bh * N + qt * KT + tid - 32];
+    };
+    const int nq = N / KT;
+    request(0);
+    for (int qt = 0; qt < nq; ++qt) {
         __syncthreads();
-        stage_tile<64 * NW>(Qs, qkv + (long)(qt * KT) * ld3, ld3, tid);
-        stage_tile<64 * NW>(Ds, dO + ((long)b * N + qt * KT) * D + h * DH, D, tid);
-        if (tid < 32) Ls[tid] = LSE[(long)bh * N + qt * KT + tid] * 1.4426950408889634f;
-        else if (tid < 64) Ls[tid] = DELTA[(long)bh * N + qt * KT + tid - 32];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
+            *(f32x4*)(Qs + row * LD + c4 * 4) = stq[i];
+            *(f32x4*)(Ds + row * LD + c4 * 4) = std_[i];
+        }
+        if (tid < 64) Ls[tid] = stl;
         __syncthreads();
+        if (qt + 1 < nq) request(qt + 1);
         if (valid) {
             f32x16 s = tile_x_regs(Qs, kreg, l31, lh);          // S[q][key]
             // dP[q][key] = dO_tile V^T : B operand = V[key = lane][d] as b128 fragments of the wave's LDS image
@@ -255,13 +233,18 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dk_kernel(const float* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                s[r] = exp2f(fmaf(s[r], c2, -Ls[q])) * (dp[r] - Ls[32 + q]) * scale;     // dS[q][key]
+                s[r] = exp2f(fmaf(s[r], c2, -Ls[q]));                        // P[q][key]
+                dp[r] = s[r] * (dp[r] - Ls[32 + q]) * scale;                 // dS[q][key]
             }
-            acc_tile_t_x_p(dk, Qs, s, l31, lh);                 // dK^T[d][key] += Q^T dS
+            acc_tile_t_x_p(dv, Ds, s, l31, lh);                 // dV^T[d][key] += dO^T P
+            acc_tile_t_x_p(dk, Qs, dp, l31, lh);                // dK^T[d][key] += Q^T dS
         }
     }
     __syncthreads();
-    if (valid) store_rows(dk, 1.0f, Vmine, dQKV + ((long)b * N + k0) * ld3 + D + h * DH, ld3, l31, lh);
+    if (valid) {
+        store_rows(dk, 1.0f, Vmine, dQKV + ((long)b * N + k0) * ld3 + D + h * DH, ld3, l31, lh);
+        store_rows(dv, 1.0f, Vmine, dQKV + ((long)b * N + k0) * ld3 + 2 * D + h * DH, ld3, l31, lh);
+    }
 }
 
 static hipError_t attention_bwd_f32_launch(const float* QKV, const float* O, const float* dO, const float* LSE, float* DELTA,
@@ -270,24 +253,21 @@ static hipError_t attention_bwd_f32_launch(const float* QKV, const float* O, con
     if (B <= 0) return hipSuccess;
     if (N % 32 != 0) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)DH);
-    constexpr int NWQ = 4, NWV = 4, NWK = 4;
-    const int qgroups = (N / 32 + NWQ - 1) / NWQ, vgroups = (N / 32 + NWV - 1) / NWV, kgroups = (N / 32 + NWK - 1) / NWK;
+    constexpr int NWQ = 4, NWK = 2;      // dK+dV: two waves per workgroup, two workgroups per CU (N = 576: 18 key blocks = 9 x 2, no idle wave; the
+                                         // workgroups drift apart, so one's barrier and softmax phases sit under the other's MFMAs)
+    const int qgroups = (N / 32 + NWQ - 1) / NWQ, kgroups = (N / 32 + NWK - 1) / NWK;
     const size_t lds_q = (size_t)(2 * KT * LD > NWQ * 32 * LD ? 2 * KT * LD : NWQ * 32 * LD) * 4;
-    const size_t lds_v = (size_t)((2 * KT * LD + 64) > NWV * 32 * LD ? (2 * KT * LD + 64) : NWV * 32 * LD) * 4;
     const size_t lds_k = (size_t)(2 * KT * LD + 64 + NWK * KT * LD) * 4;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NWQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dv_kernel<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dk_kernel<NWK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NWK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     hipLaunchKernelGGL(attn_bwd_dq_kernel<NWQ>, dim3(B * heads * qgroups), dim3(64 * NWQ), lds_q, stream, QKV, O, dO, LSE, dQKV, DELTA,
                        N, heads, qgroups, scale);
-    hipLaunchKernelGGL(attn_bwd_dv_kernel<NWV>, dim3(B * heads * vgroups), dim3(64 * NWV), lds_v, stream, QKV, dO, LSE, dQKV, N, heads,
-                       vgroups, scale);
-    hipLaunchKernelGGL(attn_bwd_dk_kernel<NWK>, dim3(B * heads * kgroups), dim3(64 * NWK), lds_k, stream, QKV, dO, LSE, DELTA, dQKV, N,
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NWK>, dim3(B * heads * kgroups), dim3(64 * NWK), lds_k, stream, QKV, dO, LSE, DELTA, dQKV, N,
                        heads, kgroups, scale);
     return hipGetLastError();
 }
