@@ -281,21 +281,36 @@ def bench_full(args, p, dev, rank, world, barrier, lib, L, mode="f32"):
     }
 
 
-def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None):
+def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from_rgb=False):
     """Secondary measurement: one optimisation step of the lifting head (train-mode forward from resident heatmaps,
     loss, backward, gradient all-reduce when world > 1, AdamW).  mode = arithmetic of the GEMMs (egotap_set_precision):
-    f32 exact, bf16x3 split (fp32-grade gradients), bf16 (BASELINE config 3: bf16 MFMA, fp32 accumulate and master weights)."""
+    f32 exact, bf16x3 split (fp32-grade gradients), bf16 (BASELINE config 3: bf16 MFMA, fp32 accumulate and master weights).
+    from_rgb: the step as train.py runs it without --use_gt_heatmap -- RGB frames through the two frozen heatmap estimators
+    (--path_to_trained_heatmap checkpoints, written here from the synthetic state_dicts; --use_amp arithmetic) and on into the head."""
+    import tempfile
     import torch
     from egotap_amd import models, parallel, spec
     from egotap_amd.options import preset_defaults
-    from egotap_amd.synthetic import synth_input, synth_state_dict
+    from egotap_amd.synthetic import synth_hm_state_dict, synth_input, synth_state_dict
     opt = preset_defaults(args.preset)
-    opt.gpu_ids, opt.isTrain, opt.use_gt_heatmap = [dev.index], True, True
+    opt.gpu_ids, opt.isTrain, opt.use_gt_heatmap = [dev.index], True, not from_rgb
     opt.lr, opt.opt_eps, opt.weight_decay = 1e-3, 1e-4, 0.0
+    tmp = None
+    if from_rgb:
+        tmp = tempfile.TemporaryDirectory()
+        J0 = p.n_joints_hm
+        for sub, n_hm, salt in (("hm_pos", J0, "hm_pos."), ("hm_" + getattr(opt, "heatmap_type", "sin"), 2 * J0, "hm_rot.")):
+            os.makedirs(os.path.join(tmp.name, sub))
+            torch.save({k: torch.from_numpy(v) for k, v in synth_hm_state_dict(n_hm, salt).items()}, os.path.join(tmp.name, sub, "best_net_HeatMap.pth"))
+        opt.log_dir = tmp.name
+        opt.path_to_trained_heatmap = os.path.join(tmp.name, "hm", "best_net_HeatMap.pth")
+        opt.use_amp, opt.amp_precision = mode != "f32", (mode if mode != "f32" else "bf16")
     m = models.create_model(opt)
     m.net_AutoEncoder.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
     m.net_AutoEncoder.set_precision(mode)
+    torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)
+    held = torch.cuda.memory_allocated(dev)      # what the earlier legs of this process still hold (the headline net and its workspace)
     B, J = batch or args.train_batch, p.n_joints_hm
     hm = torch.from_numpy(synth_input(f"hm_train_rank{rank}", (min(B, 16), p.in_channels, p.hm_size, p.hm_size))).to(dev)
     hm = hm.repeat((B + hm.shape[0] - 1) // hm.shape[0], 1, 1, 1)[:B].contiguous()
@@ -303,6 +318,11 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None):
     data = {"input_rgb_left": torch.zeros(1, 3, 4, 4), "input_rgb_right": torch.zeros(1, 3, 4, 4), "gt_heatmap_left": hm[:, :J],
             "gt_heatmap_right": hm[:, J:2 * J], "gt_limb_heatmap_left": hm[:, 2 * J:4 * J], "gt_limb_heatmap_right": hm[:, 4 * J:],
             "gt_local_pose": gt}
+    if from_rgb:
+        S = 4 * p.hm_size
+        for side in ("left", "right"):
+            blk = torch.from_numpy(synth_input(f"rgb_{side}_train_rank{rank}", (8, 3, S, S), -2.0, 2.0)).to(dev)
+            data["input_rgb_" + side] = blk.repeat((B + 7) // 8, 1, 1, 1)[:B].contiguous()
     m.set_input(data)
     m.optimize_parameters()                      # warm-up (allocator, BN buffers, optimizer state)
     barrier()
@@ -315,18 +335,25 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None):
     errs = m.get_current_errors()
     fps = world * B * args.train_steps / elapsed
     flops = 3.0 * lift_flops_per_frame(p)        # algorithmic: backward = 2 x forward (dgrad + wgrad)
-    peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    if from_rgb:                                 # + the frozen estimators' forward
+        flops += hm_flops_per_frame(2 * p.n_joints_hm, 4 * p.hm_size) + hm_flops_per_frame(4 * p.n_joints_hm, 4 * p.hm_size)
+    peak_gb = (torch.cuda.max_memory_allocated(dev) - held) / 2 ** 30
     exposed = m.net_AutoEncoder._reducer().read_exposed_ms() if world > 1 else 0.0
     del m, hm, gt, data
+    from egotap_amd import training
+    training.release_scratch()
     torch.cuda.empty_cache()
+    if tmp is not None:
+        tmp.cleanup()
     return {"value": round(fps, 1), "unit": "stereo frames/s (training step)", "ms_per_step": round(1e3 * elapsed / args.train_steps, 2),
             "steps": args.train_steps, "batch_per_gpu": B, "dtype": mode, "flops_per_frame": flops,
             "end_to_end_tflops_per_gpu": round(fps * flops / world / 1e12, 2), **frac_fields(mode, fps * flops / world / 1e12),
             "loss_pose": errs.get("pose"), "loss_cos_sim": errs.get("cos_sim"), "peak_hbm_gib": round(peak_gb, 1),
             "allreduce_exposed_ms_last_step": round(exposed, 3),
-            "note": "heatmap estimators frozen and fed from resident heatmaps (use_gt_heatmap); gradient all-reduce (N > 1) overlapped with the "
-                    "backward, bucket by bucket, in place on a flat arena; the attention backward recomputes the scores (f32 / bf16x3: three "
-                    "kernels, 8 MFMA products; bf16: two kernels, 7 products), not counted in flops_per_frame"}
+            "input": "RGB frames through the two frozen heatmap estimators (eval-mode BatchNorm, --use_amp arithmetic), then the head" if from_rgb
+                     else "resident heatmaps (--use_gt_heatmap): the frozen estimators are not run",
+            "note": "gradient all-reduce (N > 1) overlapped with the backward, bucket by bucket, in place on a flat arena; the attention "
+                    "backward recomputes the scores (two kernels, 7 MFMA products), not counted in flops_per_frame"}
 
 
 def bench_stage1(args, p, dev, rank, world, barrier, mode="f32"):
@@ -559,6 +586,9 @@ def main():
         train["bf16x3"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16x3")
         # BASELINE configs[2] / [3]: UnrealEgo training step (fwd+bwd+AdamW), bf16, batch 1024 per GPU (x N GPUs, gradient all-reduce)
         train["config3_bf16_b1024"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16", batch=args.train_batch_bf16)
+        # the same step as train.py runs it without --use_gt_heatmap: RGB frames -> two frozen heatmap estimators -> head ("RGB for full")
+        train["config3_bf16_b1024_from_rgb"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16", batch=args.train_batch_bf16,
+                                                   from_rgb=True)
         train["stage1_heatmap_estimator"] = leg(bench_stage1, args, p, dev, rank, world, barrier)
         if not args.no_fast_mode:
             train["stage1_heatmap_estimator"]["bf16x3"] = leg(bench_stage1, args, p, dev, rank, world, barrier, mode="bf16x3")

@@ -133,9 +133,14 @@ class EgoTAPAutoEncoderModel(nn.Module):
                 cat[:, :2 * J] = hm_train_forward_nograd(self.net_HeatMap, left, right)
                 cat[:, 2 * J:] = hm_train_forward_nograd(self.net_RotHeatMap, left, right)
             else:
-                ws = self.net_HeatMap._workspace(B, left.device)          # one scratch shared by both estimators
-                self.net_HeatMap.forward_into(left, right, cat, 0, workspace=ws)
-                self.net_RotHeatMap.forward_into(left, right, cat, 2 * J, workspace=ws)
+                # eval-mode estimators treat frames independently: walk a large batch in chunks so that the U-Net scratch stays at
+                # the chunk's size (B = 1024 from RGB, BASELINE config 3); one scratch shared by both estimators
+                chunk = min(B, int(getattr(self.opt, "hm_chunk", 256)))
+                ws = self.net_HeatMap._workspace(chunk, left.device)
+                for lo in range(0, B, chunk):
+                    hi = min(B, lo + chunk)
+                    self.net_HeatMap.forward_into(left[lo:hi], right[lo:hi], cat[lo:hi], 0, workspace=ws)
+                    self.net_RotHeatMap.forward_into(left[lo:hi], right[lo:hi], cat[lo:hi], 2 * J, workspace=ws)
         self.pred_heatmap_cat = cat
         self.pred_heatmap_left, self.pred_heatmap_right = cat[:, :J], cat[:, J:2 * J]
         self.pred_limb_heatmap_left, self.pred_limb_heatmap_right = cat[:, 2 * J:4 * J], cat[:, 4 * J:]
@@ -180,6 +185,10 @@ class EgoTAPAutoEncoderModel(nn.Module):
         self.net_AutoEncoder.train()
         if self.use_amp and getattr(self.net_AutoEncoder, "precision", "f32") == "f32":
             self.net_AutoEncoder.set_precision(self.amp_precision)      # --use_amp: reduced-precision training arithmetic
+        if self.use_amp:           # the reference's autocast spans the frozen estimators' forward too (egotap_autoencoder_model.py:219)
+            for n in (self.net_HeatMap, self.net_RotHeatMap):
+                if getattr(n, "precision", "f32") == "f32":
+                    n.set_precision(self.amp_precision)
         for o in self.optimizers:
             o.zero_grad()
         self.forward()
@@ -203,12 +212,17 @@ class EgoTAPAutoEncoderModel(nn.Module):
     def evaluate(self, runnning_average_dict):
         self.set_eval_mode()
         with torch.no_grad():
-            prec = getattr(self.net_AutoEncoder, "precision", "f32")
-            if self.use_amp and prec != "f32":
-                self.net_AutoEncoder.set_precision("f32")        # autocast is off in evaluation (forward(evaluate=True))
+            nets = (self.net_AutoEncoder, self.net_HeatMap, self.net_RotHeatMap)
+            prec = [getattr(n, "precision", "f32") for n in nets]
+            if self.use_amp:
+                for n, q in zip(nets, prec):
+                    if q != "f32":
+                        n.set_precision("f32")                   # autocast is off in evaluation (forward(evaluate=True))
             self.forward(evaluate=True)
-            if self.use_amp and prec != "f32":
-                self.net_AutoEncoder.set_precision(prec)
+            if self.use_amp:
+                for n, q in zip(nets, prec):
+                    if q != "f32":
+                        n.set_precision(q)
             from . import lib as _lib                     # one fused launch: per-sample MPJPE + Procrustes-aligned MPJPE
             err, pa = _lib.pose_metrics(self.pred_pose, self.gt_pose)
             err, pa = (err * self.cm2mm).cpu(), (pa * self.cm2mm).cpu()      # one device->host copy, not one per sample

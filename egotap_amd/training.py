@@ -83,6 +83,12 @@ def _publish_grads(P, G):
 _train_ws = T.Scratch()
 
 
+def release_scratch():
+    """drop the grow-only scratch buffers of the training path (between benchmark legs; the next step allocates them again)"""
+    _train_ws.buf = None
+    T._scratch.buf = None
+
+
 def _bind_grads(net, h, ga, G):
     """egotap_bind_grad for every trained tensor, once per arena"""
     sig = ga["flat"].data_ptr()

@@ -129,6 +129,7 @@ def test_create_model_with_the_reference_training_flags(tmp_path):
     before = {k: v.detach().clone() for k, v in m.net_AutoEncoder.named_parameters()}
     m.optimize_parameters()
     assert m.net_AutoEncoder.precision == "bf16"                   # --use_amp -> reduced-precision HIP mode
+    assert m.net_HeatMap.precision == "bf16" and m.net_RotHeatMap.precision == "bf16"      # autocast spans the frozen estimators too
     errs = m.get_current_errors()
     assert set(errs) == {"pose", "cos_sim"} and all(np.isfinite(v) for v in errs.values())
     moved = sum(int(not torch.equal(before[k], v.detach())) for k, v in m.net_AutoEncoder.named_parameters())
@@ -143,6 +144,15 @@ def test_create_model_with_the_reference_training_flags(tmp_path):
     avg = Avg()
     m.evaluate(avg)
     assert len(avg["mpjpe"]) == B and m.net_AutoEncoder.precision == "bf16"
+    # evaluation is fp32 for all three networks: the heatmaps it leaves behind equal an fp32 model's (bit for bit)
+    hm_eval = m.pred_heatmap_cat.clone()
+    m.set_precision("f32")
+    m.forward(evaluate=True)
+    assert torch.equal(hm_eval, m.pred_heatmap_cat)
+    # the estimators' chunked forward (opt.hm_chunk) equals the unchunked one: frames are independent in eval mode
+    m.opt.hm_chunk = 1
+    m.forward(evaluate=True)
+    assert torch.equal(hm_eval, m.pred_heatmap_cat)
 
     opt2 = options.parse_train(shlex.split(UNREALEGO_TRAIN_FLAGS.replace("--path_to_trained_heatmap ./log/unrealego_heatmap_shared/best_net_HeatMap.pth", "")))
     with pytest.raises(ValueError):
