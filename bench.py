@@ -292,6 +292,8 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
     from egotap_amd import models, parallel, spec
     from egotap_amd.options import preset_defaults
     from egotap_amd.synthetic import synth_hm_state_dict, synth_input, synth_state_dict
+    torch.cuda.empty_cache()
+    held = torch.cuda.memory_allocated(dev)      # what the earlier legs of this process still hold (the headline net and its workspace)
     opt = preset_defaults(args.preset)
     opt.gpu_ids, opt.isTrain, opt.use_gt_heatmap = [dev.index], True, not from_rgb
     opt.lr, opt.opt_eps, opt.weight_decay = 1e-3, 1e-4, 0.0
@@ -308,9 +310,7 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
     m = models.create_model(opt)
     m.net_AutoEncoder.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
     m.net_AutoEncoder.set_precision(mode)
-    torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)
-    held = torch.cuda.memory_allocated(dev)      # what the earlier legs of this process still hold (the headline net and its workspace)
     B, J = batch or args.train_batch, p.n_joints_hm
     hm = torch.from_numpy(synth_input(f"hm_train_rank{rank}", (min(B, 16), p.in_channels, p.hm_size, p.hm_size))).to(dev)
     hm = hm.repeat((B + hm.shape[0] - 1) // hm.shape[0], 1, 1, 1)[:B].contiguous()
