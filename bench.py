@@ -192,7 +192,7 @@ def bench_config5(args, dev, rank, world, barrier, lib, L):
     out = {"workload": f"EgoCap lifting head, heatmaps [B,102,128,128], batch {B} per GPU", "batch_per_gpu": B,
            "flops_per_frame": lift_flops_per_frame(p5)}
     ref = None
-    for mode in ("f32", "bf16x3"):
+    for mode in ("f32", "bf16x3", "bf16"):       # bf16 = the arithmetic BASELINE configs[4] names (bf16 activations in HBM)
         net.set_precision(mode)
         el, pose, _ = timed_lift(net, hm, 3, 1, lib, L, h, barrier, dev, False, world)
         fps = world * B * 3 / el
@@ -204,6 +204,42 @@ def bench_config5(args, dev, rank, world, barrier, lib, L):
         else:
             out[mode]["max_abs_diff_vs_f32_mode"] = float((pose - ref).abs().max())
     del net, hm
+    torch.cuda.empty_cache()
+    # the whole path at this geometry: 512x512 RGB -> two EgoCap estimators (128x128 maps) -> head, bf16 arithmetic and fp32
+    from egotap_amd import models
+    from egotap_amd.synthetic import synth_hm_state_dict
+    opt = preset_defaults("EgoCap", 128)
+    opt.gpu_ids = [dev.index]
+    m = models.create_model(opt)
+    J = p5.n_joints_hm
+    for name, sd in (("AutoEncoder", synth_state_dict(spec.lift_state_spec(p5))), ("HeatMap", synth_hm_state_dict(J, "hm_pos.")),
+                     ("RotHeatMap", synth_hm_state_dict(2 * J, "hm_rot."))):
+        getattr(m, "net_" + name).load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    Bf = min(B, 32)
+    rgb = [torch.from_numpy(synth_input(f"rgb5_{sd_}_rank{rank}", (4, 3, 512, 512), -2.0, 2.0)).to(dev).repeat(Bf // 4, 1, 1, 1).contiguous()
+           for sd_ in ("l", "r")]
+    m.set_input({"input_rgb_left": rgb[0], "input_rgb_right": rgb[1]})
+    m.set_eval_mode()
+    flops_full = out["flops_per_frame"] + hm_flops_per_frame(2 * J, 512) + hm_flops_per_frame(4 * J, 512)
+    out["full_pipeline_from_rgb_512"] = {"batch_per_gpu": Bf, "flops_per_frame": flops_full}
+    for mode in ("f32", "bf16"):
+        m.set_precision(mode)
+        with torch.no_grad():
+            m.forward(evaluate=True)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                m.forward(evaluate=True)
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+        barrier()
+        from egotap_amd import parallel
+        el = parallel.max_over_ranks(el, dev)
+        fps = world * Bf * 2 / el
+        tff = fps * flops_full / world / 1e12
+        out["full_pipeline_from_rgb_512"][mode] = {"value": round(fps, 1), "unit": "stereo frames/s", "ms_per_step": round(1e3 * el / 2, 2),
+                                                   "end_to_end_tflops_per_gpu": round(tff, 2), **frac_fields(mode, tff)}
+    del m, rgb
     torch.cuda.empty_cache()
     return out
 

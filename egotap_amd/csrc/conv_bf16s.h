@@ -1,0 +1,155 @@
+// The U-Net decoder of HeatMap_UnrealEgo_Shared (model/net_architecture.py:139-173: layerK_1x1, upsample, concat, conv_up3/2/1,
+// conv_heatmap; model/network_utils.py:144-148 convrelu) with bf16 ACTIVATIONS in HBM, channels-last -- the EGOTAP_PREC_BF16 mode of
+// egotap_hm_forward (the reference's --use_amp autocast region, egotap_autoencoder_model.py:219).  82 % of an estimator's FLOPs are
+// the three 3x3 decoder convolutions; on fp32 NCHW tensors (conv_bf16.h, one bf16 product) they were bound by the staging -- fp32
+// reads, a VALU conversion and a scattered LDS write per element, 12 MFMAs per barrier -- not by the matrix pipe.
+//
+// Channels-last turns every convolution here into the bf16-storage GEMM of gemm_bf16s.h (256 x 256 tile, LDS-DMA ring, two wave
+// groups one barrier apart) with nothing but a different X-operand loader:
+//   rows    m = (image, y, x) of the output map, S x S pixels per image (S a power of two); columns n = output channel
+//   3x3:    k = (tap, ci), ci innermost, Cp = Cin padded to a multiple of 32, so a 32-deep K-tile lies inside one tap; row m of
+//           K-tile (tap, ci0) is the 64 contiguous bytes of input pixel (y + dy, x + dx), channels ci0..ci0+31 -- one DMA per lane,
+//           from a page of zeros where the tap leaves the image (the padding of F.conv2d).  Never im2col'ed.
+//   1x1:    the plain loader (rows are pixels).
+// Weights are repacked per call into [Cout][tap][Cp] bf16 (the parameters stay the caller's live fp32 tensors).  Producers write
+// straight into channel slices of the next concat buffer (row stride = the concat's channel count): no concat pass.
+#pragma once
+#include "gemm_bf16s.h"
+
+// ---------------------------------------------------------------------------------------------------- loader
+struct XConv3 {
+    const __bf16* in;        // [Nimg * S * S, Cp] bf16, channels-last
+    const __bf16* zero;      // 64 bytes of zeros
+    int Cp, log2S, inv_ktp;  // inv_ktp = ceil(65536 / (Cp / 32)): K-tile index -> tap without a division
+    struct Row { const __bf16* p; unsigned mask; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int S = 1 << log2S, x = m & (S - 1), y = (m >> log2S) & (S - 1);
+        unsigned mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            if (y + dy >= 0 && y + dy < S && x + dx >= 0 && x + dx < S) mask |= 1u << t;
+        }
+        return Row{in + (long)m * Cp, mask};
+    }
+    __device__ __forceinline__ const __bf16* ptr(const Row& r, int k0, int ko) const {      // k0 wave-uniform: the tap arithmetic is scalar
+        const int tap = ((k0 >> 5) * inv_ktp) >> 16;
+        const int ci = k0 - tap * Cp;
+        const int dy = ((tap * 11) >> 5) - 1, dx = tap - 3 * (dy + 1) - 1;
+        const int off = ((dy << log2S) + dx) * Cp + ci;
+        return ((r.mask >> tap) & 1u) ? r.p + off + ko : zero + ko;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------- epilogues
+template <bool GUARD>
+struct SEpiConvBf16 {        // out bf16 = relu?(acc + bias); GUARD: the GEMM's N is padded, only columns < n_lim (a multiple of 8) exist
+    static constexpr int W = 8, STORES = 1;
+    const float* bias;       // N (padded) values
+    __bf16* out;
+    long ld;
+    int n_lim, relu;
+    typedef SBias8 Col;
+    typedef SNoAux Aux;
+    __device__ __forceinline__ Col col(int n) const { return load_bias8(bias, n); }
+    __device__ __forceinline__ Aux fetch(int m, int n) const { return Aux{}; }
+    __device__ __forceinline__ void emit(float* v, const Col& c, const Aux&, int m, int n) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] += c.b0[i]; v[4 + i] += c.b1[i]; }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (!GUARD || n < n_lim) store_bf16x8(out + (long)m * ld + n, v);
+    }
+};
+template <> struct s_epi_exact<SEpiConvBf16<true>> { static constexpr bool value = false; };    // its stores may be skipped: no store slack in the main loop
+
+struct SEpiHeatNCHW {        // conv_heatmap: out f32 NCHW = acc + bias at out + image * img_stride + channel * HW + pixel
+    static constexpr int W = 4, STORES = 4;
+    const float* bias;       // N (padded) values
+    float* out;
+    long img_stride;
+    int n_out, log2hw;
+    typedef f32x4 Col;
+    typedef SNoAux Aux;
+    __device__ __forceinline__ Col col(int n) const { return *(const f32x4*)(bias + n); }
+    __device__ __forceinline__ Aux fetch(int m, int n) const { return Aux{}; }
+    __device__ __forceinline__ void emit(float* v, const Col& c, const Aux&, int m, int n) const {
+        const int img = m >> log2hw, pix = m & ((1 << log2hw) - 1);
+        float* o = out + (long)img * img_stride + ((long)n << log2hw) + pix;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (n + i < n_out) o[(long)i << log2hw] = v[i] + c[i];
+    }
+};
+
+template <> struct s_epi_exact<SEpiHeatNCHW> { static constexpr bool value = false; };
+
+// ---------------------------------------------------------------------------------------------------- helpers
+// [Cout][Cin][3][3] f32 -> [Cout][tap][Cp] bf16 (channels past Cin zero).  One thread = 8 consecutive ci of one (co, tap).
+static __global__ __launch_bounds__(256) void pack_conv3x3_bf16s_kernel(const float* __restrict__ w, __bf16* __restrict__ wb, int Cout, int Cin, int Cp) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8n = Cp / 8;
+    if (i >= (long)Cout * 9 * c8n) return;
+    const int c8 = (int)(i % c8n), tap = (int)((i / c8n) % 9), co = (int)(i / (9L * c8n));
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = c8 * 8 + j;
+        o[j] = ci < Cin ? (__bf16)w[((long)co * Cin + ci) * 9 + tap] : (__bf16)0.f;
+    }
+    *(bf16x8*)(wb + ((long)co * 9 + tap) * Cp + c8 * 8) = o;
+}
+// [Cout][Cin] f32 (+ bias) -> [Np][Cin] bf16, [Np] f32: rows past Cout zero
+static __global__ __launch_bounds__(256) void pack_conv1x1_bf16s_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                                                        __bf16* __restrict__ wb, float* __restrict__ bp, int Cout, int Cin, int Np) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8n = Cin / 8;
+    if (i >= (long)Np * c8n) return;
+    const int c8 = (int)(i % c8n), co = (int)(i / c8n);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = co < Cout ? (__bf16)w[(long)co * Cin + c8 * 8 + j] : (__bf16)0.f;
+    *(bf16x8*)(wb + (long)co * Cin + c8 * 8) = o;
+    if (c8 == 0) bp[co] = co < Cout ? b[co] : 0.f;
+}
+// pyramid level: f32 NCHW [Nimg, C, HW] -> bf16 channels-last [Nimg * HW, C].  Lanes along pixels (coalesced reads), 8 channels each.
+static __global__ __launch_bounds__(256) void nchw_to_nhwc_bf16s_kernel(const float* __restrict__ in, __bf16* __restrict__ out, int C, int HW, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int pix = (int)(i % HW);
+    const long t = i / HW;
+    const int c8 = (int)(t % (C / 8));
+    const long img = t / (C / 8);
+    const float* p = in + (img * C + c8 * 8) * (long)HW + pix;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)p[(long)j * HW];
+    *(bf16x8*)(out + (img * HW + pix) * (long)C + c8 * 8) = o;
+}
+// F.interpolate(scale_factor=2, mode="bilinear", align_corners=True) on channels-last bf16: in [Nimg, h, h, C] -> the first C channels
+// of out rows [Nimg, 2h, 2h, ld].  One thread = 8 channels of one output pixel; fp32 arithmetic in the order of upsample2x_kernel.
+static __global__ __launch_bounds__(256) void upsample2x_nhwc_bf16s_kernel(const __bf16* __restrict__ in, __bf16* __restrict__ out, int C, int h, long ld,
+                                                                          long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c8n = C / 8, HO = 2 * h;
+    const int c8 = (int)(i % c8n);
+    const long pp = i / c8n;
+    const int x = (int)(pp % HO), y = (int)((pp / HO) % HO);
+    const long img = pp / ((long)HO * HO);
+    const float scale = (float)(h - 1) / (float)(HO - 1);
+    const float sy = scale * y, sx = scale * x;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < h - 1 ? 1 : 0);
+    const float ly = sy - y0, hy = 1.f - ly, lx = sx - x0, hx = 1.f - lx;
+    const __bf16* b = in + img * (long)h * h * C + c8 * 8;
+    const bf16x8 v00 = *(const bf16x8*)(b + ((long)y0 * h + x0) * C), v01 = *(const bf16x8*)(b + ((long)y0 * h + x1) * C);
+    const bf16x8 v10 = *(const bf16x8*)(b + ((long)y1 * h + x0) * C), v11 = *(const bf16x8*)(b + ((long)y1 * h + x1) * C);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        o[j] = (__bf16)(hy * (hx * (float)v00[j] + lx * (float)v01[j]) + ly * (hx * (float)v10[j] + lx * (float)v11[j]));
+    *(bf16x8*)(out + pp * ld + c8 * 8) = o;
+}

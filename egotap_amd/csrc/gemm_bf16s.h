@@ -88,6 +88,9 @@ struct XRot {
 // accumulators of row m, columns n..n+W-1 (m < M guaranteed) -> exactly STORES global store instructions (the main loop counts
 // them: vmcnt is one in-order counter for DMA, loads and stores).
 struct SNoAux {};
+// false for an epilogue whose emit() may skip its stores for whole waves (column guards): the main loop then gives the previous
+// tile's stores no allowance in its vmcnt waits (the allowance must never exceed the stores really in flight)
+template <class E> struct s_epi_exact { static constexpr bool value = true; };
 // "use" of a loaded value outside any lane predicate: the compiler then waits for the load HERE.  Without it a value whose only
 // uses sit under `if (m < M)` counts as possibly pending at the loop's back edge, and the waitcnt pass protects the registers it
 // lands in with vmcnt(0) waits in the middle of the main loop (they are reused as fragment registers there).
@@ -351,7 +354,8 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
     // of the next tile the allowance is 8 + NST, by which time the stores have had ~2 us to drain.  Only after a FULL tile (every
     // lane active in every store: the count is exact); after a ragged tile the plain allowance makes the first wait drain them.
     constexpr int IT = Epi::W == 4 ? 4 : 2, NST = 8 * IT * Epi::STORES;
-    static_assert(8 + NST <= 63, "vmcnt is a 6-bit counter");
+    constexpr int SLK = s_epi_exact<Epi>::value ? 8 + NST : 8;      // vmcnt allowance of the first K-tiles after an (exact) epilogue
+    static_assert(SLK <= 63, "vmcnt is a 6-bit counter");
     int slack_kt = 0;
     auto epilogue = [&]() __attribute__((always_inline)) {
         int tm, tn;
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
 #pragma unroll
             for (int it = 0; it < IT; ++it) ax[it] = an[it];
         }
-        slack_kt = ((tm + 1) * BM <= M && KT >= 4) ? 2 : 0;
+        slack_kt = (s_epi_exact<Epi>::value && (tm + 1) * BM <= M && KT >= 4) ? 2 : 0;
     };
 
     // ---- prologue: K-tiles 0, 1, 2 complete (W then X each), then the steady-state issues of phases 0.. pick up W(3), X(3)
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
         __builtin_amdgcn_sched_barrier(0);
         // retire the half stage issued four phases ago (this phase's and the three before it may stay in flight): it is read from
         // the next phase on.  The wait sits behind this phase's own DMA and fragment reads, which do not depend on it.
-        if (slack_kt > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST) : "memory");
+        if (slack_kt > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLK) : "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
 #pragma unroll
         for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(sa + x_base + (4 + i) * 16 * ROWB);
         __builtin_amdgcn_sched_barrier(0);
-        if (slack_kt > 0) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST) : "memory"); --slack_kt; }
+        if (slack_kt > 0) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLK) : "memory"); --slack_kt; }
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);

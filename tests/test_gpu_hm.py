@@ -109,6 +109,36 @@ def test_hm_forward_bf16x3_mode_matches_oracle(which, B):
     assert torch.equal(fast, again) and torch.equal(back, exact) and not torch.equal(fast, exact)
 
 
+@pytest.mark.parametrize("which,preset,hm,B", [("pos", "UnrealEgo", 64, 3), ("rot", "UnrealEgo", 64, 2), ("rot", "EgoCap", 128, 1)])
+def test_hm_forward_bf16_channels_last_decoder_against_float64_oracle(which, preset, hm, B):
+    """EGOTAP_PREC_BF16: the decoder runs on bf16 channels-last activations, every convolution as an implicit GEMM on the bf16-storage
+    GEMM kernel (conv_bf16s.h: 3x3 taps through a loader with a zero page for the padding, 1x1 lateral convs with padded N, the
+    concat buffers' channel slices written in place, conv_heatmap back to fp32 NCHW).  Against the FLOAT64 ORACLE: relative L2 below
+    2 % (about ten bf16 roundings deep), every frame of the batch (ragged last tile at the 8x8 level), bit-reproducible, and a frame's
+    result does not depend on the batch it is in."""
+    from gpu_util import hm_net
+    from oracle import hm_ref as H
+    net, sd_np = hm_net(which, preset=preset, hm=hm)
+    S = 4 * hm
+    left = torch.from_numpy(synth_input(f"rgbL_cl_{which}{hm}", (B, 3, S, S), -2.0, 2.0))
+    right = torch.from_numpy(synth_input(f"rgbR_cl_{which}{hm}", (B, 3, S, S), -2.0, 2.0))
+    with torch.no_grad():
+        ref = H.hm_forward(left.double(), right.double(), H.to_torch_sd(sd_np, torch.float64))
+    try:
+        net.set_precision("bf16")
+        low = net(left.cuda(), right.cuda())
+        again = net(left.cuda(), right.cuda())
+        last = net(left[B - 1:].cuda(), right[B - 1:].cuda())
+    finally:
+        net.set_precision("f32")
+    assert torch.equal(low, again) and torch.equal(low[B - 1:], last)
+    low = low.double().cpu()
+    assert tuple(low.shape) == tuple(ref.shape)
+    for b in range(B):
+        rel = float((low[b] - ref[b]).norm() / ref[b].norm())
+        assert 1e-5 < rel < 2e-2, (b, rel)
+
+
 def test_hm_forward_bf16_mode_against_float64_oracle():
     """plain bf16 operands (2^-9 per rounding) in the 3x3 convolutions of the estimator, checked against the FLOAT64 ORACLE: the
     heatmaps stay within 3 % relative L2 of it (fp32 mode: 1e-6), and are not the fp32 result"""
