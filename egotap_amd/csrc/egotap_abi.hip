@@ -950,6 +950,8 @@ static hipError_t conv_any(Handle* h, const char* role, int taps, int stride, in
     }
     if (h->precision != EGOTAP_PREC_F32 && h->conv_pack && taps == 9 && stride == 1 && a.Cout == 64 && wout == 64)   // ResNet layer1
         return h->precision == EGOTAP_PREC_BF16X3 ? conv_bf<ConvBfCfg<6, 3, 64>>(h, role, a, s) : conv_bf<ConvBfCfg<6, 1, 64>>(h, role, a, s);
+    if (h->precision == EGOTAP_PREC_BF16 && h->conv_pack && taps == 9 && stride == 1 && a.Cout == 64 && wout == 128)   // layer1 at 512x512 RGB
+        return conv_bf<ConvBfCfg<7, 1, 64>>(h, role, a, s);
     if (taps == 9 && stride == 1) {
         if (wout == 128) return a.Cout <= 64 ? conv<C3s1_128_co64>(h, role, a, s) : conv<C3s1_128>(h, role, a, s);
         if (wout == 64) return a.Cout <= 64 ? conv<C3s1_64_co64>(h, role, a, s) : conv<C3s1_64>(h, role, a, s);
