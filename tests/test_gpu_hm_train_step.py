@@ -159,3 +159,62 @@ def test_hm_train_bf16x3_mode_tracks_fp32_step():
         if float(b.norm()) < 1e-9:
             continue
         assert float((a - b).norm() / b.norm()) < 5e-2 and float(a @ b / (a.norm() * b.norm())) > 0.999, k
+
+
+def test_wrapper_stage1_step_b8_against_the_references_float64_step():
+    """The better-conditioned pin of the stage-1 step: B = 8 (BatchNorm statistics over 16 images) against ONE optimize_parameters() of
+    the reference's own HeatmapSharedModel computed in FLOAT64 (tests/golden/hm_train_step_pos_b8.npz, tools/make_golden.py
+    gen_hm_train_b8).  The fixture also records how far the reference's OWN fp32 run lands from its float64 run, per gradient tensor
+    (worst: 2.2e-4 on a norm, 3.2e-2 of a tensor's typical magnitude on a sampled element).  Gates: losses and predictions 2e-5,
+    every gradient norm 2e-3 (observed 1.0e-3; the B = 2 fixture needed 3e-2), sampled elements within 8e-2 of the tensor's typical
+    magnitude with a median below 1.5e-2 (observed median 7.5e-3, reference fp32 1.5e-3; observed worst 5.2e-2 on layer3.0.conv1.weight, where the reference's own fp32 run is at
+    5.4e-3: that gradient is a sum over 4096 pixels of a zero-mean dz against a nearly constant activation, and the fp32 MFMA
+    accumulates it sequentially where the reference's CPU kernel blocks it; the B = 2 fixture needed 0.15)."""
+    import os
+    from egotap_amd import models
+    from egotap_amd.options import preset_defaults
+    from egotap_amd.synthetic import synth_hm_state_dict
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hm_train_step_pos_b8.npz"))
+    opt = preset_defaults("UnrealEgo")
+    opt.model, opt.isTrain, opt.num_heatmap, opt.num_rot_heatmap = "heatmap_shared", True, 15, 0
+    opt.lr, opt.weight_decay, opt.lr_policy, opt.niter, opt.niter_decay, opt.epoch_iter_cnt, opt.epoch_count = 1e-3, 0.0, "cos_anneal_warmup", 1, 3, 4, 1
+    opt.lambda_heatmap = opt.lambda_rot_heatmap = 1.0
+    m = models.create_model(opt)
+    C = 15
+    m.net_HeatMap.load_state_dict({k: torch.from_numpy(v) for k, v in synth_hm_state_dict(C, "hm_pos.").items()})
+    B = 8
+    data = {"input_rgb_left": torch.from_numpy(synth_input("tr8_rgbL", (B, 3, 256, 256), -2.0, 2.0)),
+            "input_rgb_right": torch.from_numpy(synth_input("tr8_rgbR", (B, 3, 256, 256), -2.0, 2.0))}
+    gt = torch.from_numpy(synth_input("tr8_gt", (B, 2 * C, 64, 64), 0.0, 1.0))
+    data.update(gt_heatmap_left=gt[:, :C], gt_heatmap_right=gt[:, C:])
+    m.set_input(data)
+    m.optimize_parameters()
+    errs = m.get_current_errors()
+    for name in m.loss_names:
+        np.testing.assert_allclose(errs[name], float(g["loss_" + name]), rtol=2e-5, err_msg=name)
+    np.testing.assert_allclose(m.pred_heatmap_cat.detach().reshape(-1)[::97].cpu().numpy(), g["pred_sample"], atol=2e-5)
+    norms = dict(zip(g["grad_keys"], g["grad_norms"]))
+    dev = dict(zip(g["grad_keys"], g["ref_fp32_dev_sample"]))
+    params = dict(m.net_HeatMap.named_parameters())
+    assert sorted(k for k, v in params.items() if v.grad is not None) == sorted(g["grad_keys"])
+    worst_n = worst_s = 0.0
+    rows = []
+    for k in g["grad_keys"]:
+        gr = params[k].grad
+        rn = abs(float(gr.double().norm()) - norms[k]) / norms[k]
+        assert rn <= 2e-3, (k, rn)
+        got = gr.reshape(-1)[:: max(1, gr.numel() // 257)].double().cpu().numpy()
+        scale = norms[k] / np.sqrt(gr.numel())
+        es = float(np.abs(got - g["g:" + k]).max()) / scale
+        rows.append((es, dev[k], k))
+        worst_n, worst_s = max(worst_n, rn), max(worst_s, es)
+    for es, d, k in sorted(rows, reverse=True)[:12]:
+        print(f"{k}: sample error {es:.3e}, reference fp32 {d:.3e}")
+    print(f"stage-1 step B = 8 vs the reference's float64 step: worst norm error {worst_n:.2e}, worst sample error {worst_s:.2e} of typical magnitude")
+    sd = m.net_HeatMap.state_dict()
+    for k in g.files:
+        if k.startswith("buf:"):
+            np.testing.assert_allclose(sd[k[4:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+    for es, d, k in rows:
+        assert es <= 8e-2, (k, es, d)
+    assert float(np.median([r[0] for r in rows])) < 1.5e-2

@@ -394,6 +394,76 @@ def gen_hm_train():
         print(f"hm_train_step_{tag}:", {ln: float(getattr(m, "loss_" + ln)) for ln in m.loss_names}, len(names), "gradients")
 
 
+def gen_hm_train_b8():
+    """A better-conditioned pin of the stage-1 step: the same reference wrapper step as gen_hm_train for the
+    position net, but B = 8 (BatchNorm statistics over 8 x 2 eyes) and computed TWICE -- in float64 (the fixture's values) and in the
+    reference's own fp32 (recorded only as its deviation from the float64 run: what fp32 arithmetic of this network costs whoever
+    does it, i.e. the floor of any fp32 implementation's gate)."""
+    from model.heatmap_shared_model import HeatmapSharedModel
+    from egotap_amd.synthetic import synth_hm_state_dict
+
+    nh, nr, B = 15, 0, 8
+    C = nh
+
+    def run(dtype):
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            opt = make_opt("UnrealEgo")
+            opt.num_heatmap, opt.num_rot_heatmap = nh, nr
+            opt.model, opt.isTrain, opt.use_amp, opt.gpu_ids = "heatmap_shared", True, False, []
+            opt.log_dir, opt.experiment_name, opt.init_type = "/tmp", "gold_hm", "kaiming"
+            opt.path_to_trained_heatmap = None
+            opt.lr, opt.weight_decay, opt.lr_policy = 1e-3, 0.0, "cos_anneal_warmup"
+            opt.niter, opt.niter_decay, opt.epoch_iter_cnt, opt.epoch_count = 1, 3, 4, 1
+            opt.lambda_heatmap, opt.lambda_rot_heatmap, opt.distributed = 1.0, 1.0, False
+            m = HeatmapSharedModel()
+            m.initialize(opt)
+            n = m.net_HeatMap
+            n.to(dtype)
+            sd_np = synth_hm_state_dict(C, "hm_pos.")
+            n.load_state_dict({k: torch.from_numpy(v).to(dtype) if v.dtype.kind == "f" else torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+            data = {"input_rgb_left": torch.from_numpy(synth_input("tr8_rgbL", (B, 3, 256, 256), -2.0, 2.0)).to(dtype),
+                    "input_rgb_right": torch.from_numpy(synth_input("tr8_rgbR", (B, 3, 256, 256), -2.0, 2.0)).to(dtype),
+                    "gt_local_pose": torch.zeros(B, 16, 3, dtype=dtype), "gt_limb_theta": torch.zeros(B, 15, dtype=dtype)}
+            gt = torch.from_numpy(synth_input("tr8_gt", (B, 2 * C, 64, 64), 0.0, 1.0)).to(dtype)
+            data.update(gt_heatmap_left=gt[:, :C], gt_heatmap_right=gt[:, C:])
+            m.set_input(data)
+            m.optimize_parameters()
+            res = {"pred": m.pred_heatmap_cat.detach().double(), "loss": {ln: float(getattr(m, "loss_" + ln)) for ln in m.loss_names}, "grads": {}}
+            for k, prm in n.named_parameters():
+                if prm.grad is not None:
+                    res["grads"][k] = prm.grad.detach().double().clone()
+            res["bufs"] = {k: v.detach().double().clone() for k, v in n.state_dict().items()
+                           if k.startswith("backbone.backbone.backbone.") and (k.endswith("running_mean") or k.endswith("running_var"))}
+            return res
+        finally:
+            torch.set_default_dtype(old)
+
+    r64, r32 = run(torch.float64), run(torch.float32)
+    out = {"pred_sample": r64["pred"].reshape(-1)[::97].numpy().copy()}
+    for ln, v in r64["loss"].items():
+        out["loss_" + ln] = np.array(v)
+    names, norms, dev_norm, dev_samp = [], [], [], []
+    for k, g in r64["grads"].items():
+        names.append(k)
+        nrm = float(g.norm())
+        norms.append(nrm)
+        st = max(1, g.numel() // 257)
+        out["g:" + k] = g.reshape(-1)[::st].numpy().copy()
+        g32 = r32["grads"][k]
+        scale = max(nrm / np.sqrt(g.numel()), 1e-300)
+        dev_norm.append(abs(float(g32.norm()) - nrm) / max(nrm, 1e-300))
+        dev_samp.append(float((g32.reshape(-1)[::st] - g.reshape(-1)[::st]).abs().max()) / scale)
+    out["grad_keys"], out["grad_norms"] = np.array(names), np.array(norms)
+    out["ref_fp32_dev_norm"], out["ref_fp32_dev_sample"] = np.array(dev_norm), np.array(dev_samp)
+    for k, v in r64["bufs"].items():
+        out["buf:" + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "hm_train_step_pos_b8.npz"), **out)
+    print("hm_train_step_pos_b8:", r64["loss"], len(names), "gradients; reference fp32 vs float64: worst norm deviation",
+          f"{max(dev_norm):.3e}, worst sample deviation {max(dev_samp):.3e} of the tensor's typical magnitude")
+
+
 def gen_synth():
     """ground-truth heatmap synthesis by the reference's own coord2d_to_heatmap / get_limb_data; skimage.draw.line_aa (not
     installed) is supplied by oracle/heatmap_synth_ref.line_aa, so that one step is NOT pinned by this fixture"""
@@ -455,6 +525,8 @@ def main():
         gen_synth()
     if "hmtrain" in which:
         gen_hm_train()
+    if "hmtrain8" in which:
+        gen_hm_train_b8()
 
 
 if __name__ == "__main__":
