@@ -87,17 +87,18 @@ struct SEpiHeatNCHW {        // conv_heatmap: out f32 NCHW = acc + bias at out +
 template <> struct s_epi_exact<SEpiHeatNCHW> { static constexpr bool value = false; };
 
 // ---------------------------------------------------------------------------------------------------- helpers
-// [Cout][Cin][3][3] f32 -> [Cout][tap][Cp] bf16 (channels past Cin zero).  One thread = 8 consecutive ci of one (co, tap).
-static __global__ __launch_bounds__(256) void pack_conv3x3_bf16s_kernel(const float* __restrict__ w, __bf16* __restrict__ wb, int Cout, int Cin, int Cp) {
+// [Cout][Cin][3][3] f32 -> [Np][tap][Cp] bf16 (channels past Cin and rows past Cout zero).  One thread = 8 consecutive ci of one (co, tap).
+static __global__ __launch_bounds__(256) void pack_conv3x3_bf16s_kernel(const float* __restrict__ w, __bf16* __restrict__ wb, int Cout, int Cin, int Cp,
+                                                                        int Np) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c8n = Cp / 8;
-    if (i >= (long)Cout * 9 * c8n) return;
+    if (i >= (long)Np * 9 * c8n) return;
     const int c8 = (int)(i % c8n), tap = (int)((i / c8n) % 9), co = (int)(i / (9L * c8n));
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ci = c8 * 8 + j;
-        o[j] = ci < Cin ? (__bf16)w[((long)co * Cin + ci) * 9 + tap] : (__bf16)0.f;
+        o[j] = (ci < Cin && co < Cout) ? (__bf16)w[((long)co * Cin + ci) * 9 + tap] : (__bf16)0.f;
     }
     *(bf16x8*)(wb + ((long)co * 9 + tap) * Cp + c8 * 8) = o;
 }
@@ -112,7 +113,7 @@ static __global__ __launch_bounds__(256) void pack_conv1x1_bf16s_kernel(const fl
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = co < Cout ? (__bf16)w[(long)co * Cin + c8 * 8 + j] : (__bf16)0.f;
     *(bf16x8*)(wb + (long)co * Cin + c8 * 8) = o;
-    if (c8 == 0) bp[co] = co < Cout ? b[co] : 0.f;
+    if (c8 == 0 && b != nullptr) bp[co] = co < Cout ? b[co] : 0.f;
 }
 // pyramid level: f32 NCHW [Nimg, C, HW] -> bf16 channels-last [Nimg * HW, C].  Lanes along pixels (coalesced reads), 8 channels each.
 static __global__ __launch_bounds__(256) void nchw_to_nhwc_bf16s_kernel(const float* __restrict__ in, __bf16* __restrict__ out, int C, int HW, long total) {
@@ -152,4 +153,122 @@ static __global__ __launch_bounds__(256) void upsample2x_nhwc_bf16s_kernel(const
     for (int j = 0; j < 8; ++j)
         o[j] = (__bf16)(hy * (hx * (float)v00[j] + lx * (float)v01[j]) + ly * (hx * (float)v10[j] + lx * (float)v11[j]));
     *(bf16x8*)(out + pp * ld + c8 * 8) = o;
+}
+
+// ---------------------------------------------------------------------------------------------------- ResNet-18 backbone, same scheme
+// The backbone runs on 2B images (n = 2 b + eye); the decoder wants the two eyes' pyramids concatenated along the channels
+// (net_architecture.py:139-147).  Every backbone tensor is therefore stored as [B * S * S, 2 C] bf16 -- pixel (b, y, x) holds
+// [left C | right C] -- so a pyramid level IS the decoder's operand (no concat, no conversion) and a conv of image n reads / writes
+// the C-channel slice eye * C of rows b * S * S + pixel.  BasicBlock convs (3x3 stride 1 / 2, 1x1 stride-2 downsample) with
+// BatchNorm (eval, folded to scale / shift per call), residual and ReLU in the epilogue.  Cout = 64 / 128 run as N = 256 (column guard).
+struct XConvE {
+    const __bf16* in;        // [B * Si * Si, 2 C] bf16, Si = So * stride
+    const __bf16* zero;
+    int C, log2So, stride, taps, inv_ktp;
+    struct Row { const __bf16* p; unsigned mask; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int So = 1 << log2So, xo = m & (So - 1), yo = (m >> log2So) & (So - 1), n = m >> (2 * log2So);
+        const int Si = So * stride, yi = yo * stride, xi = xo * stride;
+        unsigned mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            if (yi + dy >= 0 && yi + dy < Si && xi + dx >= 0 && xi + dx < Si) mask |= 1u << t;
+        }
+        return Row{in + ((long)(n >> 1) * Si * Si + (long)yi * Si + xi) * (2 * C) + (n & 1) * C, mask};
+    }
+    __device__ __forceinline__ const __bf16* ptr(const Row& r, int k0, int ko) const {
+        if (taps == 1) return r.p + k0 + ko;                   // 1x1 (stride-2 downsample): the centre pixel, always inside
+        const int tap = ((k0 >> 5) * inv_ktp) >> 16;
+        const int ci = k0 - tap * C;
+        const int dy = ((tap * 11) >> 5) - 1, dx = tap - 3 * (dy + 1) - 1;
+        const int Si = stride << log2So;
+        const int off = (dy * Si + dx) * (2 * C) + ci;
+        return ((r.mask >> tap) & 1u) ? r.p + off + ko : zero + ko;
+    }
+};
+
+struct SBn8 { f32x4 s0, s1, h0, h1; };
+__device__ __forceinline__ void s_keep(const SBn8& b) { asm volatile("" ::"v"(b.s0), "v"(b.s1), "v"(b.h0), "v"(b.h1)); }
+template <bool GUARD>
+struct SEpiBnBf16 {          // out bf16 = relu?(acc * scale + shift (+ R)) in the eye-interleaved layout; GUARD: only columns < C exist
+    static constexpr int W = 8, STORES = 1;
+    const float* scale;      // N (padded) values each
+    const float* shift;
+    const __bf16* R;         // residual (same layout as out) or null
+    __bf16* out;
+    int C, log2So, relu;
+    typedef SBn8 Col;
+    typedef bf16x8 Aux;
+    __device__ __forceinline__ long addr(int m) const {
+        const int n = m >> (2 * log2So), pix = m & ((1 << (2 * log2So)) - 1);
+        return (((long)(n >> 1) << (2 * log2So)) + pix) * (2 * C) + (n & 1) * C;
+    }
+    __device__ __forceinline__ Col col(int n) const {
+        return Col{*(const f32x4*)(scale + n), *(const f32x4*)(scale + n + 4), *(const f32x4*)(shift + n), *(const f32x4*)(shift + n + 4)};
+    }
+    __device__ __forceinline__ Aux fetch(int m, int n) const {
+        if (R == nullptr) return bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        return *(const bf16x8*)(R + addr(m) + (GUARD ? min(n, C - 8) : n));
+    }
+    __device__ __forceinline__ void emit(float* v, const Col& c, const Aux& r, int m, int n) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = v[i] * c.s0[i] + c.h0[i] + (float)r[i];
+            v[4 + i] = v[4 + i] * c.s1[i] + c.h1[i] + (float)r[4 + i];
+        }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (!GUARD || n < C) store_bf16x8(out + addr(m) + n, v);
+    }
+};
+template <> struct s_epi_exact<SEpiBnBf16<true>> { static constexpr bool value = false; };
+
+// eval-mode BatchNorm folded to y = x * scale + shift, padded with zeros to Np channels (as conv_f32.h's epilogue computes it)
+static __global__ __launch_bounds__(256) void bn_fold_bf16s_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ m,
+                                                                   const float* __restrict__ v, float* __restrict__ scale, float* __restrict__ shift,
+                                                                   int C, int Np) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Np) return;
+    float sc = 0.f, sh = 0.f;
+    if (c < C) {
+        sc = g[c] / sqrtf(v[c] + 1e-5f);
+        sh = b[c] - m[c] * sc;
+    }
+    scale[c] = sc;
+    shift[c] = sh;
+}
+
+// max-pool 3x3 / 2 (pad 1) of the stem's output: f32 NCHW [2B, C, HIN, HIN] (image n = 2 b + eye) -> bf16 [B * HO * HO, 2 C].
+// Lanes along the output row (the window reads of a wave are contiguous segments of three input rows), 8 channels per thread.
+static __global__ __launch_bounds__(256) void maxpool3s2_nhwc_bf16s_kernel(const float* __restrict__ in, __bf16* __restrict__ out, int C, int HIN, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int HO = HIN / 2;
+    const int xo = (int)(i % HO), yo = (int)((i / HO) % HO);
+    const long t = i / ((long)HO * HO);
+    const int c8 = (int)(t % (C / 8));
+    const long n = t / (C / 8);
+    const float* p = in + (n * C + c8 * 8) * (long)HIN * HIN;
+    float mx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx[j] = -INFINITY;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = 2 * yo + dy;
+        if (yy < 0 || yy >= HIN) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = 2 * xo + dx;
+            if (xx < 0 || xx >= HIN) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx[j] = fmaxf(mx[j], p[(long)j * HIN * HIN + (long)yy * HIN + xx]);
+        }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)mx[j];
+    *(bf16x8*)(out + (((n >> 1) * HO + yo) * (long)HO + xo) * (2 * C) + (n & 1) * C + c8 * 8) = o;
 }

@@ -1062,6 +1062,115 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
 
     // E1: stem conv7x7/2 + BN + ReLU on image n = 2b + eye (the L/R channel concat of every pyramid level is then a view)
     EGO_HIP(stem_conv7_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, F(w.L0), S0, N2, device_cu_count(), s));
+    if (h->precision == EGOTAP_PREC_BF16) {
+        // bf16 mode: everything after the stem on bf16 channels-last activations, every convolution on the bf16-storage GEMM
+        // (conv_bf16s.h).  Buffers live in the fp32 path's slots (each at most half as large).
+        auto Hb = [&](size_t off) { return (__bf16*)(base + off); };
+        __bf16 *A1 = Hb(w.S[0][0]), *A2 = Hb(w.S[1][0]), *A3 = Hb(w.S[2][0]), *A4 = Hb(w.S[3][0]);
+        __bf16 *T4 = Hb(w.U4), *C3 = Hb(w.CAT3), *Y3 = Hb(w.X3), *C2 = Hb(w.CAT2), *Y2 = Hb(w.X2), *C1 = Hb(w.CAT1), *Y1 = Hb(w.X1);
+        __bf16* WP = Hb(w.WPACK);                                                   // packed weights of the running layer (<= 29 MB)
+        float* BP = (float*)(base + w.WPACK + ((size_t)40 << 20));                  // its bias, padded to the GEMM's N
+        __bf16* ZP = (__bf16*)(base + w.WPACK + ((size_t)40 << 20) + 32768);        // 256 bytes of zeros (taps outside the image)
+        const int cus = device_cu_count();
+        const long p8 = (long)s8 * s8, p16 = (long)s16 * s16, p32 = (long)s32 * s32, p64 = (long)s64 * s64;
+        auto ilog2 = [](long v) { int l = 0; while ((1L << l) < v) ++l; return l; };
+        EGO_HIP(zero_fill(ZP, 256, s));
+        auto up2 = [&](const __bf16* in, __bf16* o, int C, int hin, long ld) {
+            const long total = (long)B * 4 * hin * hin * (C / 8);
+            hipLaunchKernelGGL(upsample2x_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, o, C, hin, ld, total);
+            return hipGetLastError();
+        };
+        // 1x1 convrelu: rows = pixels; the output goes to columns [0, Cout) of o (row stride ld)
+        auto conv1 = [&](const char* role, const __bf16* in, long M, const HmParams::Cv& cv, int Cin, int Cout, __bf16* o, long ld) {
+            const int Np = (Cout + 255) / 256 * 256;
+            const long items = (long)Np * (Cin / 8);
+            hipLaunchKernelGGL(pack_conv1x1_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, cv.w, cv.b, WP, BP, Cout, Cin, Np);
+            GemmTimer t(h, s, role, "gemm_bf16s_kernel<XPlain,conv1x1>", 2.0 * M * Cout * Cin);
+            if (Np == Cout) return gemm_bf16s_launch(XPlain{in, Cin}, WP, (long)Cin, SEpiConvBf16<false>{BP, o, ld, Np, 1}, (int)M, Np, Cin, cus, s);
+            return gemm_bf16s_launch(XPlain{in, Cin}, WP, (long)Cin, SEpiConvBf16<true>{BP, o, ld, (Cout + 7) / 8 * 8, 1}, (int)M, Np, Cin, cus, s);
+        };
+        // 3x3 convrelu on a concat buffer of Cp channels per pixel (Cp a multiple of 32; channels past Cin are zero)
+        auto conv3 = [&](const char* role, const __bf16* in, long M, int side, const HmParams::Cv& cv, int Cin, int Cp, int Cout, __bf16* o) {
+            const long items = (long)Cout * 9 * (Cp / 8);
+            hipLaunchKernelGGL(pack_conv3x3_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, cv.w, WP, Cout, Cin, Cp, Cout);
+            GemmTimer t(h, s, role, "gemm_bf16s_kernel<XConv3>", 2.0 * M * Cout * 9.0 * Cin);
+            const int ktp = Cp / 32;
+            const XConv3 xl{in, ZP, Cp, ilog2(side), (65536 + ktp - 1) / ktp};
+            return gemm_bf16s_launch(xl, WP, 9L * Cp, SEpiConvBf16<false>{cv.b, o, (long)Cout, Cout, 1}, (int)M, Cout, 9 * Cp, cus, s);
+        };
+        // E2: max-pool -> bf16 [B * s64^2, 2 x 64]; E3: the four stages on the same GEMM kernel (eye-interleaved rows, see conv_bf16s.h)
+        __bf16* P0 = Hb(w.P0);
+        {
+            const long total = (long)N2 * (64 / 8) * p64;
+            hipLaunchKernelGGL(maxpool3s2_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, F(w.L0), P0, 64, S0 / 2, total);
+            EGO_HIP(hipGetLastError());
+        }
+        float *SC = BP + 1024, *SH = BP + 2048;                                    // folded BatchNorm scale / shift of the running conv
+        auto bconv = [&](const char* role, const __bf16* in, int cin, int c, int taps, int stride, int side, const float* wgt,
+                         const HmParams::Bn& bn, const __bf16* res, int relu, __bf16* o) {
+            const int Np = (c + 255) / 256 * 256;
+            if (taps == 9) {
+                const long items = (long)Np * 9 * (cin / 8);
+                hipLaunchKernelGGL(pack_conv3x3_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, wgt, WP, c, cin, cin, Np);
+            } else {
+                const long items = (long)Np * (cin / 8);
+                hipLaunchKernelGGL(pack_conv1x1_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, wgt, (const float*)nullptr, WP,
+                                   (float*)nullptr, c, cin, Np);
+            }
+            hipLaunchKernelGGL(bn_fold_bf16s_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, bn.g, bn.b, bn.m, bn.v, SC, SH, c, Np);
+            const long M = (long)N2 * side * side;
+            GemmTimer t(h, s, role, taps == 9 ? "gemm_bf16s_kernel<XConvE,3x3>" : "gemm_bf16s_kernel<XConvE,1x1>", 2.0 * M * c * taps * (double)cin);
+            const int ktp = cin / 32;
+            const XConvE xl{in, ZP, cin, ilog2(side), stride, taps, (65536 + ktp - 1) / ktp};
+            if (Np == c) return gemm_bf16s_launch(xl, WP, (long)taps * cin, SEpiBnBf16<false>{SC, SH, res, o, c, ilog2(side), relu}, (int)M, Np, taps * cin, cus, s);
+            return gemm_bf16s_launch(xl, WP, (long)taps * cin, SEpiBnBf16<true>{SC, SH, res, o, c, ilog2(side), relu}, (int)M, Np, taps * cin, cus, s);
+        };
+        {
+            static const char* r1[4][2] = {{"hm.l1.0.conv1", "hm.l1.1.conv1"}, {"hm.l2.0.conv1", "hm.l2.1.conv1"}, {"hm.l3.0.conv1", "hm.l3.1.conv1"}, {"hm.l4.0.conv1", "hm.l4.1.conv1"}};
+            static const char* r2[4][2] = {{"hm.l1.0.conv2", "hm.l1.1.conv2"}, {"hm.l2.0.conv2", "hm.l2.1.conv2"}, {"hm.l3.0.conv2", "hm.l3.1.conv2"}, {"hm.l4.0.conv2", "hm.l4.1.conv2"}};
+            static const char* rd[4] = {"", "hm.l2.down", "hm.l3.down", "hm.l4.down"};
+            const int sides[4] = {s64, s32, s16, s8};
+            __bf16* Ls[4] = {A1, A2, A3, A4};                                       // stage outputs = pyramid levels = the decoder's operands
+            const __bf16* x = P0;
+            int cin = 64;
+            for (int i = 0; i < 4; ++i) {
+                const int c = HM_CH[i], side = sides[i];
+                __bf16 *Ta = Hb(w.S[i][1]), *Tb = Hb(w.S[i][2]), *Td = Hb(w.S[i][3]);   // S[i][0] is the level itself (A1..A4)
+                for (int bk = 0; bk < 2; ++bk) {
+                    const auto& K = p.blk[i][bk];
+                    const __bf16* xin = bk == 0 ? x : Tb;
+                    const int stride = (bk == 0 && i > 0) ? 2 : 1, bc = bk == 0 ? cin : c;
+                    EGO_HIP(bconv(r1[i][bk], xin, bc, c, 9, stride, side, K.w1, K.bn1, nullptr, 1, Ta));
+                    const __bf16* idt = xin;
+                    if (K.wd) {
+                        EGO_HIP(bconv(rd[i], xin, bc, c, 1, 2, side, K.wd, K.bnd, nullptr, 0, Td));
+                        idt = Td;
+                    }
+                    EGO_HIP(bconv(r2[i][bk], Ta, c, c, 9, 1, side, K.w2, K.bn2, idt, 1, bk == 0 ? Tb : Ls[i]));
+                }
+                x = Ls[i];
+                cin = c;
+            }
+        }
+        EGO_HIP(zero_fill(C3, (size_t)B * p16 * 1568 * 2, s));                    // channels 1544..1567 of the first concat are padding
+        EGO_HIP(conv1("hm.layer4_1x1", A4, B * p8, p.l1x1[3], 1024, 1024, T4, 1024));
+        EGO_HIP(up2(T4, C3, 1024, s8, 1568));
+        EGO_HIP(conv1("hm.layer3_1x1", A3, B * p16, p.l1x1[2], 512, 516, C3 + 1024, 1568));
+        EGO_HIP(conv3("hm.conv_up3", C3, B * p16, s16, p.up[2], 1540, 1568, 1024, Y3));
+        EGO_HIP(up2(Y3, C2, 1024, s16, 1280));
+        EGO_HIP(conv1("hm.layer2_1x1", A2, B * p32, p.l1x1[1], 256, 256, C2 + 1024, 1280));
+        EGO_HIP(conv3("hm.conv_up2", C2, B * p32, s32, p.up[1], 1280, 1280, 512, Y2));
+        EGO_HIP(up2(Y2, C1, 512, s32, 640));
+        EGO_HIP(conv1("hm.layer1_1x1", A1, B * p64, p.l1x1[0], 128, 128, C1 + 512, 640));
+        EGO_HIP(conv3("hm.conv_up1", C1, B * p64, s64, p.up[0], 640, 640, 512, Y1));
+        {   // conv_heatmap: fp32 NCHW into the caller's channel slice
+            const long items = (long)256 * (512 / 8);
+            hipLaunchKernelGGL(pack_conv1x1_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p.head.w, p.head.b, WP, BP, p.n_out, 512, 256);
+            GemmTimer t(h, s, "hm.conv_heatmap", "gemm_bf16s_kernel<XPlain,heatmap>", 2.0 * B * p64 * p.n_out * 512);
+            EGO_HIP(gemm_bf16s_launch(XPlain{Y1, 512}, WP, 512L, SEpiHeatNCHW{BP, out, (long)out_image_stride, p.n_out, ilog2(p64)}, (int)(B * p64), 256, 512, cus, s));
+        }
+        return EGOTAP_OK;
+    }
     // E2: maxpool 3x3/2
     maxpool3s2_launch(F(w.L0), F(w.P0), (long)N2 * 64, S0 / 2, s);
     EGO_HIP(hipGetLastError());
@@ -1102,71 +1211,6 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
     }
     // E4-E9: decoder on the channel-concatenated pyramids ([2B, C, s, s] viewed as [B, 2C, s, s])
     const float *L1 = F(w.S[0][3]), *L2 = F(w.S[1][3]), *L3 = F(w.S[2][3]), *L4 = F(w.S[3][3]);
-    if (h->precision == EGOTAP_PREC_BF16) {
-        // bf16 mode: the decoder (91 % of the estimator's FLOPs) on bf16 channels-last activations, every convolution on the
-        // bf16-storage GEMM (conv_bf16s.h).  Buffers live in the fp32 path's slots (each at most half as large); the backbone's
-        // stage temporaries hold the channels-last copies of the four pyramid levels.
-        auto Hb = [&](size_t off) { return (__bf16*)(base + off); };
-        __bf16 *A1 = Hb(w.S[0][0]), *A2 = Hb(w.S[1][0]), *A3 = Hb(w.S[2][0]), *A4 = Hb(w.S[3][0]);
-        __bf16 *T4 = Hb(w.U4), *C3 = Hb(w.CAT3), *Y3 = Hb(w.X3), *C2 = Hb(w.CAT2), *Y2 = Hb(w.X2), *C1 = Hb(w.CAT1), *Y1 = Hb(w.X1);
-        __bf16* WP = Hb(w.WPACK);                                                   // packed weights of the running layer (<= 29 MB)
-        float* BP = (float*)(base + w.WPACK + ((size_t)40 << 20));                  // its bias, padded to the GEMM's N
-        __bf16* ZP = (__bf16*)(base + w.WPACK + ((size_t)40 << 20) + 8192);         // 256 bytes of zeros (taps outside the image)
-        const int cus = device_cu_count();
-        const long p8 = (long)s8 * s8, p16 = (long)s16 * s16, p32 = (long)s32 * s32, p64 = (long)s64 * s64;
-        auto ilog2 = [](long v) { int l = 0; while ((1L << l) < v) ++l; return l; };
-        EGO_HIP(zero_fill(ZP, 256, s));
-        auto to_nhwc = [&](const float* in, __bf16* o, int C, long hw) {
-            const long total = (long)B * (C / 8) * hw;
-            hipLaunchKernelGGL(nchw_to_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, o, C, (int)hw, total);
-            return hipGetLastError();
-        };
-        auto up2 = [&](const __bf16* in, __bf16* o, int C, int hin, long ld) {
-            const long total = (long)B * 4 * hin * hin * (C / 8);
-            hipLaunchKernelGGL(upsample2x_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, o, C, hin, ld, total);
-            return hipGetLastError();
-        };
-        // 1x1 convrelu: rows = pixels; the output goes to columns [0, Cout) of o (row stride ld)
-        auto conv1 = [&](const char* role, const __bf16* in, long M, const HmParams::Cv& cv, int Cin, int Cout, __bf16* o, long ld) {
-            const int Np = (Cout + 255) / 256 * 256;
-            const long items = (long)Np * (Cin / 8);
-            hipLaunchKernelGGL(pack_conv1x1_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, cv.w, cv.b, WP, BP, Cout, Cin, Np);
-            GemmTimer t(h, s, role, "gemm_bf16s_kernel<XPlain,conv1x1>", 2.0 * M * Cout * Cin);
-            if (Np == Cout) return gemm_bf16s_launch(XPlain{in, Cin}, WP, (long)Cin, SEpiConvBf16<false>{BP, o, ld, Np, 1}, (int)M, Np, Cin, cus, s);
-            return gemm_bf16s_launch(XPlain{in, Cin}, WP, (long)Cin, SEpiConvBf16<true>{BP, o, ld, (Cout + 7) / 8 * 8, 1}, (int)M, Np, Cin, cus, s);
-        };
-        // 3x3 convrelu on a concat buffer of Cp channels per pixel (Cp a multiple of 32; channels past Cin are zero)
-        auto conv3 = [&](const char* role, const __bf16* in, long M, int side, const HmParams::Cv& cv, int Cin, int Cp, int Cout, __bf16* o) {
-            const long items = (long)Cout * 9 * (Cp / 8);
-            hipLaunchKernelGGL(pack_conv3x3_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, cv.w, WP, Cout, Cin, Cp);
-            GemmTimer t(h, s, role, "gemm_bf16s_kernel<XConv3>", 2.0 * M * Cout * 9.0 * Cin);
-            const int ktp = Cp / 32;
-            const XConv3 xl{in, ZP, Cp, ilog2(side), (65536 + ktp - 1) / ktp};
-            return gemm_bf16s_launch(xl, WP, 9L * Cp, SEpiConvBf16<false>{cv.b, o, (long)Cout, Cout, 1}, (int)M, Cout, 9 * Cp, cus, s);
-        };
-        EGO_HIP(to_nhwc(L4, A4, 1024, p8));
-        EGO_HIP(to_nhwc(L3, A3, 512, p16));
-        EGO_HIP(to_nhwc(L2, A2, 256, p32));
-        EGO_HIP(to_nhwc(L1, A1, 128, p64));
-        EGO_HIP(zero_fill(C3, (size_t)B * p16 * 1568 * 2, s));                    // channels 1544..1567 of the first concat are padding
-        EGO_HIP(conv1("hm.layer4_1x1", A4, B * p8, p.l1x1[3], 1024, 1024, T4, 1024));
-        EGO_HIP(up2(T4, C3, 1024, s8, 1568));
-        EGO_HIP(conv1("hm.layer3_1x1", A3, B * p16, p.l1x1[2], 512, 516, C3 + 1024, 1568));
-        EGO_HIP(conv3("hm.conv_up3", C3, B * p16, s16, p.up[2], 1540, 1568, 1024, Y3));
-        EGO_HIP(up2(Y3, C2, 1024, s16, 1280));
-        EGO_HIP(conv1("hm.layer2_1x1", A2, B * p32, p.l1x1[1], 256, 256, C2 + 1024, 1280));
-        EGO_HIP(conv3("hm.conv_up2", C2, B * p32, s32, p.up[1], 1280, 1280, 512, Y2));
-        EGO_HIP(up2(Y2, C1, 512, s32, 640));
-        EGO_HIP(conv1("hm.layer1_1x1", A1, B * p64, p.l1x1[0], 128, 128, C1 + 512, 640));
-        EGO_HIP(conv3("hm.conv_up1", C1, B * p64, s64, p.up[0], 640, 640, 512, Y1));
-        {   // conv_heatmap: fp32 NCHW into the caller's channel slice
-            const long items = (long)256 * (512 / 8);
-            hipLaunchKernelGGL(pack_conv1x1_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p.head.w, p.head.b, WP, BP, p.n_out, 512, 256);
-            GemmTimer t(h, s, "hm.conv_heatmap", "gemm_bf16s_kernel<XPlain,heatmap>", 2.0 * B * p64 * p.n_out * 512);
-            EGO_HIP(gemm_bf16s_launch(XPlain{Y1, 512}, WP, 512L, SEpiHeatNCHW{BP, out, (long)out_image_stride, p.n_out, ilog2(p64)}, (int)(B * p64), 256, 512, cus, s));
-        }
-        return EGOTAP_OK;
-    }
     float *U4 = F(w.U4), *CAT3 = F(w.CAT3), *X3 = F(w.X3), *CAT2 = F(w.CAT2), *X2 = F(w.X2), *CAT1 = F(w.CAT1), *X1 = F(w.X1);
     auto up = [&](const float* in, float* o, int C, int hin, long ist_in, long ist_out) {
         const long threads = (long)B * C * (2 * hin) * (2 * hin / 4);
