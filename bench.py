@@ -364,7 +364,8 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
             blk = torch.from_numpy(synth_input(f"rgb_{side}_train_rank{rank}", (8, 3, S, S), -2.0, 2.0)).to(dev)
             data["input_rgb_" + side] = blk.repeat((B + 7) // 8, 1, 1, 1)[:B].contiguous()
     m.set_input(data)
-    m.optimize_parameters()                      # warm-up (allocator, BN buffers, optimizer state)
+    for _ in range(2):
+        m.optimize_parameters()                  # warm-up (allocator, BN buffers, optimizer state)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.train_steps):
@@ -381,7 +382,7 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
     exposed = m.net_AutoEncoder._reducer().read_exposed_ms() if world > 1 else 0.0
     del m, hm, gt, data
     from egotap_amd import training
-    training.release_scratch()
+    training.release_scratch()                   # (the model, with the activations' buffer it keeps, is gone already)
     torch.cuda.empty_cache()
     if tmp is not None:
         tmp.cleanup()

@@ -83,10 +83,12 @@ def _publish_grads(P, G):
 _train_ws = T.Scratch()
 
 
-def release_scratch():
+def release_scratch(net=None):
     """drop the grow-only scratch buffers of the training path (between benchmark legs; the next step allocates them again)"""
     _train_ws.buf = None
     T._scratch.buf = None
+    if net is not None:
+        net._saved_pool = None
 
 
 def _bind_grads(net, h, ga, G):
@@ -118,14 +120,22 @@ class LiftTrainOneCallFn(torch.autograd.Function):
         hm = hm.detach().float().contiguous()
         sb, wb = C.c_size_t(), C.c_size_t()
         _lib.check(lib.egotap_lift_train_bytes(h, B, C.byref(sb), C.byref(wb)))
-        saved = torch.empty(sb.value, dtype=torch.uint8, device=dev)
+        # the activations' buffer is kept by the module between steps (no 30 GB allocation per step, whose cost depends on what else
+        # the process has cached); a second forward before the first one's backward gets a buffer of its own
+        pool = getattr(net, "_saved_pool", None)
+        if pool is not None and not pool["busy"] and pool["buf"].numel() >= sb.value and pool["buf"].device == dev:
+            saved = pool["buf"]
+            pool["busy"] = True
+        else:                  # also after a forward whose backward never ran: the module then tracks the newer buffer
+            saved = torch.empty(sb.value, dtype=torch.uint8, device=dev)
+            net._saved_pool = pool = dict(buf=saved, busy=True)
         ws = _train_ws.get(wb.value, dev)
         pose = torch.empty((B, p.out_joints, 3), dtype=torch.float32, device=dev)
         _lib.check(lib.egotap_lift_forward_train(h, T._p(hm), B, T._p(pose), T._p(saved), saved.numel(), T._p(ws), ws.numel(), T._s()))
         for k, b in net.named_buffers():
             if k.endswith("num_batches_tracked"):
                 b.add_(1)
-        ctx.egotap = dict(net=net, P=P, keys=keys, B=B, hm=hm, saved=saved, wb=wb.value)
+        ctx.egotap = dict(net=net, P=P, keys=keys, B=B, hm=hm, saved=saved, wb=wb.value, pool=pool)
         return pose
 
     @staticmethod
@@ -152,6 +162,7 @@ class LiftTrainOneCallFn(torch.autograd.Function):
             red.bucket_ready(ga["bounds"][k], ga["bounds"][k + 1], after=e)
         red.finish()
         _publish_grads(P, G)
+        S["pool"]["busy"] = False
         ctx.egotap = None
         return (None, None) + (None,) * len(keys)
 

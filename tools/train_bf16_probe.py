@@ -11,6 +11,7 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 args = argparse.Namespace(preset="UnrealEgo", train_steps=2, train_batch=B)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
-r = bench.bench_train(args, spec.lift_preset("UnrealEgo"), dev, 0, 1, lambda: torch.cuda.synchronize(dev), mode=mode, batch=B)
-print(json.dumps({"B": B, "mode": mode, "frames_per_s": r["value"], "ms_per_step": r["ms_per_step"],
-                  "loss_pose": r["loss_pose"], "peak_hbm_gib": r["peak_hbm_gib"], "tflops": r["end_to_end_tflops_per_gpu"]}))
+for mode in mode.split(","):          # several modes: one after the other in this process, as bench.py's legs run
+    r = bench.bench_train(args, spec.lift_preset("UnrealEgo"), dev, 0, 1, lambda: torch.cuda.synchronize(dev), mode=mode, batch=B)
+    print(json.dumps({"B": B, "mode": mode, "frames_per_s": r["value"], "ms_per_step": r["ms_per_step"],
+                      "loss_pose": r["loss_pose"], "peak_hbm_gib": r["peak_hbm_gib"], "tflops": r["end_to_end_tflops_per_gpu"]}))
