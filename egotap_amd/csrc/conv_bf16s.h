@@ -7,9 +7,11 @@
 // Channels-last turns every convolution here into the bf16-storage GEMM of gemm_bf16s.h (256 x 256 tile, LDS-DMA ring, two wave
 // groups one barrier apart) with nothing but a different X-operand loader:
 //   rows    m = (image, y, x) of the output map, S x S pixels per image (S a power of two); columns n = output channel
-//   3x3:    k = (tap, ci), ci innermost, Cp = Cin padded to a multiple of 32, so a 32-deep K-tile lies inside one tap; row m of
-//           K-tile (tap, ci0) is the 64 contiguous bytes of input pixel (y + dy, x + dx), channels ci0..ci0+31 -- one DMA per lane,
-//           from a page of zeros where the tap leaves the image (the padding of F.conv2d).  Never im2col'ed.
+//   3x3:    k = (ci / 32, tap, ci % 32), Cp = Cin padded to a multiple of 32: a 32-deep K-tile is one tap of one 32-channel slab and
+//           row m of it is the 64 contiguous bytes of input pixel (y + dy, x + dx), channels 32 s..32 s + 31 -- one DMA per lane,
+//           from a page of zeros where the tap leaves the image (the padding of F.conv2d).  Never im2col'ed.  The nine taps of a
+//           slab are consecutive K-tiles, so eight of the nine reads of a pixel's 64 bytes hit L2 (tap-major order re-read the
+//           whole input from the fabric per tap: 7.5 GB per launch of conv_up1 against 1.3 GB of input).
 //   1x1:    the plain loader (rows are pixels).
 // Weights are repacked per call into [Cout][tap][Cp] bf16 (the parameters stay the caller's live fp32 tensors).  Producers write
 // straight into channel slices of the next concat buffer (row stride = the concat's channel count): no concat pass.
@@ -20,7 +22,7 @@
 struct XConv3 {
     const __bf16* in;        // [Nimg * S * S, Cp] bf16, channels-last
     const __bf16* zero;      // 64 bytes of zeros
-    int Cp, log2S, inv_ktp;  // inv_ktp = ceil(65536 / (Cp / 32)): K-tile index -> tap without a division
+    int Cp, log2S, inv_ktp;  // (inv_ktp unused: the slab / tap split of a K-tile index is a multiply by 7282 >> 16)
     struct Row { const __bf16* p; unsigned mask; };
     __device__ __forceinline__ Row row(int m) const {
         const int S = 1 << log2S, x = m & (S - 1), y = (m >> log2S) & (S - 1);
@@ -33,10 +35,9 @@ struct XConv3 {
         return Row{in + (long)m * Cp, mask};
     }
     __device__ __forceinline__ const __bf16* ptr(const Row& r, int k0, int ko) const {      // k0 wave-uniform: the tap arithmetic is scalar
-        const int tap = ((k0 >> 5) * inv_ktp) >> 16;
-        const int ci = k0 - tap * Cp;
+        const int kt = k0 >> 5, slab = (kt * 7282) >> 16, tap = kt - 9 * slab;      // kt / 9 exactly for kt < 7000
         const int dy = ((tap * 11) >> 5) - 1, dx = tap - 3 * (dy + 1) - 1;
-        const int off = ((dy << log2S) + dx) * Cp + ci;
+        const int off = ((dy << log2S) + dx) * Cp + 32 * slab;
         return ((r.mask >> tap) & 1u) ? r.p + off + ko : zero + ko;
     }
 };
@@ -87,7 +88,7 @@ struct SEpiHeatNCHW {        // conv_heatmap: out f32 NCHW = acc + bias at out +
 template <> struct s_epi_exact<SEpiHeatNCHW> { static constexpr bool value = false; };
 
 // ---------------------------------------------------------------------------------------------------- helpers
-// [Cout][Cin][3][3] f32 -> [Np][tap][Cp] bf16 (channels past Cin and rows past Cout zero).  One thread = 8 consecutive ci of one (co, tap).
+// [Cout][Cin][3][3] f32 -> [Np][Cp / 32][tap][32] bf16 (channels past Cin and rows past Cout zero).  One thread = 8 consecutive ci of one (co, tap).
 static __global__ __launch_bounds__(256) void pack_conv3x3_bf16s_kernel(const float* __restrict__ w, __bf16* __restrict__ wb, int Cout, int Cin, int Cp,
                                                                         int Np) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -100,7 +101,7 @@ static __global__ __launch_bounds__(256) void pack_conv3x3_bf16s_kernel(const fl
         const int ci = c8 * 8 + j;
         o[j] = (ci < Cin && co < Cout) ? (__bf16)w[((long)co * Cin + ci) * 9 + tap] : (__bf16)0.f;
     }
-    *(bf16x8*)(wb + ((long)co * 9 + tap) * Cp + c8 * 8) = o;
+    *(bf16x8*)(wb + (long)co * 9 * Cp + ((long)(c8 >> 2) * 9 + tap) * 32 + (c8 & 3) * 8) = o;       // k = (ci / 32, tap, ci % 32)
 }
 // [Cout][Cin] f32 (+ bias) -> [Np][Cin] bf16, [Np] f32: rows past Cout zero
 static __global__ __launch_bounds__(256) void pack_conv1x1_bf16s_kernel(const float* __restrict__ w, const float* __restrict__ b,
@@ -179,11 +180,10 @@ struct XConvE {
     }
     __device__ __forceinline__ const __bf16* ptr(const Row& r, int k0, int ko) const {
         if (taps == 1) return r.p + k0 + ko;                   // 1x1 (stride-2 downsample): the centre pixel, always inside
-        const int tap = ((k0 >> 5) * inv_ktp) >> 16;
-        const int ci = k0 - tap * C;
+        const int kt = k0 >> 5, slab = (kt * 7282) >> 16, tap = kt - 9 * slab;
         const int dy = ((tap * 11) >> 5) - 1, dx = tap - 3 * (dy + 1) - 1;
         const int Si = stride << log2So;
-        const int off = (dy * Si + dx) * (2 * C) + ci;
+        const int off = (dy * Si + dx) * (2 * C) + 32 * slab;
         return ((r.mask >> tap) & 1u) ? r.p + off + ko : zero + ko;
     }
 };

@@ -56,6 +56,11 @@ def main():
     if os.path.isdir(SRC):
         one(tag + "_config3", CONFIG3_CMD, "BASELINE config 3: UnrealEgo training step (forward + backward + AdamW), bf16 storage, batch 1024, 1 warm-up + 2 "
             "timed steps; per-launch HBM bytes are meaningful (one batch size)")
+    SRC = os.path.join(REPO, "gpurun_out", "prof_hm")
+    if os.path.isdir(SRC):
+        one(tag + "_estimators_bf16", "python3 tools/hm_bf16_probe.py 256 64 bf16", "both heatmap estimators, 256 stereo frames of 256x256 RGB, EGOTAP_PREC_BF16: "
+            "stem (fp32 MFMA) -> max-pool -> ResNet-18 stages and U-Net decoder as implicit GEMMs on bf16 channels-last tensors (conv_bf16s.h); "
+            "2 warm-up + 3 timed passes x 2 nets", traffic_json=False)
     SRC = os.path.join(REPO, "gpurun_out", "prof_all")
     if os.path.isdir(SRC):
         one(tag + "_all_legs", ALL_CMD, "every leg: fp32 headline, bf16x3 / bf16 fast modes, full pipeline in both modes, EgoCap / 128x128 geometry, "
