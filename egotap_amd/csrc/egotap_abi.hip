@@ -2450,6 +2450,70 @@ struct LiftBwdPlan {        // byte offsets into the backward workspace
 };
 static const int FC_OUT[2] = {2048, 512};
 
+// the bf16-STORAGE step (EGOTAP_PREC_BF16 with vit_dim 1024: BASELINE config 3, the wrapper's --use_amp): bf16 activations and per-step
+// bf16 weight copies, everything else as above.  Byte offsets into `saved` / the workspace.
+struct LiftTrain16Plan {
+    size_t hmb, X[9];
+    struct Layer { size_t m1, r1, y1, qkv, ctx, lse, xm, m2, r2, y2, z, hid, w_qkv, w_qkv_t, w_o, w_o_t, w_up, w_up_t, w_dn, w_dn_t, b_qkv; } layer[8];
+    size_t mf, rf, tokens, w_fc1p, w_fc1p_t, w_fc1r;
+    LiftTrainPlan::Fc pos[3], rot[3];
+    size_t pu, pu_hs1, pu_bytes, total;
+};
+struct LiftBwd16Plan {
+    size_t F[2], Rb[2], A4b, A3b, E[2], dzb, WT, dposz, drotz, dhs1, delta, zero, pu, pu_bytes, scr, scr_bytes, total;
+};
+static bool lift_train_bf16s(const Handle* h) { return h->precision == EGOTAP_PREC_BF16 && h->D == 1024; }
+
+static int lift_train16_plan(Handle* h, int B, LiftTrain16Plan& t, LiftBwd16Plan& w) {
+    const size_t M = (size_t)B * h->seq, D = h->D, BT = (size_t)B * h->T, heads = h->cfg.vit_heads, L = h->cfg.vit_layers;
+    const size_t K1 = (size_t)h->ppd * h->ppd * D, K1r = 2 * (size_t)h->cfg.hm_size * h->cfg.hm_size;
+    size_t o = 0;
+    auto bytes = [&](size_t n) { size_t r = o; o = al256(o + n); return r; };
+    auto f32 = [&](size_t n) { return bytes(n * 4); };
+    auto b16 = [&](size_t n) { return bytes(n * 2); };
+    t.hmb = b16((size_t)B * h->C * h->cfg.hm_size * h->cfg.hm_size);
+    for (size_t i = 0; i <= L; ++i) t.X[i] = f32(M * D);
+    for (size_t i = 0; i < L; ++i) {
+        auto& l = t.layer[i];
+        l.m1 = f32(M); l.r1 = f32(M); l.y1 = b16(M * D); l.qkv = b16(M * 3 * D); l.ctx = b16(M * D); l.lse = f32((size_t)B * heads * h->seq);
+        l.xm = f32(M * D); l.m2 = f32(M); l.r2 = f32(M); l.y2 = b16(M * D); l.z = b16(M * 4 * D); l.hid = b16(M * 4 * D);
+        l.w_qkv = b16(3 * D * D); l.w_qkv_t = b16(3 * D * D); l.w_o = b16(D * D); l.w_o_t = b16(D * D);
+        l.w_up = b16(4 * D * D); l.w_up_t = b16(4 * D * D); l.w_dn = b16(4 * D * D); l.w_dn_t = b16(4 * D * D); l.b_qkv = f32(3 * D);
+    }
+    t.mf = f32(M); t.rf = f32(M); t.tokens = b16(M * D);
+    t.w_fc1p = b16(2048 * K1); t.w_fc1p_t = b16(2048 * K1); t.w_fc1r = b16(2048 * K1r);
+    for (int e = 0; e < 2; ++e)
+        for (int j = 0; j < 3; ++j) {
+            const size_t n = j < 2 ? (size_t)FC_OUT[j] : (size_t)h->hid;
+            LiftTrainPlan::Fc& f = e == 0 ? t.pos[j] : t.rot[j];
+            f.z = f32(BT * n); f.y = f32(BT * n); f.mean = f32(n); f.rstd = f32(n);
+        }
+    size_t pub = 0, hs1 = 0;
+    int rc = egotap_train_pu_saved_bytes(h, B, &pub, &hs1);
+    if (rc != EGOTAP_OK) return rc;
+    t.pu = bytes(pub + 4); t.pu_hs1 = hs1; t.pu_bytes = pub;
+    t.total = o;
+
+    o = 0;
+    w.F[0] = f32(M * D); w.F[1] = f32(M * D); w.Rb[0] = b16(M * D); w.Rb[1] = b16(M * D);
+    w.A4b = b16(M * 4 * D); w.A3b = w.A4b;       // dz (MLP) is dead before dqkv (attention) is produced: one slot
+    w.E[0] = f32(BT * 2048); w.E[1] = f32(BT * 2048); w.dzb = b16(BT * 2048);
+    w.WT = f32((size_t)2048 * 512);
+    w.dposz = f32(BT * h->hid); w.drotz = f32(BT * h->hid); w.dhs1 = f32((size_t)h->J * B * h->H);
+    w.delta = f32((size_t)B * heads * h->seq);
+    w.zero = bytes(4096);
+    size_t pwb = 0;
+    rc = egotap_train_pu_bwd_ws_bytes(h, B, &pwb);
+    if (rc != EGOTAP_OK) return rc;
+    w.pu = bytes(pwb + 4); w.pu_bytes = pwb;
+    const size_t nb = (M + 63) / 64;
+    w.scr_bytes = std::max(std::max((size_t)4 * 4 * D * D * 8, (size_t)4 * 2048 * K1 * 2), (3 * nb + 3 + 3 * ((nb + 63) / 64)) * 4096 + 4096);
+    w.scr_bytes = std::max(w.scr_bytes, (size_t)64 << 20);
+    w.scr = bytes(w.scr_bytes);
+    w.total = o;
+    return EGOTAP_OK;
+}
+
 static int lift_train_plan(Handle* h, int B, LiftTrainPlan& t, LiftBwdPlan& w) {
     const size_t M = (size_t)B * h->seq, D = h->D, BT = (size_t)B * h->T, heads = h->cfg.vit_heads, L = h->cfg.vit_layers;
     size_t o = 0;
@@ -2494,6 +2558,14 @@ static int lift_train_plan(Handle* h, int B, LiftTrainPlan& t, LiftBwdPlan& w) {
 
 extern "C" int egotap_lift_train_bytes(egotap_handle h, int B, size_t* saved_bytes, size_t* ws_bytes) {
     EGO_CHECK(h && saved_bytes && ws_bytes && B > 0, "egotap_lift_train_bytes: bad argument");
+    if (lift_train_bf16s(h)) {
+        LiftTrain16Plan t; LiftBwd16Plan w;
+        const int rc = lift_train16_plan(h, B, t, w);
+        if (rc != EGOTAP_OK) return rc;
+        *saved_bytes = t.total;
+        *ws_bytes = w.total;
+        return EGOTAP_OK;
+    }
     LiftTrainPlan t; LiftBwdPlan w;
     const int rc = lift_train_plan(h, B, t, w);
     if (rc != EGOTAP_OK) return rc;
@@ -2517,10 +2589,175 @@ extern "C" int egotap_bind_grad(egotap_handle h, const char* key, void* dev_ptr,
 
 #define EGO_RC(call) do { const int rc_ = (call); if (rc_ != EGOTAP_OK) return rc_; } while (0)
 
+static int lift_forward_train16(Handle* h, const float* hm, int B, float* pose, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                                void* stream) {
+    LiftTrain16Plan t; LiftBwd16Plan w;
+    EGO_RC(lift_train16_plan(h, B, t, w));
+    EGO_CHECK(saved_bytes >= t.total, "egotap_lift_forward_train: saved buffer too small (%zu < %zu)", saved_bytes, t.total);
+    EGO_CHECK(ws_bytes >= w.total, "egotap_lift_forward_train: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    const LiftParams& p = h->lp;
+    char* sb = (char*)saved;
+    auto S = [&](size_t off) { return (float*)(sb + off); };
+    auto Hb = [&](size_t off) { return (void*)(sb + off); };
+    void* scr = (char*)ws + w.scr;
+    hipStream_t s = (hipStream_t)stream;
+    const int M = B * h->seq, D = h->D, BT = B * h->T, heads = h->cfg.vit_heads, L = h->cfg.vit_layers;
+    const int K1 = h->ppd * h->ppd * D, K1r = 2 * h->cfg.hm_size * h->cfg.hm_size;
+    // per-step bf16 copies of the GEMM weights (and transposed copies for the input-gradient GEMMs), kept with the activations
+    for (int i = 0; i < L; ++i) {
+        const auto& P_ = p.layer[i];
+        const auto& l = t.layer[i];
+        const float* qkvw[3] = {P_.q_w, P_.k_w, P_.v_w};
+        for (int q = 0; q < 3; ++q)
+            EGO_RC(egotap_bf16_prep_weight(qkvw[q], (__bf16*)Hb(l.w_qkv) + (size_t)q * D * D, (__bf16*)Hb(l.w_qkv_t) + (size_t)q * D, D, D, 3 * D, stream));
+        EGO_RC(egotap_bf16_prep_weight(P_.o_w, Hb(l.w_o), Hb(l.w_o_t), D, D, D, stream));
+        EGO_RC(egotap_bf16_prep_weight(P_.up_w, Hb(l.w_up), Hb(l.w_up_t), 4 * D, D, 4 * D, stream));
+        EGO_RC(egotap_bf16_prep_weight(P_.dn_w, Hb(l.w_dn), Hb(l.w_dn_t), D, 4 * D, D, stream));
+        hipLaunchKernelGGL(concat3_kernel, dim3((D + 255) / 256), dim3(256), 0, s, P_.q_b, P_.k_b, P_.v_b, S(l.b_qkv), D);
+        EGO_HIP(hipGetLastError());
+    }
+    EGO_RC(egotap_bf16_prep_weight(p.pos_fc[0].w, Hb(t.w_fc1p), Hb(t.w_fc1p_t), 2048, K1, 2048, stream));
+    EGO_RC(egotap_bf16_prep_weight(p.rot_fc[0].w, Hb(t.w_fc1r), nullptr, 2048, K1r, 2048, stream));
+    EGO_RC(egotap_bf16_from_f32(hm, Hb(t.hmb), (int64_t)B * h->C * h->cfg.hm_size * h->cfg.hm_size, stream));
+    EGO_RC(egotap_train_patch_fwd(h, hm, B, p.patch_w, p.patch_b, p.mask_tok, p.pos_emb, S(t.X[0]), stream));
+    for (int i = 0; i < L; ++i) {
+        const auto& P_ = p.layer[i];
+        const auto& l = t.layer[i];
+        float* x = S(t.X[i]);
+        EGO_RC(egotap_bf16_layernorm_fwd(x, Hb(l.y1), P_.ln1_g, P_.ln1_b, S(l.m1), S(l.r1), M, 1e-12f, stream));
+        EGO_RC(egotap_bf16_gemm_nt(Hb(l.y1), D, Hb(l.w_qkv), S(l.b_qkv), M, 3 * D, D, 0, nullptr, Hb(l.qkv), nullptr, 3 * D, stream));
+        EGO_RC(egotap_bf16_attention_fwd(Hb(l.qkv), Hb(l.ctx), S(l.lse), B, h->seq, heads, stream));
+        EGO_RC(egotap_bf16_gemm_nt(Hb(l.ctx), D, Hb(l.w_o), P_.o_b, M, D, D, 1, x, S(l.xm), nullptr, D, stream));
+        EGO_RC(egotap_bf16_layernorm_fwd(S(l.xm), Hb(l.y2), P_.ln2_g, P_.ln2_b, S(l.m2), S(l.r2), M, 1e-12f, stream));
+        EGO_RC(egotap_bf16_gemm_nt(Hb(l.y2), D, Hb(l.w_up), P_.up_b, M, 4 * D, D, 2, nullptr, Hb(l.z), Hb(l.hid), 4 * D, stream));
+        EGO_RC(egotap_bf16_gemm_nt(Hb(l.hid), 4 * D, Hb(l.w_dn), P_.dn_b, M, D, 4 * D, 1, S(l.xm), S(t.X[i + 1]), nullptr, D, stream));
+    }
+    EGO_RC(egotap_bf16_layernorm_fwd(S(t.X[L]), Hb(t.tokens), p.lnf_g, p.lnf_b, S(t.mf), S(t.rf), M, 1e-12f, stream));
+    for (int e = 0; e < 2; ++e) {
+        const float* a_in = nullptr;
+        int K = 0;
+        for (int j = 0; j < 3; ++j) {
+            const int n = j < 2 ? FC_OUT[j] : h->hid;
+            const LiftParams::Fc& fc = e == 0 ? p.pos_fc[j] : p.rot_fc[j];
+            const LiftTrainPlan::Fc& f = e == 0 ? t.pos[j] : t.rot[j];
+            if (j == 0) EGO_RC(egotap_bf16_fc1_fwd(h, e, e == 0 ? Hb(t.tokens) : Hb(t.hmb), e == 0 ? Hb(t.w_fc1p) : Hb(t.w_fc1r), fc.b, S(f.z), B, stream));
+            else EGO_RC(egotap_train_gemm_nt(h, 0, a_in, 0, nullptr, fc.w, fc.b, S(f.z), BT, n, K, 1, nullptr, nullptr, 0, stream));
+            EGO_RC(egotap_train_bn_lrelu_fwd(S(f.z), S(f.y), fc.g, fc.beta, S(f.mean), S(f.rstd), (float*)fc.mean, (float*)fc.var, BT, n, 1e-5f,
+                                             0.1f, scr, w.scr_bytes, stream));
+            a_in = S(f.y); K = n;
+        }
+    }
+    EGO_RC(egotap_train_pu_fwd(h, S(t.pos[2].y), S(t.rot[2].y), B, sb + t.pu, t.pu_bytes, stream));
+    EGO_RC(egotap_train_pose_head_fwd(h, S(t.pos[2].y), (const float*)(sb + t.pu + t.pu_hs1), B, pose, stream));
+    return EGOTAP_OK;
+}
+
+static int lift_backward16(Handle* h, const float* hm, const float* dpose, int B, const void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                           void* const* bucket_events, int n_events, void* stream) {
+    LiftTrain16Plan t; LiftBwd16Plan w;
+    EGO_RC(lift_train16_plan(h, B, t, w));
+    EGO_CHECK(saved_bytes >= t.total, "egotap_lift_backward: saved buffer too small (%zu < %zu)", saved_bytes, t.total);
+    EGO_CHECK(ws_bytes >= w.total, "egotap_lift_backward: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    const int L = h->cfg.vit_layers;
+    const LiftParams& p = h->lp;
+    const LiftParams& g = h->lg;
+    auto G = [](const float* q) { return (float*)q; };
+    const char* sb = (const char*)saved;
+    auto S = [&](size_t off) { return (const float*)(sb + off); };
+    auto Hb = [&](size_t off) { return (const void*)(sb + off); };
+    char* wb = (char*)ws;
+    auto W = [&](size_t off) { return (float*)(wb + off); };
+    auto Wh = [&](size_t off) { return (void*)(wb + off); };
+    void* scr = wb + w.scr;
+    const size_t scrb = w.scr_bytes;
+    hipStream_t s = (hipStream_t)stream;
+    const int M = B * h->seq, D = h->D, BT = B * h->T, heads = h->cfg.vit_heads;
+    const void* ZERO = wb + w.zero;
+    EGO_HIP(zero_fill(wb + w.zero, 4096, s));
+    int bucket = 0;
+    auto bucket_done = [&]() -> int {
+        if (n_events) EGO_HIP(hipEventRecord((hipEvent_t)bucket_events[bucket], s));
+        ++bucket;
+        return EGOTAP_OK;
+    };
+    const float *posz = S(t.pos[2].y), *rotz = S(t.rot[2].y), *hs1 = (const float*)(sb + t.pu + t.pu_hs1);
+    EGO_RC(egotap_train_pose_head_bwd(h, posz, hs1, dpose, B, W(w.dposz), W(w.dhs1), G(g.pose_w), G(g.pose_b), G(g.glob_w), G(g.glob_b), 0, stream));
+    float* pug[14] = {G(g.x2f0_w), G(g.x2f0_b), G(g.x2h0_w), G(g.x2h0_b), G(g.b2h0_w), G(g.b2h0_b), G(g.h2h0_w), G(g.h2h0_b),
+                      G(g.x2f1_w), G(g.x2f1_b), G(g.x2h1_w), G(g.x2h1_b), G(g.h2h1_w), G(g.h2h1_b)};
+    EGO_RC(egotap_train_pu_bwd(h, posz, rotz, B, sb + t.pu, W(w.dhs1), W(w.dposz), W(w.drotz), pug, 0, wb + w.pu, w.pu_bytes, stream));
+    // FC encoders: fc3, fc2 in fp32 (small), fc1 on the bf16 kernels; the position encoder returns the token gradient (bf16, token order)
+    auto encoder_bwd = [&](int e, const float* dy, void* dtok) -> int {
+        for (int j = 2; j >= 0; --j) {
+            const int n = j < 2 ? FC_OUT[j] : h->hid;
+            const LiftParams::Fc& fc = e == 0 ? p.pos_fc[j] : p.rot_fc[j];
+            const LiftParams::Fc& gc = e == 0 ? g.pos_fc[j] : g.rot_fc[j];
+            const LiftTrainPlan::Fc& f = e == 0 ? t.pos[j] : t.rot[j];
+            float* dz = W(w.E[0]);
+            EGO_RC(egotap_train_bn_lrelu_bwd(S(f.z), S(f.y), dy, fc.g, S(f.mean), S(f.rstd), dz, G(gc.g), G(gc.beta), BT, n, 0, scr, scrb, stream));
+            EGO_RC(egotap_train_colsum(dz, 0, G(gc.b), BT, n, 0, scr, scrb, stream));
+            if (j > 0) {
+                const int K = FC_OUT[j - 1];
+                const float* a_in = S((e == 0 ? t.pos[j - 1] : t.rot[j - 1]).y);
+                EGO_RC(egotap_train_gemm_tn(h, 0, dz, 0, a_in, nullptr, G(gc.w), BT, n, K, 0, 0, scr, scrb, stream));
+                EGO_RC(egotap_train_transpose(fc.w, W(w.WT), n, K, 0, stream));
+                EGO_RC(egotap_train_gemm_nt(h, 0, dz, 0, nullptr, W(w.WT), nullptr, W(w.E[1]), BT, K, n, 0, nullptr, nullptr, 0, stream));
+                dy = W(w.E[1]);
+            } else {
+                EGO_RC(egotap_bf16_from_f32(dz, Wh(w.dzb), (int64_t)BT * 2048, stream));
+                EGO_RC(egotap_bf16_fc1_wgrad(h, e, Wh(w.dzb), e == 0 ? Hb(t.tokens) : Hb(t.hmb), G(gc.w), B, ZERO, scr, scrb, stream));
+                if (e == 0) EGO_RC(egotap_bf16_fc1_dgrad_tokens(h, Wh(w.dzb), Hb(t.w_fc1p_t), dtok, B, stream));
+            }
+        }
+        return EGOTAP_OK;
+    };
+    EGO_RC(encoder_bwd(1, W(w.drotz), nullptr));
+    EGO_RC(encoder_bwd(0, W(w.dposz), Wh(w.Rb[0])));
+    float *F0 = W(w.F[0]), *F1 = W(w.F[1]);
+    void *R0 = Wh(w.Rb[0]), *R1 = Wh(w.Rb[1]), *A4 = Wh(w.A4b), *A3 = Wh(w.A3b);
+    // final LayerNorm: dtok (R0) -> dx (F0, bf16 copy R1); column sums of dx = the last layer's output.dense.bias gradient
+    EGO_RC(egotap_bf16_layernorm_bwd(S(t.X[L]), R0, p.lnf_g, S(t.mf), S(t.rf), nullptr, F0, R1, G(g.lnf_g), G(g.lnf_b), G(g.layer[L - 1].dn_b), M, 0,
+                                     scr, scrb, stream));
+    for (int i = L - 1; i >= 0; --i) {
+        EGO_RC(bucket_done());                                                   // everything above layer i is final
+        const auto& P_ = p.layer[i];
+        const auto& G_ = g.layer[i];
+        const auto& l = t.layer[i];
+        // MLP (dx = F0 fp32, R1 bf16)
+        EGO_RC(egotap_bf16_gemm_tn(R1, D, Hb(l.hid), 4 * D, G(G_.dn_w), M, D, 4 * D, 0, ZERO, scr, scrb, stream));
+        EGO_RC(egotap_bf16_gemm_nt(R1, D, Hb(l.w_dn_t), nullptr, M, 4 * D, D, 3, Hb(l.z), A4, nullptr, 4 * D, stream));              // dz
+        EGO_RC(egotap_bf16_gemm_tn(A4, 4 * D, Hb(l.y2), D, G(G_.up_w), M, 4 * D, D, 0, ZERO, scr, scrb, stream));
+        EGO_RC(egotap_bf16_colsum(A4, 4 * D, G(G_.up_b), M, 4 * D, 0, scr, scrb, stream));
+        EGO_RC(egotap_bf16_gemm_nt(A4, 4 * D, Hb(l.w_up_t), nullptr, M, D, 4 * D, 0, nullptr, R0, nullptr, D, stream));             // dy2
+        EGO_RC(egotap_bf16_layernorm_bwd(S(l.xm), R0, P_.ln2_g, S(l.m2), S(l.r2), F0, F1, R1, G(G_.ln2_g), G(G_.ln2_b), G(G_.o_b), M, 0, scr, scrb,
+                                         stream));                                                                                   // dxm = F1, R1
+        // attention
+        EGO_RC(egotap_bf16_gemm_tn(R1, D, Hb(l.ctx), D, G(G_.o_w), M, D, D, 0, ZERO, scr, scrb, stream));
+        EGO_RC(egotap_bf16_gemm_nt(R1, D, Hb(l.w_o_t), nullptr, M, D, D, 0, nullptr, R0, nullptr, D, stream));                       // dctx
+        EGO_RC(egotap_bf16_attention_bwd(Hb(l.qkv), Hb(l.ctx), R0, S(l.lse), W(w.delta), A3, B, h->seq, heads, stream));            // dqkv
+        float* gw[3] = {G(G_.q_w), G(G_.k_w), G(G_.v_w)};
+        float* gb[3] = {G(G_.q_b), G(G_.k_b), G(G_.v_b)};
+        for (int q = 0; q < 3; ++q) {
+            EGO_RC(egotap_bf16_gemm_tn((const __bf16*)A3 + (size_t)q * D, 3 * D, Hb(l.y1), D, gw[q], M, D, D, 0, ZERO, scr, scrb, stream));
+            EGO_RC(egotap_bf16_colsum((const __bf16*)A3 + (size_t)q * D, 3 * D, gb[q], M, D, 0, scr, scrb, stream));
+        }
+        EGO_RC(egotap_bf16_gemm_nt(A3, 3 * D, Hb(l.w_qkv_t), nullptr, M, D, 3 * D, 0, nullptr, R0, nullptr, D, stream));             // dy1
+        EGO_RC(egotap_bf16_layernorm_bwd(S(t.X[i]), R0, P_.ln1_g, S(l.m1), S(l.r1), F1, F0, i > 0 ? R1 : nullptr, G(G_.ln1_g), G(G_.ln1_b),
+                                         i > 0 ? G(g.layer[i - 1].dn_b) : nullptr, M, 0, scr, scrb, stream));                        // dx = F0, R1
+    }
+    // patch embedding (fp32 operands: the input heatmaps)
+    EGO_RC(egotap_train_gemm_tn(h, 1, F0, 0, hm, nullptr, G(g.patch_w), M, D, 256, 0, 0, scr, scrb, stream));
+    EGO_RC(egotap_train_colsum(F0, 0, G(g.pos_emb), B, h->seq * D, 0, scr, scrb, stream));
+    EGO_RC(egotap_train_patch_split(h, g.pos_emb, G(g.patch_b), G(g.mask_tok), 0, stream));
+    EGO_RC(bucket_done());
+    EGO_RC(bucket_done());
+    return EGOTAP_OK;
+}
+
 extern "C" int egotap_lift_forward_train(egotap_handle h, const float* hm, int B, float* pose, void* saved, size_t saved_bytes, void* ws,
                                          size_t ws_bytes, void* stream) {
     EGO_CHECK(h && hm && pose && saved && ws && B > 0, "egotap_lift_forward_train: bad argument");
     EGO_RC(lift_resolve(h));
+    if (lift_train_bf16s(h)) return lift_forward_train16(h, hm, B, pose, saved, saved_bytes, ws, ws_bytes, stream);
     LiftTrainPlan t; LiftBwdPlan w;
     EGO_RC(lift_train_plan(h, B, t, w));
     EGO_CHECK(saved_bytes >= t.total, "egotap_lift_forward_train: saved buffer too small (%zu < %zu)", saved_bytes, t.total);
@@ -2572,12 +2809,13 @@ extern "C" int egotap_lift_backward(egotap_handle h, const float* hm, const floa
         EGO_RC(lift_resolve_into(h, h->bound_grad, h->lg, false));
         h->grad_resolved = true;
     }
+    const int L = h->cfg.vit_layers;
+    EGO_CHECK(n_events == 0 || (bucket_events && n_events == L + 2), "egotap_lift_backward: %d bucket events, the arena has %d buckets", n_events, L + 2);
+    if (lift_train_bf16s(h)) return lift_backward16(h, hm, dpose, B, saved, saved_bytes, ws, ws_bytes, bucket_events, n_events, stream);
     LiftTrainPlan t; LiftBwdPlan w;
     EGO_RC(lift_train_plan(h, B, t, w));
     EGO_CHECK(saved_bytes >= t.total, "egotap_lift_backward: saved buffer too small (%zu < %zu)", saved_bytes, t.total);
     EGO_CHECK(ws_bytes >= w.total, "egotap_lift_backward: workspace too small (%zu < %zu)", ws_bytes, w.total);
-    const int L = h->cfg.vit_layers;
-    EGO_CHECK(n_events == 0 || (bucket_events && n_events == L + 2), "egotap_lift_backward: %d bucket events, the arena has %d buckets", n_events, L + 2);
     const LiftParams& p = h->lp;
     const LiftParams& g = h->lg;
     auto G = [](const float* q) { return (float*)q; };

@@ -102,7 +102,7 @@ def _bind_grads(net, h, ga, G):
 
 
 class LiftTrainOneCallFn(torch.autograd.Function):
-    """The fp32 / bf16x3 training step on the one-call ABI: egotap_lift_forward_train keeps the activations in one caller-owned buffer,
+    """The training step (fp32 / bf16x3 arithmetic on fp32 tensors, or the bf16-storage step under EGOTAP_PREC_BF16) on the one-call ABI: egotap_lift_forward_train keeps the activations in one caller-owned buffer,
     egotap_lift_backward writes every gradient into the flat arena (bound once with egotap_bind_grad) and records one event per arena
     bucket, behind which the bucket's all-reduce starts on a side stream while the rest of the backward runs (parallel.GradReducer)."""
 
@@ -580,10 +580,12 @@ def lift_train_forward(net, hm):
     """training-mode forward of EgoTAPAutoEncoder through the HIP operators, differentiable w.r.t. net.parameters()"""
     params = dict(net.named_parameters())
     # net.bf16_storage = False keeps fp32 tensors in HBM under the bf16 arithmetic (round 1's path: operands converted per launch)
-    if getattr(net, "precision", "f32") == "bf16" and net.preset.vit_dim == 1024 and getattr(net, "bf16_storage", True):
-        fn = LiftTrainBf16Fn
+    bf16 = getattr(net, "precision", "f32") == "bf16"
+    bf16s = bf16 and net.preset.vit_dim == 1024 and getattr(net, "bf16_storage", True)
+    if getattr(net, "one_call_training", True) and (bf16s or not bf16 or net.preset.vit_dim != 1024):
+        fn = LiftTrainOneCallFn        # the library picks the bf16-storage step itself (precision bf16, vit_dim 1024)
     else:
-        fn = LiftTrainOneCallFn if getattr(net, "one_call_training", True) else LiftTrainFn
+        fn = LiftTrainBf16Fn if bf16s else LiftTrainFn
     return fn.apply(net, hm, *[params[k] for k in _param_order(net.preset)])
 
 

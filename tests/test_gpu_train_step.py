@@ -210,8 +210,8 @@ def test_wrapper_checkpoint_roundtrip_and_scheduler(tmp_path):
     b.optimize_parameters()
 
 
-@pytest.mark.parametrize("preset,B", [("UnrealEgo", 3), ("EgoCap", 2)])
-def test_one_call_training_abi_equals_the_operator_composition(preset, B):
+@pytest.mark.parametrize("preset,B,mode", [("UnrealEgo", 3, "f32"), ("EgoCap", 2, "f32"), ("UnrealEgo", 3, "bf16"), ("EgoCap", 2, "bf16x3")])
+def test_one_call_training_abi_equals_the_operator_composition(preset, B, mode):
     """egotap_lift_forward_train + egotap_lift_backward (the one-call ABI the wrapper trains through) against the same step composed
     operator by operator from Python (net.one_call_training = False): pose, every gradient and the BatchNorm running statistics are
     bit-identical -- the library composes the same launches in the same order -- and num_batches_tracked advances"""
@@ -226,6 +226,7 @@ def test_one_call_training_abi_equals_the_operator_composition(preset, B):
         net = networks.EgoTAPAutoEncoder(preset_defaults(preset), input_channel_scale=2)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
         net = net.cuda().train()
+        net.set_precision(mode)
         net.one_call_training = one_call
         pose = net(hm)[0]
         PoseLossFn.apply(net, pose, gt, 0.1, -0.01).sum().backward()
