@@ -461,6 +461,18 @@ def bench_latency(net, p, dev):
                 ts.append(time.perf_counter() - t0)
             ts.sort()
             out[f"b{B}_{mode}"] = round(1e3 * ts[len(ts) // 2], 3)
+            if mode == "f32":                      # the same forward replayed from a captured HIP graph (one launch on the host side)
+                for _ in range(3):
+                    net.predict_pose_graphed(hm)
+                ts = []
+                for _ in range(20):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    net.predict_pose_graphed(hm)
+                    torch.cuda.synchronize(dev)
+                    ts.append(time.perf_counter() - t0)
+                ts.sort()
+                out[f"b{B}_{mode}_hip_graph"] = round(1e3 * ts[len(ts) // 2], 3)
     net.set_precision("f32")
     return out
 

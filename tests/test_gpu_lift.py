@@ -236,6 +236,23 @@ def test_lift_forward_graph_capture_replays_bit_identically():
         assert torch.equal(static_out, ref)
 
 
+def test_predict_pose_graphed_equals_eager():
+    """the wrapper's graph-replay inference path (serving at small batches): same bits as the eager call, for two batch sizes and
+    changing inputs; a re-bound parameter (new storage) gets a fresh capture"""
+    from gpu_util import lift_net
+    net, sd_np, p = lift_net("UnrealEgo")
+    for B in (1, 6):
+        for tag in ("a", "b"):
+            hm = torch.from_numpy(synth_input(f"hm_pg_{tag}{B}", (B, p.in_channels, 64, 64))).cuda()
+            assert torch.equal(net.predict_pose_graphed(hm), net.predict_pose(hm))
+    assert len(net._graphs) == 2
+    w = dict(net.named_parameters())["pose_mlp.pose_fcs.0.bias"]
+    w.data = w.data.clone() * 2.0                                  # new storage, new values
+    hm = torch.from_numpy(synth_input("hm_pg_a1", (1, p.in_channels, 64, 64))).cuda()
+    assert torch.equal(net.predict_pose_graphed(hm), net.predict_pose(hm))
+    w.data = w.data / 2.0
+
+
 @pytest.mark.parametrize("preset,B", [("UnrealEgo", 17), ("EgoCap", 9)])
 def test_lift_forward_bf16_storage_mode_against_oracle(preset, B):
     """EGOTAP_PREC_BF16 at a batch that takes the bf16-storage forward (B * 576 >= 4096: bf16 activations in the workspace, LDS-DMA
