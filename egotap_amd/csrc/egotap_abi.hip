@@ -857,7 +857,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     }
     EGO_HIP(hipGetLastError());
     // H15: per-joint pose head (+ global offset and head joint for UnrealEgo)
-    hipLaunchKernelGGL(pose_head_kernel, dim3(B), dim3(256), 0, s, POSZ, HS1, p.pose_w, p.pose_b, p.glob_w, p.glob_b, pose, B,
+    hipLaunchKernelGGL(pose_head_kernel, dim3(B, h->J + 1), dim3(256), 0, s, POSZ, HS1, p.pose_w, p.pose_b, p.glob_w, p.glob_b, pose, B,
                        J, hid, H, h->cfg.estimate_head);
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
@@ -1912,7 +1912,7 @@ extern "C" int egotap_train_pose_head_fwd(egotap_handle h, const float* posz, co
     int rc = lift_resolve(h);
     if (rc != EGOTAP_OK) return rc;
     const LiftParams& p = h->lp;
-    hipLaunchKernelGGL(pose_head_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, posz, hs1, p.pose_w, p.pose_b, p.glob_w, p.glob_b, pose, B,
+    hipLaunchKernelGGL(pose_head_kernel, dim3(B, h->J + 1), dim3(256), 0, (hipStream_t)stream, posz, hs1, p.pose_w, p.pose_b, p.glob_w, p.glob_b, pose, B,
                        h->J, h->hid, h->H, h->cfg.estimate_head);
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;

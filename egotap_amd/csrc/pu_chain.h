@@ -295,7 +295,7 @@ static inline bool pu_chain_launch(hipStream_t s, int resident1, int resident2, 
     return true;
 }
 
-// Pose head: one block per sample.
+// Pose head.
 //   pose_j = Wp . [left_j | right_j | skel_j] + bp  (+ global offset) ; UnrealEgo: head joint = global_mlp[3:6], output LAST.
 // posz: [B*2J, hid] position embeddings (eye-major), hseq: [J, B, H] PU output (time-major).
 static __global__ __launch_bounds__(256) void pose_head_kernel(const float* __restrict__ posz, const float* __restrict__ hseq,
@@ -303,39 +303,39 @@ static __global__ __launch_bounds__(256) void pose_head_kernel(const float* __re
                                                         const float* __restrict__ Wg, const float* __restrict__ bg,
                                                         float* __restrict__ pose, int B, int J, int hid, int H,
                                                         int estimate_head) {
-    __shared__ float other[8];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nw = blockDim.x >> 6;
-    if (tid < 8) other[tid] = 0.f;
-    __syncthreads();
+    // grid (B, J + 1): block (b, j) = joint j of sample b, block (b, J) = the head joint (UnrealEgo).  Wave c < 3 owns coordinate c:
+    // it computes the global output it needs itself (offset c for a joint, head coordinate c for the head block -- a 7680-long dot,
+    // recomputed per joint: 16 x redundant and free) and then its joint's dot, so no wave waits for another and a B = 1 forward
+    // spreads over 17 workgroups instead of running 54 dots on 4 waves (119 us).  Per-lane order and the wave reduction are the
+    // one-block-per-sample kernel's: same bits.
+    const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63, c = tid >> 6;
+    if (c >= 3 || (j == J && !estimate_head)) return;
+    float other = 0.f;
     if (estimate_head) {
-        for (int o = wid; o < 6; o += nw) {
-            float s = 0.f;
-            for (int j = 0; j < J; ++j) {
-                const float* hrow = hseq + ((long)j * B + b) * H;
-                const float* wrow = Wg + (long)o * J * H + (long)j * H;
-                for (int u = lane; u < H; u += 64) s += hrow[u] * wrow[u];
-            }
-            s = wave_sum(s);
-            if (lane == 0) other[o] = s + bg[o];
+        const int o = j == J ? 3 + c : c;
+        float s = 0.f;
+        for (int jj = 0; jj < J; ++jj) {
+            const float* hrow = hseq + ((long)jj * B + b) * H;
+            const float* wrow = Wg + (long)o * J * H + (long)jj * H;
+            for (int u = lane; u < H; u += 64) s += hrow[u] * wrow[u];
         }
-        __syncthreads();
+        s = wave_sum(s);
+        other = s + bg[o];
+    }
+    if (j == J) {
+        if (lane == 0) pose[((long)b * (J + 1) + J) * 3 + c] = other;
+        return;
     }
     const int kin = 2 * hid + H;
-    const int nout = J * 3;
-    for (int o = wid; o < nout; o += nw) {
-        const int j = o / 3, cdim = o - j * 3;
-        const float* wrow = Wp + (long)cdim * kin;
-        const float* left = posz + ((long)b * 2 * J + j) * hid;
-        const float* right = posz + ((long)b * 2 * J + J + j) * hid;
-        const float* hrow = hseq + ((long)j * B + b) * H;
-        float s = 0.f;
-        for (int u = lane; u < hid; u += 64) s += left[u] * wrow[u] + right[u] * wrow[hid + u];
-        for (int u = lane; u < H; u += 64) s += hrow[u] * wrow[2 * hid + u];
-        s = wave_sum(s);
-        if (lane == 0) pose[((long)b * (J + (estimate_head ? 1 : 0)) + j) * 3 + cdim] = s + bp[cdim] + other[cdim];
-    }
-    if (estimate_head && tid < 3) pose[((long)b * (J + 1) + J) * 3 + tid] = other[3 + tid];
+    const float* wrow = Wp + (long)c * kin;
+    const float* left = posz + ((long)b * 2 * J + j) * hid;
+    const float* right = posz + ((long)b * 2 * J + J + j) * hid;
+    const float* hrow = hseq + ((long)j * B + b) * H;
+    float s = 0.f;
+    for (int u = lane; u < hid; u += 64) s += left[u] * wrow[u] + right[u] * wrow[hid + u];
+    for (int u = lane; u < H; u += 64) s += hrow[u] * wrow[2 * hid + u];
+    s = wave_sum(s);
+    if (lane == 0) pose[((long)b * (J + (estimate_head ? 1 : 0)) + j) * 3 + c] = s + bp[c] + other;
 }
 
 
