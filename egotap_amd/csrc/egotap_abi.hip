@@ -616,8 +616,9 @@ static LiftWs lift_ws(const Handle* h, int B) {
     w.F0 = take(JB * (H + 2 * h->hid)); w.G0 = take(JB * 4 * H); w.HS0 = take(JB * H);
     w.F1 = take(JB * H); w.G1 = take(JB * 4 * H); w.HS1 = take(JB * H);
     w.C0 = take((size_t)B * H); w.C1 = take((size_t)B * H); w.ZERO = take((size_t)B * H);
-    w.HPA = take((size_t)B * H); w.HPB = take((size_t)B * H);      // the propagation units' gated state, ping-pong
-    w.FLAGS = take((size_t)((B + 15) / 16) * PU_FLAG_STRIDE);      // step flags of the one-launch PU chain
+    w.HPA = take((size_t)h->J * B * H);                            // the propagation units' gated state: one [B, H] buffer per step
+    w.HPB = w.HPA + al256((size_t)B * H * 4);                      // (the per-step fallback kernels ping-pong between the first two)
+    w.FLAGS = 0;
     w.SPLITK = take(SPLITK_FLOATS);       // split-K partial sums of the small-batch GEMMs (gemm_small)
     w.total = o;
     return w;
@@ -837,8 +838,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     // ... then the two J-step recurrences (layer 0 never reads layer-1 state, so the layers run one after the other)
     EGO_HIP(zero_fill(C0, (size_t)(w.ZERO - w.C0) + al256((size_t)B * H * 4), s));   // C0, C1, ZERO are contiguous (256-byte aligned slices)
     pu_chain_probe(h);
-    unsigned* FLAGS = (unsigned*)F(w.FLAGS);
-    const PuChain ch0{F0, (long)B * NF0, NF0, G0, (long)B * 4 * H, p.h2h0_w, p.h2h0_b, nullptr, 0, HS0, (long)B * H, HPA, (long)(HPB - HPA), FLAGS, B, H, J, 0};
+    const PuChain ch0{F0, (long)B * NF0, NF0, G0, (long)B * 4 * H, p.h2h0_w, p.h2h0_b, nullptr, 0, HS0, (long)B * H, HPA, (long)B * H, B, H, J, 0};
     if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch0, B))
     for (int t = 0; t < J; ++t) {       // the gated state of step t + 1 comes out of step t (ping-pong buffers; zeros at t = 0)
         const float* hp_in = t == 0 ? ZERO : ((t & 1) ? HPA : HPB);
@@ -848,7 +848,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     EGO_HIP(hipGetLastError());
     EGO_HIP((gemm<Tile>(h, "pu1_x2f", ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
     EGO_HIP((gemm<Tile>(h, "pu1_x2h", ALoadPlain{HS0, H}, segmat1(p.x2h1_w, 4 * H, H), EpiBias{segvec1(p.x2h1_b, 4 * H)}, G1, 4L * H, JB, 4 * H, H, s)));
-    const PuChain ch1{F1, (long)B * H, H, G1, (long)B * 4 * H, p.h2h1_w, p.h2h1_b, nullptr, 0, HS1, (long)B * H, HPA, (long)(HPB - HPA), FLAGS, B, H, J, 0};
+    const PuChain ch1{F1, (long)B * H, H, G1, (long)B * 4 * H, p.h2h1_w, p.h2h1_b, nullptr, 0, HS1, (long)B * H, HPA, (long)B * H, B, H, J, 0};
     if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch1, B))
     for (int t = 0; t < J; ++t) {
         const float* hp_in = t == 0 ? ZERO : ((t & 1) ? HPA : HPB);
@@ -1705,8 +1705,8 @@ static PuSaved pu_saved(const Handle* h, int B) {
     w.F0 = take(JB * NF0); w.G0 = take(JB * 4 * H); w.HS0 = take(JB * H); w.C0 = take(JB * H);
     w.F1 = take(JB * H); w.G1 = take(JB * 4 * H); w.HS1 = take(JB * H); w.C1 = take(JB * H);
     w.ZERO = take((size_t)B * H);
-    w.HPA = take((size_t)B * H); w.HPB = take((size_t)B * H);
-    w.FLAGS = take((size_t)((B + 15) / 16) * PU_FLAG_STRIDE);
+    w.HPA = take((size_t)h->J * B * H); w.HPB = w.HPA + al256((size_t)B * H * 4);
+    w.FLAGS = 0;
     w.total = o;
     return w;
 }
@@ -1746,9 +1746,8 @@ extern "C" int egotap_train_pu_fwd(egotap_handle h, const float* posz, const flo
     }
     EGO_HIP(zero_fill(ZERO, (size_t)B * H * 4, s));
     pu_chain_probe(h);
-    unsigned* FLAGS = (unsigned*)F(w.FLAGS);
     // G0 / G1 hold Gin on entry and the full gate pre-activations on exit (in place); C0 / C1 keep the cell state of every step
-    const PuChain ch0{F0, (long)B * NF0, NF0, G0, (long)B * 4 * H, p.h2h0_w, p.h2h0_b, C0, (long)B * H, HS0, (long)B * H, HPA, (long)(HPB - HPA), FLAGS, B, H, J, 1};
+    const PuChain ch0{F0, (long)B * NF0, NF0, G0, (long)B * 4 * H, p.h2h0_w, p.h2h0_b, C0, (long)B * H, HS0, (long)B * H, HPA, (long)B * H, B, H, J, 1};
     if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch0, B))
     for (int t = 0; t < J; ++t) {
         const float* hp_in = t == 0 ? ZERO : ((t & 1) ? HPA : HPB);
@@ -1760,7 +1759,7 @@ extern "C" int egotap_train_pu_fwd(egotap_handle h, const float* posz, const flo
     EGO_HIP(hipGetLastError());
     EGO_HIP((gemm<Tile>(h, "pu1_x2f", ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
     EGO_HIP((gemm<Tile>(h, "pu1_x2h", ALoadPlain{HS0, H}, segmat1(p.x2h1_w, 4 * H, H), EpiBias{segvec1(p.x2h1_b, 4 * H)}, G1, 4L * H, JB, 4 * H, H, s)));
-    const PuChain ch1{F1, (long)B * H, H, G1, (long)B * 4 * H, p.h2h1_w, p.h2h1_b, C1, (long)B * H, HS1, (long)B * H, HPA, (long)(HPB - HPA), FLAGS, B, H, J, 1};
+    const PuChain ch1{F1, (long)B * H, H, G1, (long)B * 4 * H, p.h2h1_w, p.h2h1_b, C1, (long)B * H, HS1, (long)B * H, HPA, (long)B * H, B, H, J, 1};
     if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch1, B))
     for (int t = 0; t < J; ++t) {
         const float* hp_in = t == 0 ? ZERO : ((t & 1) ? HPA : HPB);

@@ -15,9 +15,9 @@
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-static __global__ void zero_fill_u32_kernel(unsigned* p, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0u;
+static __global__ void fill_u32_kernel(unsigned* p, long n, unsigned v) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 
 // One recurrent step of a PU layer.  The gated state hp_t = sigmoid(F_t[:, 0:H]) * h_{t-1} is produced by the PREVIOUS step's pointwise
@@ -117,22 +117,24 @@ static inline void pu_step_launch(hipStream_t s, int B, int H, const float* hp_i
 
 // The whole J-step recurrence of one PU layer in ONE launch.  What a step kernel re-reads every step -- its 256 KiB slice of Whh, at the
 // 66-73 GB/s per CU an XCD's L2 serves (4 us of a 14 us step, 8 us as measured with half-used lines) -- lives in the waves' registers
-// here (64 VGPRs per lane for UT = 2), and the launch boundary becomes a flag wait among the workgroups that share a row block:
+// here (64 VGPRs per lane for UT = 2), and the launch boundary becomes a hand-off among the workgroups that share a row block:
 // the only cross-workgroup dependence of step t is on the gated state hp_t of the SAME 16 rows, all H units (H / (16 UT) workgroups).
-//   hp is stored write-through (agent-scope atomic stores) and read with sc1 loads, so no L2 write-back / invalidate is needed:
-//   __syncthreads (stores acknowledged), publish this workgroup's step flag, bounded spin on the row block's flags, __syncthreads, hp loads.
+//   Hand-off (cdna_hip_programming.md Guideline 16, form R2 "the data is the flag"): every step has its own hp buffer, armed with a
+//   sentinel word before the launch; owners store hp write-through (agent-scope atomic stores), consumers re-read their fragments
+//   with sc1 loads until no word is the sentinel.  No flag, no L2 write-back / invalidate, no drain-barrier-publish-poll sequence.
+//   (Earlier forms, per step at B = 256: release / acquire fences from every wave 85 us, from one wave 19.7; one atomic counter per row
+//   block 18.1 -- 16 XCD-crossing adders queue on a line; one flag word per workgroup 9.9; this 9.5.)
 // Workgroups of a row block must be co-resident (they wait for each other): the launcher sizes the grid from the occupancy query and
 // walks larger batches in row chunks; the spin is bounded so that a wave always reaches its exit.
 // Arithmetic, k order and reduction order are those of pu_step_r16_kernel (bit-identical results).
-constexpr int PU_FLAG_STRIDE = 64;              // unsigned per row block: 256 B, so that row blocks do not share a line / channel
+constexpr unsigned PU_SENTINEL = 0x7fc0deadu;   // "not stored yet" in the gated-state buffers (a NaN payload arithmetic never produces)
 struct PuChain {
     const float* F; long f_step; int ldf;       // gate logits: F + t * f_step + row * ldf + unit  (sigmoid gates h_{t-1})
     float* G; long g_step;                      // Gin_t [rows, 4H] at G + t * g_step; keep_gates: overwritten with the gate pre-activations
     const float* Whh; const float* bhh;
     float* C; long c_step;                      // c_t of every step (training) or nullptr
     float* HS; long hs_step;                    // h_t at HS + t * hs_step
-    float* HP; long hp_stride;                  // gated state, two buffers
-    unsigned* cnt;                              // PU_FLAG_STRIDE step flags per row block (one per workgroup), zero on entry
+    float* HP; long hp_stride;                  // gated state hp_{t+1} at HP + t * hp_stride (J - 1 buffers), PU_SENTINEL-filled on entry
     int rows, H, J, keep_gates;
 };
 
@@ -167,8 +169,7 @@ static __global__ __launch_bounds__(1024) void pu_chain_kernel(const PuChain p) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) bg[q] = p.bhh[q * H + punit];
     }
-    unsigned* flags = p.cnt + (long)rb * PU_FLAG_STRIDE;
-    bool dead = false;                           // wave 0: a wait ran out (the group is not co-resident); stop waiting, finish
+    bool dead = false;                           // this wave: a wait ran out (the row block is not co-resident); stop waiting, finish
     // what does not depend on the state is requested one step ahead, before the wait
     float gin[4] = {0.f, 0.f, 0.f, 0.f}, fnext = 0.f;
     auto fetch = [&](int t) {
@@ -185,22 +186,36 @@ static __global__ __launch_bounds__(1024) void pu_chain_kernel(const PuChain p) 
 #pragma unroll
         for (int tl = 0; tl < UT; ++tl) acc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (t > 0) {                             // hp_0 = 0: the recurrent product of the first step is the bias alone
-            const float* hp = p.HP + (long)((t - 1) & 1) * p.hp_stride + (long)arow * H + k0 + 4 * lg;
+            const float* hp = p.HP + (long)(t - 1) * p.hp_stride + (long)arow * H + k0 + 4 * lg;
             f32x4 a[8];
-            // agent-coherent reads (sc1): served from memory / the Infinity Cache, never from a line this XCD cached a step ago
-            asm volatile(
-                "global_load_dwordx4 %0, %8, off sc1\n\t"
-                "global_load_dwordx4 %1, %8, off offset:64 sc1\n\t"
-                "global_load_dwordx4 %2, %8, off offset:128 sc1\n\t"
-                "global_load_dwordx4 %3, %8, off offset:192 sc1\n\t"
-                "global_load_dwordx4 %4, %8, off offset:256 sc1\n\t"
-                "global_load_dwordx4 %5, %8, off offset:320 sc1\n\t"
-                "global_load_dwordx4 %6, %8, off offset:384 sc1\n\t"
-                "global_load_dwordx4 %7, %8, off offset:448 sc1\n\t"
-                "s_waitcnt vmcnt(0)"
-                : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
-                : "v"(hp)
-                : "memory");
+            // THE DATA IS THE FLAG: hp_t's buffer holds PU_SENTINEL words until its owners have stored it (write-through); each wave
+            // re-reads its own fragments with agent-coherent loads (sc1: from memory / the Infinity Cache, never from a cached line)
+            // until none of its 32 words is the sentinel.  No flag word, no drain + barrier + publish + poll round trips on the
+            // critical path: one store and one load per hand-off.  hp = sigmoid * o * tanh is finite and a computed NaN is the
+            // canonical 0x7fc00000, never the sentinel.
+            for (int spins = 0;;) {
+                asm volatile(
+                    "global_load_dwordx4 %0, %8, off sc1\n\t"
+                    "global_load_dwordx4 %1, %8, off offset:64 sc1\n\t"
+                    "global_load_dwordx4 %2, %8, off offset:128 sc1\n\t"
+                    "global_load_dwordx4 %3, %8, off offset:192 sc1\n\t"
+                    "global_load_dwordx4 %4, %8, off offset:256 sc1\n\t"
+                    "global_load_dwordx4 %5, %8, off offset:320 sc1\n\t"
+                    "global_load_dwordx4 %6, %8, off offset:384 sc1\n\t"
+                    "global_load_dwordx4 %7, %8, off offset:448 sc1\n\t"
+                    "s_waitcnt vmcnt(0)"
+                    : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
+                    : "v"(hp)
+                    : "memory");
+                bool missing = false;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) missing |= __float_as_uint(a[i][u]) == PU_SENTINEL;
+                if (__builtin_amdgcn_ballot_w64(missing) == 0) break;
+                if (dead || ++spins > (1 << 16)) { dead = true; break; }     // the row block is not co-resident: stop waiting, finish (NaNs)
+                __builtin_amdgcn_s_sleep(1);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -234,31 +249,12 @@ static __global__ __launch_bounds__(1024) void pu_chain_kernel(const PuChain p) 
             p.HS[(long)t * p.hs_step + (long)prow * H + punit] = hn;
             // written through to memory (agent scope): no L2 write-back needed before the other XCDs may read it
             if (t + 1 < p.J)
-                __hip_atomic_store(p.HP + (long)(t & 1) * p.hp_stride + (long)prow * H + punit, sigmoidf_(fnext) * hn, __ATOMIC_RELAXED,
+                __hip_atomic_store(p.HP + (long)t * p.hp_stride + (long)prow * H + punit, sigmoidf_(fnext) * hn, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
         if (t + 1 < p.J) {
             fetch(t + 1);
-            // workgroup barrier: every wave's hp stores are acknowledged (vmcnt) and every read of red is done; then one thread
-            // counts the workgroup in and waits for the other workgroups of the row block.  No cache maintenance: hp moves with
-            // write-through stores and sc1 loads, everything else a workgroup reads back is its own.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores itself
-            __syncthreads();
-            if (wid == 0) {
-                // one flag per workgroup (no read-modify-write, no shared counter for 16 XCD-crossing adders to queue on): the
-                // workgroup publishes the step it has finished, lanes 0..NBG-1 watch the row block's NBG flags (one line)
-                if (lane == 0) __hip_atomic_store(flags + (blockIdx.x % NBG), (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!dead) {
-                    int spins = 0;
-                    for (;;) {
-                        const unsigned f = lane < NBG ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-                        if (__builtin_amdgcn_ballot_w64(f < (unsigned)(t + 1)) == 0) break;
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1 << 18)) { dead = true; break; }
-                    }
-                }
-            }
-            __syncthreads();
+            __syncthreads();                     // every read of red is done before the next step's partial sums are written
         }
     }
 }
@@ -273,7 +269,7 @@ static inline int pu_chain_resident() {
     return per_cu * prop.multiProcessorCount;
 }
 
-// One PU layer over all J steps of B rows.  cnt: PU_FLAG_STRIDE * ((B + 15) / 16) flags, zeroed here.  resident1/resident2: pu_chain_resident<1/2>().
+// One PU layer over all J steps of B rows (p.HP: (J - 1) * hp_stride floats, armed here).  resident1/resident2: pu_chain_resident<1/2>().
 // Returns false when the chain kernel cannot run here (the caller then walks the steps with pu_step_launch).
 static inline bool pu_chain_launch(hipStream_t s, int resident1, int resident2, PuChain p, int B) {
     const int nrb = (B + 15) / 16;
@@ -281,13 +277,15 @@ static inline bool pu_chain_launch(hipStream_t s, int resident1, int resident2, 
     const int nbg = small ? 32 : 16, resident = small ? resident1 : resident2;
     const int chunk_rb = resident / nbg;
     if (chunk_rb < 1) return false;
-    hipLaunchKernelGGL(zero_fill_u32_kernel, dim3((nrb * PU_FLAG_STRIDE + 255) / 256), dim3(256), 0, s, p.cnt, nrb * PU_FLAG_STRIDE);
+    {   // every gated-state word starts as "not stored yet" (a kernel, so a captured graph re-arms it on every replay)
+        const long n = (long)(p.J - 1) * p.hp_stride;
+        hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned*)p.HP, n, PU_SENTINEL);
+    }
     for (int rb0 = 0; rb0 < nrb; rb0 += chunk_rb) {
         const int nb = min(chunk_rb, nrb - rb0), row0 = rb0 * 16;
         PuChain q = p;
         q.F = p.F + (long)row0 * p.ldf; q.G = p.G + (long)row0 * 4 * p.H; q.HS = p.HS + (long)row0 * p.H; q.HP = p.HP + (long)row0 * p.H;
         if (p.C) q.C = p.C + (long)row0 * p.H;
-        q.cnt = p.cnt + (long)rb0 * PU_FLAG_STRIDE;
         q.rows = min(B - row0, nb * 16);
         if (small) hipLaunchKernelGGL(pu_chain_kernel<1>, dim3(nb * nbg), dim3(1024), 0, s, q);
         else hipLaunchKernelGGL(pu_chain_kernel<2>, dim3(nb * nbg), dim3(1024), 0, s, q);

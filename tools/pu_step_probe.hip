@@ -157,9 +157,8 @@ int main(int argc, char** argv) {
     }
     // the one-launch chain against the step kernels: same bits, time per step
     {
-        float *G2, *HS2, *HP2; unsigned* cnt;
-        CK(hipMalloc(&G2, (size_t)J * B * 4 * H * 4)); CK(hipMalloc(&HS2, (size_t)J * B * H * 4)); CK(hipMalloc(&HP2, (size_t)2 * B * H * 4));
-        CK(hipMalloc(&cnt, (size_t)((B + 15) / 16) * PU_FLAG_STRIDE * 4));
+        float *G2, *HS2, *HP2;
+        CK(hipMalloc(&G2, (size_t)J * B * 4 * H * 4)); CK(hipMalloc(&HS2, (size_t)J * B * H * 4)); CK(hipMalloc(&HP2, (size_t)J * B * H * 4));
         CK(hipMemcpy(G2, hw.data(), (size_t)J * B * 4 * H * 4, hipMemcpyHostToDevice));
         // reference: step kernels (library launcher)
         CK(hipMemset(C, 0, (size_t)B * H * 4));
@@ -171,7 +170,7 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(s));
         const int r1 = pu_chain_resident<1>(), r2 = pu_chain_resident<2>();
         printf("resident workgroups: UT=1 %d, UT=2 %d\n", r1, r2);
-        PuChain pc{F, (long)B * NF, NF, G2, (long)B * 4 * H, W, b, nullptr, 0, HS2, (long)B * H, HP2, (long)B * H, cnt, B, H, J, 0};
+        PuChain pc{F, (long)B * NF, NF, G2, (long)B * 4 * H, W, b, nullptr, 0, HS2, (long)B * H, HP2, (long)B * H, B, H, J, 0};
         float best = 1e9f;
         for (int rep = 0; rep < 6; ++rep) {
             CK(hipEventRecord(e0, s));
