@@ -316,3 +316,49 @@ def test_config4_two_rank_wrapper_step_on_one_gpu(tmp_path):
             assert float((a - mean).abs().max()) <= tol, (k, r, float((a - mean).abs().max()), tol)
     for k in got[0]:
         assert torch.equal(got[0][k], got[1][k]), k                 # ranks stay in lock step (grads and parameters)
+
+
+# ------------------------------------------------------------------------------------------------------------ frozen estimators' BatchNorm
+def test_frozen_estimators_batchnorm_flag_reproduces_the_reference_train_mode(tmp_path):
+    """train.py:91 calls model.train() on the wrapper, so the reference's FROZEN estimators normalise with batch statistics and keep
+    updating their running statistics while the head trains (egotap_autoencoder_model.py:127-129 freezes parameters only).  Default
+    here: eval-mode estimators (what the stage-1 checkpoints were validated with); opt.frozen_heatmap_bn_train
+    reproduces the reference: heatmaps = the train-mode forward of hm_training (oracle-checked in test_gpu_hm_train_step.py), running
+    statistics move, parameters do not."""
+    from egotap_amd import models, options, spec
+    from egotap_amd.hm_training import hm_train_forward_nograd
+    from egotap_amd.synthetic import synth_hm_state_dict
+    sd_pos = {k: torch.from_numpy(v) for k, v in synth_hm_state_dict(15, "hm_pos.").items()}
+    sd_rot = {k: torch.from_numpy(v) for k, v in synth_hm_state_dict(30, "hm_rot.").items()}
+    for sub, sd in (("hm_pos", sd_pos), ("hm_sin", sd_rot)):
+        os.makedirs(tmp_path / sub)
+        torch.save(sd, tmp_path / sub / "best_net_HeatMap.pth")
+    B = 2
+    data = {"input_rgb_left": torch.from_numpy(synth_input("rgb_l_bn", (B, 3, 256, 256), -2.0, 2.0)),
+            "input_rgb_right": torch.from_numpy(synth_input("rgb_r_bn", (B, 3, 256, 256), -2.0, 2.0)),
+            "gt_local_pose": torch.from_numpy(synth_input("gt_bn", (B, 16, 3), -20.0, 20.0))}
+    key = "backbone.backbone.backbone.bn1.running_mean"
+    cats = {}
+    for flag in (False, True):
+        m, p = _model(use_gt_heatmap=False, log_dir=str(tmp_path), path_to_trained_heatmap=str(tmp_path / "hm" / "best_net_HeatMap.pth"),
+                      frozen_heatmap_bn_train=flag)
+        m.train() if hasattr(m, "train") else None
+        m.net_HeatMap.train(); m.net_RotHeatMap.train()                       # what train.py's model.train() does to the sub-modules
+        before = {k: v.clone() for k, v in m.net_HeatMap.state_dict().items()}
+        m.set_input(data)
+        m.optimize_parameters()
+        after = m.net_HeatMap.state_dict()
+        moved = not torch.equal(before[key], after[key])
+        assert moved == flag
+        for k, v in m.net_HeatMap.named_parameters():
+            assert torch.equal(before[k], after[k]) and not v.requires_grad      # frozen either way
+        cats[flag] = m.pred_heatmap_cat.clone()
+        if flag:
+            # the heatmaps the head trained on are the train-mode forward (batch statistics per eye) of the estimators as they were
+            ref = models.create_model(m.opt)
+            ref.net_HeatMap.load_state_dict(before)
+            ref.net_HeatMap.train()
+            J = p.n_joints_hm
+            want = hm_train_forward_nograd(ref.net_HeatMap, m.input_rgb_left.float().contiguous(), m.input_rgb_right.float().contiguous())
+            assert torch.equal(cats[True][:, :2 * J], want)
+    assert not torch.equal(cats[False], cats[True])
