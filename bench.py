@@ -367,11 +367,14 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
     for _ in range(2):
         m.optimize_parameters()                  # warm-up (allocator, BN buffers, optimizer state)
     barrier()
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for _ in range(args.train_steps):
         m.optimize_parameters()
     torch.cuda.synchronize(dev)
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    ms1 = torch.cuda.memory_stats(dev)
+    dev_allocs = ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)      # hipMalloc calls inside the timed region (should be 0)
     barrier()
     errs = m.get_current_errors()
     fps = world * B * args.train_steps / elapsed
@@ -390,7 +393,7 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
             "steps": args.train_steps, "batch_per_gpu": B, "dtype": mode, "flops_per_frame": flops,
             "end_to_end_tflops_per_gpu": round(fps * flops / world / 1e12, 2), **frac_fields(mode, fps * flops / world / 1e12),
             "loss_pose": errs.get("pose"), "loss_cos_sim": errs.get("cos_sim"), "peak_hbm_gib": round(peak_gb, 1),
-            "allreduce_exposed_ms_last_step": round(exposed, 3),
+            "allreduce_exposed_ms_last_step": round(exposed, 3), "device_allocations_in_timed_region": int(dev_allocs),
             "input": "RGB frames through the two frozen heatmap estimators (eval-mode BatchNorm, --use_amp arithmetic), then the head" if from_rgb
                      else "resident heatmaps (--use_gt_heatmap): the frozen estimators are not run",
             "note": "gradient all-reduce (N > 1) overlapped with the backward, bucket by bucket, in place on a flat arena; the attention "
@@ -515,6 +518,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     # rehearsal on a one-GPU box: EGOTAP_DIST_BACKEND=gloo lets several ranks share cuda:0 (RCCL needs one device per rank)
     backend = os.environ.get("EGOTAP_DIST_BACKEND", "nccl")
+    if backend != "nccl" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ["EGOTAP_SHARED_DEVICE"] = "1"      # ranks share one GPU: kernels that need the device to themselves are switched off
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)

@@ -136,6 +136,7 @@ struct egotap_handle_s {
     HmParams hp[EGOTAP_NET_COUNT];
     int debug_stop = 0;
     int pu_resident[2] = {-1, -1};     // workgroups of pu_chain_kernel<1> / <2> the device keeps resident (-1: not asked yet)
+    bool pu_chain = true;              // egotap_set_pu_chain: one-launch recurrence (needs the device to itself) or per-step kernels
     int precision = EGOTAP_PREC_F32;   // arithmetic of the large GEMMs (egotap_set_precision)
     __bf16* wscratch = nullptr;        // scratch for the bf16 copy of a GEMM's weight matrix (plain-bf16 mode), caller-owned
     size_t wscratch_bytes = 0;
@@ -596,7 +597,8 @@ static hipError_t fc_gemm(Handle* h, const char* role, const AL& al, const SegMa
 // ------------------------------------------------------------------------------------------------ workspace
 // asks the device once how many workgroups of the one-launch PU chain it keeps resident (pu_chain.h)
 static void pu_chain_probe(Handle* h) {
-    if (h->pu_resident[0] < 0) {
+    if (!h->pu_chain) { h->pu_resident[0] = h->pu_resident[1] = 0; return; }      // 0 resident workgroups: pu_chain_launch declines
+    if (h->pu_resident[0] <= 0) {
         h->pu_resident[0] = pu_chain_resident<1>();
         h->pu_resident[1] = pu_chain_resident<2>();
     }
@@ -649,6 +651,12 @@ extern "C" int egotap_lift_intermediate(egotap_handle h, int B, const char* name
 #endif
 
 #if EGOTAP_IN(0)
+extern "C" int egotap_set_pu_chain(egotap_handle h, int enable) {
+    EGO_CHECK(h, "null handle");
+    h->pu_chain = enable != 0;
+    h->pu_resident[0] = h->pu_resident[1] = -1;
+    return EGOTAP_OK;
+}
 extern "C" int egotap_set_precision(egotap_handle h, int mode) {
     EGO_CHECK(h, "null handle");
     EGO_CHECK(mode == EGOTAP_PREC_F32 || mode == EGOTAP_PREC_BF16X3 || mode == EGOTAP_PREC_BF16, "egotap_set_precision: unknown mode %d", mode);

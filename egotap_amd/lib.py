@@ -37,6 +37,7 @@ _PROTOS = {
     "egotap_lift_intermediate": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "egotap_lift_debug_stop": (C.c_int, [C.c_void_p, C.c_int]),
     "egotap_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "egotap_set_pu_chain": (C.c_int, [C.c_void_p, C.c_int]),
     "egotap_set_weight_scratch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "egotap_set_act_scratch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "egotap_hm_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),

@@ -9,6 +9,7 @@ the HIP library or off the GPU these modules raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -106,7 +107,16 @@ class EgoTAPAutoEncoder(nn.Module):
             h = C.c_void_p()
             _lib.check(_lib.load().egotap_create(C.byref(cfg), C.byref(h)))
             self._handle = h
+            if os.environ.get("EGOTAP_SHARED_DEVICE", "0") == "1":      # several processes on one GPU (rehearsals, tests): see set_pu_chain
+                _lib.check(_lib.load().egotap_set_pu_chain(h, 0))
         return self._handle
+
+    def set_pu_chain(self, enable: bool = True):
+        """The propagation units' recurrence as one launch per layer (default; its workgroups wait for each other, so the process must
+        have the GPU to itself while a forward runs) or as one kernel per step (enable = False: safe on a shared device, same bits).
+        EGOTAP_SHARED_DEVICE=1 in the environment selects the per-step kernels for every module of the process."""
+        _lib.check(_lib.load().egotap_set_pu_chain(self._ensure_handle(), int(bool(enable))))
+        return self
 
     def _bind(self, device):
         sd = dict(self.named_parameters())

@@ -105,6 +105,13 @@ int egotap_hm_intermediate(egotap_handle h, int B, const char* name, size_t* off
  * weight-gradient GEMMs of the training step) for shapes the bf16 kernels cover (N, K multiples of 256, M >= 1024). */
 enum { EGOTAP_PREC_F32 = 0, EGOTAP_PREC_BF16X3 = 1, EGOTAP_PREC_BF16 = 2 };
 int egotap_set_precision(egotap_handle h, int mode);
+/* The propagation units' recurrence (custom_cells.py:149-197) runs as ONE launch per layer whose workgroups hand the state to each other
+ * inside the launch: they must all be resident together, which holds when the calling process has the device to itself while a
+ * forward runs (one process per GPU, the deployment this library is written for).  Where the device is shared -- another process, or
+ * another stream of this one running long kernels -- pass enable = 0: the recurrence then runs as one kernel per step (same bits,
+ * ~2x the latency of that part).  With the chain enabled on a shared device the waits inside it are bounded and run out: the call
+ * returns, the poses are NaN. */
+int egotap_set_pu_chain(egotap_handle h, int enable);
 /* EGOTAP_PREC_BF16 only: caller-owned device scratch (16-byte aligned) into which a GEMM's weight matrix is rounded to bf16 right
  * before the launch (stream ordered; nothing is cached, the live fp32 parameters stay the source of truth).  Halves the W operand's
  * vector-memory bytes, which bound that mode.  bytes >= 2 * the largest N*K (67 MB for fc1 of the position encoder); NULL = off. */

@@ -267,7 +267,7 @@ def test_config5_egocap_hm128_train_step_against_oracle():
 # ------------------------------------------------------------------------------------------------------------ config 4 (2 ranks)
 def _ddp_worker(rank, world, port, out_dir):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", EGOTAP_SHARED_DEVICE="1")      # two processes on one GPU: per-step PU kernels
     import sys
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))

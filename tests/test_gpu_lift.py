@@ -236,6 +236,26 @@ def test_lift_forward_graph_capture_replays_bit_identically():
         assert torch.equal(static_out, ref)
 
 
+def test_pu_chain_switch_gives_the_same_bits():
+    """egotap_set_pu_chain(h, 0) -- the propagation units' recurrence as one kernel per step, for a device shared with other
+    processes -- against the default one-launch recurrence: same poses bit for bit, inference and training forward"""
+    from gpu_util import lift_net
+    net, sd_np, p = lift_net("UnrealEgo")
+    hm = torch.from_numpy(synth_input("hm_chain_switch", (37, p.in_channels, 64, 64))).cuda()
+    a = net.predict_pose(hm).clone()
+    try:
+        net.set_pu_chain(False)
+        b = net.predict_pose(hm).clone()
+        net.train()
+        tb = net(hm)[0].detach().clone()
+        net.set_pu_chain(True)
+        ta = net(hm)[0].detach().clone()
+    finally:
+        net.set_pu_chain(True)
+        net.eval()
+    assert torch.equal(a, b) and torch.equal(ta, tb) and torch.isfinite(a).all()
+
+
 def test_predict_pose_graphed_equals_eager():
     """the wrapper's graph-replay inference path (serving at small batches): same bits as the eager call, for two batch sizes and
     changing inputs; a re-bound parameter (new storage) gets a fresh capture"""
