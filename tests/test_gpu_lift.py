@@ -243,16 +243,21 @@ def test_pu_chain_switch_gives_the_same_bits():
     net, sd_np, p = lift_net("UnrealEgo")
     hm = torch.from_numpy(synth_input("hm_chain_switch", (37, p.in_channels, 64, 64))).cuda()
     a = net.predict_pose(hm).clone()
+    bufs = {k: v.clone() for k, v in net.named_buffers()}        # the net is shared by the tests: a train-mode forward moves its BatchNorm statistics
     try:
         net.set_pu_chain(False)
         b = net.predict_pose(hm).clone()
         net.train()
         tb = net(hm)[0].detach().clone()
+        for k, v in net.named_buffers():
+            v.copy_(bufs[k])
         net.set_pu_chain(True)
         ta = net(hm)[0].detach().clone()
     finally:
         net.set_pu_chain(True)
         net.eval()
+        for k, v in net.named_buffers():
+            v.copy_(bufs[k])
     assert torch.equal(a, b) and torch.equal(ta, tb) and torch.isfinite(a).all()
 
 
