@@ -149,6 +149,12 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
         }
     };
 
+    // Tried in round 2 and dropped: the two-group schedule of gemm_bf16s.h (two groups of four waves one barrier apart, a phase =
+    // [DMA of half a slab; fragment reads; vmcnt] barrier [32 MFMAs] barrier, so that one wave's DMA issue, fragment reads and barrier
+    // skew sit under the other wave's MFMA burst).  Correct and bit-identical, but 130.6 TF against 139.0 on the same box (129.8 with
+    // the fragments prefetched one phase ahead): with v_mfma_f32_32x32x2_f32 a SIMD's matrix pipe is fed better by two waves
+    // interleaving their MFMAs than by one wave at a time -- a single wave leaves a few idle cycles between its back-to-back MFMAs,
+    // which costs more than the ~8 % of exposed issue work the lockstep schedule pays per slab.
     // Pipeline.  The barrier sits in the MIDDLE of a slab: [fragments t=1 of slab gs] [32 MFMAs t=0] wait + barrier (slab gs+1
     // has landed for everyone, nobody reads stage gs-1 any more) [DMA slab gs+3 -> stage gs-1] [fragments t=0 of slab gs+1]
     // [32 MFMAs t=1].  Every fragment read is issued one MFMA group ahead of its use, so no LDS latency is exposed after the
