@@ -78,18 +78,24 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
     };
     // one slab of this block's slab stream -> stage st.  Unconditional (past the end it re-reads the last slab into a stage
     // nobody reads) so that the number of DMA instructions in flight is a constant the waits below can count on.
-    auto dma = [&](int st) __attribute__((always_inline)) {
+    auto dma_part = [&](int st, int part) __attribute__((always_inline)) {       // one of the four DMA instructions of a slab
         const unsigned sa = lds0 + st * Cfg::STAGE + wid * 1024;
         const int k0 = l_kt * BK;
-        dma1(al.ptr(ra0, k0 + dchunk * 4), sa);
-        dma1(al.ptr(ra1, k0 + dchunk * 4), sa + 8 * 1024);
-        dma1(pb0 + k0, sa + BM * ROWB);
-        dma1(pb1 + k0, sa + BM * ROWB + 8 * 1024);
+        if (part == 0) dma1(al.ptr(ra0, k0 + dchunk * 4), sa);
+        else if (part == 1) dma1(al.ptr(ra1, k0 + dchunk * 4), sa + 8 * 1024);
+        else if (part == 2) dma1(pb0 + k0, sa + BM * ROWB);
+        else dma1(pb1 + k0, sa + BM * ROWB + 8 * 1024);
+    };
+    auto dma_advance = [&]() __attribute__((always_inline)) {
         if (l_tile < my_n && ++l_kt == KT) {
             l_kt = 0;
             if (++l_tile < my_n) set_rows(l_tile);
             else l_kt = KT - 1;                 // stream exhausted: keep pointing at the last slab
         }
+    };
+    auto dma = [&](int st) __attribute__((always_inline)) {
+        dma_part(st, 0); dma_part(st, 1); dma_part(st, 2); dma_part(st, 3);
+        dma_advance();
     };
 
     f32x16 acc[TM][TN];
@@ -174,16 +180,23 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
     for (int gs = 0; gs < total; ++gs) {
         const char* sa = smem_dmaf + st * Cfg::STAGE;
         const int st1 = st + 1 == NS ? 0 : st + 1;
+        // the six fragment reads of the NEXT burst are issued one by one behind the first MFMAs of this one (same reason as the DMA
+        // issues below: in front of the burst they are issue cycles with the matrix pipe idle)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a1[i] = *(const f32x4*)(sa + a_base + i * 32 * ROWB + f1);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b1[j] = *(const f32x4*)(sa + b_base + j * 32 * ROWB + f1);
+        for (int q = 0; q < 6; ++q) {
+            acc[q & 1][q >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q & 1][0], b0[q >> 1][0], acc[q & 1][q >> 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q < TM) a1[q] = *(const f32x4*)(sa + a_base + q * 32 * ROWB + f1);
+            else b1[q - TM] = *(const f32x4*)(sa + b_base + (q - TM) * 32 * ROWB + f1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][u], b0[j][u], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+                    if (u > 0 || j >= 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][u], b0[j][u], acc[i][j], 0, 0, 0);
         // slab gs+1 has landed once at most the 4 DMA instructions of slab gs+2 are outstanding (vmcnt is in order; stores of an
         // epilogue in between only make the wait longer)
         // ... which is why the wait is skipped right after an epilogue: it was done in front of the epilogue's stores (below), and
@@ -191,18 +204,36 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
         if (!after_epi) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         after_epi = false;
         __syncthreads();
-        dma(st == 0 ? NS - 1 : st - 1);
+        // The four DMA instructions of slab gs+3 are issued BETWEEN the first MFMAs of this burst (their operands a1 / b1 were read
+        // before the barrier): a DMA costs the issuing SIMD ~56 issue cycles, and issued in front of the burst -- by both waves of
+        // the SIMD at once, they leave the barrier together -- those 224 cycles per slab were matrix-pipe idle time.
+        const int sd = st == 0 ? NS - 1 : st - 1;
         const char* sn = smem_dmaf + st1 * Cfg::STAGE;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a0[i] = *(const f32x4*)(sn + a_base + i * 32 * ROWB + f0);
+        for (int q = 0; q < 4; ++q) {
+            acc[q & 1][q >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q & 1][0], b1[q >> 1][0], acc[q & 1][q >> 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_part(sd, q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dma_advance();
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b0[j] = *(const f32x4*)(sn + b_base + j * 32 * ROWB + f0);
+        for (int q = 0; q < 6; ++q) {             // (i, j) = (0, 2), (1, 2), (0, 3), (1, 3) at u = 0, then (0, 0), (1, 0) at u = 1
+            const int i = q & 1, j = q < 4 ? 2 + (q >> 1) : 0, u = q < 4 ? 0 : 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][u], b1[j][u], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q < TM) a0[q] = *(const f32x4*)(sn + a_base + q * 32 * ROWB + f0);
+            else b0[q - TM] = *(const f32x4*)(sn + b_base + (q - TM) * 32 * ROWB + f0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][u], b1[j][u], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+                    if (u > 1 || (u == 1 && j >= 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][u], b1[j][u], acc[i][j], 0, 0, 0);
         st = st1;
         if (++c_kt == KT) {
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // slab gs+2 (only slab gs+3 may still be in flight)
