@@ -404,6 +404,11 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
         slack_kt = (s_epi_exact<Epi>::value && (tm + 1) * BM <= M && KT >= 4) ? 2 : 0;
     };
 
+    // Tried and dropped (round 2): all 8 waves in lockstep with one barrier per K-tile in its middle and every DMA issue / fragment
+    // read placed between the MFMAs of a burst (the schedule that gained 2 % on gemm_f32_dma.h).  bf16-output GEMMs within +-3 % of
+    // the two-group schedule below (864 / 1069 / 1110 / 1170 TF against 857 / 1072 / 1068 / 1215 at N x K = 3072x1024, 1024x1024,
+    // 4096x1024, 1024x4096), but the fp32-output + residual epilogue, which the two groups run side by side under each other's MFMAs,
+    // falls from 710-1100 TF to 545-790.
     // ---- prologue: K-tiles 0, 1, 2 complete (W then X each), then the steady-state issues of phases 0.. pick up W(3), X(3)
     issue_w(0); issue_x(0);
     issue_w(1); issue_x(1);
