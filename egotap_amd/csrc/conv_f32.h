@@ -314,6 +314,9 @@ struct StemCfg {
     static constexpr int LDS_BYTES = (XS_FLOATS + WS_FLOATS) * 4;
     static constexpr int THREADS = 64 * RG;
 };
+// BF16OUT: the output goes out as bf16 channels-last with the two eyes interleaved -- [B * HO * HO, 2 x 64], image n = 2 b + eye in
+// the 64-channel slice eye * 64 of pixel row b * HO * HO + y * HO + x (the layout of conv_bf16s.h's backbone) -- instead of fp32 NCHW.
+template <bool BF16OUT>
 static __global__ __launch_bounds__(StemCfg::THREADS, 2) void stem_conv7_mfma_kernel(const float* __restrict__ left, const float* __restrict__ right,
                                                                                     const float* __restrict__ w, const float* __restrict__ gamma,
                                                                                     const float* __restrict__ beta, const float* __restrict__ mean,
@@ -400,6 +403,21 @@ static __global__ __launch_bounds__(StemCfg::THREADS, 2) void stem_conv7_mfma_ke
                 for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
         }
         const int y = yg * RG + wid;
+        if constexpr (BF16OUT) {
+            // lane = channel: 32 lanes write the 64 contiguous bytes of 32 channels of one pixel (the lane halves: two pixels)
+            __bf16* ob = (__bf16*)out + ((((long)(n >> 1) * HO + y) * HO + xseg * XT) * 2 + (n & 1)) * 64 + l31;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int x = mt * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                        const float t = acc[mt][nt][r] * sc[nt] + sh[nt];
+                        ob[(long)x * 128 + nt * 32] = (__bf16)(gamma != nullptr ? fmaxf(t, 0.f) : t);
+                    }
+            continue;
+        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             float* dst = out + ((long)n * 64 + nt * 32 + l31) * HO * HO + (long)y * HO + xseg * XT;
@@ -419,19 +437,24 @@ static __global__ __launch_bounds__(StemCfg::THREADS, 2) void stem_conv7_mfma_ke
     }
 }
 static inline hipError_t stem_conv7_launch(const float* left, const float* right, const float* w, const float* gamma, const float* beta,
-                                           const float* mean, const float* var, float* out, int HIN, int nimg, int num_cu, hipStream_t s) {
+                                           const float* mean, const float* var, float* out, int HIN, int nimg, int num_cu, hipStream_t s,
+                                           bool bf16_nhwc = false) {
     using Cfg = StemCfg;
     const int HO = HIN / 2;
     if (HO % Cfg::XT == 0 && HO % Cfg::RG == 0 && ((uintptr_t)out & 15) == 0) {
         static bool attr_done = false;
         if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute((const void*)stem_conv7_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+            hipError_t e = hipFuncSetAttribute((const void*)stem_conv7_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_conv7_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
             if (e != hipSuccess) return e;
             attr_done = true;
         }
         const long items = (long)nimg * (HO / Cfg::RG) * (HO / Cfg::XT);
         const int grid = (int)(items < num_cu ? items : num_cu);
-        hipLaunchKernelGGL(stem_conv7_mfma_kernel, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, left, right, w, gamma, beta, mean, var, out, HIN, nimg);
+        if (bf16_nhwc) hipLaunchKernelGGL(stem_conv7_mfma_kernel<true>, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, left, right, w, gamma, beta, mean, var, out, HIN, nimg);
+        else hipLaunchKernelGGL(stem_conv7_mfma_kernel<false>, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, left, right, w, gamma, beta, mean, var, out, HIN, nimg);
+    } else if (bf16_nhwc) {
+        return hipErrorInvalidValue;
     } else {
         hipLaunchKernelGGL(stem_conv7_kernel, dim3(HO / 16, HO / 16, nimg), dim3(256), 0, s, left, right, w, gamma, beta, mean, var, out, HIN);
     }

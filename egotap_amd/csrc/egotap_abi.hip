@@ -1068,8 +1068,10 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
     auto F = [&](size_t off) { return (float*)(base + off); };
     const int N2 = 2 * B;
 
-    // E1: stem conv7x7/2 + BN + ReLU on image n = 2b + eye (the L/R channel concat of every pyramid level is then a view)
-    EGO_HIP(stem_conv7_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, F(w.L0), S0, N2, device_cu_count(), s));
+    // E1: stem conv7x7/2 + BN + ReLU on image n = 2b + eye (the L/R channel concat of every pyramid level is then a view); in the
+    // bf16 mode it writes bf16 channels-last itself (half the bytes, and the layout the max-pool and the stages read)
+    EGO_HIP(stem_conv7_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, F(w.L0), S0, N2, device_cu_count(), s,
+                              h->precision == EGOTAP_PREC_BF16));
     if (h->precision == EGOTAP_PREC_BF16) {
         // bf16 mode: everything after the stem on bf16 channels-last activations, every convolution on the bf16-storage GEMM
         // (conv_bf16s.h).  Buffers live in the fp32 path's slots (each at most half as large).
@@ -1106,11 +1108,11 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
             const XConv3 xl{in, ZP, Cp, ilog2(side), (65536 + ktp - 1) / ktp};
             return gemm_bf16s_launch(xl, WP, 9L * Cp, SEpiConvBf16<false>{cv.b, o, (long)Cout, Cout, 1}, (int)M, Cout, 9 * Cp, cus, s);
         };
-        // E2: max-pool -> bf16 [B * s64^2, 2 x 64]; E3: the four stages on the same GEMM kernel (eye-interleaved rows, see conv_bf16s.h)
+        // E2: max-pool of the stem's bf16 [B * (2 s64)^2, 2 x 64] -> [B * s64^2, 2 x 64]; E3: the four stages on the same GEMM kernel (eye-interleaved rows, see conv_bf16s.h)
         __bf16* P0 = Hb(w.P0);
         {
-            const long total = (long)N2 * (64 / 8) * p64;
-            hipLaunchKernelGGL(maxpool3s2_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, F(w.L0), P0, 64, S0 / 2, total);
+            const long total = (long)B * p64 * (128 / 8);
+            hipLaunchKernelGGL(maxpool3s2_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const __bf16*)F(w.L0), P0, 128, S0 / 2, total);
             EGO_HIP(hipGetLastError());
         }
         float *SC = BP + 1024, *SH = BP + 2048;                                    // folded BatchNorm scale / shift of the running conv
