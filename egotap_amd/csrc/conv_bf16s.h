@@ -22,7 +22,7 @@
 struct XConv3 {
     const __bf16* in;        // [Nimg * S * S, Cp] bf16, channels-last
     const __bf16* zero;      // 64 bytes of zeros
-    int Cp, log2S, inv_ktp;  // (inv_ktp unused: the slab / tap split of a K-tile index is a multiply by 7282 >> 16)
+    int Cp, log2S;           // the slab / tap split of a K-tile index is a multiply by 7282 >> 16 (kt / 9 exactly for kt < 7000)
     struct Row { const __bf16* p; unsigned mask; };
     __device__ __forceinline__ Row row(int m) const {
         const int S = 1 << log2S, x = m & (S - 1), y = (m >> log2S) & (S - 1);
@@ -165,7 +165,7 @@ static __global__ __launch_bounds__(256) void upsample2x_nhwc_bf16s_kernel(const
 struct XConvE {
     const __bf16* in;        // [B * Si * Si, 2 C] bf16, Si = So * stride
     const __bf16* zero;
-    int C, log2So, stride, taps, inv_ktp;
+    int C, log2So, stride, taps;
     struct Row { const __bf16* p; unsigned mask; };
     __device__ __forceinline__ Row row(int m) const {
         const int So = 1 << log2So, xo = m & (So - 1), yo = (m >> log2So) & (So - 1), n = m >> (2 * log2So);

@@ -605,7 +605,7 @@ static void pu_chain_probe(Handle* h) {
 }
 
 struct LiftWs {
-    size_t X, Y, QKV, CTX, HID, Z1, Z2, POSZ, ROTZ, F0, G0, HS0, F1, G1, HS1, C0, C1, ZERO, HPA, HPB, FLAGS, SPLITK, total;
+    size_t X, Y, QKV, CTX, HID, Z1, Z2, POSZ, ROTZ, F0, G0, HS0, F1, G1, HS1, C0, C1, ZERO, HPA, HPB, SPLITK, total;
 };
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static LiftWs lift_ws(const Handle* h, int B) {
@@ -620,7 +620,6 @@ static LiftWs lift_ws(const Handle* h, int B) {
     w.C0 = take((size_t)B * H); w.C1 = take((size_t)B * H); w.ZERO = take((size_t)B * H);
     w.HPA = take((size_t)h->J * B * H);                            // the propagation units' gated state: one [B, H] buffer per step
     w.HPB = w.HPA + al256((size_t)B * H * 4);                      // (the per-step fallback kernels ping-pong between the first two)
-    w.FLAGS = 0;
     w.SPLITK = take(SPLITK_FLOATS);       // split-K partial sums of the small-batch GEMMs (gemm_small)
     w.total = o;
     return w;
@@ -1104,8 +1103,7 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
             const long items = (long)Cout * 9 * (Cp / 8);
             hipLaunchKernelGGL(pack_conv3x3_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, cv.w, WP, Cout, Cin, Cp, Cout);
             GemmTimer t(h, s, role, "gemm_bf16s_kernel<XConv3>", 2.0 * M * Cout * 9.0 * Cin);
-            const int ktp = Cp / 32;
-            const XConv3 xl{in, ZP, Cp, ilog2(side), (65536 + ktp - 1) / ktp};
+            const XConv3 xl{in, ZP, Cp, ilog2(side)};
             return gemm_bf16s_launch(xl, WP, 9L * Cp, SEpiConvBf16<false>{cv.b, o, (long)Cout, Cout, 1}, (int)M, Cout, 9 * Cp, cus, s);
         };
         // E2: max-pool of the stem's bf16 [B * (2 s64)^2, 2 x 64] -> [B * s64^2, 2 x 64]; E3: the four stages on the same GEMM kernel (eye-interleaved rows, see conv_bf16s.h)
@@ -1130,8 +1128,7 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
             hipLaunchKernelGGL(bn_fold_bf16s_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, bn.g, bn.b, bn.m, bn.v, SC, SH, c, Np);
             const long M = (long)N2 * side * side;
             GemmTimer t(h, s, role, taps == 9 ? "gemm_bf16s_kernel<XConvE,3x3>" : "gemm_bf16s_kernel<XConvE,1x1>", 2.0 * M * c * taps * (double)cin);
-            const int ktp = cin / 32;
-            const XConvE xl{in, ZP, cin, ilog2(side), stride, taps, (65536 + ktp - 1) / ktp};
+            const XConvE xl{in, ZP, cin, ilog2(side), stride, taps};
             if (Np == c) return gemm_bf16s_launch(xl, WP, (long)taps * cin, SEpiBnBf16<false>{SC, SH, res, o, c, ilog2(side), relu}, (int)M, Np, taps * cin, cus, s);
             return gemm_bf16s_launch(xl, WP, (long)taps * cin, SEpiBnBf16<true>{SC, SH, res, o, c, ilog2(side), relu}, (int)M, Np, taps * cin, cus, s);
         };
@@ -1706,7 +1703,7 @@ extern "C" int egotap_train_add_inplace(float* out, const float* in, int64_t n, 
 #endif
 
 // ------------------------------------------------------------------------------------------------ PU chain + pose head (training)
-struct PuSaved { size_t F0, G0, HS0, C0, F1, G1, HS1, C1, ZERO, HPA, HPB, FLAGS, total; };
+struct PuSaved { size_t F0, G0, HS0, C0, F1, G1, HS1, C1, ZERO, HPA, HPB, total; };
 static PuSaved pu_saved(const Handle* h, int B) {
     PuSaved w;
     const size_t JB = (size_t)h->J * B, H = h->H, NF0 = H + 2 * h->hid;
@@ -1716,7 +1713,6 @@ static PuSaved pu_saved(const Handle* h, int B) {
     w.F1 = take(JB * H); w.G1 = take(JB * 4 * H); w.HS1 = take(JB * H); w.C1 = take(JB * H);
     w.ZERO = take((size_t)B * H);
     w.HPA = take((size_t)h->J * B * H); w.HPB = w.HPA + al256((size_t)B * H * 4);
-    w.FLAGS = 0;
     w.total = o;
     return w;
 }
