@@ -151,6 +151,11 @@ def measured_traffic(by_kernel, batch):
     return tot / n, os.path.basename(files[-1])
 
 
+def dist_backend():
+    import torch.distributed as dist
+    return dist.get_backend() if dist.is_initialized() else None
+
+
 def timed_lift(net, hm, steps, warmup, lib, L, h, barrier, dev, timing, world):
     """W warm-up + K timed forwards bracketed by barrier + synchronize; returns (elapsed max over ranks, pose, timing detail)"""
     import torch
@@ -165,6 +170,7 @@ def timed_lift(net, hm, steps, warmup, lib, L, h, barrier, dev, timing, world):
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
+    timed_lift.per_rank_ms = [round(1e3 * t / steps, 3) for t in parallel.gather_floats(elapsed, dev)]
     elapsed = parallel.max_over_ranks(elapsed, dev)
     out = None
     if timing:
@@ -372,7 +378,9 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
     for _ in range(args.train_steps):
         m.optimize_parameters()
     torch.cuda.synchronize(dev)
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    own = time.perf_counter() - t0
+    per_rank = [round(1e3 * t / args.train_steps, 3) for t in parallel.gather_floats(own, dev)]
+    elapsed = parallel.max_over_ranks(own, dev)
     ms1 = torch.cuda.memory_stats(dev)
     dev_allocs = ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)      # hipMalloc calls inside the timed region (should be 0)
     barrier()
@@ -382,7 +390,9 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
     if from_rgb:                                 # + the frozen estimators' forward
         flops += hm_flops_per_frame(2 * p.n_joints_hm, 4 * p.hm_size) + hm_flops_per_frame(4 * p.n_joints_hm, 4 * p.hm_size)
     peak_gb = (torch.cuda.max_memory_allocated(dev) - held) / 2 ** 30
-    exposed = m.net_AutoEncoder._reducer().read_exposed_ms() if world > 1 else 0.0
+    red = m.net_AutoEncoder._reducer()
+    exposed = red.read_exposed_ms() if world > 1 else None       # None at N = 1: there is no collective to be exposed
+    ar_bytes, ar_buckets = (red.last_bytes, red.last_buckets) if world > 1 else (0, 0)
     del m, hm, gt, data
     from egotap_amd import training
     training.release_scratch()                   # (the model, with the activations' buffer it keeps, is gone already)
@@ -393,7 +403,11 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
             "steps": args.train_steps, "batch_per_gpu": B, "dtype": mode, "flops_per_frame": flops,
             "end_to_end_tflops_per_gpu": round(fps * flops / world / 1e12, 2), **frac_fields(mode, fps * flops / world / 1e12),
             "loss_pose": errs.get("pose"), "loss_cos_sim": errs.get("cos_sim"), "peak_hbm_gib": round(peak_gb, 1),
-            "allreduce_exposed_ms_last_step": round(exposed, 3), "device_allocations_in_timed_region": int(dev_allocs),
+            "allreduce_exposed_ms_last_step": None if exposed is None else round(exposed, 3),
+            "allreduce_bytes_per_step": int(ar_bytes), "allreduce_buckets": int(ar_buckets),
+            "allreduce_op": ("avg (RCCL ReduceOp.AVG, in place on the gradient arena)" if world > 1 and dist_backend() == "nccl" else
+                             "sum + 1/world scaling pass (gloo)" if world > 1 else None),
+            "per_rank_ms_per_step": per_rank, "device_allocations_in_timed_region": int(dev_allocs),
             "input": "RGB frames through the two frozen heatmap estimators (eval-mode BatchNorm, --use_amp arithmetic), then the head" if from_rgb
                      else "resident heatmaps (--use_gt_heatmap): the frozen estimators are not run",
             "note": "gradient all-reduce (N > 1) overlapped with the backward, bucket by bucket, in place on a flat arena; the attention "
@@ -498,7 +512,24 @@ def main():
     ap.add_argument("--config5-batch", type=int, default=64, help="per-GPU batch of the EgoCap / 128x128-heatmap measurement (0 = skip)")
     ap.add_argument("--stage1-batch", type=int, default=32, help="per-GPU batch of the stage-1 heatmap-estimator training measurement")
     ap.add_argument("--train-batch-bf16", type=int, default=1024, help="per-GPU batch of the bf16 training measurement (BASELINE config 3)")
+    ap.add_argument("--all-legs", action="store_true", help="N > 1: also run the single-GPU secondary legs on every rank (default at N > 1: "
+                                                            "headline + the data-parallel training legs, the ones with a collective)")
     args = ap.parse_args()
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as CHILD processes, before anything in this
+        # process has touched the GPU (never an exec from a process that has initialised HIP), and return the launcher's exit code.
+        # The children check that N devices exist and fail with a clear message if not.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import torch
     import torch.distributed as dist
@@ -508,24 +539,32 @@ def main():
     from egotap_amd import networks
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = world_env
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+        args.gpus = world                      # launched by torch.distributed.run: the launcher's world size is authoritative
     # rehearsal on a one-GPU box: EGOTAP_DIST_BACKEND=gloo lets several ranks share cuda:0 (RCCL needs one device per rank)
     backend = os.environ.get("EGOTAP_DIST_BACKEND", "nccl")
-    if backend != "nccl" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    n_dev = torch.cuda.device_count()          # counting devices does not initialise HIP
+    if n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"bench.py --gpus {world} needs {world} devices (one rank per GPU over RCCL); this node has {n_dev} "
+                         f"[rank {rank}] -- for a rehearsal with ranks sharing a GPU set EGOTAP_DIST_BACKEND=gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    if backend != "nccl" and world > 1:
         os.environ["EGOTAP_SHARED_DEVICE"] = "1"      # ranks share one GPU: kernels that need the device to themselves are switched off
     if backend != "nccl":
-        local = local % max(torch.cuda.device_count(), 1)
+        local = local % max(n_dev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from egotap_amd import parallel
     parallel.init_from_env(backend, dev)     # "nccl" is RCCL on ROCm; no-op for one rank
+    if world > 1 and not args.all_legs:        # N > 1 measures what N > 1 changes: the sharded headline and the data-parallel training step
+        args.lift_only_secondary = True
+    else:
+        args.lift_only_secondary = False
 
     p = spec.lift_preset(args.preset)
     sd_np = synth_state_dict(spec.lift_state_spec(p))
@@ -543,6 +582,7 @@ def main():
 
     timing = not args.no_kernel_timing
     elapsed, pose, t1 = timed_lift(net, hm, args.steps, args.warmup, lib, L, h, barrier, dev, timing, world)
+    headline_per_rank_ms = list(timed_lift.per_rank_ms)
 
     roof = None
     if timing:
@@ -621,8 +661,9 @@ def main():
             torch.cuda.empty_cache()
             return {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
+    single_gpu_legs = not args.lift_only and not args.lift_only_secondary
     full = None
-    if not args.lift_only:
+    if single_gpu_legs:
         full = leg(bench_full, args, p, dev, rank, world, barrier, lib, L)
         if not args.no_fast_mode:
             ff = leg(bench_full, args, p, dev, rank, world, barrier, lib, L, mode="bf16x3")
@@ -643,7 +684,7 @@ def main():
         full.pop("_pose", None)
 
     config5 = None
-    if not args.lift_only and not args.no_fast_mode and args.config5_batch > 0:
+    if single_gpu_legs and not args.no_fast_mode and args.config5_batch > 0:
         config5 = leg(bench_config5, args, dev, rank, world, barrier, lib, L)
 
     train = None
@@ -652,12 +693,15 @@ def main():
         train["bf16x3"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16x3")
         # BASELINE configs[2] / [3]: UnrealEgo training step (fwd+bwd+AdamW), bf16, batch 1024 per GPU (x N GPUs, gradient all-reduce)
         train["config3_bf16_b1024"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16", batch=args.train_batch_bf16)
-        # the same step as train.py runs it without --use_gt_heatmap: RGB frames -> two frozen heatmap estimators -> head ("RGB for full")
-        train["config3_bf16_b1024_from_rgb"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16", batch=args.train_batch_bf16,
-                                                   from_rgb=True)
-        train["stage1_heatmap_estimator"] = leg(bench_stage1, args, p, dev, rank, world, barrier)
-        if not args.no_fast_mode:
-            train["stage1_heatmap_estimator"]["bf16x3"] = leg(bench_stage1, args, p, dev, rank, world, barrier, mode="bf16x3")
+        if world > 1:
+            train["config3_bf16_b1024"]["config4_global_batch"] = world * args.train_batch_bf16
+        if single_gpu_legs:
+            # the same step as train.py runs it without --use_gt_heatmap: RGB frames -> two frozen heatmap estimators -> head ("RGB for full")
+            train["config3_bf16_b1024_from_rgb"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16", batch=args.train_batch_bf16,
+                                                       from_rgb=True)
+            train["stage1_heatmap_estimator"] = leg(bench_stage1, args, p, dev, rank, world, barrier)
+            if not args.no_fast_mode:
+                train["stage1_heatmap_estimator"]["bf16x3"] = leg(bench_stage1, args, p, dev, rank, world, barrier, mode="bf16x3")
 
     latency = None
     if rank == 0 and world == 1 and not args.lift_only:
@@ -665,7 +709,7 @@ def main():
 
     cpu = None
     gpu_vs_oracle = None
-    if rank == 0 and not args.no_cpu_baseline:      # rank 0 only, at every N (the other ranks wait at the final barrier)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # rank 0 at N = 1 only
         cpu, ref = cpu_baseline(p, sd_np, args.cpu_batch, 3)
         # parity spot check on the same inputs the CPU leg used (first frames)
         hm_c = torch.from_numpy(synth_input("hm_cpu_baseline", (args.cpu_batch, p.in_channels, p.hm_size, p.hm_size))).to(dev)
@@ -696,6 +740,12 @@ def main():
             "flops_per_frame": flops_frame,
             "end_to_end_tflops_per_gpu": round(fps * flops_frame / world / 1e12, 2),
             "end_to_end_frac_of_f32_mfma_peak": round(fps * flops_frame / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "distributed": {"backend": dist_backend(), "world_size_seen": dist.get_world_size() if dist.is_initialized() else 1,
+                            "launched_as": "torch.distributed.run, one rank per GPU" if world > 1 else "single process",
+                            "per_rank_ms_per_step": headline_per_rank_ms,
+                            "data_path_collective": "none (batch shards; samples are independent in eval)",
+                            "legs_at_this_n": "all" if single_gpu_legs or args.lift_only else
+                                              "headline + fast modes + data-parallel training legs (single-GPU legs: run with --gpus 1 or --all-legs)"},
             "roofline": roof, "cpu_baseline": cpu, "max_abs_diff_vs_oracle": gpu_vs_oracle,
             "fast_mode_bf16x3": fast, "fast_mode_bf16": fast16, "full_pipeline_from_rgb": full, "config5_geometry_egocap_hm128": config5,
             "train_step_lifting_head": train, "small_batch_latency": latency,

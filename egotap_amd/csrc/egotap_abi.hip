@@ -137,6 +137,10 @@ struct egotap_handle_s {
     int debug_stop = 0;
     int pu_resident[2] = {-1, -1};     // workgroups of pu_chain_kernel<1> / <2> the device keeps resident (-1: not asked yet)
     bool pu_chain = true;              // egotap_set_pu_chain: one-launch recurrence (needs the device to itself) or per-step kernels
+    unsigned* pu_fault_host = nullptr; // pinned, device-mapped word: set by pu_solo_kernel when a chain launch had to be redone (pu_chain.h)
+    unsigned* pu_fault_dev = nullptr;  // the same word as the device sees it
+    int pu_faults = 0;                 // chain launches found faulted so far (the chain is switched off for the handle at the first)
+    int pu_debug_drop = 0;             // egotap_debug_pu_drop_workgroups
     int precision = EGOTAP_PREC_F32;   // arithmetic of the large GEMMs (egotap_set_precision)
     __bf16* wscratch = nullptr;        // scratch for the bf16 copy of a GEMM's weight matrix (plain-bf16 mode), caller-owned
     size_t wscratch_bytes = 0;
@@ -265,6 +269,7 @@ extern "C" int egotap_create(const egotap_config* cfg, egotap_handle* out) {
 extern "C" void egotap_destroy(egotap_handle h) {
     if (!h) return;
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    if (h->pu_fault_host) (void)hipHostFree(h->pu_fault_host);
     delete h;
 }
 #endif
@@ -597,7 +602,25 @@ static hipError_t fc_gemm(Handle* h, const char* role, const AL& al, const SegMa
 // ------------------------------------------------------------------------------------------------ workspace
 // asks the device once how many workgroups of the one-launch PU chain it keeps resident (pu_chain.h)
 static void pu_chain_probe(Handle* h) {
+    // A chain launch of an EARLIER call whose row blocks were not co-resident (shared device) was redone on the device by
+    // pu_solo_kernel -- the results were right, but it cost a ~0.1 s stall: from now on this handle walks the steps with the per-step
+    // kernels (same bits).  Read without synchronising: the word is host memory the device writes through.
+    if (h->pu_fault_host && __atomic_load_n(h->pu_fault_host, __ATOMIC_RELAXED) != 0u) {
+        __atomic_store_n(h->pu_fault_host, 0u, __ATOMIC_RELAXED);
+        h->pu_faults++;
+        h->pu_chain = false;
+    }
     if (!h->pu_chain) { h->pu_resident[0] = h->pu_resident[1] = 0; return; }      // 0 resident workgroups: pu_chain_launch declines
+    if (!h->pu_fault_host) {           // once per handle, at its first forward (never inside a stream capture: wrappers run eagerly first)
+        void* hp = nullptr; void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            h->pu_fault_host = (unsigned*)hp; h->pu_fault_dev = (unsigned*)dp;
+            *h->pu_fault_host = 0u;
+        } else {
+            if (hp) (void)hipHostFree(hp);
+            (void)hipGetLastError();
+        }
+    }
     if (h->pu_resident[0] <= 0) {
         h->pu_resident[0] = pu_chain_resident<1>();
         h->pu_resident[1] = pu_chain_resident<2>();
@@ -605,7 +628,7 @@ static void pu_chain_probe(Handle* h) {
 }
 
 struct LiftWs {
-    size_t X, Y, QKV, CTX, HID, Z1, Z2, POSZ, ROTZ, F0, G0, HS0, F1, G1, HS1, C0, C1, ZERO, HPA, HPB, SPLITK, total;
+    size_t X, Y, QKV, CTX, HID, Z1, Z2, POSZ, ROTZ, F0, G0, HS0, F1, G1, HS1, C0, C1, ZERO, HPA, HPB, FAULT, SPLITK, total;
 };
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static LiftWs lift_ws(const Handle* h, int B) {
@@ -620,6 +643,7 @@ static LiftWs lift_ws(const Handle* h, int B) {
     w.C0 = take((size_t)B * H); w.C1 = take((size_t)B * H); w.ZERO = take((size_t)B * H);
     w.HPA = take((size_t)h->J * B * H);                            // the propagation units' gated state: one [B, H] buffer per step
     w.HPB = w.HPA + al256((size_t)B * H * 4);                      // (the per-step fallback kernels ping-pong between the first two)
+    w.FAULT = take(64);                                            // fault word of the one-launch recurrence (pu_chain.h)
     w.SPLITK = take(SPLITK_FLOATS);       // split-K partial sums of the small-batch GEMMs (gemm_small)
     w.total = o;
     return w;
@@ -654,6 +678,24 @@ extern "C" int egotap_set_pu_chain(egotap_handle h, int enable) {
     EGO_CHECK(h, "null handle");
     h->pu_chain = enable != 0;
     h->pu_resident[0] = h->pu_resident[1] = -1;
+    return EGOTAP_OK;
+}
+extern "C" int egotap_debug_pu_drop_workgroups(egotap_handle h, int n) {
+    EGO_CHECK(h && n >= 0 && n < 16, "egotap_debug_pu_drop_workgroups: n in [0, 16)");
+    h->pu_debug_drop = n;
+    return EGOTAP_OK;
+}
+extern "C" int egotap_pu_chain_status(egotap_handle h, int* enabled, int* faults) {
+    EGO_CHECK(h, "null handle");
+    // meaningful after the caller has synchronised the stream of the call it asks about (the word is written by the device)
+    if (h->pu_fault_host && __atomic_load_n(h->pu_fault_host, __ATOMIC_RELAXED) != 0u) {
+        __atomic_store_n(h->pu_fault_host, 0u, __ATOMIC_RELAXED);
+        h->pu_faults++;
+        h->pu_chain = false;
+        h->pu_resident[0] = h->pu_resident[1] = -1;
+    }
+    if (enabled) *enabled = h->pu_chain ? 1 : 0;
+    if (faults) *faults = h->pu_faults;
     return EGOTAP_OK;
 }
 extern "C" int egotap_set_precision(egotap_handle h, int mode) {
@@ -845,8 +887,10 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     // ... then the two J-step recurrences (layer 0 never reads layer-1 state, so the layers run one after the other)
     EGO_HIP(zero_fill(C0, (size_t)(w.ZERO - w.C0) + al256((size_t)B * H * 4), s));   // C0, C1, ZERO are contiguous (256-byte aligned slices)
     pu_chain_probe(h);
-    const PuChain ch0{F0, (long)B * NF0, NF0, G0, (long)B * 4 * H, p.h2h0_w, p.h2h0_b, nullptr, 0, HS0, (long)B * H, HPA, (long)B * H, B, H, J, 0};
-    if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch0, B))
+    unsigned* FAULT = (unsigned*)(base + w.FAULT);
+    const PuChain ch0{F0, (long)B * NF0, NF0, G0, (long)B * 4 * H, nullptr, p.h2h0_w, p.h2h0_b, nullptr, 0, HS0, (long)B * H, HPA, (long)B * H, B, H, J,
+                      FAULT, h->pu_fault_dev};
+    if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch0, B, h->pu_debug_drop))
     for (int t = 0; t < J; ++t) {       // the gated state of step t + 1 comes out of step t (ping-pong buffers; zeros at t = 0)
         const float* hp_in = t == 0 ? ZERO : ((t & 1) ? HPA : HPB);
         pu_step_launch(s, B, H, hp_in, G0 + (size_t)t * B * 4 * H, p.h2h0_w, p.h2h0_b, C0, C0, HS0 + (size_t)t * B * H,
@@ -855,8 +899,9 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     EGO_HIP(hipGetLastError());
     EGO_HIP((gemm<Tile>(h, "pu1_x2f", ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
     EGO_HIP((gemm<Tile>(h, "pu1_x2h", ALoadPlain{HS0, H}, segmat1(p.x2h1_w, 4 * H, H), EpiBias{segvec1(p.x2h1_b, 4 * H)}, G1, 4L * H, JB, 4 * H, H, s)));
-    const PuChain ch1{F1, (long)B * H, H, G1, (long)B * 4 * H, p.h2h1_w, p.h2h1_b, nullptr, 0, HS1, (long)B * H, HPA, (long)B * H, B, H, J, 0};
-    if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch1, B))
+    const PuChain ch1{F1, (long)B * H, H, G1, (long)B * 4 * H, nullptr, p.h2h1_w, p.h2h1_b, nullptr, 0, HS1, (long)B * H, HPA, (long)B * H, B, H, J,
+                      FAULT, h->pu_fault_dev};
+    if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch1, B, h->pu_debug_drop))
     for (int t = 0; t < J; ++t) {
         const float* hp_in = t == 0 ? ZERO : ((t & 1) ? HPA : HPB);
         pu_step_launch(s, B, H, hp_in, G1 + (size_t)t * B * 4 * H, p.h2h1_w, p.h2h1_b, C1, C1, HS1 + (size_t)t * B * H,
@@ -1703,16 +1748,19 @@ extern "C" int egotap_train_add_inplace(float* out, const float* in, int64_t n, 
 #endif
 
 // ------------------------------------------------------------------------------------------------ PU chain + pose head (training)
-struct PuSaved { size_t F0, G0, HS0, C0, F1, G1, HS1, C1, ZERO, HPA, HPB, total; };
+struct PuSaved { size_t F0, G0, GP0, HS0, C0, F1, G1, GP1, HS1, C1, ZERO, HPA, HPB, FAULT, total; };
 static PuSaved pu_saved(const Handle* h, int B) {
     PuSaved w;
     const size_t JB = (size_t)h->J * B, H = h->H, NF0 = H + 2 * h->hid;
     size_t o = 0;
     auto take = [&](size_t floats) { size_t r = o; o = al256(o + floats * 4); return r; };
-    w.F0 = take(JB * NF0); w.G0 = take(JB * 4 * H); w.HS0 = take(JB * H); w.C0 = take(JB * H);
-    w.F1 = take(JB * H); w.G1 = take(JB * 4 * H); w.HS1 = take(JB * H); w.C1 = take(JB * H);
+    // G0 / G1: the state-independent gate inputs Gin of every step (kept intact, so that a faulted one-launch recurrence can be
+    // redone from them); GP0 / GP1: the full gate pre-activations the backward reads
+    w.F0 = take(JB * NF0); w.G0 = take(JB * 4 * H); w.GP0 = take(JB * 4 * H); w.HS0 = take(JB * H); w.C0 = take(JB * H);
+    w.F1 = take(JB * H); w.G1 = take(JB * 4 * H); w.GP1 = take(JB * 4 * H); w.HS1 = take(JB * H); w.C1 = take(JB * H);
     w.ZERO = take((size_t)B * H);
     w.HPA = take((size_t)h->J * B * H); w.HPB = w.HPA + al256((size_t)B * H * 4);
+    w.FAULT = take(64);
     w.total = o;
     return w;
 }
@@ -1740,7 +1788,8 @@ extern "C" int egotap_train_pu_fwd(egotap_handle h, const float* posz, const flo
     char* base = (char*)saved;
     auto F = [&](size_t off) { return (float*)(base + off); };
     float *F0 = F(w.F0), *G0 = F(w.G0), *HS0 = F(w.HS0), *C0 = F(w.C0), *F1 = F(w.F1), *G1 = F(w.G1), *HS1 = F(w.HS1), *C1 = F(w.C1), *ZERO = F(w.ZERO);
-    float *HPA = F(w.HPA), *HPB = F(w.HPB);
+    float *HPA = F(w.HPA), *HPB = F(w.HPB), *GP0 = F(w.GP0), *GP1 = F(w.GP1);
+    unsigned* FAULT = (unsigned*)(base + w.FAULT);
     const int J = h->J, H = h->H, hid = h->hid, JB = J * B, x = 2 * hid, NF0 = H + x;
     using Tile = TileA;
     ALoadStereo xs{posz, B, J, hid};
@@ -1752,27 +1801,27 @@ extern "C" int egotap_train_pu_fwd(egotap_handle h, const float* posz, const flo
     }
     EGO_HIP(zero_fill(ZERO, (size_t)B * H * 4, s));
     pu_chain_probe(h);
-    // G0 / G1 hold Gin on entry and the full gate pre-activations on exit (in place); C0 / C1 keep the cell state of every step
-    const PuChain ch0{F0, (long)B * NF0, NF0, G0, (long)B * 4 * H, p.h2h0_w, p.h2h0_b, C0, (long)B * H, HS0, (long)B * H, HPA, (long)B * H, B, H, J, 1};
-    if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch0, B))
+    // G0 / G1 hold Gin, GP0 / GP1 receive the full gate pre-activations; C0 / C1 keep the cell state of every step
+    const PuChain ch0{F0, (long)B * NF0, NF0, G0, (long)B * 4 * H, GP0, p.h2h0_w, p.h2h0_b, C0, (long)B * H, HS0, (long)B * H, HPA, (long)B * H, B, H, J,
+                      FAULT, h->pu_fault_dev};
+    if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch0, B, h->pu_debug_drop))
     for (int t = 0; t < J; ++t) {
         const float* hp_in = t == 0 ? ZERO : ((t & 1) ? HPA : HPB);
         const float* cprev = t == 0 ? ZERO : C0 + (size_t)(t - 1) * B * H;
-        float* g = G0 + (size_t)t * B * 4 * H;
-        pu_step_launch(s, B, H, hp_in, g, p.h2h0_w, p.h2h0_b, cprev, C0 + (size_t)t * B * H, HS0 + (size_t)t * B * H,
-                       t + 1 < J ? F0 + (size_t)(t + 1) * B * NF0 : nullptr, NF0, (t & 1) ? HPB : HPA, g);
+        pu_step_launch(s, B, H, hp_in, G0 + (size_t)t * B * 4 * H, p.h2h0_w, p.h2h0_b, cprev, C0 + (size_t)t * B * H, HS0 + (size_t)t * B * H,
+                       t + 1 < J ? F0 + (size_t)(t + 1) * B * NF0 : nullptr, NF0, (t & 1) ? HPB : HPA, GP0 + (size_t)t * B * 4 * H);
     }
     EGO_HIP(hipGetLastError());
     EGO_HIP((gemm<Tile>(h, "pu1_x2f", ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
     EGO_HIP((gemm<Tile>(h, "pu1_x2h", ALoadPlain{HS0, H}, segmat1(p.x2h1_w, 4 * H, H), EpiBias{segvec1(p.x2h1_b, 4 * H)}, G1, 4L * H, JB, 4 * H, H, s)));
-    const PuChain ch1{F1, (long)B * H, H, G1, (long)B * 4 * H, p.h2h1_w, p.h2h1_b, C1, (long)B * H, HS1, (long)B * H, HPA, (long)B * H, B, H, J, 1};
-    if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch1, B))
+    const PuChain ch1{F1, (long)B * H, H, G1, (long)B * 4 * H, GP1, p.h2h1_w, p.h2h1_b, C1, (long)B * H, HS1, (long)B * H, HPA, (long)B * H, B, H, J,
+                      FAULT, h->pu_fault_dev};
+    if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch1, B, h->pu_debug_drop))
     for (int t = 0; t < J; ++t) {
         const float* hp_in = t == 0 ? ZERO : ((t & 1) ? HPA : HPB);
         const float* cprev = t == 0 ? ZERO : C1 + (size_t)(t - 1) * B * H;
-        float* g = G1 + (size_t)t * B * 4 * H;
-        pu_step_launch(s, B, H, hp_in, g, p.h2h1_w, p.h2h1_b, cprev, C1 + (size_t)t * B * H, HS1 + (size_t)t * B * H,
-                       t + 1 < J ? F1 + (size_t)(t + 1) * B * H : nullptr, H, (t & 1) ? HPB : HPA, g);
+        pu_step_launch(s, B, H, hp_in, G1 + (size_t)t * B * 4 * H, p.h2h1_w, p.h2h1_b, cprev, C1 + (size_t)t * B * H, HS1 + (size_t)t * B * H,
+                       t + 1 < J ? F1 + (size_t)(t + 1) * B * H : nullptr, H, (t & 1) ? HPB : HPA, GP1 + (size_t)t * B * 4 * H);
     }
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
@@ -1819,7 +1868,7 @@ extern "C" int egotap_train_pu_bwd(egotap_handle h, const float* posz, const flo
     auto SF = [&](size_t off) { return (const float*)(sb + off); };
     char* wb = (char*)ws;
     auto WF = [&](size_t off) { return (float*)(wb + off); };
-    const float *F0 = SF(sv.F0), *G0 = SF(sv.G0), *HS0 = SF(sv.HS0), *C0 = SF(sv.C0), *F1 = SF(sv.F1), *G1 = SF(sv.G1), *HS1 = SF(sv.HS1),
+    const float *F0 = SF(sv.F0), *G0 = SF(sv.GP0), *HS0 = SF(sv.HS0), *C0 = SF(sv.C0), *F1 = SF(sv.F1), *G1 = SF(sv.GP1), *HS1 = SF(sv.HS1),
                 *C1 = SF(sv.C1), *ZERO = SF(sv.ZERO);
     float *dG = WF(w.dG), *dF = WF(w.dF), *HP = WF(w.HP), *dHS0 = WF(w.dHS0), *dXs = WF(w.dXs), *dBp = WF(w.dBp), *DHP = WF(w.DHP), *WT = WF(w.WT),
           *part = WF(w.part);

@@ -15,9 +15,10 @@
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-static __global__ void fill_u32_kernel(unsigned* p, long n, unsigned v) {
+static __global__ void fill_u32_kernel(unsigned* p, long n, unsigned v, unsigned* zero_word = nullptr) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
+    if (i == 0 && zero_word) *zero_word = 0u;
 }
 
 // One recurrent step of a PU layer.  The gated state hp_t = sigmoid(F_t[:, 0:H]) * h_{t-1} is produced by the PREVIOUS step's pointwise
@@ -130,23 +131,29 @@ static inline void pu_step_launch(hipStream_t s, int B, int H, const float* hp_i
 constexpr unsigned PU_SENTINEL = 0x7fc0deadu;   // "not stored yet" in the gated-state buffers (a NaN payload arithmetic never produces)
 struct PuChain {
     const float* F; long f_step; int ldf;       // gate logits: F + t * f_step + row * ldf + unit  (sigmoid gates h_{t-1})
-    float* G; long g_step;                      // Gin_t [rows, 4H] at G + t * g_step; keep_gates: overwritten with the gate pre-activations
+    const float* G; long g_step;                // Gin_t [rows, 4H] at G + t * g_step (read only: a faulted launch can be redone from it)
+    float* GP;                                  // training: the gate pre-activations of step t go to GP + t * g_step (nullptr: not kept)
     const float* Whh; const float* bhh;
     float* C; long c_step;                      // c_t of every step (training) or nullptr
     float* HS; long hs_step;                    // h_t at HS + t * hs_step
     float* HP; long hp_stride;                  // gated state hp_{t+1} at HP + t * hp_stride (J - 1 buffers), PU_SENTINEL-filled on entry
-    int rows, H, J, keep_gates;
+    int rows, H, J;
+    unsigned* fault;                            // device word, zero on entry: set by a workgroup whose wait ran out (-> pu_solo_kernel redoes the launch)
+    unsigned* fault_host;                       // host-mapped word (or nullptr): set by pu_solo_kernel when it had to run, read by the next ABI call
 };
 
 template <int UT>
 static __global__ __launch_bounds__(1024) void pu_chain_kernel(const PuChain p) {
     constexpr int NBG = 32 / UT;                 // workgroups per row block (H = 512)
     constexpr int PW = 256 * UT;                 // pointwise threads: 16 rows x 16 UT units
-    __shared__ f32x4 red[4 * 4 * UT * 64];       // [quarter][gate][unit tile][lane]
+    __shared__ f32x4 red[4 * 4 * UT * 64 + 1];   // [quarter][gate][unit tile][lane] + one slot for the workgroup's "gave up" flag
+    int* wg_dead = (int*)&red[4 * 4 * UT * 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int g = wid & 3, kq4 = wid >> 2;
     const int H = p.H;
+    if (tid == 0) *wg_dead = 0;
+    __syncthreads();
     const int rb = blockIdx.x / NBG, r0 = rb * 16, u0 = (blockIdx.x % NBG) * (16 * UT);
     const int arow = min(r0 + l15, p.rows - 1);
     const int k0 = kq4 * 128;
@@ -169,7 +176,10 @@ static __global__ __launch_bounds__(1024) void pu_chain_kernel(const PuChain p) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) bg[q] = p.bhh[q * H + punit];
     }
-    bool dead = false;                           // this wave: a wait ran out (the row block is not co-resident); stop waiting, finish
+    // A wait that runs out (the row block's workgroups are not co-resident: another process's kernels hold CUs) marks the WHOLE
+    // workgroup dead at the next barrier: it stores nothing from then on (no garbage reaches memory, its consumers' waits run out
+    // in turn) and raises the launch's fault word, behind which pu_solo_kernel redoes the launch without cross-workgroup waits.
+    bool dead = false, reported = false;
     // what does not depend on the state is requested one step ahead, before the wait
     float gin[4] = {0.f, 0.f, 0.f, 0.f}, fnext = 0.f;
     auto fetch = [&](int t) {
@@ -213,7 +223,7 @@ static __global__ __launch_bounds__(1024) void pu_chain_kernel(const PuChain p) 
 #pragma unroll
                     for (int u = 0; u < 4; ++u) missing |= __float_as_uint(a[i][u]) == PU_SENTINEL;
                 if (__builtin_amdgcn_ballot_w64(missing) == 0) break;
-                if (dead || ++spins > (1 << 16)) { dead = true; break; }     // the row block is not co-resident: stop waiting, finish (NaNs)
+                if (dead || ++spins > (1 << 16)) { dead = true; break; }     // the row block is not co-resident: stop waiting
                 __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
@@ -227,8 +237,13 @@ static __global__ __launch_bounds__(1024) void pu_chain_kernel(const PuChain p) 
         }
 #pragma unroll
         for (int tl = 0; tl < UT; ++tl) red[((kq4 * 4 + g) * UT + tl) * 64 + lane] = acc[tl];
+        if (dead && lane == 0) *wg_dead = 1;
         __syncthreads();
-        if (pw && prow < p.rows) {
+        if (*wg_dead) {
+            if (!reported && tid == 0) __hip_atomic_store(p.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dead = reported = true;
+        }
+        if (pw && prow < p.rows && !dead) {
             float pre[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -238,8 +253,8 @@ static __global__ __launch_bounds__(1024) void pu_chain_kernel(const PuChain p) 
                 pre[q] = v + bg[q];
             }
             const float pf = pre[0] + gin[0], pi = pre[1] + gin[1], pc = pre[2] + gin[2], po = pre[3] + gin[3];
-            if (p.keep_gates) {
-                float* gt = p.G + (long)t * p.g_step + (long)prow * 4 * H + punit;
+            if (p.GP) {
+                float* gt = p.GP + (long)t * p.g_step + (long)prow * 4 * H + punit;
                 gt[0] = pf; gt[H] = pi; gt[2L * H] = pc; gt[3L * H] = po;
             }
             const float fg = sigmoidf_(pf), ig = sigmoidf_(pi), cg = tanhf(pc), og = sigmoidf_(po);
@@ -259,6 +274,95 @@ static __global__ __launch_bounds__(1024) void pu_chain_kernel(const PuChain p) 
     }
 }
 
+// The same J-step recurrence WITHOUT cross-workgroup waits: one workgroup owns a row block (16 rows) and walks all H / 32 unit blocks
+// of every step itself (Whh re-read from L2 each step: ~16 x slower than the chain).  Launched behind every pu_chain_kernel launch and
+// exits at once unless that launch raised its fault word (a row block whose workgroups were not co-resident: the device is shared with
+// another process, CU-masked, or being debugged) -- then it redoes the launch from the untouched inputs, so the caller still gets the
+// right answer; the host learns about it through the mapped word and stops using the chain for the handle (egotap_abi.hip).
+// Same k order, reduction order and pointwise expressions as pu_chain_kernel / pu_step_r16_kernel: bit-identical results.
+static __global__ __launch_bounds__(1024) void pu_solo_kernel(const PuChain p) {
+    if (__hip_atomic_load(p.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    constexpr int UT = 2;
+    __shared__ f32x4 red[4 * 4 * UT * 64];       // [quarter][gate][unit tile][lane]   (32 KiB)
+    __shared__ float cst[16 * 512];              // cell state of the row block        (32 KiB; H = 512)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int g = wid & 3, kq4 = wid >> 2;
+    const int H = p.H;
+    const int r0 = blockIdx.x * 16;
+    const int arow = min(r0 + l15, p.rows - 1);
+    const int k0 = kq4 * 128;
+    const int rl = tid / (16 * UT), ul = tid % (16 * UT);
+    const int prow = r0 + rl, prc = min(prow, p.rows - 1);
+    const bool pw = tid < 256 * UT;
+    const int idx = (ul >> 4) * 64 + (ul & 15) + 16 * ((rl & 15) >> 2), reg = rl & 3;
+    for (int i = tid; i < 16 * 512; i += 1024) cst[i] = 0.f;
+    if (blockIdx.x == 0 && tid == 0 && p.fault_host) __hip_atomic_store(p.fault_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    for (int t = 0; t < p.J; ++t) {
+        f32x4 a[8];
+        if (t > 0) {
+            const float* hp = p.HP + (long)(t - 1) * p.hp_stride + (long)arow * H + k0 + 4 * lg;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = *(const f32x4*)(hp + 16 * i);
+        }
+        for (int ub = 0; ub < H / (16 * UT); ++ub) {
+            const int u0 = ub * 16 * UT, punit = u0 + ul;
+            f32x4 acc[UT];
+#pragma unroll
+            for (int tl = 0; tl < UT; ++tl) acc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t > 0) {
+                f32x4 w[UT][8];
+                const float* wp = p.Whh + (long)g * H * H + (long)(u0 + l15) * H + k0 + 4 * lg;
+#pragma unroll
+                for (int tl = 0; tl < UT; ++tl)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) w[tl][i] = *(const f32x4*)(wp + (long)tl * 16 * H + 16 * i);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int tl = 0; tl < UT; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][u], w[tl][i][u], acc[tl], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int tl = 0; tl < UT; ++tl) red[((kq4 * 4 + g) * UT + tl) * 64 + lane] = acc[tl];
+            __syncthreads();
+            if (pw && prow < p.rows) {
+                const float* gt = p.G + (long)t * p.g_step + (long)prc * 4 * H + punit;
+                float pre[4], gin[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    gin[q] = gt[(long)q * H];
+                    float v = red[(0 * 4 + q) * (UT * 64) + idx][reg];
+#pragma unroll
+                    for (int wq = 1; wq < 4; ++wq) v += red[(wq * 4 + q) * (UT * 64) + idx][reg];
+                    pre[q] = v + p.bhh[q * H + punit];
+                }
+                const float fnext = t + 1 < p.J ? p.F[(long)(t + 1) * p.f_step + (long)prc * p.ldf + punit] : 0.f;
+                const float pf = pre[0] + gin[0], pi = pre[1] + gin[1], pc = pre[2] + gin[2], po = pre[3] + gin[3];
+                if (p.GP) {
+                    float* gp = p.GP + (long)t * p.g_step + (long)prow * 4 * H + punit;
+                    gp[0] = pf; gp[H] = pi; gp[2L * H] = pc; gp[3L * H] = po;
+                }
+                const float fg = sigmoidf_(pf), ig = sigmoidf_(pi), cg = tanhf(pc), og = sigmoidf_(po);
+                const float c = cst[rl * 512 + punit] * fg + ig * cg;
+                cst[rl * 512 + punit] = c;
+                const float hn = og * tanhf(c);
+                if (p.C) p.C[(long)t * p.c_step + (long)prow * H + punit] = c;
+                p.HS[(long)t * p.hs_step + (long)prow * H + punit] = hn;
+                if (t + 1 < p.J) p.HP[(long)t * p.hp_stride + (long)prow * H + punit] = sigmoidf_(fnext) * hn;
+            }
+            __syncthreads();                     // red is free again
+        }
+        // the gated state of this step was written by this workgroup's own waves: complete the stores, then everyone may read it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
 // Workgroups of pu_chain_kernel<UT> the device keeps resident at once (0: the chain kernel cannot be used).
 template <int UT>
 static inline int pu_chain_resident() {
@@ -269,9 +373,10 @@ static inline int pu_chain_resident() {
     return per_cu * prop.multiProcessorCount;
 }
 
-// One PU layer over all J steps of B rows (p.HP: (J - 1) * hp_stride floats, armed here).  resident1/resident2: pu_chain_resident<1/2>().
-// Returns false when the chain kernel cannot run here (the caller then walks the steps with pu_step_launch).
-static inline bool pu_chain_launch(hipStream_t s, int resident1, int resident2, PuChain p, int B) {
+// One PU layer over all J steps of B rows (p.HP: (J - 1) * hp_stride floats, armed here; p.fault zeroed here).
+// resident1/resident2: pu_chain_resident<1/2>().  Returns false when the chain kernel cannot run here (the caller then walks the steps
+// with pu_step_launch).  Every chain launch is followed by its pu_solo_kernel, which does nothing unless the launch faulted.
+static inline bool pu_chain_launch(hipStream_t s, int resident1, int resident2, PuChain p, int B, int debug_drop = 0) {
     const int nrb = (B + 15) / 16;
     const bool small = nrb * 32 <= resident1 && nrb <= 8;      // few rows: 16 units per workgroup, twice the workgroups
     const int nbg = small ? 32 : 16, resident = small ? resident1 : resident2;
@@ -279,16 +384,19 @@ static inline bool pu_chain_launch(hipStream_t s, int resident1, int resident2, 
     if (chunk_rb < 1) return false;
     {   // every gated-state word starts as "not stored yet" (a kernel, so a captured graph re-arms it on every replay)
         const long n = (long)(p.J - 1) * p.hp_stride;
-        hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned*)p.HP, n, PU_SENTINEL);
+        hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned*)p.HP, n, PU_SENTINEL, p.fault);
     }
     for (int rb0 = 0; rb0 < nrb; rb0 += chunk_rb) {
         const int nb = min(chunk_rb, nrb - rb0), row0 = rb0 * 16;
         PuChain q = p;
         q.F = p.F + (long)row0 * p.ldf; q.G = p.G + (long)row0 * 4 * p.H; q.HS = p.HS + (long)row0 * p.H; q.HP = p.HP + (long)row0 * p.H;
+        if (p.GP) q.GP = p.GP + (long)row0 * 4 * p.H;
         if (p.C) q.C = p.C + (long)row0 * p.H;
         q.rows = min(B - row0, nb * 16);
-        if (small) hipLaunchKernelGGL(pu_chain_kernel<1>, dim3(nb * nbg), dim3(1024), 0, s, q);
-        else hipLaunchKernelGGL(pu_chain_kernel<2>, dim3(nb * nbg), dim3(1024), 0, s, q);
+        const int wgs = nb * nbg - (rb0 + chunk_rb >= nrb ? debug_drop : 0);      // debug_drop: the last row block is starved (test hook)
+        if (small) hipLaunchKernelGGL(pu_chain_kernel<1>, dim3(wgs), dim3(1024), 0, s, q);
+        else hipLaunchKernelGGL(pu_chain_kernel<2>, dim3(wgs), dim3(1024), 0, s, q);
+        hipLaunchKernelGGL(pu_solo_kernel, dim3(nb), dim3(1024), 0, s, q);
     }
     return true;
 }

@@ -183,11 +183,11 @@ class EgoTAPAutoEncoderModel(nn.Module):
         if not self.isTrain:
             raise RuntimeError("optimize_parameters() needs a model created with opt.isTrain = True")
         self.net_AutoEncoder.train()
-        if self.use_amp and getattr(self.net_AutoEncoder, "precision", "f32") == "f32":
-            self.net_AutoEncoder.set_precision(self.amp_precision)      # --use_amp: reduced-precision training arithmetic
-        if self.use_amp:           # the reference's autocast spans the frozen estimators' forward too (egotap_autoencoder_model.py:219)
-            for n in (self.net_HeatMap, self.net_RotHeatMap):
-                if getattr(n, "precision", "f32") == "f32":
+        if self.use_amp:           # --use_amp: reduced-precision training arithmetic (opt.amp_precision, default "bf16"); the reference's
+            # autocast spans the frozen estimators' forward too (egotap_autoencoder_model.py:219).  The requested mode is set
+            # explicitly: whatever a caller (or evaluate()) left on the networks, the step runs in opt.amp_precision.
+            for n in (self.net_AutoEncoder, self.net_HeatMap, self.net_RotHeatMap):
+                if getattr(n, "precision", "f32") != self.amp_precision:
                     n.set_precision(self.amp_precision)
         for o in self.optimizers:
             o.zero_grad()
@@ -214,15 +214,17 @@ class EgoTAPAutoEncoderModel(nn.Module):
         with torch.no_grad():
             nets = (self.net_AutoEncoder, self.net_HeatMap, self.net_RotHeatMap)
             prec = [getattr(n, "precision", "f32") for n in nets]
-            if self.use_amp:
-                for n, q in zip(nets, prec):
-                    if q != "f32":
-                        n.set_precision("f32")                   # autocast is off in evaluation (forward(evaluate=True))
-            self.forward(evaluate=True)
-            if self.use_amp:
-                for n, q in zip(nets, prec):
-                    if q != "f32":
-                        n.set_precision(q)
+            try:
+                if self.use_amp:
+                    for n, q in zip(nets, prec):
+                        if q != "f32":
+                            n.set_precision("f32")               # autocast is off in evaluation (forward(evaluate=True))
+                self.forward(evaluate=True)
+            finally:                                             # an exception in the forward must not leave training in fp32
+                if self.use_amp:
+                    for n, q in zip(nets, prec):
+                        if getattr(n, "precision", "f32") != q:
+                            n.set_precision(q)
             from . import lib as _lib                     # one fused launch: per-sample MPJPE + Procrustes-aligned MPJPE
             err, pa = _lib.pose_metrics(self.pred_pose, self.gt_pose)
             err, pa = (err * self.cm2mm).cpu(), (pa * self.cm2mm).cpu()      # one device->host copy, not one per sample

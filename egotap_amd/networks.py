@@ -118,6 +118,14 @@ class EgoTAPAutoEncoder(nn.Module):
         _lib.check(_lib.load().egotap_set_pu_chain(self._ensure_handle(), int(bool(enable))))
         return self
 
+    def pu_chain_status(self):
+        """(enabled, faults): whether this module still runs the recurrence as one launch per layer, and how many of its launches had
+        to be redone on the device because their workgroups were not co-resident (egotap.h egotap_pu_chain_status; results were
+        right every time -- the library switches itself to the per-step kernels after the first).  Exact after a synchronise."""
+        en, nf = C.c_int(), C.c_int()
+        _lib.check(_lib.load().egotap_pu_chain_status(self._ensure_handle(), C.byref(en), C.byref(nf)))
+        return bool(en.value), nf.value
+
     def _bind(self, device):
         sd = dict(self.named_parameters())
         sd.update(dict(self.named_buffers()))
@@ -249,24 +257,40 @@ class EgoTAPAutoEncoder(nn.Module):
             raise ValueError(f"expected input [B, {p.in_channels}, {p.hm_size}, {p.hm_size}], got {tuple(input.shape)}")
         dev = input.device
         self._bind(dev)
-        key = (input.shape[0], str(dev), getattr(self, "precision", "f32"), self._bound_sig)
+        B = input.shape[0]
+        key = (B, str(dev), getattr(self, "precision", "f32"), self._bound_sig)
         graphs = self.__dict__.setdefault("_graphs", {})
         g = graphs.get(key)
         if g is None:
+            # Every pointer a captured launch takes is baked into the graph, so the graph OWNS what it replays into: a workspace of
+            # its own (the module's grow-only self._ws is replaced -- and the old one handed back to the allocator -- as soon as a
+            # larger batch arrives) and references to the bf16 scratch buffers attached to the handle at capture time (replaced, not
+            # resized, when they grow; their contents are transient within one launch, so sharing them between graphs is fine).
+            lib, h = _lib.load(), self._ensure_handle()
             static_in = input.detach().float().contiguous().clone()
+            static_out = torch.empty((B, p.out_joints, 3), dtype=torch.float32, device=dev)
             self.predict_pose(static_in)                   # eager once: lazy occupancy queries and allocations happen here
+            need = C.c_size_t()
+            _lib.check(lib.egotap_lift_workspace_bytes(h, B, C.byref(need)))
+            ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+            self._act_scratch(B, dev)
+            keep = (ws, getattr(self, "_ascratch", None), getattr(self, "_wscratch", None))
+
+            def run():
+                _lib.check(lib.egotap_lift_forward(h, C.c_void_p(static_in.data_ptr()), B, C.c_void_p(static_out.data_ptr()),
+                                                   C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                self.predict_pose(static_in)
+            with torch.cuda.device(dev), torch.cuda.stream(side):
+                run()
             torch.cuda.current_stream(dev).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                static_out = self.predict_pose(static_in)
+            with torch.cuda.device(dev), torch.cuda.graph(graph, stream=side):
+                run()
             if len(graphs) >= 8:                           # a handful of serving batch sizes; drop the oldest beyond that
                 graphs.pop(next(iter(graphs)))
-            g = graphs[key] = (graph, static_in, static_out)
-        graph, static_in, static_out = g
+            g = graphs[key] = (graph, static_in, static_out, keep)
+        graph, static_in, static_out, _ = g
         static_in.copy_(input)
         graph.replay()
         return static_out

@@ -51,6 +51,16 @@ def max_over_ranks(value: float, device: torch.device | None = None) -> float:
     return float(t.item())
 
 
+def gather_floats(value: float, device: torch.device | None = None):
+    """every rank's value, in rank order (per-rank step times of a measurement)"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def gather_poses(pose: torch.Tensor, counts=None) -> torch.Tensor:
     """All ranks' [b_r, J, 3] poses concatenated in rank order (equal shard sizes unless ``counts`` is given)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -107,18 +117,28 @@ class GradReducer:
     in the order the backward finishes them (head + encoders first, then ViT layers last to first, patch embedding last); as soon as
     a bucket's kernels are enqueued the training Function calls ``bucket_ready(lo, hi)`` and the bucket's all-reduce starts on the
     process group's own stream (RCCL: torch orders it behind the compute stream's current point) while the backward goes on.
-    ``finish()`` waits for the outstanding buckets, scales by 1 / world in place and reports how long the compute stream had to wait
-    (the EXPOSED all-reduce time).  In place on arena slices: no torch.cat pack, no copy-back.  No-op for one rank."""
+    ``finish()`` makes the compute stream wait for the outstanding buckets (bucket by bucket: on gloo, which has no averaging
+    reduction, bucket k is scaled by 1 / world while bucket k+1 is still on the wire; on RCCL the collective itself averages,
+    ReduceOp.AVG, and there is no scaling pass) and brackets that wait with two events: ``read_exposed_ms()`` is the EXPOSED
+    all-reduce time of the last step.  In place on arena slices: no torch.cat pack, no copy-back.  No-op for one rank unless
+    ``force`` is set (tests: a one-rank RCCL group still runs every collective, the side stream and the event hand-off)."""
 
     def __init__(self):
         self.pending = []
-        self.exposed_ms = 0.0
-        self.steps = 0
+        self.exposed_ms = 0.0        # sum of the exposed waits read so far (read_exposed_ms accumulates)
+        self.steps = 0               # finish() calls that had collectives to wait for
+        self.force = False           # run the collectives on a one-rank group too
+        self.last_buckets = 0        # collectives issued by the last step
+        self.last_bytes = 0          # bytes all-reduced by the last step
         self._ev = None
+        self._side = None
 
-    @staticmethod
-    def active():
-        return dist.is_initialized() and dist.get_world_size() > 1
+    def active(self):
+        return dist.is_initialized() and (dist.get_world_size() > 1 or self.force)
+
+    def _op(self):
+        """RCCL averages inside the collective; gloo has no AVG (sum, then a scaling pass in finish())"""
+        return dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
 
     def begin(self, arena):
         self.arena = arena
@@ -138,36 +158,49 @@ class GradReducer:
         if not self.active() or hi <= lo:
             return
         if after is None or not self.arena.is_cuda:
-            self.pending.append((dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi))
+            self.pending.append((dist.all_reduce(self.arena[lo:hi], op=self._op(), async_op=True), lo, hi))
             return
-        if getattr(self, "_side", None) is None:
+        if self._side is None:
             self._side = torch.cuda.Stream()
         with torch.cuda.stream(self._side):
             self._side.wait_event(after)
-            self.pending.append((dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi))
+            self.pending.append((dist.all_reduce(self.arena[lo:hi], op=self._op(), async_op=True), lo, hi))
 
     def finish(self):
+        """Order the caller's stream behind every outstanding bucket.  Returns the number of collectives waited for; the time the
+        stream spent waiting is only known once the GPU got there: read_exposed_ms()."""
         if not self.active():
-            return 0.0
+            return 0
         world = dist.get_world_size()
+        scale = self._op() == dist.ReduceOp.SUM and world > 1
         cuda = self.arena.is_cuda
         if cuda:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         for work, lo, hi in self.pending:
             work.wait()
+            if scale and not cuda:
+                self.arena[lo:hi].mul_(1.0 / world)
         if cuda:
             e1.record()
             self._ev = (e0, e1)
-        for _, lo, hi in self.pending:
-            self.arena[lo:hi].mul_(1.0 / world)
+            if scale:                                        # (gloo on device tensors: the one-GPU rehearsal)
+                for _, lo, hi in self.pending:
+                    self.arena[lo:hi].mul_(1.0 / world)
+        n = len(self.pending)
+        self.last_buckets = n
+        self.last_bytes = sum((hi - lo) * self.arena.element_size() for _, lo, hi in self.pending)
         self.pending = []
-        self.steps += 1
-        return 0.0
+        self.steps += 1 if n else 0
+        return n
 
     def read_exposed_ms(self):
-        """exposed wait of the LAST finish() in milliseconds (synchronises)"""
+        """exposed wait of the LAST finish() in milliseconds (synchronises on its closing event); accumulated in ``exposed_ms``"""
         if self._ev is None:
             return 0.0
         self._ev[1].synchronize()
-        return float(self._ev[0].elapsed_time(self._ev[1]))
+        ms = float(self._ev[0].elapsed_time(self._ev[1]))
+        self.exposed_ms += ms
+        self._ev = None
+        self._last_ms = ms
+        return ms

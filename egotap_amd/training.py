@@ -69,15 +69,28 @@ def _grad_arena(net, P):
     return ga, G
 
 
-def _publish_grads(P, G):
+def _held_grads(P, G):
+    """A backward writes the whole arena (accumulate = 0 in every gradient kernel).  Parameters whose .grad still IS their arena
+    view (a second backward before zero_grad: gradient accumulation, several losses) would lose the gradient they hold, so it is
+    copied aside here, before the kernels run, and added back by _publish_grads.  Empty in the reference's loop (zero_grad, one
+    backward, step: model/egotap_autoencoder_model.py:299-323)."""
+    return {k: prm.grad.clone() for k, prm in P.items() if prm.grad is not None and prm.grad.data_ptr() == G[k].data_ptr()}
+
+
+def _publish_grads(P, G, held=None):
     """hand the arena views to the parameters directly (.grad), instead of returning them through autograd's accumulation (which
     would copy 384 MB unless it can steal the buffers): the optimizer and the gradient reducer then work in place on the arena.
-    A parameter that already holds a gradient (a second backward before zero_grad) accumulates."""
+    A parameter that already holds a gradient (a second backward before zero_grad) accumulates: into its own tensor when that is
+    not the arena view, through the copy _held_grads took when it is."""
     for k, prm in P.items():
         if prm.grad is None:
             prm.grad = G[k]
         elif prm.grad.data_ptr() != G[k].data_ptr():
             prm.grad.add_(G[k])
+        elif held is not None and k in held:
+            G[k].add_(held[k])
+        else:
+            raise RuntimeError(f"{k}: .grad aliases the gradient arena but was not saved before the backward overwrote it")
 
 
 _train_ws = T.Scratch()
@@ -126,7 +139,12 @@ class LiftTrainOneCallFn(torch.autograd.Function):
         if pool is not None and not pool["busy"] and pool["buf"].numel() >= sb.value and pool["buf"].device == dev:
             saved = pool["buf"]
             pool["busy"] = True
-        else:                  # also after a forward whose backward never ran: the module then tracks the newer buffer
+        else:
+            # too small, another device, or still marked busy.  Busy means a forward whose backward has not run: either it is
+            # still to come (two forwards, then two backwards: its ctx holds the buffer, dropping the module's reference frees
+            # nothing early) or it never will (a no_grad train-mode forward, an exception): then this reference was the last one
+            # and releasing it BEFORE the new allocation keeps the peak at one buffer (~30 GB at B = 1024) instead of two.
+            net._saved_pool = pool = None
             saved = torch.empty(sb.value, dtype=torch.uint8, device=dev)
             net._saved_pool = pool = dict(buf=saved, busy=True)
         ws = _train_ws.get(wb.value, dev)
@@ -146,6 +164,7 @@ class LiftTrainOneCallFn(torch.autograd.Function):
         lib = _lib.load()
         dev = dpose.device
         ga, G = _grad_arena(net, P)
+        held = _held_grads(P, G)
         _bind_grads(net, h, ga, G)
         red = net._reducer()
         red.begin(ga["flat"])
@@ -161,7 +180,7 @@ class LiftTrainOneCallFn(torch.autograd.Function):
         for k, e in enumerate(events):
             red.bucket_ready(ga["bounds"][k], ga["bounds"][k + 1], after=e)
         red.finish()
-        _publish_grads(P, G)
+        _publish_grads(P, G, held)
         S["pool"]["busy"] = False
         ctx.egotap = None
         return (None, None) + (None,) * len(keys)
@@ -257,6 +276,7 @@ class LiftTrainFn(torch.autograd.Function):
         lib = _lib.load()
         st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ga, G = _grad_arena(net, P)                            # every entry is fully overwritten below
+        held = _held_grads(P, G)
         red = net._reducer()
         red.begin(ga["flat"])
         dpose = dpose.detach().float().contiguous()
@@ -344,7 +364,7 @@ class LiftTrainFn(torch.autograd.Function):
         red.bucket_ready(ga["bounds"][nb - 3], ga["bounds"][nb - 2])
         red.bucket_ready(ga["bounds"][nb - 2], ga["bounds"][nb - 1])
         red.finish()
-        _publish_grads(P, G)
+        _publish_grads(P, G, held)
         ctx.egotap = None
         return (None, None) + (None,) * len(keys)
 
@@ -468,6 +488,7 @@ class LiftTrainBf16Fn(torch.autograd.Function):
         lib = _lib.load()
         st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)      # noqa: E731
         ga, G = _grad_arena(net, P)                            # every entry is fully overwritten below
+        held = _held_grads(P, G)
         red = net._reducer()
         red.begin(ga["flat"])
         dpose = dpose.detach().float().contiguous()
@@ -555,7 +576,7 @@ class LiftTrainBf16Fn(torch.autograd.Function):
         red.bucket_ready(ga["bounds"][nb - 3], ga["bounds"][nb - 2])
         red.bucket_ready(ga["bounds"][nb - 2], ga["bounds"][nb - 1])
         red.finish()
-        _publish_grads(P, G)
+        _publish_grads(P, G, held)
         ctx.egotap = None
         return (None, None) + (None,) * len(keys)
 

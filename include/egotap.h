@@ -109,9 +109,18 @@ int egotap_set_precision(egotap_handle h, int mode);
  * inside the launch: they must all be resident together, which holds when the calling process has the device to itself while a
  * forward runs (one process per GPU, the deployment this library is written for).  Where the device is shared -- another process, or
  * another stream of this one running long kernels -- pass enable = 0: the recurrence then runs as one kernel per step (same bits,
- * ~2x the latency of that part).  With the chain enabled on a shared device the waits inside it are bounded and run out: the call
- * returns, the poses are NaN. */
+ * ~2x the latency of that part).  With the chain enabled on a shared device the waits inside it are bounded and run out: the
+ * workgroups concerned store nothing and raise a fault word in the workspace, and a second kernel queued behind every chain launch
+ * (idle otherwise) then redoes that launch without cross-workgroup waits -- the call's results are RIGHT (same bits), it only took
+ * ~0.1-0.2 s longer.  The library notices at its next call on the handle (a host-mapped word, no synchronisation) and from then on
+ * uses the per-step kernels for that handle by itself. */
 int egotap_set_pu_chain(egotap_handle h, int enable);
+/* *enabled: whether the handle still uses the one-launch recurrence; *faults: chain launches that had to be redone so far (see above).
+ * Exact for calls whose stream the caller has synchronised. */
+int egotap_pu_chain_status(egotap_handle h, int* enabled, int* faults);
+/* Test hook: launch the one-launch recurrence with its last `n` workgroups missing (0 = off), which starves a row block exactly as a
+ * shared device does. */
+int egotap_debug_pu_drop_workgroups(egotap_handle h, int n);
 /* EGOTAP_PREC_BF16 only: caller-owned device scratch (16-byte aligned) into which a GEMM's weight matrix is rounded to bf16 right
  * before the launch (stream ordered; nothing is cached, the live fp32 parameters stay the source of truth).  Halves the W operand's
  * vector-memory bytes, which bound that mode.  bytes >= 2 * the largest N*K (67 MB for fc1 of the position encoder); NULL = off. */

@@ -242,3 +242,93 @@ def test_one_call_training_abi_equals_the_operator_composition(preset, B, mode):
     for k in b_a:
         assert torch.equal(b_a[k], b_b[k]), k
     assert int(b_a["pos_heatmap_encoder.fc1.bn.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("one_call", [True, False])
+def test_second_backward_before_zero_grad_accumulates(one_call):
+    """.grad is a view of the flat gradient arena, which every backward overwrites: a second backward before zero_grad() must ADD to
+    the gradient the parameters hold (gradient accumulation, several losses), not replace it"""
+    from egotap_amd.training import PoseLossFn
+    net, p = _fresh_net()
+    net.train()
+    net.one_call_training = one_call
+    hm = torch.from_numpy(synth_input("hm_train", (2, 90, 64, 64))).cuda()
+    gts = [torch.from_numpy(synth_input(f"gt_acc{i}", (2, 16, 3), -1.0, 1.0)).cuda() for i in range(2)]
+    bufs = {k: v.clone() for k, v in net.named_buffers()}
+    singles = []
+    for gt in gts:
+        for k, v in net.named_buffers():
+            v.copy_(bufs[k])
+        net.zero_grad()
+        PoseLossFn.apply(net, net(hm)[0], gt, 0.1, -0.01).sum().backward()
+        singles.append({k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None})
+    net.zero_grad()
+    for gt in gts:                                               # two backwards, no zero_grad in between
+        for k, v in net.named_buffers():
+            v.copy_(bufs[k])
+        PoseLossFn.apply(net, net(hm)[0], gt, 0.1, -0.01).sum().backward()
+    torch.cuda.synchronize()
+    for k, v in net.named_parameters():
+        if v.grad is not None:
+            assert torch.equal(v.grad, singles[0][k] + singles[1][k]), k
+
+
+def test_no_grad_train_forward_does_not_keep_a_second_activation_buffer():
+    """a train-mode forward whose backward never runs (no_grad, an exception) leaves the activations' buffer marked busy; the next
+    forward must release it before allocating its replacement (30 GB each at B = 1024)"""
+    net, p = _fresh_net()
+    net.train()
+    hm = torch.from_numpy(synth_input("hm_train", (2, 90, 64, 64))).cuda()
+    with torch.no_grad():
+        net(hm)
+    first = net._saved_pool["buf"]
+    ptr, size = first.data_ptr(), first.numel()
+    del first
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    with torch.no_grad():
+        net(hm)
+    torch.cuda.synchronize()
+    assert net._saved_pool["buf"].numel() == size
+    assert torch.cuda.max_memory_allocated() - base < size // 2      # never two activation buffers alive at once
+
+
+def test_one_call_backward_on_a_one_rank_rccl_group():
+    """RCCL on the box's one GPU: a world-size-1 "nccl" process group, the reducer forced on -- the one-call backward records its
+    bucket events, every bucket is all-reduced (ReduceOp.AVG) on the side stream behind its event, finish() orders the compute
+    stream behind them.  Averaging over one rank is the identity: gradients equal the no-collective step bit for bit."""
+    import socket
+    import torch.distributed as dist
+    from egotap_amd.training import PoseLossFn
+    hm = torch.from_numpy(synth_input("hm_train", (2, 90, 64, 64))).cuda()
+    gt = torch.from_numpy(synth_input("gt_train", (2, 16, 3), -1.0, 1.0)).cuda()
+    net, p = _fresh_net()
+    net.train()
+    bufs = {k: v.clone() for k, v in net.named_buffers()}
+    PoseLossFn.apply(net, net(hm)[0], gt, 0.1, -0.01).sum().backward()
+    want = {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None}
+    assert not dist.is_initialized()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl"
+        red = net._reducer()
+        red.force = True
+        for k, v in net.named_buffers():
+            v.copy_(bufs[k])
+        net.zero_grad()
+        PoseLossFn.apply(net, net(hm)[0], gt, 0.1, -0.01).sum().backward()
+        torch.cuda.synchronize()
+        assert red.last_buckets == p.vit_layers + 2 and red.steps == 1
+        n_params = sum(v.numel() for v in net.parameters() if v.grad is not None)
+        assert 4 * n_params <= red.last_bytes <= 4 * n_params + 256 * 200      # whole arena (256-byte aligned slices), once
+        assert red.read_exposed_ms() >= 0.0
+        for k, v in net.named_parameters():
+            if v.grad is not None:
+                assert torch.equal(v.grad, want[k]), k
+    finally:
+        net._reducer().force = False
+        dist.destroy_process_group()

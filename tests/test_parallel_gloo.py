@@ -85,3 +85,52 @@ def test_gradient_allreduce_two_ranks(tmp_path):
     ref = torch.cat(ref).numpy()
     for rank in range(2):
         np.testing.assert_allclose(np.load(tmp_path / f"g{rank}.npy"), ref, rtol=1e-6)
+
+
+def _reducer_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    P.init_from_env("gloo")
+    g = torch.Generator().manual_seed(11)
+    base = torch.rand(10_000, generator=g)
+    arena = base * (rank + 1)                                   # this rank's gradients, already in arena order
+    bounds = [0, 3000, 3000, 7168, 10_000]                      # four buckets, one of them empty
+    red = P.GradReducer()
+    assert red.active()
+    red.begin(arena)
+    for lo, hi in zip(bounds, bounds[1:]):                      # the training Function calls this as each bucket becomes final
+        red.bucket_ready(lo, hi)
+    assert len(red.pending) == 3
+    n = red.finish()
+    assert n == 3 and red.last_buckets == 3 and red.last_bytes == 4 * 10_000 and red.steps == 1 and red.pending == []
+    assert red.read_exposed_ms() == 0.0                         # CPU tensors: nothing to time
+    # the same gradients through the generic bucketed reducer (what the stage-1 wrapper uses)
+    prm = torch.nn.Parameter(torch.zeros(10_000))
+    prm.grad = base * (rank + 1)
+    P.allreduce_gradients([prm], bucket_bytes=8_000)
+    np.save(os.path.join(out_dir, f"a{rank}.npy"), np.stack([arena.numpy(), prm.grad.numpy()]))
+    torch.distributed.destroy_process_group()
+
+
+def test_grad_reducer_two_ranks(tmp_path):
+    """parallel.GradReducer (the in-backward bucketed all-reduce on the flat gradient arena): after finish() every rank holds the
+    MEAN of the per-rank arenas, bucket by bucket in place, identical to allreduce_gradients"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_reducer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(11)
+    ref = (torch.rand(10_000, generator=g) * 1.5).numpy()
+    for rank in range(2):
+        got = np.load(tmp_path / f"a{rank}.npy")
+        np.testing.assert_allclose(got[0], ref, rtol=1e-6)
+        np.testing.assert_array_equal(got[0], got[1])
+
+
+def test_grad_reducer_is_a_noop_without_a_group():
+    red = P.GradReducer()
+    assert not red.active()
+    arena = torch.ones(8)
+    red.begin(arena)
+    red.bucket_ready(0, 8)
+    assert red.finish() == 0 and red.pending == [] and torch.equal(arena, torch.ones(8))
