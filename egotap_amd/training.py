@@ -494,6 +494,11 @@ class LiftTrainBf16Fn(torch.autograd.Function):
         dpose = dpose.detach().float().contiguous()
         v = "pos_heatmap_encoder.vit."
         posz, rotz, hs1 = Sv["pos_acts"][-1]["y"], Sv["rot_acts"][-1]["y"], Sv["hs1"]
+        # net._stage_trace = {} (tests): every intermediate of this backward is kept under a name, together with the forward's saved
+        # activations, so that each stage can be checked against its own inputs (tests/test_gpu_bf16_stages.py)
+        tr = getattr(net, "_stage_trace", None)
+        if tr is not None:
+            tr.update(saved=Sv, W=W, dpose=dpose)
         # pose head + propagation units (fp32, as in every mode)
         dposz, drotz = torch.empty_like(posz), torch.empty_like(rotz)
         dhs1 = torch.empty(J * B * H, dtype=torch.float32, device=dev)
@@ -529,10 +534,14 @@ class LiftTrainBf16Fn(torch.autograd.Function):
 
         encoder_bwd(Sv["rot_acts"], drotz, 1, Sv["hm_b"], None)
         dtok = encoder_bwd(Sv["pos_acts"], dposz, 0, Sv["tokens"], W["fc1p_t"])       # bf16 [M, D], token order
+        if tr is not None:
+            tr.update(dposz=dposz, drotz=drotz, dtok=dtok)
         nl = p.vit_layers
         last = f"{v}encoder.layer.{nl - 1}."
         dx, dxb = S.layernorm_bwd(Sv["xf"], dtok, P[v + "layernorm.weight"], Sv["mf"], Sv["rf"], G[v + "layernorm.weight"], G[v + "layernorm.bias"],
                                   dcolsum=G[last + "output.dense.bias"])
+        if tr is not None:
+            tr["dx_final"], tr["dxb_final"] = dx, dxb
         del dtok
         for i in reversed(range(nl)):
             red.bucket_ready(ga["bounds"][nl - 1 - i], ga["bounds"][nl - i])      # everything above layer i is final: start its all-reduce
@@ -543,6 +552,8 @@ class LiftTrainBf16Fn(torch.autograd.Function):
             # MLP: dx is the output gradient of output.dense (its bias gradient came with the LayerNorm backward that produced dx)
             S.gemm_tn(dxb, L["hid"], G[l + "output.dense.weight"])
             dz = S.gemm_nt(dxb, Wl["dn_t"], None, epi="gelu_grad", aux=L["z"])
+            if tr is not None:
+                tr[f"L{i}"] = t_ = dict(dx_in=dx, dxb_in=dxb, dz=dz)
             del dxb
             S.gemm_tn(dz, L["y2"], G[l + "intermediate.dense.weight"])
             S.colsum(dz, G[l + "intermediate.dense.bias"])
@@ -550,21 +561,29 @@ class LiftTrainBf16Fn(torch.autograd.Function):
             del dz
             dxm, dxmb = S.layernorm_bwd(L["xm"], dy2, P[l + "layernorm_after.weight"], L["m2"], L["r2"], G[l + "layernorm_after.weight"],
                                         G[l + "layernorm_after.bias"], dres=dx, dcolsum=G[l + "attention.output.dense.bias"])
+            if tr is not None:
+                t_.update(dy2=dy2, dxm=dxm, dxmb=dxmb)
             del dy2, dx
             # attention
             S.gemm_tn(dxmb, L["ctx"], G[l + "attention.output.dense.weight"])
             dctx = S.gemm_nt(dxmb, Wl["o_t"], None)
             del dxmb
             dqkv = S.attention_bwd(L["qkv"], L["ctx"], dctx, L["lse"], B, seq, heads)
+            if tr is not None:
+                t_.update(dctx=dctx, dqkv=dqkv)
             del dctx
             for sidx, nme in enumerate(("query", "key", "value")):
                 S.gemm_tn(dqkv[:, sidx * D:(sidx + 1) * D], L["y1"], G[a + nme + ".weight"])
                 S.colsum(dqkv[:, sidx * D:(sidx + 1) * D], G[a + nme + ".bias"])
             dy1 = S.gemm_nt(dqkv, Wl["qkv_t"], None)
+            if tr is not None:
+                t_["dy1"] = dy1
             del dqkv
             prev_bias = G[f"{v}encoder.layer.{i - 1}.output.dense.bias"] if i > 0 else None
             dx, dxb = S.layernorm_bwd(L["x"], dy1, P[l + "layernorm_before.weight"], L["m1"], L["r1"], G[l + "layernorm_before.weight"],
                                       G[l + "layernorm_before.bias"], dres=dxm, dcolsum=prev_bias, want_bf16=i > 0)
+            if tr is not None:
+                t_.update(dx_out=dx, dxb_out=dxb)
             del dy1, dxm
         # patch embedding (fp32 operands: the input heatmaps): weight, position embeddings, bias / mask token
         T.gemm_tn(h, dx, Sv["hm"], G[v + "embeddings.patch_embeddings.projection.weight"], M, D, 256, loader=T.LD_PATCH)

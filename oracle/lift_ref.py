@@ -7,8 +7,13 @@ captured from the reference's own modules (tests/golden/lift_fwd_*.npz,
 pu_chain_*.npz, fcblock.npz, loss_*.npz; generator tools/make_golden.py), see
 tests/test_oracle_golden.py.
 
-Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline
-leg may import this file.
+Only ``tests/``, ``__graft_entry__.smoke()``, ``bench.py``'s cpu_baseline leg and the
+measurement probes under ``tools/`` may import this file.
+
+``round=Bf16Storage`` (optional argument of the forward / training functions) rounds
+to bf16 at the tensors the HIP bf16-storage mode keeps in bf16: an emulation of THIS
+repo's reduced-precision arithmetic for tighter test gates, not reference behaviour;
+``round=None`` is the pinned restatement.
 
 Reference lines restated (all under /root/reference):
   model/net_architecture.py:682-758   EgoTAPAutoEncoder.forward  -> lift_forward
@@ -92,13 +97,69 @@ def gelu_erf(x):
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
-def fc_block(x, sd, prefix, training=False, momentum=0.1, eps=1e-5):
+# ---------------------------------------------------------------------------
+# Optional emulation of the bf16-storage mode (DESIGN.md section 2 "bf16-storage mode"; what --use_amp maps to).  The reference has
+# no such arithmetic (it autocasts to fp16): this hook exists so that the HIP bf16 path can be gated against an oracle that rounds
+# at the SAME tensors (~1e-3) instead of against exact float64 with a 20 % allowance.  round=None (the default everywhere) leaves
+# every function below exactly as pinned by the golden vectors.
+def bf16_round(x):
+    return x.to(torch.float32).to(torch.bfloat16).to(x.dtype)
+
+
+class _Q(torch.autograd.Function):
+    """identity whose forward and / or backward value is rounded to bf16"""
+
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return bf16_round(x) if fwd else x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (bf16_round(g) if ctx.bwd else g), None, None
+
+
+class _GeluStored(torch.autograd.Function):
+    """SEpiGeluSave / SEpiGeluGrad (csrc/gemm_bf16s.h): hid = bf16(GELU(z)) from the fp32 pre-activation; the backward evaluates
+    GELU' at the STORED pre-activation bf16(z) and writes dz as bf16"""
+
+    @staticmethod
+    def forward(ctx, z):
+        ctx.save_for_backward(bf16_round(z))
+        return bf16_round(gelu_erf(z))
+
+    @staticmethod
+    def backward(ctx, g):
+        (zs,) = ctx.saved_tensors
+        d = 0.5 * (1.0 + torch.erf(zs / math.sqrt(2.0))) + zs * torch.exp(-0.5 * zs * zs) / math.sqrt(2.0 * math.pi)
+        return bf16_round(g * d)
+
+
+class Bf16Storage:
+    """round= hook: where the bf16-storage step keeps bf16 in HBM.
+      act : tensor stored as bf16 whose gradient is stored as bf16 too (LayerNorm outputs, qkv, ctx, tokens)
+      fwd : forward value rounded, gradient untouched (probabilities entering P.V; GEMM inputs that get no gradient)
+      bwd : gradient rounded, value untouched (the bf16 copy of dx a GEMM branch consumes; dS inside attention)
+      w   : per-step bf16 copy of a weight, gradient passed straight through to the fp32 master
+      gelu: the MLP's saved pre-activation / activation pair"""
+    act = staticmethod(lambda x: _Q.apply(x, True, True))
+    fwd = staticmethod(lambda x: _Q.apply(x, True, False))
+    bwd = staticmethod(lambda x: _Q.apply(x, False, True))
+    w = staticmethod(lambda x: _Q.apply(x, True, False))
+    gelu = staticmethod(_GeluStored.apply)
+
+
+def fc_block(x, sd, prefix, training=False, momentum=0.1, eps=1e-5, round=None, round_input=False):
     """LeakyReLU_0.2(BatchNorm1d(x W^T + b)); network_utils.py:123-142.
 
     training=True uses batch statistics and returns the updated running stats
     (unbiased variance, momentum 0.1) as torch's BatchNorm1d does.
     """
-    z = x @ sd[prefix + ".fc.weight"].T + sd[prefix + ".fc.bias"]
+    if round is not None:       # fc1 of both encoders: bf16 operands; dz is rounded for the weight- / input-gradient GEMMs, the bias sees fp32
+        xin = round.fwd(x) if round_input else x
+        z = round.bwd(xin @ round.w(sd[prefix + ".fc.weight"]).T) + sd[prefix + ".fc.bias"]
+    else:
+        z = x @ sd[prefix + ".fc.weight"].T + sd[prefix + ".fc.bias"]
     g, beta = sd[prefix + ".bn.weight"], sd[prefix + ".bn.bias"]
     if training:
         mean = z.mean(dim=0)
@@ -131,17 +192,22 @@ def tile_to_patches(pos_hm, p: LiftPreset):
     return patches, dummy
 
 
-def vit_embed(pos_hm, sd, p: LiftPreset, pre="pos_heatmap_encoder.vit."):
+def vit_embed(pos_hm, sd, p: LiftPreset, pre="pos_heatmap_encoder.vit.", round=None):
     patches, dummy = tile_to_patches(pos_hm, p)
     w = sd[pre + "embeddings.patch_embeddings.projection.weight"].reshape(p.vit_dim, -1)
     b = sd[pre + "embeddings.patch_embeddings.projection.bias"]
-    emb = patches @ w.T + b
+    if round is not None:       # operands rounded in registers, fp32 result (round-1 kernels in this mode)
+        emb = round.bwd(round.fwd(patches) @ round.w(w).T) + b
+    else:
+        emb = patches @ w.T + b
     mask_tok = sd[pre + "embeddings.mask_token"].reshape(-1)
     emb = torch.where(dummy[None, :, None], mask_tok[None, None, :], emb)
     return emb + sd[pre + "embeddings.position_embeddings"]
 
 
-def vit_layer(x, sd, pre, heads):
+def vit_layer(x, sd, pre, heads, round=None):
+    if round is not None:
+        return _vit_layer_bf16(x, sd, pre, heads, round)
     B, N, D = x.shape
     dh = D // heads
     h = layer_norm(x, sd[pre + "layernorm_before.weight"], sd[pre + "layernorm_before.bias"])
@@ -157,17 +223,36 @@ def vit_layer(x, sd, pre, heads):
     return x + h @ sd[pre + "output.dense.weight"].T + sd[pre + "output.dense.bias"]
 
 
-def pos_encoder(pos_hm, sd, p: LiftPreset, trace=None, training=False):
+def _vit_layer_bf16(x, sd, pre, heads, r):
+    """the same layer with the bf16-storage step's rounding points (training.py LiftTrainBf16Fn / egotap_lift_forward_train):
+    fp32 residual stream; y1, qkv, ctx, y2, z, hid in bf16; every large product on bf16 operands; P and dS rounded inside attention"""
+    B, N, D = x.shape
+    dh = D // heads
+    h = r.act(layer_norm(x, sd[pre + "layernorm_before.weight"], sd[pre + "layernorm_before.bias"]))
+    a = pre + "attention.attention."
+    lin = lambda t, n: r.act(t @ r.w(sd[a + n + ".weight"]).T + sd[a + n + ".bias"])      # noqa: E731   (bias gradient = column sums of bf16 dqkv)
+    q, k, v = (lin(h, n).view(B, N, heads, dh).transpose(1, 2) for n in ("query", "key", "value"))
+    s = r.bwd((q @ k.transpose(-1, -2)) / math.sqrt(dh))
+    ctx = r.act((r.fwd(torch.softmax(s, dim=-1)) @ v).transpose(1, 2).reshape(B, N, D))
+    x = x + r.bwd(ctx @ r.w(sd[pre + "attention.output.dense.weight"]).T) + sd[pre + "attention.output.dense.bias"]
+    h = r.act(layer_norm(x, sd[pre + "layernorm_after.weight"], sd[pre + "layernorm_after.bias"]))
+    h = r.gelu(h @ r.w(sd[pre + "intermediate.dense.weight"]).T + sd[pre + "intermediate.dense.bias"])
+    return x + r.bwd(h @ r.w(sd[pre + "output.dense.weight"]).T) + sd[pre + "output.dense.bias"]
+
+
+def pos_encoder(pos_hm, sd, p: LiftPreset, trace=None, training=False, round=None):
     """[B,T,hm,hm] -> [B*T, hidden]  (T tokens in [L_1..L_J, R_1..R_J] order)."""
     pre = "pos_heatmap_encoder."
-    x = vit_embed(pos_hm, sd, p)
+    x = vit_embed(pos_hm, sd, p, round=round)
     if trace is not None:
         trace["emb"] = x
     for i in range(p.vit_layers):
-        x = vit_layer(x, sd, f"{pre}vit.encoder.layer.{i}.", p.vit_heads)
+        x = vit_layer(x, sd, f"{pre}vit.encoder.layer.{i}.", p.vit_heads, round=round)
         if trace is not None:
             trace[f"layer{i}"] = x
     x = layer_norm(x, sd[pre + "vit.layernorm.weight"], sd[pre + "vit.layernorm.bias"])
+    if round is not None:
+        x = round.act(x)
     if trace is not None:
         trace["final_ln"] = x
     B, T, G, q, S, D = pos_hm.shape[0], p.tokens, p.grid, p.ppd, p.side, p.vit_dim
@@ -176,7 +261,7 @@ def pos_encoder(pos_hm, sd, p: LiftPreset, trace=None, training=False):
     z = grid[:, :T].reshape(B * T, q * q * D)
     stats = {}
     for name in ("fc1", "fc2", "fc3"):
-        z = fc_block(z, sd, pre + name, training)
+        z = fc_block(z, sd, pre + name, training, round=round if name == "fc1" else None)
         if training:
             z, stats[pre + name] = z
     return (z, stats) if training else z
@@ -189,11 +274,11 @@ def rot_relayout(rot_hm, p: LiftPreset):
     return rot_hm.view(B, 2, 2, J, hm * hm).permute(0, 1, 3, 2, 4).reshape(B * 2 * J, 2 * hm * hm)
 
 
-def rot_encoder(rot_hm, sd, p: LiftPreset, training=False):
+def rot_encoder(rot_hm, sd, p: LiftPreset, training=False, round=None):
     z = rot_relayout(rot_hm, p)
     stats = {}
     for name in ("fc1", "fc2", "fc3"):
-        z = fc_block(z, sd, "rot_heatmap_encoder." + name, training)
+        z = fc_block(z, sd, "rot_heatmap_encoder." + name, training, round=round if name == "fc1" else None, round_input=True)
         if training:
             z, stats["rot_heatmap_encoder." + name] = z
     return (z, stats) if training else z
@@ -261,11 +346,11 @@ def pose_head(pos_j, skel, sd, p: LiftPreset):
     return pose
 
 
-def lift_forward(hm, sd, p: LiftPreset, trace=None):
-    """hm [B, 6J, hm, hm] -> pose [B, out_joints, 3] (eval mode)."""
+def lift_forward(hm, sd, p: LiftPreset, trace=None, round=None):
+    """hm [B, 6J, hm, hm] -> pose [B, out_joints, 3] (eval mode).  round: None (the reference's arithmetic) or Bf16Storage."""
     B, J = hm.shape[0], p.n_joints_hm
-    pos = pos_encoder(hm[:, : 2 * J], sd, p, trace)
-    rot = rot_encoder(hm[:, 2 * J:], sd, p)
+    pos = pos_encoder(hm[:, : 2 * J], sd, p, trace, round=round)
+    rot = rot_encoder(hm[:, 2 * J:], sd, p, round=round)
     pos_j = stereo_interleave(pos, B, p)
     rot_j = stereo_interleave(rot, B, p)
     skel = pu_chain(pos_j.transpose(0, 1), rot_j.transpose(0, 1), sd)
@@ -297,12 +382,12 @@ def loss_cos_sim(pred, gt, p: LiftPreset, eps=1e-8):
     return cos.sum(dim=1).mean()
 
 
-def lift_forward_train(hm, sd, p: LiftPreset):
+def lift_forward_train(hm, sd, p: LiftPreset, round=None):
     """Training-mode forward (BatchNorm1d batch statistics in the six FC blocks): returns (pose, {bn prefix: (new running
     mean, new running var)}).  Differentiable with torch autograd w.r.t. every tensor of sd that requires grad."""
     B, J = hm.shape[0], p.n_joints_hm
-    pos, st1 = pos_encoder(hm[:, : 2 * J], sd, p, None, training=True)
-    rot, st2 = rot_encoder(hm[:, 2 * J:], sd, p, training=True)
+    pos, st1 = pos_encoder(hm[:, : 2 * J], sd, p, None, training=True, round=round)
+    rot, st2 = rot_encoder(hm[:, 2 * J:], sd, p, training=True, round=round)
     pos_j = stereo_interleave(pos, B, p)
     rot_j = stereo_interleave(rot, B, p)
     skel = pu_chain(pos_j.transpose(0, 1), rot_j.transpose(0, 1), sd)
@@ -310,7 +395,7 @@ def lift_forward_train(hm, sd, p: LiftPreset):
     return pose_head(pos_j, skel, sd, p), st1
 
 
-def train_step(hm, gt, sd, p: LiftPreset, lam_mpjpe=0.1, lam_cos=-0.01, lr=1e-3, eps=1e-4, wd=0.0):
+def train_step(hm, gt, sd, p: LiftPreset, lam_mpjpe=0.1, lam_cos=-0.01, lr=1e-3, eps=1e-4, wd=0.0, round=None):
     """One optimisation step of egotap_autoencoder_model.py:299-323 (fp32, no AMP): forward in train mode, loss =
     lam_mpjpe * MPJPE + lam_cos * lam_mpjpe * CosSim, backward, AdamW (network.py:72-78; betas 0.9 / 0.999).
     Returns dict(pose, loss_pose, loss_cos_sim, grads{key}, new_params{key}, bn{prefix: (rm, rv)})."""
@@ -319,7 +404,7 @@ def train_step(hm, gt, sd, p: LiftPreset, lam_mpjpe=0.1, lam_cos=-0.01, lr=1e-3,
               if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) and not any(d in k for d in dead)}
     full = dict(sd)
     full.update(leaves)
-    pose, bn = lift_forward_train(hm, full, p)
+    pose, bn = lift_forward_train(hm, full, p, round=round)
     lp = loss_mpjpe(pose, gt) * lam_mpjpe
     lc = loss_cos_sim(pose, gt, p) * lam_cos * lam_mpjpe
     grads = dict(zip(leaves.keys(), torch.autograd.grad(lp + lc, list(leaves.values()), allow_unused=True)))

@@ -1,0 +1,156 @@
+"""egotap_amd.models.EgoTAPAutoEncoderModel against fixtures produced by the REFERENCE'S OWN WRAPPER
+(model/egotap_autoencoder_model.py:155-237, 284-350; tools/make_golden.py gen_wrapper): three optimize_parameters() with the
+shipped training flags (frozen estimators from <dir>_pos / <dir>_sin checkpoints, --use_gt_heatmap, AdamW, cos_anneal_warmup,
+update_learning_rate between steps) and evaluate() of the test-mode wrapper after load_networks('best')."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from egotap_amd.synthetic import synth_hm_state_dict, synth_input, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _opt(tmp, is_train, use_gt_heatmap):
+    """the same flag values tools/make_golden.py::_wrapper_opt gave the reference"""
+    from egotap_amd.options import preset_defaults
+    opt = preset_defaults("UnrealEgo")
+    opt.model, opt.isTrain, opt.use_amp, opt.gpu_ids = "egotap_autoencoder", is_train, False, [0]
+    opt.log_dir, opt.experiment_name = str(tmp), "gold_wrapper"
+    opt.use_gt_heatmap = use_gt_heatmap
+    opt.path_to_trained_heatmap = "hm/best_net_HeatMap.pth" if is_train else None
+    opt.optimizer_type, opt.lr, opt.opt_eps, opt.weight_decay, opt.lr_policy = "AdamW", 1e-3, 1e-4, 0.0, "cos_anneal_warmup"
+    opt.niter, opt.niter_decay, opt.epoch_iter_cnt, opt.epoch_count = 1, 15, 4, 1
+    opt.lambda_mpjpe, opt.lambda_cos_sim = 0.1, -0.01
+    return opt
+
+
+def _data(B, tag):
+    hm = torch.from_numpy(synth_input(f"wrap_hm_{tag}", (B, 90, 64, 64)))
+    return {"input_rgb_left": torch.from_numpy(synth_input(f"wrap_rgbL_{tag}", (B, 3, 256, 256), -2.0, 2.0)),
+            "input_rgb_right": torch.from_numpy(synth_input(f"wrap_rgbR_{tag}", (B, 3, 256, 256), -2.0, 2.0)),
+            "gt_heatmap_left": hm[:, :15], "gt_heatmap_right": hm[:, 15:30],
+            "gt_limb_heatmap_left": hm[:, 30:60], "gt_limb_heatmap_right": hm[:, 60:],
+            "gt_local_pose": torch.from_numpy(synth_input(f"wrap_gt_{tag}", (B, 16, 3), -20.0, 20.0)),
+            "gt_local_rot": torch.zeros(B, 16, 3), "gt_limb_theta": torch.zeros(B, 15),
+            "gt_pelvis_left": torch.zeros(B, 3), "gt_pelvis_right": torch.zeros(B, 3),
+            "gt_plength_left": torch.ones(B, 30), "gt_plength_right": torch.ones(B, 30)}
+
+
+def _state_dicts():
+    from egotap_amd import spec
+    lift = {k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(spec.lift_preset("UnrealEgo"))).items()}
+    pos = {k: torch.from_numpy(v) for k, v in synth_hm_state_dict(15, "hm_pos.").items()}
+    rot = {k: torch.from_numpy(v) for k, v in synth_hm_state_dict(30, "hm_rot.").items()}
+    return lift, pos, rot
+
+
+def _strided(t):
+    return t.detach().reshape(-1)[:: max(1, t.numel() // 257)].cpu().numpy()
+
+
+def test_three_wrapper_steps_match_the_reference_wrapper(tmp_path):
+    from egotap_amd import models
+    g = np.load(os.path.join(GOLD, "wrapper_step_ue_b2.npz"))
+    lift, pos, rot = _state_dicts()
+    for sub, sd in (("hm_pos", pos), ("hm_sin", rot)):
+        os.makedirs(tmp_path / sub)
+        torch.save(sd, tmp_path / sub / "best_net_HeatMap.pth")
+    m = models.create_model(_opt(tmp_path, True, True))
+    m.net_AutoEncoder.load_state_dict(lift, strict=True)
+    assert list(m.loss_names) == list(g["loss_names"])
+    # frozen estimators: loaded from the two checkpoints, no parameter trains (egotap_autoencoder_model.py:113-129)
+    assert [int(any(q.requires_grad for q in n.parameters())) for n in (m.net_HeatMap, m.net_RotHeatMap)] == list(g["frozen_requires_grad"])
+    assert torch.equal(m.net_HeatMap.state_dict()["after_backbone.conv_heatmap.weight"].cpu(), pos["after_backbone.conv_heatmap.weight"])
+    assert m.optimizers[0].param_groups[0]["lr"] == float(g["lr_before"][0])            # warm-up starts at zero
+    m.set_input(_data(2, "step"))
+    params = dict(m.net_AutoEncoder.named_parameters())
+    norms = dict(zip(g["grad_keys"], g["grad_norms"]))
+
+    # ---- step 1 (lr = 0: gradients and BatchNorm statistics move, parameters do not)
+    m.optimize_parameters()
+    torch.cuda.synchronize()
+    errs = m.get_current_errors()
+    assert list(errs.keys()) == list(g["errors_keys"])
+    np.testing.assert_allclose([errs[k] for k in errs], g["errors_step1"], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(m.pred_pose.detach().cpu().numpy(), g["pred_pose_step1"], atol=1e-4)
+    cat = m.pred_heatmap_cat
+    np.testing.assert_allclose(cat.reshape(-1)[::997].cpu().numpy(), g["pred_heatmap_cat_sample"], atol=0, rtol=0)      # the channel order of the concat
+    np.testing.assert_allclose([float(cat.double().sum()), float(cat.double().abs().sum())], g["pred_heatmap_cat_stats"], rtol=1e-9)
+    shapes = [list(getattr(m, n).shape) for n in ("pred_heatmap_left_rec", "pred_heatmap_right_rec", "pred_limb_heatmap_left_rec",
+                                                  "pred_limb_heatmap_right_rec")]
+    assert shapes == g["rec_shapes"].tolist() and float(m.pred_heatmap_rec_cat.abs().sum()) == float(g["rec_abs_sum"][0])
+    assert list(m.pred_rot.shape) == list(g["pred_rot_shape"]) and list(m.pred_indep_pos.shape) == list(g["pred_indep_pos_shape"])
+    assert sorted(k for k, v in params.items() if v.grad is None) == sorted(g["no_grad_keys"])
+    assert sorted(k for k, v in params.items() if v.grad is not None) == sorted(g["grad_keys"])
+    for k in g["grad_keys"]:
+        gr = params[k].grad
+        scale = max(norms[k] / np.sqrt(gr.numel()), 1e-12)
+        err = np.abs(_strided(gr) - g["g:" + k]).max()
+        assert err <= 5e-3 * scale + 1e-8, f"{k}: sample err {err:.3e} vs typical magnitude {scale:.3e}"
+        np.testing.assert_allclose(float(gr.double().norm()), norms[k], rtol=1e-3, atol=5e-9 * np.sqrt(gr.numel()) + 1e-8, err_msg=k)
+        np.testing.assert_allclose(_strided(params[k]), g["p1:" + k], atol=0, rtol=0, err_msg=k)        # lr 0: bit-unchanged
+    m.update_learning_rate()
+    np.testing.assert_allclose(m.optimizers[0].param_groups[0]["lr"], g["lr_after_step1"][0], rtol=1e-12)
+
+    # ---- step 2 (same parameters -> same losses; first real update)
+    m.optimize_parameters()
+    torch.cuda.synchronize()
+    errs2 = m.get_current_errors()
+    np.testing.assert_allclose([errs2[k] for k in errs2], g["errors_step2"], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(m.pred_pose.detach().cpu().numpy(), g["pred_pose_step2"], atol=1e-4)
+    for k, want in zip(g["grad_keys"], g["param_sums_step2"]):
+        np.testing.assert_allclose(_strided(params[k]), g["p2:" + k], atol=3e-5, err_msg=k)
+        np.testing.assert_allclose(float(params[k].detach().double().sum()), want, rtol=1e-4, atol=3e-5 * np.sqrt(params[k].numel()) + 1e-4, err_msg=k)
+    m.update_learning_rate()
+    np.testing.assert_allclose(m.optimizers[0].param_groups[0]["lr"], g["lr_after_step2"][0], rtol=1e-12)
+
+    # ---- step 3: the forward now runs on updated parameters (AdamW's first step moves every weight by ~lr)
+    m.optimize_parameters()
+    torch.cuda.synchronize()
+    errs3 = m.get_current_errors()
+    np.testing.assert_allclose([errs3[k] for k in errs3], g["errors_step3"], rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(m.pred_pose.detach().cpu().numpy(), g["pred_pose_step3"], atol=2e-3)
+    sd = m.net_AutoEncoder.state_dict()                          # BatchNorm1d running statistics after the three train-mode forwards
+    for k in g.files:
+        if k.startswith("buf:"):
+            np.testing.assert_allclose(sd[k[4:]].cpu().numpy(), g[k], atol=2e-4, rtol=1e-3, err_msg=k)
+
+
+class _Acc:
+    def __init__(self):
+        self.rows = []
+
+    def update(self, d):
+        self.rows.append({k: float(v) for k, v in d.items()})
+
+
+@pytest.mark.parametrize("tag,use_gt", [("gt", True), ("rgb", False)])
+def test_wrapper_evaluate_matches_the_reference_wrapper(tmp_path, tag, use_gt):
+    """test.py's flow: create_model (isTrain False) -> load_networks('best') from the reference's file names -> evaluate().
+    'gt': the pure head path; 'rgb': through both estimators (the fixture ran them over this repo's ResNet-18 restatement standing in
+    for torchvision: pins the wrapper's plumbing -- which net fills which channels, concat order -- not torchvision's arithmetic)."""
+    from egotap_amd import models
+    g = np.load(os.path.join(GOLD, "wrapper_eval_ue_b4.npz"))
+    lift, pos, rot = _state_dicts()
+    save_dir = tmp_path / "gold_wrapper"
+    os.makedirs(save_dir)
+    for name, sd in (("HeatMap", pos), ("RotHeatMap", rot), ("AutoEncoder", lift)):
+        torch.save(sd, save_dir / f"best_net_{name}.pth")
+    m = models.create_model(_opt(tmp_path, False, use_gt))
+    m.load_networks("best")
+    m.eval()
+    m.set_input(_data(4, "eval"))
+    acc = _Acc()
+    pose, cat, _ = m.evaluate(acc)
+    torch.cuda.synchronize()
+    tol = 1e-4 if use_gt else 5e-4             # from RGB: 2 x 21 conv layers in fp32 in front of the head (oracle-vs-reference distance)
+    np.testing.assert_allclose(pose.cpu().numpy(), g[f"{tag}_pred_pose"], atol=tol)
+    np.testing.assert_allclose(cat.reshape(-1)[::997].cpu().numpy(), g[f"{tag}_heatmap_cat_sample"], atol=0 if use_gt else 3e-4)
+    np.testing.assert_allclose([float(cat.double().sum()), float(cat.double().abs().sum())], g[f"{tag}_heatmap_cat_stats"], rtol=1e-9 if use_gt else 1e-4)
+    assert len(acc.rows) == 4
+    np.testing.assert_allclose([r["mpjpe"] for r in acc.rows], g[f"{tag}_mpjpe"], rtol=1e-4)
+    np.testing.assert_allclose([r["pa_mpjpe"] for r in acc.rows], g[f"{tag}_pa_mpjpe"], rtol=1e-3)
