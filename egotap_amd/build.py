@@ -38,9 +38,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = _hipcc()
-    objdir = os.path.join(PKG, "build")
+    # experiment builds (EGOTAP_LIB=<other .so>, EGOTAP_CXXFLAGS="-DEGOTAP_ABL=1 ..."): objects next to their library, extra flags
+    objdir = os.path.join(PKG, "build") if "EGOTAP_LIB" not in os.environ else LIB + ".build"
     os.makedirs(objdir, exist_ok=True)
     common = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
+    common += os.environ.get("EGOTAP_CXXFLAGS", "").split()
     procs, objs = [], []
     for src in SOURCES:
         for part in PARTS:

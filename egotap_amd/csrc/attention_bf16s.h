@@ -338,9 +338,12 @@ static hipError_t attention_bf16s_fwd_launch(const __bf16* QKV, __bf16* CTX, flo
     return N % 64 == 0 ? attention_bf16s_fwd_launch_t<2>(QKV, CTX, LSE, B, N, heads, stream) : attention_bf16s_fwd_launch_t<1>(QKV, CTX, LSE, B, N, heads, stream);
 }
 
+static hipError_t attention_bf16s2_dkv_launch(const __bf16* QKV, const __bf16* dO, const float* LSE, const float* DELTA, __bf16* dQKV, int B, int N,
+                                              int heads, hipStream_t stream);      // attention_bf16s2.h
+
 template <int SUB>
 static hipError_t attention_bf16s_bwd_launch_t(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
-                                               int heads, hipStream_t stream) {
+                                               int heads, hipStream_t stream, int gen) {
     using namespace attns;
     constexpr int NW = 4;
     const float scale = 1.0f / sqrtf((float)DH);
@@ -358,13 +361,14 @@ static hipError_t attention_bf16s_bwd_launch_t(const __bf16* QKV, const __bf16* 
         attr_done = true;
     }
     hipLaunchKernelGGL((attn_bwd_dq_bf16s_kernel<NW, SUB>), dim3(B * heads * groups), dim3(64 * NW), lds_q, stream, QKV, O, dO, LSE, dQKV, DELTA, N, heads, groups, scale);
+    if (gen >= 2) return attention_bf16s2_dkv_launch(QKV, dO, LSE, DELTA, dQKV, B, N, heads, stream);
     hipLaunchKernelGGL((attn_bwd_dkv_bf16s_kernel<NW, SKV>), dim3(B * heads * groups), dim3(64 * NW), lds_kv, stream, QKV, dO, LSE, DELTA, dQKV, N, heads, groups, scale);
     return hipGetLastError();
 }
 static hipError_t attention_bf16s_bwd_launch(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
-                                             int heads, hipStream_t stream) {
+                                             int heads, hipStream_t stream, int gen = 2) {
     if (B <= 0) return hipSuccess;
     if (N % 32 != 0) return hipErrorInvalidValue;
-    return N % 64 == 0 ? attention_bf16s_bwd_launch_t<2>(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream)
-                       : attention_bf16s_bwd_launch_t<1>(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream);
+    return N % 64 == 0 ? attention_bf16s_bwd_launch_t<2>(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream, gen)
+                       : attention_bf16s_bwd_launch_t<1>(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream, gen);
 }

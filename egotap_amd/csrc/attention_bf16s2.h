@@ -1,0 +1,219 @@
+// [r3] Attention backward on bf16 tensors, second generation (bf16-storage training mode; model/modeling_vit.py:226-252 backward).
+//
+// Round 2's dK + dV kernel (attention_bf16s.h) staged each 32-query tile of Q and dO through registers into FOUR padded LDS images
+// (a row image and a transposed-read image each) with NO prefetch -- 160 accumulator / fragment registers left no room for staging
+// registers -- so every tile paid a global-load round trip between two barriers: MFMA busy 0.295, the furthest kernel from its
+// roofline in the whole step.  Here:
+//   * ONE image per tile serves the row reads (ds_read_b128: S = Q K^T, dP = dO V^T) AND the transposed reads (ds_read_b64_tr_b16:
+//     dV^T += dO^T P, dK^T += Q^T dS): cdna_hip_programming.md T10 image (a), 8-row x 32-column subtiles of 512 bytes,
+//       off(row, ch) = 2048 (row >> 3) + 512 (ch >> 2) + 64 (row & 7) + 16 ((ch & 3) ^ ((row >> 2) & 3)),
+//     conflict-free for both kinds of read with only two base registers each (constant offsets fold into the DS immediates);
+//   * the image is filled by the LDS DMA (global_load_lds_dwordx4: 16 wave-instructions per 32-query step and workgroup, no staging
+//     registers, no ds_write); the swizzle is applied on the global side -- which 16 bytes a lane fetches -- the DMA writes lane i
+//     at base + 16 i (one instruction = 8 rows x two 64-byte column blocks);
+//   * double buffered: the DMA of tile t + 1 is issued right after the barrier that opens tile t and lands under tile t's 32 MFMAs;
+//     ONE barrier per tile (own DMA retired by s_waitcnt vmcnt(0), then s_barrier: every wave's pieces have landed and every wave
+//     is done reading the buffer about to be refilled);
+//   * log-sum-exp and delta of the tile's 32 queries ride along as one global_load_lds_dword.
+// Arithmetic per (32 queries x 32 keys) pair and wave is round 2's: S, dV, dP, dK = 4 products, P and dS rounded to bf16 where they
+// become MFMA operands, fixed summation order, no atomics -> bitwise reproducible.
+#pragma once
+#include "attention_bf16s.h"
+
+namespace att2 {
+using namespace attnbf;
+constexpr int TILEB = 32 * 256;                    // one 32 x 128 bf16 image
+constexpr int LSB = 256;                           // 32 log-sum-exp + 32 delta values (fp32)
+constexpr int BUF = 2 * TILEB + LSB;               // Q image | dO image | lse, delta
+
+__device__ __forceinline__ void dma16(const void* g, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* g, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+}
+
+// element offset (row * ld + column) this lane fetches for DMA piece e (0..7) of a 32 x 128 tile whose rows are ld elements apart:
+// piece e covers image bytes [1024 e, 1024 e + 1024) = rows 8 (e >> 1) .. + 7, column blocks 2 (e & 1) and 2 (e & 1) + 1
+__device__ __forceinline__ int dma_src(int e, int lane, int ld) {
+    const int row = 8 * (e >> 1) + ((lane >> 2) & 7);
+    const int ch = 4 * (2 * (e & 1) + (lane >> 5)) + ((lane & 3) ^ ((row >> 2) & 3));
+    return row * ld + 8 * ch;
+}
+
+struct LaneAddr {
+    unsigned row0, row1;     // row read (32x32x16 A / B operand: row lane & 31, chunk 2 t + lane >> 5): t even / odd; + 512 (t >> 1)
+    unsigned tr0, tr1;       // transposed read: rows 16 ss + 4 lh + q (tr0) and + 8 (tr1); + 4096 ss + 512 dt
+};
+__device__ __forceinline__ LaneAddr lane_addr(int lane) {
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int s2 = (l31 >> 2) & 3;
+    const unsigned rb = 2048 * (l31 >> 3) + 64 * (l31 & 7);
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+    const unsigned tb = 64 * (4 * lh + tq) + 8 * (tp & 1);
+    LaneAddr a;
+    a.row0 = rb + 16 * (lh ^ s2);
+    a.row1 = rb + 16 * ((lh ^ s2) ^ 2);
+    a.tr0 = tb + 16 * ((2 * tg + (tp >> 1)) ^ lh);
+    a.tr1 = tb + 2048 + 16 * ((2 * tg + (tp >> 1)) ^ (lh + 2));
+    return a;
+}
+
+// T[32][32] = A_img[32 rows][128] x B^T, B given as 8 k-step fragments in registers: acc col = B's row (lane), rows = A's rows
+__device__ __forceinline__ f32x16 rows_x_frags(const char* img, const LaneAddr& la, const Frags<1>& fr) {
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const bf16x8 a = *(const bf16x8*)(img + ((t & 1) ? la.row1 : la.row0) + 512 * (t >> 1));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, fr.f[0][t], s, 0, 0, 0);
+    }
+    return s;
+}
+// the same with B read from a second image (same lane pattern): T = A_img x B_img^T
+__device__ __forceinline__ f32x16 rows_x_rows(const char* aimg, const char* bimg, const LaneAddr& la) {
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const unsigned o = ((t & 1) ? la.row1 : la.row0) + 512 * (t >> 1);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(aimg + o), *(const bf16x8*)(bimg + o), s, 0, 0, 0);
+    }
+    return s;
+}
+// o^T[4 d-tiles][d][lane col] += sum_rows img[row][d] * p[row][lane col]: p's accumulator registers, rounded to bf16 where they
+// stand, are the B operand (k order 16 ss + 8 (j >> 2) + 4 lh + (j & 3)); the image comes back transposed in exactly that order
+__device__ __forceinline__ void imgT_x_p(f32x16 (&o)[4], const char* img, const LaneAddr& la, const f32x16& p) {
+    bf16x8 ph[2];
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ph[ss][e] = (__bf16)p[8 * ss + e];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + la.tr0 + 4096 * ss + 512 * dt));
+            const bf16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + la.tr1 + 4096 * ss + 512 * dt));
+            bf16x8 f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[e] = a[e];
+                f[4 + e] = c[e];
+            }
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, ph[ss], o[dt], 0, 0, 0);
+        }
+}
+}  // namespace att2
+
+// ------------------------------------------------------------------------------------------------- dK and dV
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_bf16s2_kernel(const __bf16* __restrict__ QKV, const __bf16* __restrict__ dO,
+                                                                        const float* __restrict__ LSE, const float* __restrict__ DELTA,
+                                                                        __bf16* __restrict__ dQKV, int N, int heads, int kgroups, float scale) {
+    using namespace att2;
+    static_assert(NW == 4, "a workgroup's four waves stage the four 8-row groups of a tile");
+    extern __shared__ __attribute__((aligned(16))) char sm2[];
+    const int lin = xcd_lin(blockIdx.x, gridDim.x);          // the key blocks of one (batch, head) share Q / dO tiles in one L2
+    const int bh = lin / kgroups, kg = lin - bh * kgroups;
+    const int b = bh / heads, h = bh - b * heads;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
+    const int D = heads * DH;
+    const int ld3 = 3 * D;
+    const __bf16* qkv = QKV + (long)b * N * ld3 + h * DH;
+    const __bf16* dob = dO + (long)b * N * D + h * DH;
+    const float* lsep = LSE + (long)bh * N;
+    const float* delp = DELTA + (long)bh * N;
+    const int kb = kg * NW + wid;
+    const bool valid = kb * 32 < N;            // invalid waves (last group of a head) redo the last key block and skip the store
+    const int k0 = min(kb * 32, N - 32);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sm2;
+    const unsigned vimg = 2 * BUF + wid * TILEB;               // this wave's V rows (dP = dO V^T reads them as the B operand)
+
+    Frags<1> kf;                                               // K rows of this wave's 32 keys, all 128 d: B operand of S = Q K^T
+    attns::load_row_frags(kf, qkv + (long)(k0 + l31) * ld3 + D, lh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dma16(qkv + (long)k0 * ld3 + 2 * D + dma_src(e, lane, ld3), lds0 + vimg + 1024 * e);
+
+    // DMA duty per tile: 8-row group `wid` of the Q tile and of the dO tile (two pieces each); wave 0 also fetches lse | delta
+    const int oq0 = dma_src(2 * wid, lane, ld3), oq1 = dma_src(2 * wid + 1, lane, ld3);
+    const int od0 = dma_src(2 * wid, lane, D), od1 = dma_src(2 * wid + 1, lane, D);
+    auto issue = [&](int qt, unsigned boff) __attribute__((always_inline)) {
+        const __bf16* qs = qkv + (long)(qt * 32) * ld3;
+        const __bf16* ds = dob + (long)(qt * 32) * D;
+        const unsigned a = lds0 + boff + 2048 * wid;
+        dma16(qs + oq0, a);
+        dma16(qs + oq1, a + 1024);
+        dma16(ds + od0, a + TILEB);
+        dma16(ds + od1, a + TILEB + 1024);
+        if (wid == 0) dma4((lane < 32 ? lsep : delp - 32) + qt * 32 + lane, lds0 + boff + 2 * TILEB);
+    };
+    const LaneAddr la = lane_addr(lane);
+    const float c2 = scale * 1.4426950408889634f;
+    f32x16 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
+
+    const int ntiles = N / 32;
+    issue(0, 0);
+    auto step = [&](int qt, unsigned boff) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile qt (issued a whole tile ago) have landed ...
+        __builtin_amdgcn_s_barrier();                           // ... and so have everyone's; everyone is done with the other buffer
+        __builtin_amdgcn_sched_barrier(0);
+        if (qt + 1 < ntiles) issue(qt + 1, boff ^ BUF);         // lands under this tile's MFMAs
+        const char* Qi = sm2 + boff;
+        const char* Di = sm2 + boff + TILEB;
+        const float* Ls = (const float*)(sm2 + boff + 2 * TILEB);
+        f32x16 p = rows_x_frags(Qi, la, kf);                   // S[q][key]
+        // accumulator register r holds query (r & 3) + 8 (r >> 2) + 4 lh: registers 4 g .. 4 g + 3 are four consecutive queries
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 l4 = *(const f32x4*)(Ls + 8 * g + 4 * lh);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[4 * g + c] = __builtin_amdgcn_exp2f(fmaf(p[4 * g + c], c2, -1.4426950408889634f * l4[c]));
+        }
+        imgT_x_p(dv, Di, la, p);                                // dV^T[d][key] += dO^T P
+        const f32x16 dp = rows_x_rows(Di, sm2 + vimg, la);      // dP[q][key] = dO V^T
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 d4 = *(const f32x4*)(Ls + 32 + 8 * g + 4 * lh);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[4 * g + c] = p[4 * g + c] * (dp[4 * g + c] - d4[c]) * scale;      // dS[q][key]
+        }
+        imgT_x_p(dk, Qi, la, p);                                // dK^T[d][key] += Q^T dS
+    };
+    for (int qt = 0; qt < ntiles; qt += 2) {
+        step(qt, 0);
+        if (qt + 1 < ntiles) step(qt + 1, BUF);
+    }
+    __syncthreads();                                           // the images are dead: their space becomes the output patches
+    if (valid) {
+        float* patch = (float*)sm2 + wid * 32 * OLD;
+        __bf16* dst = dQKV + ((long)b * N + k0) * ld3 + h * DH;
+        attns::store_rows_bf16(dk, 1.0f, patch, dst + D, ld3, lane);
+        attns::store_rows_bf16(dv, 1.0f, patch, dst + 2 * D, ld3, lane);    // same wave, same patch: program order
+    }
+}
+
+static hipError_t attention_bf16s2_dkv_launch(const __bf16* QKV, const __bf16* dO, const float* LSE, const float* DELTA, __bf16* dQKV, int B, int N,
+                                              int heads, hipStream_t stream) {
+    using namespace att2;
+    constexpr int NW = 4;
+    constexpr size_t img = 2 * BUF + (size_t)NW * TILEB, patch = (size_t)NW * 32 * OLD * 4;
+    constexpr size_t lds = img > patch ? img : patch;
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    auto kern = attn_bwd_dkv_bf16s2_kernel<NW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int groups = (N / 32 + NW - 1) / NW;
+    hipLaunchKernelGGL(kern, dim3(B * heads * groups), dim3(64 * NW), lds, stream, QKV, dO, LSE, DELTA, dQKV, N, heads, groups, 1.0f / sqrtf((float)DH));
+    return hipGetLastError();
+}

@@ -28,6 +28,7 @@
 #include "gemm_tn_bf16s.h"
 #include "bf16s_ops.h"
 #include "attention_bf16s.h"
+#include "attention_bf16s2.h"
 #include "conv_bf16s.h"
 
 // The library is ONE source compiled as four translation units in parallel (egotap_amd/build.py: -DEGOTAP_PART=0 core and
@@ -2432,10 +2433,20 @@ extern "C" int egotap_bf16_attention_fwd(const void* qkv, void* ctx, float* lse,
 #endif
 
 #if EGOTAP_IN(3)
+static int g_attn_gen = 2;     // egotap_debug_attention_gen: 2 = the DMA-staged kernels of attention_bf16s2.h (default), 1 = round 2's (A/B timing, tests)
+extern "C" int egotap_debug_attention_gen(int gen) {
+    EGO_CHECK(gen == 1 || gen == 2, "egotap_debug_attention_gen: 1 or 2");
+    g_attn_gen = gen;
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(3)
 extern "C" int egotap_bf16_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv, int B, int N, int heads,
                                          void* stream) {
     EGO_CHECK(qkv && ctx && dctx && lse && delta && dqkv, "egotap_bf16_attention_bwd: null argument");
-    hipError_t e = attention_bf16s_bwd_launch((const __bf16*)qkv, (const __bf16*)ctx, (const __bf16*)dctx, lse, delta, (__bf16*)dqkv, B, N, heads, (hipStream_t)stream);
+    hipError_t e = attention_bf16s_bwd_launch((const __bf16*)qkv, (const __bf16*)ctx, (const __bf16*)dctx, lse, delta, (__bf16*)dqkv, B, N, heads, (hipStream_t)stream,
+                                              g_attn_gen);
     if (e == hipErrorInvalidValue) { egotap_set_error("egotap_bf16_attention_bwd: sequence length %d is not a multiple of 32", N); return EGOTAP_ERR_INVALID; }
     EGO_HIP(e);
     return EGOTAP_OK;

@@ -101,7 +101,9 @@ __device__ __forceinline__ void store_bf16x8(__bf16* p, const float* v) {
     bf16x8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
-    *(bf16x8*)p = o;
+    // [r3] streaming store: a bf16 activation is 0.3-2.4 GB, written once and read by the NEXT kernel -- keeping its lines out of
+    // the L2 leaves the operand panels this kernel re-reads there (+2-3 % on every bf16-output GEMM, profiles/r03_gemm_ablation.md)
+    __builtin_nontemporal_store(o, (bf16x8*)p);
 }
 struct SBias8 { f32x4 b0, b1; };
 __device__ __forceinline__ void s_keep(const SBias8& b) { asm volatile("" ::"v"(b.b0), "v"(b.b1)); }
@@ -288,7 +290,11 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
 
     // ---- DMA duty of this wave per part: 16-row blocks wid and wid + 8.  Lane -> row lane >> 2 of the block, chunk position
     // lane & 3, which holds logical chunk (lane & 3) ^ swz(row), swz(row) = (4 - ((row >> 2) & 3)) & 3 and (row >> 2) & 3 = lane >> 4.
+#if defined(EGOTAP_ABL) && (EGOTAP_ABL & 1)      // timing-only: every DMA wave-instruction reads 8 rows x 128 B instead of 16 rows x 64 B (wrong data)
+    const int drow = lane >> 3, dchunk = lane & 7;
+#else
     const int drow = lane >> 2, dchunk = (lane & 3) ^ ((4 - (lane >> 4)) & 3);
+#endif
     typename XL::Row xr0, xr1;
     const __bf16 *pw0, *pw1;
     int lx_tile = 0, lx_kt = 0, lw_tile = 0, lw_kt = 0;       // position of the X / W issue streams (the W stream runs one phase ahead)
@@ -389,13 +395,21 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
                 if constexpr (Epi::W == 4) {
                     const f32x4 v = *(const f32x4*)(Es + r * 64 + ((l15 ^ r) << 2));
                     float vv[4] = {v[0], v[1], v[2], v[3]};
+#if !(defined(EGOTAP_ABL) && (EGOTAP_ABL & 2))      // timing-only: the epilogue without its global stores / functor
                     if (m0 + r < M) epi.emit(vv, cc, ax[it], m0 + r, en);
+#else
+                    asm volatile("" ::"v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]));
+#endif
                 } else {
                     const int c2 = lane & 7;
                     const f32x4 v0 = *(const f32x4*)(Es + r * 64 + (((2 * c2) ^ r) << 2));
                     const f32x4 v1 = *(const f32x4*)(Es + r * 64 + (((2 * c2 + 1) ^ r) << 2));
                     float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#if !(defined(EGOTAP_ABL) && (EGOTAP_ABL & 2))
                     if (m0 + r < M) epi.emit(vv, cc, ax[it], m0 + r, en);
+#else
+                    asm volatile("" ::"v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]), "v"(vv[4]), "v"(vv[5]), "v"(vv[6]), "v"(vv[7]));
+#endif
                 }
             }
 #pragma unroll

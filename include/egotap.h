@@ -121,6 +121,9 @@ int egotap_pu_chain_status(egotap_handle h, int* enabled, int* faults);
 /* Test hook: launch the one-launch recurrence with its last `n` workgroups missing (0 = off), which starves a row block exactly as a
  * shared device does. */
 int egotap_debug_pu_drop_workgroups(egotap_handle h, int n);
+/* Test / measurement hook (process wide): which generation of the bf16 attention kernels egotap_bf16_attention_fwd / _bwd (and the
+ * training step built on them) launch: 2 = DMA-staged kernels (default), 1 = round 2's register-staged kernels. */
+int egotap_debug_attention_gen(int gen);
 /* EGOTAP_PREC_BF16 only: caller-owned device scratch (16-byte aligned) into which a GEMM's weight matrix is rounded to bf16 right
  * before the launch (stream ordered; nothing is cached, the live fp32 parameters stay the source of truth).  Halves the W operand's
  * vector-memory bytes, which bound that mode.  bytes >= 2 * the largest N*K (67 MB for fc1 of the position encoder); NULL = off. */

@@ -37,8 +37,16 @@ def main():
         r = torch.zeros((M, N), device="cuda")
         ms = timed(lambda: bf16s.gemm_nt(x, w, b, epi="residual", aux=r, out=r))
         row["nt_res_f32_ms"], row["nt_res_f32_tf"] = round(ms, 3), round(2.0 * M * N * K / ms / 1e9, 1)
-        ms = timed(lambda: lib.linear_bf16_dma(x, w, b))
-        row["r1_dma_f32out_ms"], row["r1_dma_f32out_tf"] = round(ms, 3), round(2.0 * M * N * K / ms / 1e9, 1)
+        if os.environ.get("PROBE_R1"):
+            ms = timed(lambda: lib.linear_bf16_dma(x, w, b))
+            row["r1_dma_f32out_ms"], row["r1_dma_f32out_tf"] = round(ms, 3), round(2.0 * M * N * K / ms / 1e9, 1)
+        if N == 4096:
+            ms = timed(lambda: bf16s.gemm_nt(x, w, b, epi="gelu_save"))
+            row["nt_gelu_save_ms"], row["nt_gelu_save_tf"] = round(ms, 3), round(2.0 * M * N * K / ms / 1e9, 1)
+            z = (torch.rand(M, N, device="cuda") - 0.5).bfloat16()
+            ms = timed(lambda: bf16s.gemm_nt(x, w, None, epi="gelu_grad", aux=z))
+            row["nt_gelu_grad_ms"], row["nt_gelu_grad_tf"] = round(ms, 3), round(2.0 * M * N * K / ms / 1e9, 1)
+            del z
         if hasattr(bf16s, "gemm_tn"):
             dy = (torch.rand(M, N, device="cuda") - 0.5).bfloat16()
             dw = torch.empty((N, K), device="cuda")
