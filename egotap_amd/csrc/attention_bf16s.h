@@ -332,14 +332,18 @@ static hipError_t attention_bf16s_fwd_launch_t(const __bf16* QKV, __bf16* CTX, f
     hipLaunchKernelGGL(kern, dim3(B * heads * qgroups), dim3(64 * NW), lds, stream, QKV, CTX, N, heads, qgroups, 1.4426950408889634f / sqrtf(128.0f), LSE);
     return hipGetLastError();
 }
-static hipError_t attention_bf16s_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream) {
+static hipError_t attention_bf16s2_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream);      // attention_bf16s2.h
+static hipError_t attention_bf16s_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream, int gen = 2) {
     if (B <= 0) return hipSuccess;
     if (N % 32 != 0) return hipErrorInvalidValue;
+    if (gen >= 2 && N % 64 == 0) return attention_bf16s2_fwd_launch(QKV, CTX, LSE, B, N, heads, stream);
     return N % 64 == 0 ? attention_bf16s_fwd_launch_t<2>(QKV, CTX, LSE, B, N, heads, stream) : attention_bf16s_fwd_launch_t<1>(QKV, CTX, LSE, B, N, heads, stream);
 }
 
 static hipError_t attention_bf16s2_dkv_launch(const __bf16* QKV, const __bf16* dO, const float* LSE, const float* DELTA, __bf16* dQKV, int B, int N,
                                               int heads, hipStream_t stream);      // attention_bf16s2.h
+static hipError_t attention_bf16s2_dq_launch(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
+                                             int heads, hipStream_t stream);
 
 template <int SUB>
 static hipError_t attention_bf16s_bwd_launch_t(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
@@ -360,6 +364,10 @@ static hipError_t attention_bf16s_bwd_launch_t(const __bf16* QKV, const __bf16* 
         if (e != hipSuccess) return e;
         attr_done = true;
     }
+    if (gen >= 2 && SUB == 2) {       // N % 64 == 0: the DMA-staged dQ kernel walks the keys 64 at a time
+        hipError_t e = attention_bf16s2_dq_launch(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream);
+        if (e != hipSuccess) return e;
+    } else
     hipLaunchKernelGGL((attn_bwd_dq_bf16s_kernel<NW, SUB>), dim3(B * heads * groups), dim3(64 * NW), lds_q, stream, QKV, O, dO, LSE, dQKV, DELTA, N, heads, groups, scale);
     if (gen >= 2) return attention_bf16s2_dkv_launch(QKV, dO, LSE, DELTA, dQKV, B, N, heads, stream);
     hipLaunchKernelGGL((attn_bwd_dkv_bf16s_kernel<NW, SKV>), dim3(B * heads * groups), dim3(64 * NW), lds_kv, stream, QKV, dO, LSE, DELTA, dQKV, N, heads, groups, scale);

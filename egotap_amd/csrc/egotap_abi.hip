@@ -2423,20 +2423,20 @@ extern "C" int egotap_bf16_from_f32(const float* src, void* dst, int64_t n, void
 #endif
 
 #if EGOTAP_IN(3)
-extern "C" int egotap_bf16_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int N, int heads, void* stream) {
-    EGO_CHECK(qkv && ctx, "egotap_bf16_attention_fwd: null argument");
-    hipError_t e = attention_bf16s_fwd_launch((const __bf16*)qkv, (__bf16*)ctx, lse, B, N, heads, (hipStream_t)stream);
-    if (e == hipErrorInvalidValue) { egotap_set_error("egotap_bf16_attention_fwd: sequence length %d is not a multiple of 32", N); return EGOTAP_ERR_INVALID; }
-    EGO_HIP(e);
+static int g_attn_gen = 2;     // egotap_debug_attention_gen: 2 = the DMA-staged kernels of attention_bf16s2.h (default), 1 = round 2's (A/B timing, tests)
+extern "C" int egotap_debug_attention_gen(int gen) {
+    EGO_CHECK(gen == 1 || gen == 2, "egotap_debug_attention_gen: 1 or 2");
+    g_attn_gen = gen;
     return EGOTAP_OK;
 }
 #endif
 
 #if EGOTAP_IN(3)
-static int g_attn_gen = 2;     // egotap_debug_attention_gen: 2 = the DMA-staged kernels of attention_bf16s2.h (default), 1 = round 2's (A/B timing, tests)
-extern "C" int egotap_debug_attention_gen(int gen) {
-    EGO_CHECK(gen == 1 || gen == 2, "egotap_debug_attention_gen: 1 or 2");
-    g_attn_gen = gen;
+extern "C" int egotap_bf16_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int N, int heads, void* stream) {
+    EGO_CHECK(qkv && ctx, "egotap_bf16_attention_fwd: null argument");
+    hipError_t e = attention_bf16s_fwd_launch((const __bf16*)qkv, (__bf16*)ctx, lse, B, N, heads, (hipStream_t)stream, g_attn_gen);
+    if (e == hipErrorInvalidValue) { egotap_set_error("egotap_bf16_attention_fwd: sequence length %d is not a multiple of 32", N); return EGOTAP_ERR_INVALID; }
+    EGO_HIP(e);
     return EGOTAP_OK;
 }
 #endif
