@@ -165,6 +165,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_bf16s2_kernel(const _
         __builtin_amdgcn_s_barrier();                           // ... and so have everyone's; everyone is done with the other buffer
         __builtin_amdgcn_sched_barrier(0);
         if (qt + 1 < ntiles) issue(qt + 1, boff ^ BUF);         // lands under this tile's MFMAs
+        if (!valid) return;                                     // (wave-uniform) a wave past the last key block only stages: its SIMD's matrix pipe goes to the CU's other workgroup
         const char* Qi = sm2 + boff;
         const char* Di = sm2 + boff + TILEB;
         const float* Ls = (const float*)(sm2 + boff + 2 * TILEB);
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_bf16s2_kernel(const __
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < ntiles) issue(kt + 1, boff ^ KVBUF);
+        if (!valid) return;                                     // (wave-uniform) stage only
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const char* Ki = sm2 + boff + sub * TILEB;
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16s2_kernel(const __bf
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < ntiles) issue(kt + 1, boff ^ KVBUF);
+        if (!valid) return;                                     // (wave-uniform) stage only
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             f32x16 s = rows_x_frags(sm2 + boff + sub * TILEB, la, qf);     // S^T[key][q]
