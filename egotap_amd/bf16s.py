@@ -25,9 +25,10 @@ def _bf(t, what):
         raise _lib.EgotapError(f"{what}: bfloat16 CUDA tensor with contiguous rows expected")
 
 
-def gemm_nt(x, w, bias, epi="bf16", aux=None, out=None, out1=None):
+def gemm_nt(x, w, bias, epi="bf16", aux=None, out=None, out1=None, colsum_out=None):
     """OUT = epi(x[M,K] @ w[N,K]^T) on gemm_bf16s_kernel.  x, w bf16; epi: bf16 | residual (aux f32 R) | gelu_save (returns z, h) |
-    gelu_grad (aux bf16 z) | f32"""
+    gelu_grad (aux bf16 z; colsum_out fp32 [N]: also the column sums of the stored output, i.e. the bias gradient of the layer whose
+    output gradient this is -- they leave the GEMM's epilogue as per-wave partial sums, finished by a small fp32 column sum) | f32"""
     _bf(x, "x"); _bf(w, "w")
     M, K = x.shape
     N = w.shape[0]
@@ -37,8 +38,15 @@ def gemm_nt(x, w, bias, epi="bf16", aux=None, out=None, out1=None):
         out = torch.empty((M, N), dtype=torch.float32 if f32_out else torch.bfloat16, device=dev)
     if epi == "gelu_save" and out1 is None:
         out1 = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    if colsum_out is not None:
+        if epi != "gelu_grad":
+            raise ValueError("colsum_out rides on the gelu_grad epilogue")
+        out1 = torch.empty((2 * ((M + 255) // 256), N), dtype=torch.float32, device=dev)      # one row of partial sums per 128-row wave block
     _lib.check(_lib.load().egotap_bf16_gemm_nt(_p(x), x.stride(0), _p(w), _p(bias), M, N, K, EPI[epi], _p(aux), _p(out), _p(out1),
                                                out.stride(0), _s()))
+    if colsum_out is not None:
+        from .train_ops import colsum as _colsum_f32
+        _colsum_f32(out1, colsum_out, out1.shape[0], N)
     return (out, out1) if epi == "gelu_save" else out
 
 

@@ -98,7 +98,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const float* __
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                  // [32][132]
     float* Vs = smem + KT * LD;        // [32][132]
-    const int bh = blockIdx.x / qgroups, qg = blockIdx.x - bh * qgroups;
+    // [r3] XCD-aware block order (as the forward and the bf16 kernels): the query blocks of one (batch, head) stream the same K / V
+    // tiles; dealt round-robin over the 8 XCDs every L2 fetched them again (7.5 GB of L2-side reads per launch against 2.4 GB)
+    const int lin_ = xcd_lin(blockIdx.x, gridDim.x);
+    const int bh = lin_ / qgroups, qg = lin_ - bh * qgroups;
     const int b = bh / heads, h = bh - b * heads;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int D = heads * DH;
@@ -162,7 +165,8 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dkv_kernel(const float* _
     float* Ds = smem + KT * LD;                    // dO tile
     float* Ls = smem + 2 * KT * LD;                // [32] lse (log2 units), [32] delta
     float* Vw = smem + 2 * KT * LD + 64;           // per wave: V of its 32 keys [32][132]
-    const int bh = blockIdx.x / kgroups, kg = blockIdx.x - bh * kgroups;
+    const int lin_ = xcd_lin(blockIdx.x, gridDim.x);          // [r3] the key blocks of one (batch, head) share their Q / dO tiles in one L2 (10.5 GB -> see profiles/r03)
+    const int bh = lin_ / kgroups, kg = lin_ - bh * kgroups;
     const int b = bh / heads, h = bh - b * heads;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int D = heads * DH;

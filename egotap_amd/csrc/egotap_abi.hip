@@ -2332,7 +2332,10 @@ extern "C" int egotap_bf16_gemm_nt(const void* x, int64_t ldx, const void* w, co
         case 2: EGO_CHECK(bias && out1, "egotap_bf16_gemm_nt: epi 2 needs bias and the second output");
                 e = gemm_bf16s_launch(xl, wb, (long)K, SEpiGeluSave{bias, (__bf16*)out0, (__bf16*)out1, (long)ldo}, M, N, K, cu, s); break;
         case 3: EGO_CHECK(aux, "egotap_bf16_gemm_nt: epi 3 needs the saved pre-activation");
-                e = gemm_bf16s_launch(xl, wb, (long)K, SEpiGeluGrad{(const __bf16*)aux, (__bf16*)out0, (long)ldo}, M, N, K, cu, s); break;
+                // out1 (optional): fp32 [2 * ceil(M / 256)][N] partial column sums of the stored output, one row per 128-row wave block
+                if (out1) e = gemm_bf16s_launch(xl, wb, (long)K, SEpiGeluGradCS{{(const __bf16*)aux, (__bf16*)out0, (long)ldo}, (float*)out1}, M, N, K, cu, s);
+                else e = gemm_bf16s_launch(xl, wb, (long)K, SEpiGeluGrad{(const __bf16*)aux, (__bf16*)out0, (long)ldo}, M, N, K, cu, s);
+                break;
         case 4: EGO_CHECK(bias, "egotap_bf16_gemm_nt: epi 4 needs bias");
                 e = gemm_bf16s_launch(xl, wb, (long)K, SEpiF32{bias, (float*)out0, (long)ldo}, M, N, K, cu, s); break;
         default: egotap_set_error("egotap_bf16_gemm_nt: unknown epilogue %d", epi); return EGOTAP_ERR_INVALID;
@@ -2789,9 +2792,10 @@ static int lift_backward16(Handle* h, const float* hm, const float* dpose, int B
         const auto& l = t.layer[i];
         // MLP (dx = F0 fp32, R1 bf16)
         EGO_RC(egotap_bf16_gemm_tn(R1, D, Hb(l.hid), 4 * D, G(G_.dn_w), M, D, 4 * D, 0, ZERO, scr, scrb, stream));
-        EGO_RC(egotap_bf16_gemm_nt(R1, D, Hb(l.w_dn_t), nullptr, M, 4 * D, D, 3, Hb(l.z), A4, nullptr, 4 * D, stream));              // dz
+        // dz; its column sums (= the intermediate.dense bias gradient) leave the epilogue as per-wave partial sums in R0 (free until dy2)
+        EGO_RC(egotap_bf16_gemm_nt(R1, D, Hb(l.w_dn_t), nullptr, M, 4 * D, D, 3, Hb(l.z), A4, R0, 4 * D, stream));
+        EGO_RC(egotap_train_colsum((const float*)R0, 0, G(G_.up_b), 2 * ((M + 255) / 256), 4 * D, 0, scr, scrb, stream));
         EGO_RC(egotap_bf16_gemm_tn(A4, 4 * D, Hb(l.y2), D, G(G_.up_w), M, 4 * D, D, 0, ZERO, scr, scrb, stream));
-        EGO_RC(egotap_bf16_colsum(A4, 4 * D, G(G_.up_b), M, 4 * D, 0, scr, scrb, stream));
         EGO_RC(egotap_bf16_gemm_nt(A4, 4 * D, Hb(l.w_up_t), nullptr, M, D, 4 * D, 0, nullptr, R0, nullptr, D, stream));             // dy2
         EGO_RC(egotap_bf16_layernorm_bwd(S(l.xm), R0, P_.ln2_g, S(l.m2), S(l.r2), F0, F1, R1, G(G_.ln2_g), G(G_.ln2_b), G(G_.o_b), M, 0, scr, scrb,
                                          stream));                                                                                   // dxm = F1, R1

@@ -237,6 +237,17 @@ struct SEpiGeluGrad {        // out bf16 = acc * GELU'(Z)   (Z bf16: the saved p
         store_bf16x8(out + (long)m * ld + n, v);
     }
 };
+// [r3] the same, also emitting column sums of the bf16 values it stores: the bias gradient of the layer whose output gradient this
+// is (intermediate.dense: d bias = column sums of dz) leaves the kernel as per-wave partial sums -- row 2 tile_m + group of
+// colpart[2 tiles_m][N] holds the sums over that wave's 128 rows -- instead of costing a pass over the 4.8 GB tensor
+// (colsum_bf16_partial_kernel: 2.5 ms of the B = 1024 step).  A small fp32 column sum over the 2 tiles_m rows finishes it.
+struct SEpiGeluGradCS : SEpiGeluGrad {
+    float* colpart;
+};
+template <class E> struct s_epi_colsum { static constexpr bool value = false; };
+template <class E> struct s_epi_stagger { static constexpr bool value = false; };
+template <> struct s_epi_stagger<SEpiResF32> { static constexpr bool value = true; };
+template <> struct s_epi_colsum<SEpiGeluGradCS> { static constexpr bool value = true; };
 // input gradient of fc1 of the position encoder, scattered back to token order: row (b, i), column (s, c) -> token
 // (b, patch s of heatmap i), channel c.  The gather of XTokens is a bijection onto the non-dummy tokens (dummy rows stay zero:
 // the caller clears the buffer once).  out bf16 [B*seq, D]
@@ -359,7 +370,9 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
     // the (up to) four half stages in flight and older than the ones issued after it, so for the first two K-tiles (four phases)
     // of the next tile the allowance is 8 + NST, by which time the stores have had ~2 us to drain.  Only after a FULL tile (every
     // lane active in every store: the count is exact); after a ragged tile the plain allowance makes the first wait drain them.
-    constexpr int IT = Epi::W == 4 ? 4 : 2, NST = 8 * IT * Epi::STORES;
+    constexpr bool CS = s_epi_colsum<Epi>::value;
+    static_assert(!CS || Epi::W == 8, "column sums ride on the bf16-output epilogues");
+    constexpr int IT = Epi::W == 4 ? 4 : 2, NST = 8 * IT * Epi::STORES + (CS ? 2 : 0);
     constexpr int SLK = s_epi_exact<Epi>::value ? 8 + NST : 8;      // vmcnt allowance of the first K-tiles after an (exact) epilogue
     static_assert(SLK <= 63, "vmcnt is a 6-bit counter");
     int slack_kt = 0;
@@ -372,6 +385,7 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
         const int er = Epi::W == 4 ? q : (lane >> 3), en = n_wave + (Epi::W == 4 ? l15 * 4 : (lane & 7) * 8);
         const typename Epi::Col cc = epi.col(en);
         typename Epi::Aux ax[IT], an[IT];
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // column sums of this lane's 8 columns over its 16 rows (CS epilogues)
 #pragma unroll
         for (int it = 0; it < IT; ++it) ax[it] = epi.fetch(min(m_wave + (16 / IT) * it + er, M - 1), en);
 #pragma unroll
@@ -406,7 +420,13 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
                     const f32x4 v1 = *(const f32x4*)(Es + r * 64 + (((2 * c2 + 1) ^ r) << 2));
                     float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #if !(defined(EGOTAP_ABL) && (EGOTAP_ABL & 2))
-                    if (m0 + r < M) epi.emit(vv, cc, ax[it], m0 + r, en);
+                    if (m0 + r < M) {
+                        epi.emit(vv, cc, ax[it], m0 + r, en);              // (leaves the values it stored in vv)
+                        if constexpr (CS) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) cs[i] += (float)(__bf16)vv[i];      // the sum of what was STORED (bf16)
+                        }
+                    }
 #else
                     asm volatile("" ::"v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]), "v"(vv[4]), "v"(vv[5]), "v"(vv[6]), "v"(vv[7]));
 #endif
@@ -414,6 +434,20 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
             }
 #pragma unroll
             for (int it = 0; it < IT; ++it) ax[it] = an[it];
+        }
+        if constexpr (CS) {
+            // lanes with equal lane & 7 hold the same 8 columns for different rows: fold the 8 row groups (fixed order), lanes 0..7 store
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                cs[i] += __shfl_xor(cs[i], 8, 64);
+                cs[i] += __shfl_xor(cs[i], 16, 64);
+                cs[i] += __shfl_xor(cs[i], 32, 64);
+            }
+            if (lane < 8) {
+                float* cp = epi.colpart + (long)(2 * tm + grp) * N + en;
+                *(f32x4*)cp = f32x4{cs[0], cs[1], cs[2], cs[3]};
+                *(f32x4*)(cp + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+            }
         }
         slack_kt = (s_epi_exact<Epi>::value && (tm + 1) * BM <= M && KT >= 4) ? 2 : 0;
     };
@@ -423,6 +457,13 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
     // the two-group schedule below (864 / 1069 / 1110 / 1170 TF against 857 / 1072 / 1068 / 1215 at N x K = 3072x1024, 1024x1024,
     // 4096x1024, 1024x4096), but the fp32-output + residual epilogue, which the two groups run side by side under each other's MFMAs,
     // falls from 710-1100 TF to 545-790.
+    // [r3] Epilogues that move 8 bytes per element both ways (fp32 residual in, fp32 out: 512 KB per tile) are paced by the memory
+    // system when all 256 workgroups reach them together -- they all start together and every tile takes the same time.  Starting
+    // the workgroups a quarter tile apart (four phases, ~8 k cycles each, once per launch) spreads the bursts: +7-9 % on the
+    // attention-output and MLP-down GEMMs (profiles/r03_gemm_ablation.md); bf16-output epilogues (2 bytes, one way) gain nothing.
+    if constexpr (s_epi_stagger<Epi>::value) {
+        for (int i = 0; i < (int)((blockIdx.x >> 3) & 3); ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // ---- prologue: K-tiles 0, 1, 2 complete (W then X each), then the steady-state issues of phases 0.. pick up W(3), X(3)
     issue_w(0); issue_x(0);
     issue_w(1); issue_x(1);

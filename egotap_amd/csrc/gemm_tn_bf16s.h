@@ -69,10 +69,29 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
     // XCD-aware order: an XCD takes a contiguous range of (split, tile) pairs with the tile index fastest, so the tiles_n x tiles_k tiles
     // of one split -- which read the same 32-row steps of dY and X -- share them in one L2 instead of fetching them once per XCD
     // (measured before: 6.9 GB of L2-side reads per launch against 3.6 GB algorithmic)
-    const int tiles = tiles_n * (K / BK);
+    const int tiles_k = K / BK;
+    const int tiles = tiles_n * tiles_k;
     const int bid = xcd_lin(blockIdx.x, gridDim.x);
     const int split = bid / tiles, tile = bid - split * tiles;
-    const int tn = tile % tiles_n, tk = tile / tiles_n;
+    // [r3] tile order inside a split: an XCD's 32 workgroups read a dY column slabs and b X column slabs of the split (a x b tiles);
+    // with the n index fastest a 16 x 4 tile grid (MLP-up weight gradient) gave an XCD 16 + 2 slabs and made the second XCD fetch
+    // the 16 dY slabs again (36 slab reads per split against 20 algorithmic: the 2.1 x of the round-2 profile); walking the grid in
+    // 8 x 4 blocks makes it 2 x (8 + 4) = 24.  Blocks of PA x PB tiles, PA * PB = 32, both dividing the grid (else the plain order).
+    int tn, tk;
+    {
+        int pa = 0, pb = 0;
+        if (tiles > 32) {
+            if (tiles_n % 8 == 0 && tiles_k % 4 == 0) { pa = 8; pb = 4; }
+            else if (tiles_n % 4 == 0 && tiles_k % 8 == 0) { pa = 4; pb = 8; }
+        }
+        if (pa == 0) { tn = tile % tiles_n; tk = tile / tiles_n; }
+        else {
+            const int blk = tile >> 5, in = tile & 31;
+            const int bn = tiles_n / pa;                    // blocks along n
+            tn = (blk % bn) * pa + in % pa;
+            tk = (blk / bn) * pb + in / pa;
+        }
+    }
     const int n0 = tn * BN, k0 = tk * BK;
     const int m_lo = split * rows_per, m_hi = min(M, m_lo + rows_per);
     const int total = m_hi > m_lo ? (m_hi - m_lo + BKM - 1) / BKM : 0;      // 32-row steps of this split

@@ -551,12 +551,11 @@ class LiftTrainBf16Fn(torch.autograd.Function):
             a = l + "attention.attention."
             # MLP: dx is the output gradient of output.dense (its bias gradient came with the LayerNorm backward that produced dx)
             S.gemm_tn(dxb, L["hid"], G[l + "output.dense.weight"])
-            dz = S.gemm_nt(dxb, Wl["dn_t"], None, epi="gelu_grad", aux=L["z"])
+            dz = S.gemm_nt(dxb, Wl["dn_t"], None, epi="gelu_grad", aux=L["z"], colsum_out=G[l + "intermediate.dense.bias"])
             if tr is not None:
                 tr[f"L{i}"] = t_ = dict(dx_in=dx, dxb_in=dxb, dz=dz)
             del dxb
             S.gemm_tn(dz, L["y2"], G[l + "intermediate.dense.weight"])
-            S.colsum(dz, G[l + "intermediate.dense.bias"])
             dy2 = S.gemm_nt(dz, Wl["up_t"], None)
             del dz
             dxm, dxmb = S.layernorm_bwd(L["xm"], dy2, P[l + "layernorm_after.weight"], L["m2"], L["r2"], G[l + "layernorm_after.weight"],

@@ -292,8 +292,10 @@ int egotap_hmtrain_mse(const float* pred, const float* gt, const float* plen, fl
  * nn.Linear forward / input gradient on bf16 operands:  OUT = epi(x[M,K] w[N,K]^T), x row stride ldx, outputs row stride ldo
  * (elements).  N % 256 == 0, K % 32 == 0, 16-byte aligned pointers.  epi:
  *   0  out0 bf16 = acc (+ bias if not NULL)                    1  out0 f32 = acc + bias + aux (aux: f32 residual, may alias out0)
- *   2  out0 bf16 = z = acc + bias (may be NULL), out1 bf16 = GELU(z)      3  out0 bf16 = acc * GELU'(aux), aux: bf16 z
- *   4  out0 f32 = acc + bias */
+ *   2  out0 bf16 = z = acc + bias (may be NULL), out1 bf16 = GELU(z)      3  out0 bf16 = acc * GELU'(aux), aux: bf16 z;
+ *   4  out0 f32 = acc + bias                                        with epi 3, out1 (optional) f32 [2 ceil(M / 256)][N]: per
+ *      128-row block partial column sums of the stored out0 (finish with egotap_train_colsum over those rows: the bias gradient of
+ *      the layer whose output gradient out0 is, without another pass over out0) */
 int egotap_bf16_gemm_nt(const void* x, int64_t ldx, const void* w, const float* bias, int M, int N, int K, int epi, const void* aux,
                         void* out0, void* out1, int64_t ldo, void* stream);
 
