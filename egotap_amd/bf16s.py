@@ -127,10 +127,16 @@ def attention_fwd(qkv, B, N, heads, want_lse=True):
     return ctx, lse
 
 
-def attention_bwd(qkv, ctx, dctx, lse, B, N, heads):
+def attention_bwd(qkv, ctx, dctx, lse, B, N, heads, bias_grads=None):
+    """dqkv; bias_grads = (dq_bias, dk_bias, dv_bias) fp32 [heads * 128] each: also the column sums of dqkv, from the kernels' epilogues"""
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
-    _lib.check(_lib.load().egotap_bf16_attention_bwd(_p(qkv), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), B, N, heads, _s()))
+    if bias_grads is None:
+        _lib.check(_lib.load().egotap_bf16_attention_bwd(_p(qkv), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), B, N, heads, _s()))
+        return dqkv
+    ws = _ws(B * (N // 32) * 3 * heads * 128 * 4 + (64 << 20), qkv.device)
+    _lib.check(_lib.load().egotap_bf16_attention_bwd_bias(_p(qkv), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), _p(bias_grads[0]), _p(bias_grads[1]),
+                                                          _p(bias_grads[2]), B, N, heads, _p(ws), ws.numel(), _s()))
     return dqkv
 
 

@@ -66,8 +66,10 @@ __device__ __forceinline__ void load_row_frags(Frags<1>& fr, const __bf16* rowp,
     for (int s = 0; s < 8; ++s) fr.f[0][s] = *(const bf16x8*)(rowp + 16 * s + 8 * lh);
 }
 
-// a wave's [4][32 d x 32 lane-rows] accumulators (times mul) as 32 rows of 128 bf16 (row stride ld) through an fp32 LDS patch
-__device__ __forceinline__ void store_rows_bf16(const f32x16 (&o)[4], float mul, float* patch, __bf16* out, long ld, int lane) {
+// a wave's [4][32 d x 32 lane-rows] accumulators (times mul) as 32 rows of 128 bf16 (row stride ld) through an fp32 LDS patch.
+// [r3] colpart (optional): 128 floats that receive the column sums of the 32 STORED (bf16) rows -- the per-block share of the
+// q / k / v bias gradient, so that no kernel has to read the gradient tensor again just to sum its columns.
+__device__ __forceinline__ void store_rows_bf16(const f32x16 (&o)[4], float mul, float* patch, __bf16* out, long ld, int lane, float* colpart = nullptr) {
     const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -78,12 +80,28 @@ __device__ __forceinline__ void store_rows_bf16(const f32x16 (&o)[4], float mul,
             for (int c = 0; c < 4; ++c) v[c] = o[dt][4 * g + c] * mul;
             *(f32x4*)(patch + l31 * OLD + dt * 32 + 8 * g + 4 * lh) = v;
         }
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int row = it * 4 + (lane >> 4), c8 = lane & 15;
         const f32x4 a = *(const f32x4*)(patch + row * OLD + c8 * 8), b = *(const f32x4*)(patch + row * OLD + c8 * 8 + 4);
         float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
         store_bf16x8(out + (long)row * ld + c8 * 8, v);
+        if (colpart != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cs[i] += (float)(__bf16)v[i];
+        }
+    }
+    if (colpart != nullptr) {          // lanes l, l + 16, l + 32, l + 48 hold the same 8 columns for different rows
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            cs[i] += __shfl_xor(cs[i], 16, 64);
+            cs[i] += __shfl_xor(cs[i], 32, 64);
+        }
+        if (lane < 16) {
+            *(f32x4*)(colpart + lane * 8) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+            *(f32x4*)(colpart + lane * 8 + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+        }
     }
 }
 }  // namespace attns
@@ -341,13 +359,13 @@ static hipError_t attention_bf16s_fwd_launch(const __bf16* QKV, __bf16* CTX, flo
 }
 
 static hipError_t attention_bf16s2_dkv_launch(const __bf16* QKV, const __bf16* dO, const float* LSE, const float* DELTA, __bf16* dQKV, int B, int N,
-                                              int heads, hipStream_t stream);      // attention_bf16s2.h
+                                              int heads, hipStream_t stream, float* colpart);      // attention_bf16s2.h
 static hipError_t attention_bf16s2_dq_launch(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
-                                             int heads, hipStream_t stream);
+                                             int heads, hipStream_t stream, float* colpart);
 
 template <int SUB>
 static hipError_t attention_bf16s_bwd_launch_t(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
-                                               int heads, hipStream_t stream, int gen) {
+                                               int heads, hipStream_t stream, int gen, float* colpart) {
     using namespace attns;
     constexpr int NW = 4;
     const float scale = 1.0f / sqrtf((float)DH);
@@ -365,18 +383,21 @@ static hipError_t attention_bf16s_bwd_launch_t(const __bf16* QKV, const __bf16* 
         attr_done = true;
     }
     if (gen >= 2 && SUB == 2) {       // N % 64 == 0: the DMA-staged dQ kernel walks the keys 64 at a time
-        hipError_t e = attention_bf16s2_dq_launch(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream);
+        hipError_t e = attention_bf16s2_dq_launch(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream, colpart);
         if (e != hipSuccess) return e;
     } else
     hipLaunchKernelGGL((attn_bwd_dq_bf16s_kernel<NW, SUB>), dim3(B * heads * groups), dim3(64 * NW), lds_q, stream, QKV, O, dO, LSE, dQKV, DELTA, N, heads, groups, scale);
-    if (gen >= 2) return attention_bf16s2_dkv_launch(QKV, dO, LSE, DELTA, dQKV, B, N, heads, stream);
+    if (gen >= 2) return attention_bf16s2_dkv_launch(QKV, dO, LSE, DELTA, dQKV, B, N, heads, stream, colpart);
     hipLaunchKernelGGL((attn_bwd_dkv_bf16s_kernel<NW, SKV>), dim3(B * heads * groups), dim3(64 * NW), lds_kv, stream, QKV, dO, LSE, DELTA, dQKV, N, heads, groups, scale);
     return hipGetLastError();
 }
 static hipError_t attention_bf16s_bwd_launch(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
-                                             int heads, hipStream_t stream, int gen = 2) {
+                                             int heads, hipStream_t stream, int gen = 2, float* colpart = nullptr) {
+    // colpart (generation 2, N % 64 == 0 only; the caller checks with attention_bf16s_bwd_colsums()): fp32 [B * N / 32][3 * heads * 128]
+    // partial column sums of dQKV, one row per 32-row block -- summed over the rows they give the q | k | v bias gradients
     if (B <= 0) return hipSuccess;
     if (N % 32 != 0) return hipErrorInvalidValue;
-    return N % 64 == 0 ? attention_bf16s_bwd_launch_t<2>(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream, gen)
-                       : attention_bf16s_bwd_launch_t<1>(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream, gen);
+    if (colpart != nullptr && !(gen >= 2 && N % 64 == 0)) return hipErrorInvalidValue;
+    return N % 64 == 0 ? attention_bf16s_bwd_launch_t<2>(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream, gen, colpart)
+                       : attention_bf16s_bwd_launch_t<1>(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream, gen, colpart);
 }

@@ -112,7 +112,10 @@ __device__ __forceinline__ void imgT_x_p(f32x16 (&o)[4], const char* img, const 
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_bf16s2_kernel(const __bf16* __restrict__ QKV, const __bf16* __restrict__ dO,
                                                                         const float* __restrict__ LSE, const float* __restrict__ DELTA,
-                                                                        __bf16* __restrict__ dQKV, int N, int heads, int kgroups, float scale) {
+                                                                        __bf16* __restrict__ dQKV, int N, int heads, int kgroups, float scale,
+                                                                        float* __restrict__ colpart) {
+    // colpart (or null): fp32 [B * N / 32][3 * heads * 128]; row (b, key block) receives the column sums of the block's 32 dK rows at
+    // columns D + h * 128 .. and of its dV rows at 2 D + h * 128 ..  (the dQ kernel fills columns h * 128 .. of row (b, query block))
     using namespace att2;
     static_assert(NW == 4, "a workgroup's four waves stage the four 8-row groups of a tile");
     extern __shared__ __attribute__((aligned(16))) char sm2[];
@@ -195,13 +198,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_bf16s2_kernel(const _
     if (valid) {
         float* patch = (float*)sm2 + wid * 32 * OLD;
         __bf16* dst = dQKV + ((long)b * N + k0) * ld3 + h * DH;
-        attns::store_rows_bf16(dk, 1.0f, patch, dst + D, ld3, lane);
-        attns::store_rows_bf16(dv, 1.0f, patch, dst + 2 * D, ld3, lane);    // same wave, same patch: program order
+        float* cp = colpart ? colpart + ((long)b * (N / 32) + kb) * ld3 + h * DH : nullptr;
+        attns::store_rows_bf16(dk, 1.0f, patch, dst + D, ld3, lane, cp ? cp + D : nullptr);
+        attns::store_rows_bf16(dv, 1.0f, patch, dst + 2 * D, ld3, lane, cp ? cp + 2 * D : nullptr);    // same wave, same patch: program order
     }
 }
 
 static hipError_t attention_bf16s2_dkv_launch(const __bf16* QKV, const __bf16* dO, const float* LSE, const float* DELTA, __bf16* dQKV, int B, int N,
-                                              int heads, hipStream_t stream) {
+                                              int heads, hipStream_t stream, float* colpart) {
     using namespace att2;
     constexpr int NW = 4;
     constexpr size_t img = 2 * BUF + (size_t)NW * TILEB, patch = (size_t)NW * 32 * OLD * 4;
@@ -215,7 +219,8 @@ static hipError_t attention_bf16s2_dkv_launch(const __bf16* QKV, const __bf16* d
         attr_done = true;
     }
     const int groups = (N / 32 + NW - 1) / NW;
-    hipLaunchKernelGGL(kern, dim3(B * heads * groups), dim3(64 * NW), lds, stream, QKV, dO, LSE, DELTA, dQKV, N, heads, groups, 1.0f / sqrtf((float)DH));
+    hipLaunchKernelGGL(kern, dim3(B * heads * groups), dim3(64 * NW), lds, stream, QKV, dO, LSE, DELTA, dQKV, N, heads, groups, 1.0f / sqrtf((float)DH),
+                       colpart);
     return hipGetLastError();
 }
 
@@ -227,7 +232,7 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_bf16s2_kernel(const __bf16* __restrict__ QKV, const __bf16* __restrict__ O,
                                                                        const __bf16* __restrict__ dO, const float* __restrict__ LSE,
                                                                        __bf16* __restrict__ dQKV, float* __restrict__ DELTA, int N, int heads,
-                                                                       int qgroups, float scale) {
+                                                                       int qgroups, float scale, float* __restrict__ colpart) {
     using namespace att2;
     static_assert(NW == 4, "four waves share the DMA duty of a 64-key step");
     constexpr unsigned KVBUF = 4 * TILEB;                      // K keys 0-31 | K keys 32-63 | V keys 0-31 | V keys 32-63
@@ -303,7 +308,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_bf16s2_kernel(const __
         if (kt + 1 < ntiles) step(kt + 1, KVBUF);
     }
     __syncthreads();
-    if (valid) attns::store_rows_bf16(dq, 1.0f, (float*)sm2 + wid * 32 * OLD, dQKV + ((long)b * N + q0) * ld3 + h * DH, ld3, lane);
+    if (valid)
+        attns::store_rows_bf16(dq, 1.0f, (float*)sm2 + wid * 32 * OLD, dQKV + ((long)b * N + q0) * ld3 + h * DH, ld3, lane,
+                               colpart ? colpart + ((long)b * (N / 32) + qb) * ld3 + h * DH : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------- forward, generation 2
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16s2_kernel(const __bf
 }
 
 static hipError_t attention_bf16s2_dq_launch(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
-                                             int heads, hipStream_t stream) {
+                                             int heads, hipStream_t stream, float* colpart) {
     using namespace att2;
     constexpr int NW = 4;
     constexpr size_t img = 2 * 4 * (size_t)TILEB, patch = (size_t)NW * 32 * OLD * 4;
@@ -415,7 +422,8 @@ static hipError_t attention_bf16s2_dq_launch(const __bf16* QKV, const __bf16* O,
         attr_done = true;
     }
     const int groups = (N / 32 + NW - 1) / NW;
-    hipLaunchKernelGGL(kern, dim3(B * heads * groups), dim3(64 * NW), lds, stream, QKV, O, dO, LSE, dQKV, DELTA, N, heads, groups, 1.0f / sqrtf((float)DH));
+    hipLaunchKernelGGL(kern, dim3(B * heads * groups), dim3(64 * NW), lds, stream, QKV, O, dO, LSE, dQKV, DELTA, N, heads, groups, 1.0f / sqrtf((float)DH),
+                       colpart);
     return hipGetLastError();
 }
 

@@ -1162,7 +1162,8 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
         float *SC = BP + 1024, *SH = BP + 2048;                                    // folded BatchNorm scale / shift of the running conv
         auto bconv = [&](const char* role, const __bf16* in, int cin, int c, int taps, int stride, int side, const float* wgt,
                          const HmParams::Bn& bn, const __bf16* res, int relu, __bf16* o) {
-            const int Np = (c + 255) / 256 * 256;
+            // [r3] Cout = 64 / 128 run on the 64- / 128-column tile (256 x 64 NI, gemm_bf16s.h) instead of N = 256 with a column guard
+            const int Np = c <= 64 ? 64 : c <= 128 ? 128 : (c + 255) / 256 * 256;
             if (taps == 9) {
                 const long items = (long)Np * 9 * (cin / 8);
                 hipLaunchKernelGGL(pack_conv3x3_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, wgt, WP, c, cin, cin, Np);
@@ -1175,7 +1176,10 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
             const long M = (long)N2 * side * side;
             GemmTimer t(h, s, role, taps == 9 ? "gemm_bf16s_kernel<XConvE,3x3>" : "gemm_bf16s_kernel<XConvE,1x1>", 2.0 * M * c * taps * (double)cin);
             const XConvE xl{in, ZP, cin, ilog2(side), stride, taps};
-            if (Np == c) return gemm_bf16s_launch(xl, WP, (long)taps * cin, SEpiBnBf16<false>{SC, SH, res, o, c, ilog2(side), relu}, (int)M, Np, taps * cin, cus, s);
+            const SEpiBnBf16<false> ep{SC, SH, res, o, c, ilog2(side), relu};
+            if (Np == 64 && c == 64) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 1>(xl, WP, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
+            if (Np == 128 && c == 128) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 2>(xl, WP, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
+            if (Np == c) return gemm_bf16s_launch(xl, WP, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
             return gemm_bf16s_launch(xl, WP, (long)taps * cin, SEpiBnBf16<true>{SC, SH, res, o, c, ilog2(side), relu}, (int)M, Np, taps * cin, cus, s);
         };
         {
@@ -2456,6 +2460,35 @@ extern "C" int egotap_bf16_attention_bwd(const void* qkv, const void* ctx, const
 }
 #endif
 
+#if EGOTAP_IN(3)
+// the same, also producing the q | k | v BIAS gradients (column sums of dqkv) without a pass over dqkv: the kernels' epilogues leave
+// per-block partial sums in ws (fp32 [B * N / 32][3 * heads * 128]); three small fp32 column sums finish them.  Shapes or kernel
+// generations without that epilogue (N % 64 != 0, egotap_debug_attention_gen(1)) take the column-sum pass over dqkv instead.
+extern "C" int egotap_bf16_attention_bwd_bias(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv, float* dq_bias,
+                                              float* dk_bias, float* dv_bias, int B, int N, int heads, void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(qkv && ctx && dctx && lse && delta && dqkv && dq_bias && dk_bias && dv_bias && ws, "egotap_bf16_attention_bwd_bias: null argument");
+    const int D = heads * 128, M = B * N;
+    float* db[3] = {dq_bias, dk_bias, dv_bias};
+    const size_t part_bytes = (size_t)B * (N / 32) * 3 * D * 4;
+    const bool fused = g_attn_gen >= 2 && N % 64 == 0 && ws_bytes >= part_bytes + (64u << 20);
+    hipError_t e = attention_bf16s_bwd_launch((const __bf16*)qkv, (const __bf16*)ctx, (const __bf16*)dctx, lse, delta, (__bf16*)dqkv, B, N, heads, (hipStream_t)stream,
+                                              g_attn_gen, fused ? (float*)ws : nullptr);
+    if (e == hipErrorInvalidValue) { egotap_set_error("egotap_bf16_attention_bwd_bias: sequence length %d is not a multiple of 32", N); return EGOTAP_ERR_INVALID; }
+    EGO_HIP(e);
+    for (int q = 0; q < 3; ++q) {
+        if (fused) {
+            EGO_HIP(colsum_f32_launch((const float*)ws + (size_t)q * D, 3L * D, db[q], (float*)((char*)ws + part_bytes), ws_bytes - part_bytes, B * (N / 32), D, 0,
+                                      (hipStream_t)stream));
+        } else {
+            hipError_t e2 = colsum_bf16_launch((const __bf16*)dqkv + (size_t)q * D, 3L * D, db[q], M, D, 0, (float*)ws, ws_bytes, (hipStream_t)stream);
+            if (e2 == hipErrorOutOfMemory) { egotap_set_error("egotap_bf16_attention_bwd_bias: workspace too small"); return EGOTAP_ERR_WORKSPACE; }
+            EGO_HIP(e2);
+        }
+    }
+    return EGOTAP_OK;
+}
+#endif
+
 // fc1 of the two heatmap encoders on bf16 operands, the gathers folded into the loaders (net_architecture.py:388-406, 690-694):
 //   which 0: rows = per-heatmap patch tokens gathered from tokens bf16 [B*seq, D];  1: rows = [cos | sin] maps from hm bf16 [B, C, S, S]
 #if EGOTAP_IN(3)
@@ -2577,6 +2610,7 @@ static int lift_train16_plan(Handle* h, int B, LiftTrain16Plan& t, LiftBwd16Plan
     const size_t nb = (M + 63) / 64;
     w.scr_bytes = std::max(std::max((size_t)4 * 4 * D * D * 8, (size_t)4 * 2048 * K1 * 2), (3 * nb + 3 + 3 * ((nb + 63) / 64)) * 4096 + 4096);
     w.scr_bytes = std::max(w.scr_bytes, (size_t)64 << 20);
+    w.scr_bytes = std::max(w.scr_bytes, (size_t)B * (h->seq / 32) * 3 * D * 4 + ((size_t)64 << 20));      // per-block bias-gradient sums of the attention backward
     w.scr = bytes(w.scr_bytes);
     w.total = o;
     return EGOTAP_OK;
@@ -2802,13 +2836,12 @@ static int lift_backward16(Handle* h, const float* hm, const float* dpose, int B
         // attention
         EGO_RC(egotap_bf16_gemm_tn(R1, D, Hb(l.ctx), D, G(G_.o_w), M, D, D, 0, ZERO, scr, scrb, stream));
         EGO_RC(egotap_bf16_gemm_nt(R1, D, Hb(l.w_o_t), nullptr, M, D, D, 0, nullptr, R0, nullptr, D, stream));                       // dctx
-        EGO_RC(egotap_bf16_attention_bwd(Hb(l.qkv), Hb(l.ctx), R0, S(l.lse), W(w.delta), A3, B, h->seq, heads, stream));            // dqkv
+        // dqkv, and the q | k | v bias gradients from the kernels' epilogues (no pass over dqkv)
+        EGO_RC(egotap_bf16_attention_bwd_bias(Hb(l.qkv), Hb(l.ctx), R0, S(l.lse), W(w.delta), A3, G(G_.q_b), G(G_.k_b), G(G_.v_b), B, h->seq, heads, scr, scrb,
+                                              stream));
         float* gw[3] = {G(G_.q_w), G(G_.k_w), G(G_.v_w)};
-        float* gb[3] = {G(G_.q_b), G(G_.k_b), G(G_.v_b)};
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < 3; ++q)
             EGO_RC(egotap_bf16_gemm_tn((const __bf16*)A3 + (size_t)q * D, 3 * D, Hb(l.y1), D, gw[q], M, D, D, 0, ZERO, scr, scrb, stream));
-            EGO_RC(egotap_bf16_colsum((const __bf16*)A3 + (size_t)q * D, 3 * D, gb[q], M, D, 0, scr, scrb, stream));
-        }
         EGO_RC(egotap_bf16_gemm_nt(A3, 3 * D, Hb(l.w_qkv_t), nullptr, M, D, 3 * D, 0, nullptr, R0, nullptr, D, stream));             // dy1
         EGO_RC(egotap_bf16_layernorm_bwd(S(t.X[i]), R0, P_.ln1_g, S(l.m1), S(l.r1), F1, F0, i > 0 ? R1 : nullptr, G(G_.ln1_g), G(G_.ln1_b),
                                          i > 0 ? G(g.layer[i - 1].dn_b) : nullptr, M, 0, scr, scrb, stream));                        // dx = F0, R1

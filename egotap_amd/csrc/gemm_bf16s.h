@@ -269,11 +269,17 @@ struct SEpiScatterTokens {
 };
 
 // ---------------------------------------------------------------------------------------------------- kernel
-template <class XL, class Epi>
+// NI = 16-column MFMA tiles per wave: 4 -> a 256 x 256 output tile (the default); [r3] 2 -> 256 x 128, 1 -> 256 x 64, for GEMMs whose N
+// is 128 / 64 (the ResNet-18 stages with 128 / 64 output channels ran as N = 256 with a column guard: 2-4 x the executed FLOPs).  The W
+// part of a stage shrinks to 64 NI rows, a phase to 4 NI MFMAs per wave; ring, barriers and X traffic are unchanged.
+template <class XL, class Epi, int NI = 4>
 __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, const __bf16* __restrict__ Wb, long ldw, Epi epi, int M, int N, int K,
                                                                        int tiles_m, int tiles_n) {
     using Cfg = SCfg;
-    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NS = Cfg::NS, ROWB = Cfg::ROWB, PART = Cfg::PART, STAGE = Cfg::STAGE;
+    static_assert(NI == 4 || NI == 2 || NI == 1, "n-tiles per wave");
+    constexpr int BM = Cfg::BM, BN = 64 * NI, BK = Cfg::BK, NS = Cfg::NS, ROWB = Cfg::ROWB, PART = Cfg::PART, STAGE = Cfg::STAGE;
+    constexpr int NWI = NI == 4 ? 2 : 1;             // W-part DMA instructions per wave and K-tile (NI = 1: waves w and w + 4 fetch the same block)
+    constexpr int VMC = 4 + 2 * NWI;                 // vmcnt allowance: the four newest half stages (2 X + 2 W) may stay in flight
     extern __shared__ __attribute__((aligned(16))) char smem_s[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wid >> 2, wc = wid & 3;
@@ -318,8 +324,9 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
     auto set_w = [&](int i) __attribute__((always_inline)) {
         int tm, tn;
         tile_of(i, tm, tn);
-        pw0 = Wb + (long)(tn * BN + wid * 16 + drow) * ldw + dchunk * 8;
-        pw1 = Wb + (long)(tn * BN + (wid + 8) * 16 + drow) * ldw + dchunk * 8;
+        constexpr int WBLK = BN / 16;                // 16-row blocks of the W part
+        pw0 = Wb + (long)(tn * BN + (wid % WBLK) * 16 + drow) * ldw + dchunk * 8;
+        pw1 = NI == 4 ? Wb + (long)(tn * BN + (wid + 8) * 16 + drow) * ldw + dchunk * 8 : pw0;
     };
     set_x(0);
     set_w(0);
@@ -330,10 +337,10 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
         asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
     auto issue_w = [&](int st) __attribute__((always_inline)) {        // W part of the next K-tile of the W stream -> stage st
-        const unsigned sa = lds0 + st * STAGE + PART + wid * 1024;
+        const unsigned sa = lds0 + st * STAGE + PART + (wid % (BN / 16)) * 1024;
         const int k0 = lw_kt * BK;
         dma1(pw0 + k0, sa);
-        dma1(pw1 + k0, sa + 8 * 1024);
+        if constexpr (NI == 4) dma1(pw1 + k0, sa + 8 * 1024);
         if (lw_tile < my_n && ++lw_kt == KT) {
             lw_kt = 0;
             if (++lw_tile < my_n) set_w(lw_tile);
@@ -352,17 +359,17 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
         }
     };
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][NI];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment byte offset of this lane inside a 16-row block: row lane & 15, logical chunk lane >> 4
     const int l15 = lane & 15;
     const int foff = l15 * ROWB + (((lane >> 4) ^ ((4 - (l15 >> 2)) & 3)) << 4);
     const int x_base = (grp * 128) * ROWB + foff;             // + mi * 16 * ROWB
-    const int w_base = PART + (wc * 64) * ROWB + foff;        // + ni * 16 * ROWB
+    const int w_base = PART + (wc * 16 * NI) * ROWB + foff;   // + ni * 16 * ROWB
 
     int c_tile = 0, c_kt = 0;
     // number of K-tiles (from the start of a tile) whose waits must leave the previous epilogue's stores in flight: vmcnt is ONE
@@ -371,18 +378,21 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
     // of the next tile the allowance is 8 + NST, by which time the stores have had ~2 us to drain.  Only after a FULL tile (every
     // lane active in every store: the count is exact); after a ragged tile the plain allowance makes the first wait drain them.
     constexpr bool CS = s_epi_colsum<Epi>::value;
-    static_assert(!CS || Epi::W == 8, "column sums ride on the bf16-output epilogues");
+    static_assert(!CS || (Epi::W == 8 && NI == 4), "column sums ride on the bf16-output epilogues of the 256-column tile");
     constexpr int IT = Epi::W == 4 ? 4 : 2, NST = 8 * IT * Epi::STORES + (CS ? 2 : 0);
-    constexpr int SLK = s_epi_exact<Epi>::value ? 8 + NST : 8;      // vmcnt allowance of the first K-tiles after an (exact) epilogue
+    constexpr int SLK = s_epi_exact<Epi>::value ? VMC + NST : VMC;      // vmcnt allowance of the first K-tiles after an (exact) epilogue
     static_assert(SLK <= 63, "vmcnt is a 6-bit counter");
     int slack_kt = 0;
     auto epilogue = [&]() __attribute__((always_inline)) {
         int tm, tn;
         tile_of(c_tile, tm, tn);
-        const int m_wave = tm * BM + grp * 128, n_wave = tn * BN + wc * 64;
+        const int m_wave = tm * BM + grp * 128, n_wave = tn * BN + wc * 16 * NI;
         const int q = lane >> 4;
-        // lane -> (row of the 16-row block, first column) of its IT pieces
-        const int er = Epi::W == 4 ? q : (lane >> 3), en = n_wave + (Epi::W == 4 ? l15 * 4 : (lane & 7) * 8);
+        // lane -> (row of the 16-row block, first column) of its IT pieces; with NI < 4 the wave owns 16 NI columns: the lanes of the
+        // columns past them idle in the epilogue (cact)
+        const int er = Epi::W == 4 ? q : (lane >> 3), ecol = Epi::W == 4 ? l15 * 4 : (lane & 7) * 8;
+        const bool cact = ecol < 16 * NI;
+        const int en = n_wave + (cact ? ecol : 0);
         const typename Epi::Col cc = epi.col(en);
         typename Epi::Aux ax[IT], an[IT];
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // column sums of this lane's 8 columns over its 16 rows (CS epilogues)
@@ -396,7 +406,7 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
             }
             // accumulators -> patch[16 m][64 n] (fp32), 16-byte chunk ch of row r at position ch ^ r
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
+            for (int ni = 0; ni < NI; ++ni) {
                 *(f32x4*)(Es + l15 * 64 + (((4 * ni + q) ^ l15) << 2)) = acc[mi][ni];
                 acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
                     const f32x4 v = *(const f32x4*)(Es + r * 64 + ((l15 ^ r) << 2));
                     float vv[4] = {v[0], v[1], v[2], v[3]};
 #if !(defined(EGOTAP_ABL) && (EGOTAP_ABL & 2))      // timing-only: the epilogue without its global stores / functor
-                    if (m0 + r < M) epi.emit(vv, cc, ax[it], m0 + r, en);
+                    if (m0 + r < M && cact) epi.emit(vv, cc, ax[it], m0 + r, en);
 #else
                     asm volatile("" ::"v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]));
 #endif
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
                     const f32x4 v1 = *(const f32x4*)(Es + r * 64 + (((2 * c2 + 1) ^ r) << 2));
                     float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #if !(defined(EGOTAP_ABL) && (EGOTAP_ABL & 2))
-                    if (m0 + r < M) {
+                    if (m0 + r < M && cact) {
                         epi.emit(vv, cc, ax[it], m0 + r, en);              // (leaves the values it stored in vv)
                         if constexpr (CS) {
 #pragma unroll
@@ -468,12 +478,12 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
     issue_w(0); issue_x(0);
     issue_w(1); issue_x(1);
     issue_w(2); issue_x(2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // K-tile 0 has landed (K-tiles 1, 2 may be in flight) ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMC) : "memory");      // K-tile 0 has landed (K-tiles 1, 2 may be in flight) ...
     __builtin_amdgcn_s_barrier();                          // ... for every wave: phase 0 may read it
     __builtin_amdgcn_sched_barrier(0);
     if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
 
-    bf16x8 wf[4], xf[4];
+    bf16x8 wf[NI], xf[4];
     int st = 0;
     for (int T = 0; T < total; ++T) {
         const char* sa = smem_s + st * STAGE;
@@ -481,21 +491,21 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
         // ---------------- phase 2T: row half 0
         issue_w(st3);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(sa + w_base + j * 16 * ROWB);
+        for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8*)(sa + w_base + j * 16 * ROWB);
 #pragma unroll
         for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(sa + x_base + i * 16 * ROWB);
         __builtin_amdgcn_sched_barrier(0);
         // retire the half stage issued four phases ago (this phase's and the three before it may stay in flight): it is read from
         // the next phase on.  The wait sits behind this phase's own DMA and fragment reads, which do not depend on it.
         if (slack_kt > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLK) : "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMC) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -506,14 +516,14 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
         for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(sa + x_base + (4 + i) * 16 * ROWB);
         __builtin_amdgcn_sched_barrier(0);
         if (slack_kt > 0) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLK) : "memory"); --slack_kt; }
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMC) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[4 + i][j], 0, 0, 0);
+            for (int j = 0; j < NI; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[4 + i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -535,19 +545,20 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing (dummy) DMAs must not outlive the workgroup's LDS
 }
 
-template <class XL, class Epi>
+template <class XL, class Epi, int NI = 4>
 static hipError_t gemm_bf16s_launch(const XL& xl, const __bf16* Wb, long ldw, const Epi& epi, int M, int N, int K, int num_cu, hipStream_t stream) {
     using Cfg = SCfg;
+    constexpr int BN = 64 * NI;
     if (M <= 0) return hipSuccess;
-    if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || ldw % 8 != 0) return hipErrorInvalidValue;
-    auto kern = gemm_bf16s_kernel<XL, Epi>;
+    if (N % BN != 0 || K % Cfg::BK != 0 || ldw % 8 != 0) return hipErrorInvalidValue;
+    auto kern = gemm_bf16s_kernel<XL, Epi, NI>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
+    const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / BN;
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < num_cu ? ntiles : num_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xl, Wb, ldw, epi, M, N, K, tiles_m, tiles_n);

@@ -567,13 +567,13 @@ class LiftTrainBf16Fn(torch.autograd.Function):
             S.gemm_tn(dxmb, L["ctx"], G[l + "attention.output.dense.weight"])
             dctx = S.gemm_nt(dxmb, Wl["o_t"], None)
             del dxmb
-            dqkv = S.attention_bwd(L["qkv"], L["ctx"], dctx, L["lse"], B, seq, heads)
+            dqkv = S.attention_bwd(L["qkv"], L["ctx"], dctx, L["lse"], B, seq, heads,
+                                   bias_grads=tuple(G[a + nme + ".bias"] for nme in ("query", "key", "value")))
             if tr is not None:
                 t_.update(dctx=dctx, dqkv=dqkv)
             del dctx
             for sidx, nme in enumerate(("query", "key", "value")):
                 S.gemm_tn(dqkv[:, sidx * D:(sidx + 1) * D], L["y1"], G[a + nme + ".weight"])
-                S.colsum(dqkv[:, sidx * D:(sidx + 1) * D], G[a + nme + ".bias"])
             dy1 = S.gemm_nt(dqkv, Wl["qkv_t"], None)
             if tr is not None:
                 t_["dy1"] = dy1

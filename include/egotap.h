@@ -322,6 +322,11 @@ int egotap_bf16_from_f32(const float* src, void* dst, int64_t n, void* stream);
 int egotap_bf16_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int N, int heads, void* stream);
 int egotap_bf16_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv, int B, int N, int heads,
                               void* stream);
+/* The same, and the q | k | v bias gradients (column sums of dqkv) as well: the kernels' epilogues leave per-block partial sums in ws
+ * (needs (B N / 32)(3 heads 128) floats + 64 MB), three small fp32 column sums finish them -- no pass over dqkv.  Shapes without that
+ * epilogue (N % 64 != 0) fall back to the column-sum pass. */
+int egotap_bf16_attention_bwd_bias(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv, float* dq_bias,
+                                   float* dk_bias, float* dv_bias, int B, int N, int heads, void* ws, size_t ws_bytes, void* stream);
 /* fc1 of the two heatmap encoders on bf16 operands (which 0: position encoder, src = final-LayerNorm tokens bf16 [B*seq, D];
  * 1: rotation encoder, src = the head's input heatmaps as bf16 [B, 6J, S, S]); z fp32 [B*T, 2048] = x w^T + bias.
  * wgrad: dw fp32 [2048, K1] = dz^T x;  dgrad_tokens (position encoder): dtok bf16 [B*seq, D] = scatter(dz wt^T), wt bf16 [K1, 2048] */
