@@ -76,8 +76,15 @@ __global__ __launch_bounds__(256) void ln_bwd_bf16_kernel(const float* __restric
     const int r_lo = wave * rows_per_wave, r_hi = min(rows, r_lo + rows_per_wave);
     for (int r = r_lo; r < r_hi; ++r) {
         const float mu = mean[r], rs = rstd[r];
-        f32x4 xh[V][2], dy[V][2];
+        f32x4 xh[V][2], dy[V][2], rsd[V][2];
         float s1 = 0.f, s2 = 0.f;
+        // [r3] the residual gradient of the row is requested together with x and dy, ahead of the two wave reductions (it used to be
+        // loaded after them: one more exposed round trip per row and wave)
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                rsd[i][h] = dres ? *(const f32x4*)(dres + (long)r * D + (i * 64 + lane) * 8 + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const int c = (i * 64 + lane) * 8;
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256) void ln_bwd_bf16_kernel(const float* __restric
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][h][e] * dy[i][h][e] - m1 - xh[i][h][e] * m2);
-                if (dres) o += *(const f32x4*)(dres + (long)r * D + c + 4 * h);
+                o += rsd[i][h];
                 *(f32x4*)(dX + (long)r * D + c + 4 * h) = o;
                 ds[i][h] += o;
 #pragma unroll
