@@ -149,11 +149,17 @@ class Bf16Storage:
     gelu = staticmethod(_GeluStored.apply)
 
 
-def fc_block(x, sd, prefix, training=False, momentum=0.1, eps=1e-5, round=None, round_input=False):
+def fc_block(x, sd, prefix, training=False, momentum=0.1, eps=1e-5, round=None, round_input=False, lrelu=None):
     """LeakyReLU_0.2(BatchNorm1d(x W^T + b)); network_utils.py:123-142.
 
     training=True uses batch statistics and returns the updated running stats
     (unbiased variance, momentum 0.1) as torch's BatchNorm1d does.
+
+    lrelu (tests only; None everywhere else = the pinned function): {"masks": {prefix: bool [R, N]}, "pre": {}}.  The gradient of
+    this block is discontinuous where the LeakyReLU input crosses zero, and two fp32 implementations of the matrix product in front of
+    it disagree about the sign of an input within rounding of zero (a few elements per step at fc1's 16384-long dot products): with
+    a mask given, the positive branch is taken exactly where the mask says (the function "as the implementation under test evaluated
+    it"); "pre" receives the float64 LeakyReLU input so that the test can check that the two only differ where it is ~0.
     """
     if round is not None:       # fc1 of both encoders: bf16 operands; dz is rounded for the weight- / input-gradient GEMMs, the bias sees fp32
         xin = round.fwd(x) if round_input else x
@@ -168,6 +174,10 @@ def fc_block(x, sd, prefix, training=False, momentum=0.1, eps=1e-5, round=None, 
         new_rm = (1 - momentum) * sd[prefix + ".bn.running_mean"] + momentum * mean
         new_rv = (1 - momentum) * sd[prefix + ".bn.running_var"] + momentum * var_b * n / (n - 1)
         y = (z - mean) / torch.sqrt(var_b + eps) * g + beta
+        if lrelu is not None:
+            lrelu["pre"][prefix] = y.detach()
+            if prefix in lrelu["masks"]:
+                return torch.where(lrelu["masks"][prefix], y, 0.2 * y), (new_rm, new_rv)
         return F.leaky_relu(y, 0.2), (new_rm, new_rv)
     mean, var = sd[prefix + ".bn.running_mean"], sd[prefix + ".bn.running_var"]
     y = (z - mean) / torch.sqrt(var + eps) * g + beta
@@ -240,7 +250,7 @@ def _vit_layer_bf16(x, sd, pre, heads, r):
     return x + r.bwd(h @ r.w(sd[pre + "output.dense.weight"]).T) + sd[pre + "output.dense.bias"]
 
 
-def pos_encoder(pos_hm, sd, p: LiftPreset, trace=None, training=False, round=None):
+def pos_encoder(pos_hm, sd, p: LiftPreset, trace=None, training=False, round=None, lrelu=None):
     """[B,T,hm,hm] -> [B*T, hidden]  (T tokens in [L_1..L_J, R_1..R_J] order)."""
     pre = "pos_heatmap_encoder."
     x = vit_embed(pos_hm, sd, p, round=round)
@@ -261,7 +271,7 @@ def pos_encoder(pos_hm, sd, p: LiftPreset, trace=None, training=False, round=Non
     z = grid[:, :T].reshape(B * T, q * q * D)
     stats = {}
     for name in ("fc1", "fc2", "fc3"):
-        z = fc_block(z, sd, pre + name, training, round=round if name == "fc1" else None)
+        z = fc_block(z, sd, pre + name, training, round=round if name == "fc1" else None, lrelu=lrelu)
         if training:
             z, stats[pre + name] = z
     return (z, stats) if training else z
@@ -274,11 +284,11 @@ def rot_relayout(rot_hm, p: LiftPreset):
     return rot_hm.view(B, 2, 2, J, hm * hm).permute(0, 1, 3, 2, 4).reshape(B * 2 * J, 2 * hm * hm)
 
 
-def rot_encoder(rot_hm, sd, p: LiftPreset, training=False, round=None):
+def rot_encoder(rot_hm, sd, p: LiftPreset, training=False, round=None, lrelu=None):
     z = rot_relayout(rot_hm, p)
     stats = {}
     for name in ("fc1", "fc2", "fc3"):
-        z = fc_block(z, sd, "rot_heatmap_encoder." + name, training, round=round if name == "fc1" else None, round_input=True)
+        z = fc_block(z, sd, "rot_heatmap_encoder." + name, training, round=round if name == "fc1" else None, round_input=True, lrelu=lrelu)
         if training:
             z, stats["rot_heatmap_encoder." + name] = z
     return (z, stats) if training else z
@@ -382,12 +392,12 @@ def loss_cos_sim(pred, gt, p: LiftPreset, eps=1e-8):
     return cos.sum(dim=1).mean()
 
 
-def lift_forward_train(hm, sd, p: LiftPreset, round=None):
+def lift_forward_train(hm, sd, p: LiftPreset, round=None, lrelu=None):
     """Training-mode forward (BatchNorm1d batch statistics in the six FC blocks): returns (pose, {bn prefix: (new running
     mean, new running var)}).  Differentiable with torch autograd w.r.t. every tensor of sd that requires grad."""
     B, J = hm.shape[0], p.n_joints_hm
-    pos, st1 = pos_encoder(hm[:, : 2 * J], sd, p, None, training=True, round=round)
-    rot, st2 = rot_encoder(hm[:, 2 * J:], sd, p, training=True, round=round)
+    pos, st1 = pos_encoder(hm[:, : 2 * J], sd, p, None, training=True, round=round, lrelu=lrelu)
+    rot, st2 = rot_encoder(hm[:, 2 * J:], sd, p, training=True, round=round, lrelu=lrelu)
     pos_j = stereo_interleave(pos, B, p)
     rot_j = stereo_interleave(rot, B, p)
     skel = pu_chain(pos_j.transpose(0, 1), rot_j.transpose(0, 1), sd)
@@ -395,7 +405,7 @@ def lift_forward_train(hm, sd, p: LiftPreset, round=None):
     return pose_head(pos_j, skel, sd, p), st1
 
 
-def train_step(hm, gt, sd, p: LiftPreset, lam_mpjpe=0.1, lam_cos=-0.01, lr=1e-3, eps=1e-4, wd=0.0, round=None):
+def train_step(hm, gt, sd, p: LiftPreset, lam_mpjpe=0.1, lam_cos=-0.01, lr=1e-3, eps=1e-4, wd=0.0, round=None, lrelu=None):
     """One optimisation step of egotap_autoencoder_model.py:299-323 (fp32, no AMP): forward in train mode, loss =
     lam_mpjpe * MPJPE + lam_cos * lam_mpjpe * CosSim, backward, AdamW (network.py:72-78; betas 0.9 / 0.999).
     Returns dict(pose, loss_pose, loss_cos_sim, grads{key}, new_params{key}, bn{prefix: (rm, rv)})."""
@@ -404,7 +414,7 @@ def train_step(hm, gt, sd, p: LiftPreset, lam_mpjpe=0.1, lam_cos=-0.01, lr=1e-3,
               if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) and not any(d in k for d in dead)}
     full = dict(sd)
     full.update(leaves)
-    pose, bn = lift_forward_train(hm, full, p, round=round)
+    pose, bn = lift_forward_train(hm, full, p, round=round, lrelu=lrelu)
     lp = loss_mpjpe(pose, gt) * lam_mpjpe
     lc = loss_cos_sim(pose, gt, p) * lam_cos * lam_mpjpe
     grads = dict(zip(leaves.keys(), torch.autograd.grad(lp + lc, list(leaves.values()), allow_unused=True)))

@@ -195,3 +195,34 @@ def test_attention_fwd_bwd_bf16(B, N):
         assert cos > 0.999, (name, cos)
     again = bf16s.attention_bwd(qkv.cuda(), ctx, dctx.cuda(), lse, B, N, heads)
     assert torch.equal(dqkv, again)
+
+
+def test_attention_backward_bias_sums_from_the_epilogues_equal_a_column_sum_pass():
+    """egotap_bf16_attention_bwd_bias: the q | k | v bias gradients as per-block partial sums written by the dQ / dK+dV kernels'
+    epilogues (generation 2, N % 64 == 0) against the column sums of the dqkv tensor it returns (float64), and against the fallback
+    that reads dqkv again (generation 1 kernels): the same dqkv bits, bias sums equal to fp32 summation order"""
+    import ctypes as C
+    from egotap_amd import bf16s, lib
+    L = lib.load()
+    B, N, heads, D = 3, 576, 8, 1024
+    torch.manual_seed(5)
+    qkv = (torch.randn(B * N, 3 * D, device="cuda") * 0.5).bfloat16()
+    dctx = (torch.randn(B * N, D, device="cuda") * 0.1).bfloat16()
+    ctx, lse = bf16s.attention_fwd(qkv, B, N, heads)
+    outs = {}
+    for gen in (2, 1):
+        lib.check(L.egotap_debug_attention_gen(gen))
+        try:
+            gb = tuple(torch.full((D,), float("nan"), device="cuda") for _ in range(3))
+            dqkv = bf16s.attention_bwd(qkv, ctx, dctx, lse, B, N, heads, bias_grads=gb)
+            torch.cuda.synchronize()
+            outs[gen] = (dqkv.clone(), [t.clone() for t in gb])
+        finally:
+            lib.check(L.egotap_debug_attention_gen(2))
+    assert torch.equal(outs[1][0], outs[2][0])
+    ref = outs[2][0].double().sum(0)
+    for gen in (1, 2):
+        for q in range(3):
+            got = outs[gen][1][q].double()
+            want = ref[q * D:(q + 1) * D]
+            assert float((got - want).abs().max()) <= 2e-6 * float(outs[2][0].double().abs().sum(0)[q * D:(q + 1) * D].max()) + 1e-9, (gen, q)

@@ -154,3 +154,99 @@ def test_wrapper_evaluate_matches_the_reference_wrapper(tmp_path, tag, use_gt):
     assert len(acc.rows) == 4
     np.testing.assert_allclose([r["mpjpe"] for r in acc.rows], g[f"{tag}_mpjpe"], rtol=1e-4)
     np.testing.assert_allclose([r["pa_mpjpe"] for r in acc.rows], g[f"{tag}_pa_mpjpe"], rtol=1e-3)
+
+
+def test_egocap_wrapper_step_and_evaluate_match_the_reference_wrapper(tmp_path):
+    """the EgoCap preset (17 heatmaps per eye, 17 joints, no head joint, zero root prepended in the bone loss, utils/loss.py:56-74)
+    through the reference's wrapper: first step (lr 0), third step (two updates later) and evaluate() from ground-truth heatmaps.
+
+    Gradients at 102 encoder rows: the LeakyReLU behind every BatchNorm1d makes the gradient discontinuous where its input crosses
+    zero, and fc1's 16384-long fp32 dot products leave the sign of an input within ~1e-5 of zero to the summation order (about one
+    element per step; the whole row of dA behind it then differs by a few per cent of the typical magnitude, and so does every ViT
+    gradient).  So the chain is: (1) tests/test_oracle_golden.py pins the float64 oracle to the reference wrapper's gradients of this
+    very fixture at 1e-3 (CPU); (2) here the HIP gradients are compared with the oracle evaluated with the LeakyReLU branches the HIP
+    forward took, and (3) those branches may differ from the oracle's own only where the input is ~0."""
+    from egotap_amd import models, spec, training
+    from egotap_amd import train_ops as T
+    from egotap_amd.options import preset_defaults
+    from oracle import lift_ref as O
+    g = np.load(os.path.join(GOLD, "wrapper_ec.npz"))
+    p = spec.lift_preset("EgoCap")
+    sd_np = synth_state_dict(spec.lift_state_spec(p))
+    sd_ec = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    for sub, nh, salt in (("hm_pos", 17, "hm_pos."), ("hm_sin", 34, "hm_rot.")):
+        os.makedirs(tmp_path / sub)
+        torch.save({k: torch.from_numpy(v) for k, v in synth_hm_state_dict(nh, salt).items()}, tmp_path / sub / "best_net_HeatMap.pth")
+    opt = preset_defaults("EgoCap")
+    ref = _opt(tmp_path, True, True)
+    for k in ("model", "isTrain", "use_amp", "gpu_ids", "log_dir", "experiment_name", "use_gt_heatmap", "path_to_trained_heatmap", "optimizer_type", "lr", "opt_eps",
+              "weight_decay", "lr_policy", "niter", "niter_decay", "epoch_iter_cnt", "epoch_count", "lambda_mpjpe", "lambda_cos_sim"):
+        setattr(opt, k, getattr(ref, k))
+    m = models.create_model(opt)
+    m.net_AutoEncoder.load_state_dict(sd_ec, strict=True)
+    assert list(m.loss_names) == list(g["loss_names"])
+
+    def data(B, tag):
+        hm = torch.from_numpy(synth_input(f"wrap_hm_{tag}", (B, 102, 64, 64)))
+        return {"input_rgb_left": torch.from_numpy(synth_input(f"wrap_rgbL_{tag}", (B, 3, 256, 256), -2.0, 2.0)),
+                "input_rgb_right": torch.from_numpy(synth_input(f"wrap_rgbR_{tag}", (B, 3, 256, 256), -2.0, 2.0)),
+                "gt_heatmap_left": hm[:, :17], "gt_heatmap_right": hm[:, 17:34], "gt_limb_heatmap_left": hm[:, 34:68], "gt_limb_heatmap_right": hm[:, 68:],
+                "gt_local_pose": torch.from_numpy(synth_input(f"wrap_gt_{tag}", (B, 17, 3), -20.0, 20.0))}
+    step = data(3, "ec_step")
+    m.set_input(step)
+    # the operator-by-operator composition of the step (bit-identical to the one-call ABI, tests/test_gpu_train_step.py) hands every
+    # block's activation to Python: record which LeakyReLU branch each element took
+    taken, real = [], T.bn_lrelu_bwd
+
+    def spy(z, y, *a, **k):
+        taken.append((y > 0).cpu())
+        return real(z, y, *a, **k)
+    m.net_AutoEncoder.one_call_training = False
+    training.T.bn_lrelu_bwd = spy
+    try:
+        m.optimize_parameters()
+        torch.cuda.synchronize()
+    finally:
+        training.T.bn_lrelu_bwd = real
+        m.net_AutoEncoder.one_call_training = True
+    e1 = m.get_current_errors()
+    assert list(e1.keys()) == list(g["errors_keys"])
+    np.testing.assert_allclose([e1[k] for k in e1], g["errors_step1"], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(m.pred_pose.detach().cpu().numpy(), g["pred_pose_step1"], atol=1e-4)
+    params = dict(m.net_AutoEncoder.named_parameters())
+    assert sorted(k for k, v in params.items() if v.grad is not None) == sorted(g["grad_keys"])
+    order = [f"{e}_heatmap_encoder.fc{j}" for e in ("rot", "pos") for j in (3, 2, 1)]          # the backward's order
+    assert len(taken) == 6
+    hook = {"masks": dict(zip(order, taken)), "pre": {}}
+    hm = torch.cat([step["gt_heatmap_left"], step["gt_heatmap_right"], step["gt_limb_heatmap_left"], step["gt_limb_heatmap_right"]], 1)
+    want = O.train_step(hm.double(), step["gt_local_pose"].double(), O.to_torch_sd(sd_np, torch.float64), p, lrelu=hook)["grads"]
+    flips = 0
+    for k in order:
+        differ = hook["masks"][k] != (hook["pre"][k] > 0)
+        flips += int(differ.sum())
+        assert float(hook["pre"][k][differ].abs().max()) < 1e-4 if differ.any() else True, k          # BatchNorm outputs are O(1)
+    print(f"LeakyReLU branches that differ from the float64 oracle's: {flips} of {sum(t.numel() for t in taken)}")
+    norms = dict(zip(g["grad_keys"], g["grad_norms"]))
+    for k in g["grad_keys"]:
+        gr = params[k].grad
+        scale = max(norms[k] / np.sqrt(gr.numel()), 1e-12)
+        err = float((gr.double().cpu() - want[k]).abs().max())
+        assert err <= 5e-3 * scale + 1e-8, f"{k}: err {err:.3e} vs typical magnitude {scale:.3e}"
+        if flips == 0:      # same branches everywhere: the reference wrapper's own numbers apply directly
+            assert np.abs(_strided(gr) - g["g:" + k]).max() <= 5e-3 * scale + 1e-8, k
+    m.update_learning_rate()
+    m.optimize_parameters()
+    m.update_learning_rate()
+    m.optimize_parameters()
+    torch.cuda.synchronize()
+    e3 = m.get_current_errors()
+    np.testing.assert_allclose([e3[k] for k in e3], g["errors_step3"], rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(m.pred_pose.detach().cpu().numpy(), g["pred_pose_step3"], atol=2e-3)
+    m.eval()
+    m.set_input(data(4, "ec_eval"))
+    acc = _Acc()
+    pose, _, _ = m.evaluate(acc)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pose.cpu().numpy(), g["eval_pred_pose"], atol=2e-3)          # three AdamW steps away from the initial weights
+    np.testing.assert_allclose([r["mpjpe"] for r in acc.rows], g["eval_mpjpe"], rtol=1e-3)
+    np.testing.assert_allclose([r["pa_mpjpe"] for r in acc.rows], g["eval_pa_mpjpe"], rtol=2e-3)

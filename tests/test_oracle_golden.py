@@ -209,3 +209,30 @@ def test_bf16_storage_hook_changes_only_what_it_should():
     assert torch.equal(w, O.bf16_round(x))
     (gw,) = torch.autograd.grad((w * 1.2345678).sum(), x)
     assert torch.equal(gw, torch.full_like(x, 1.2345678))               # straight through to the fp32 master
+
+
+def test_oracle_gradients_match_the_reference_wrapper_egocap_step():
+    """wrapper_ec.npz (tools/make_golden.py gen_wrapper: one optimize_parameters() of the reference's EgoTAPAutoEncoderModel, EgoCap
+    preset, 3 frames = 102 encoder rows, fp32 on CPU) against the float64 oracle: losses, pose and a strided sample of every gradient.
+    This is the link tests/test_gpu_wrapper_golden.py::test_egocap_wrapper_step... leans on when it compares the HIP gradients with
+    the oracle evaluated on the HIP forward's LeakyReLU branches."""
+    g = _load("wrapper_ec.npz")
+    p = spec.lift_preset("EgoCap")
+    sd = O.to_torch_sd(synth_state_dict(spec.lift_state_spec(p)), torch.float64)
+    hm = torch.from_numpy(synth_input("wrap_hm_ec_step", (3, p.in_channels, 64, 64))).double()
+    gt = torch.from_numpy(synth_input("wrap_gt_ec_step", (3, p.out_joints, 3), -20.0, 20.0)).double()
+    hook = {"masks": {}, "pre": {}}
+    ref = O.train_step(hm, gt, sd, p, lrelu=hook)
+    np.testing.assert_allclose(ref["pose"].numpy(), g["pred_pose_step1"], atol=2e-5)
+    assert sorted(k for k, v in ref["grads"].items() if v is not None) == sorted(g["grad_keys"])
+    norms = dict(zip(g["grad_keys"], g["grad_norms"]))
+    for k in g["grad_keys"]:
+        gr = ref["grads"][k].reshape(-1)
+        scale = norms[k] / np.sqrt(gr.numel())
+        if scale < 1e-8:          # biases in front of a train-mode BatchNorm: exactly zero in exact arithmetic, rounding noise in fp32
+            continue
+        err = np.abs(gr[:: max(1, gr.numel() // 257)].numpy() - g["g:" + k]).max()
+        assert err <= 1e-3 * scale, f"{k}: {err:.3e} vs typical magnitude {scale:.3e}"
+    # the hook with no masks is the pinned function; it reports the LeakyReLU inputs of the six blocks
+    assert sorted(hook["pre"]) == sorted(f"{e}_heatmap_encoder.fc{j}" for e in ("pos", "rot") for j in (1, 2, 3))
+    assert hook["pre"]["pos_heatmap_encoder.fc1"].shape == (102, 2048)

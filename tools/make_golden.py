@@ -257,10 +257,10 @@ def gen_train():
     print("train_step: losses", float(loss_pose), float(loss_cos), "params without grad:", no_grad)
 
 
-def _wrapper_opt(tmp, is_train, use_gt_heatmap):
-    """the shipped PoseEstimator flag set (scripts/train/PoseEstimator/unrealego.sh, scripts/test/unrealego.sh) without --use_amp
-    (fp16 autocast needs a GPU) on CPU"""
-    opt = make_opt("UnrealEgo")
+def _wrapper_opt(tmp, is_train, use_gt_heatmap, preset="UnrealEgo"):
+    """the shipped PoseEstimator flag set (scripts/train/PoseEstimator/unrealego.sh, scripts/test/unrealego.sh; egocap.sh for the
+    EgoCap preset) without --use_amp (fp16 autocast needs a GPU) on CPU"""
+    opt = make_opt(preset)
     opt.model, opt.isTrain, opt.use_amp, opt.gpu_ids, opt.distributed = "egotap_autoencoder", is_train, False, [], False
     opt.log_dir, opt.experiment_name, opt.init_type = tmp, "gold_wrapper", "kaiming"
     opt.use_gt_heatmap = use_gt_heatmap
@@ -271,17 +271,17 @@ def _wrapper_opt(tmp, is_train, use_gt_heatmap):
     return opt
 
 
-def _wrapper_data(B, tag):
-    hm = torch.from_numpy(synth_input(f"wrap_hm_{tag}", (B, 90, 64, 64)))
+def _wrapper_data(B, tag, J=15, out_joints=16):
+    hm = torch.from_numpy(synth_input(f"wrap_hm_{tag}", (B, 6 * J, 64, 64)))
     return {
         "input_rgb_left": torch.from_numpy(synth_input(f"wrap_rgbL_{tag}", (B, 3, 256, 256), -2.0, 2.0)),
         "input_rgb_right": torch.from_numpy(synth_input(f"wrap_rgbR_{tag}", (B, 3, 256, 256), -2.0, 2.0)),
-        "gt_heatmap_left": hm[:, :15], "gt_heatmap_right": hm[:, 15:30],
-        "gt_limb_heatmap_left": hm[:, 30:60], "gt_limb_heatmap_right": hm[:, 60:],
-        "gt_local_pose": torch.from_numpy(synth_input(f"wrap_gt_{tag}", (B, 16, 3), -20.0, 20.0)),
-        "gt_local_rot": torch.zeros(B, 16, 3), "gt_limb_theta": torch.zeros(B, 15),
+        "gt_heatmap_left": hm[:, :J], "gt_heatmap_right": hm[:, J:2 * J],
+        "gt_limb_heatmap_left": hm[:, 2 * J:4 * J], "gt_limb_heatmap_right": hm[:, 4 * J:],
+        "gt_local_pose": torch.from_numpy(synth_input(f"wrap_gt_{tag}", (B, out_joints, 3), -20.0, 20.0)),
+        "gt_local_rot": torch.zeros(B, out_joints, 3), "gt_limb_theta": torch.zeros(B, J),
         "gt_pelvis_left": torch.zeros(B, 3), "gt_pelvis_right": torch.zeros(B, 3),
-        "gt_plength_left": torch.ones(B, 30), "gt_plength_right": torch.ones(B, 30),
+        "gt_plength_left": torch.ones(B, 2 * J), "gt_plength_right": torch.ones(B, 2 * J),
     }
 
 
@@ -404,6 +404,49 @@ def gen_wrapper():
     out["quirk_b2_gt_mpjpe"] = np.array([r["mpjpe"] for r in acc.rows])
     print("batch-of-2 quirk: pa_mpjpe", out["quirk_b2_gt_pa_mpjpe"], "vs the same frames in the batch of 4:", out["gt_pa_mpjpe"][:2])
     np.savez_compressed(os.path.join(GOLD, "wrapper_eval_ue_b4.npz"), **out)
+
+    # ---- the EgoCap preset through the same wrapper (17 heatmaps per eye, 17 joints, no head joint, zero root in the bone loss):
+    # one optimisation step after the lr-0 warm-up step, and evaluate() from ground-truth heatmaps
+    sd_ec = {k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(spec.lift_preset("EgoCap"))).items()}
+    for sub, nh in (("hm_pos", 17), ("hm_sin", 34)):
+        torch.save({k: torch.from_numpy(v) for k, v in synth_hm_state_dict(nh, "hm_pos." if sub == "hm_pos" else "hm_rot.").items()},
+                   os.path.join(tmp, sub, "best_net_HeatMap.pth"))
+    opt = _wrapper_opt(tmp, True, True, "EgoCap")
+    m = EgoTAPAutoEncoderModel()
+    m.initialize(opt)
+    m.net_AutoEncoder.load_state_dict(sd_ec, strict=True)
+    m.train()
+    m.set_input(_wrapper_data(3, "ec_step", 17, 17))
+    m.optimize_parameters()
+    out = {"loss_names": np.array(m.loss_names)}
+    e1 = m.get_current_errors()
+    out["errors_keys"], out["errors_step1"] = np.array(list(e1.keys())), np.array([e1[k] for k in e1], dtype=np.float64)
+    out["pred_pose_step1"] = m.pred_pose.detach().numpy().copy()
+    names, norms = [], []
+    for k, prm in m.net_AutoEncoder.named_parameters():
+        if prm.grad is None:
+            continue
+        names.append(k)
+        norms.append(float(prm.grad.double().norm()))
+        out["g:" + k] = prm.grad.reshape(-1)[:: max(1, prm.numel() // 257)].numpy().copy()
+    out["grad_keys"], out["grad_norms"] = np.array(names), np.array(norms)
+    m.update_learning_rate()
+    m.optimize_parameters()
+    m.update_learning_rate()
+    m.optimize_parameters()
+    e3 = m.get_current_errors()
+    out["errors_step3"] = np.array([e3[k] for k in e3], dtype=np.float64)
+    out["pred_pose_step3"] = m.pred_pose.detach().numpy().copy()
+    m.eval()
+    m.opt.use_gt_heatmap = True
+    m.set_input(_wrapper_data(4, "ec_eval", 17, 17))
+    acc = Acc()
+    pose, cat, _ = m.evaluate(acc)
+    out["eval_pred_pose"] = pose.detach().numpy().copy()
+    out["eval_mpjpe"] = np.array([r["mpjpe"] for r in acc.rows])
+    out["eval_pa_mpjpe"] = np.array([r["pa_mpjpe"] for r in acc.rows])
+    np.savez_compressed(os.path.join(GOLD, "wrapper_ec.npz"), **out)
+    print("wrapper_ec:", e1, e3, "eval mpjpe", out["eval_mpjpe"])
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
 
