@@ -30,6 +30,7 @@
 #include "attention_bf16s.h"
 #include "attention_bf16s2.h"
 #include "conv_bf16s.h"
+#include "stem_bf16s.h"
 
 // The library is ONE source compiled as four translation units in parallel (egotap_amd/build.py: -DEGOTAP_PART=0 core and
 // inference, 1 lifting-head training operators, 2 heatmap-estimator training operators, 3 bf16-storage operators); every exported function belongs to one
@@ -1071,6 +1072,7 @@ extern "C" int egotap_hm_intermediate(egotap_handle h, int B, const char* name, 
     const int64_t N2 = 2LL * B, S0 = h->cfg.hm_size * 4;
     auto sq = [](int64_t v) { return v * v; };
     if (!strcmp(name, "layer0")) { *offset = w.L0; *numel = N2 * 64 * sq(S0 / 2); }
+    else if (!strcmp(name, "pool0")) { *offset = w.P0; *numel = N2 * 64 * sq(S0 / 4); }      // stem + max-pool: fp32 NCHW, or (bf16 mode) bf16 [B * (S0/4)^2, 2 x 64]
     else if (!strcmp(name, "layer1")) { *offset = w.S[0][3]; *numel = N2 * 64 * sq(S0 / 4); }
     else if (!strcmp(name, "layer2")) { *offset = w.S[1][3]; *numel = N2 * 128 * sq(S0 / 8); }
     else if (!strcmp(name, "layer3")) { *offset = w.S[2][3]; *numel = N2 * 256 * sq(S0 / 16); }
@@ -1088,6 +1090,13 @@ extern "C" int egotap_hm_intermediate(egotap_handle h, int B, const char* name, 
 #endif
 
 // HeatMap_UnrealEgo_Shared.forward(left, right) (model/net_architecture.py:32-36, 45-51, 75-85, 139-173), eval mode.
+#if EGOTAP_IN(0)
+static int g_stem_split = 0;   // egotap_debug_stem_split: 1 = the bf16 estimators run stem and max-pool as two kernels (round 2's form; A/B timing, tests)
+extern "C" int egotap_debug_stem_split(int on) {
+    g_stem_split = on ? 1 : 0;
+    return EGOTAP_OK;
+}
+#endif
 #if EGOTAP_IN(0)
 extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, const float* right, int B, float* out,
                                  int64_t out_image_stride, void* ws, size_t ws_bytes, void* stream) {
@@ -1115,8 +1124,13 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
 
     // E1: stem conv7x7/2 + BN + ReLU on image n = 2b + eye (the L/R channel concat of every pyramid level is then a view); in the
     // bf16 mode it writes bf16 channels-last itself (half the bytes, and the layout the max-pool and the stages read)
-    EGO_HIP(stem_conv7_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, F(w.L0), S0, N2, device_cu_count(), s,
-                              h->precision == EGOTAP_PREC_BF16));
+    // [r3] ... bf16 mode: stem, BatchNorm, ReLU AND the max-pool in one kernel on the bf16 matrix cores (stem_bf16s.h): the 128 x 128 x 64
+    // map never reaches HBM.  h->stem_split (egotap_debug_stem_split, tests / A-B timing) keeps the two-kernel form: fp32-MFMA stem
+    // writing bf16 channels-last, then the channels-last max-pool.
+    const bool fused_stem = h->precision == EGOTAP_PREC_BF16 && !g_stem_split;
+    if (!fused_stem)
+        EGO_HIP(stem_conv7_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, F(w.L0), S0, N2, device_cu_count(), s,
+                                  h->precision == EGOTAP_PREC_BF16));
     if (h->precision == EGOTAP_PREC_BF16) {
         // bf16 mode: everything after the stem on bf16 channels-last activations, every convolution on the bf16-storage GEMM
         // (conv_bf16s.h).  Buffers live in the fp32 path's slots (each at most half as large).
@@ -1154,7 +1168,9 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
         };
         // E2: max-pool of the stem's bf16 [B * (2 s64)^2, 2 x 64] -> [B * s64^2, 2 x 64]; E3: the four stages on the same GEMM kernel (eye-interleaved rows, see conv_bf16s.h)
         __bf16* P0 = Hb(w.P0);
-        {
+        if (fused_stem) {
+            EGO_HIP(stem_pool_bf16s_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, P0, S0, N2, cus, s));
+        } else {
             const long total = (long)B * p64 * (128 / 8);
             hipLaunchKernelGGL(maxpool3s2_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const __bf16*)F(w.L0), P0, 128, S0 / 2, total);
             EGO_HIP(hipGetLastError());

@@ -158,3 +158,51 @@ def test_hm_forward_bf16_mode_against_float64_oracle():
     rel = float((low - ref).norm() / ref.norm())
     assert float((exact - ref).norm() / ref.norm()) < 1e-5
     assert 1e-5 < rel < 3e-2, rel
+
+
+@pytest.mark.parametrize("preset,hm,B", [("UnrealEgo", 64, 3), ("EgoCap", 128, 2)])
+def test_bf16_fused_stem_and_maxpool_kernel(preset, hm, B):
+    """csrc/stem_bf16s.h: conv 7x7/2 + BatchNorm(eval) + ReLU + MaxPool(3, 2, 1) as one bf16-MFMA kernel (net_architecture.py:69-70),
+    read back from the workspace (bf16 [B * hm * hm, 2 x 64], eye-interleaved) against float64 arithmetic on the SAME bf16-rounded
+    inputs and weights, rounded to bf16 once at the same place: equal up to one bf16 ulp where the fp32 accumulation order decides a
+    rounding; image borders (max-pool padding, zero halo), both eyes, the segment seams and, at 512 x 512, four segments per row.
+    Then the two-kernel form (egotap_debug_stem_split: fp32 stem, separate pool) must give the same heatmaps to bf16 accuracy."""
+    import ctypes as C
+    from gpu_util import hm_net
+    from egotap_amd import lib
+    L = lib.load()
+    net, sd_np = hm_net("pos", preset=preset, hm=hm)
+    S = 4 * hm
+    left = torch.from_numpy(synth_input(f"rgbL_stem_{hm}", (B, 3, S, S), -2.0, 2.0))
+    right = torch.from_numpy(synth_input(f"rgbR_stem_{hm}", (B, 3, S, S), -2.0, 2.0))
+    try:
+        net.set_precision("bf16")
+        fused = net(left.cuda(), right.cuda())
+        off, n = C.c_size_t(), C.c_int64()
+        lib.check(L.egotap_hm_intermediate(net._ensure_handle(), B, b"pool0", C.byref(off), C.byref(n)))
+        got = net._ws[off.value: off.value + 2 * n.value].view(torch.bfloat16).reshape(B, hm, hm, 2, 64).double().cpu()
+        lib.check(L.egotap_debug_stem_split(1))
+        split = net(left.cuda(), right.cuda())
+    finally:
+        lib.check(L.egotap_debug_stem_split(0))
+        net.set_precision("f32")
+    rb = lambda t: t.float().bfloat16().double()
+    w = rb(torch.from_numpy(sd_np["backbone.backbone.backbone.conv1.weight"]))
+    bn = {k: torch.from_numpy(sd_np["backbone.backbone.backbone.bn1." + k]).double() for k in ("weight", "bias", "running_mean", "running_var")}
+    sc = (bn["weight"].float() / torch.sqrt(bn["running_var"].float() + 1e-5)).double()          # the kernel folds in fp32
+    sh = (bn["bias"].float() - bn["running_mean"].float() * sc.float()).double()
+    for eye, img in enumerate((left, right)):
+        z = torch.nn.functional.conv2d(rb(img), w, stride=2, padding=3)
+        y = rb(torch.relu(z * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))
+        want = torch.nn.functional.max_pool2d(y, 3, 2, 1).permute(0, 2, 3, 1)                 # [B, hm, hm, 64]
+        have = got[:, :, :, eye]
+        err = (have - want).abs()
+        # one bf16 ulp of the value, plus the fp32 accumulation noise of the 147-term sum where BatchNorm's shift cancels it
+        tol = 2.0 ** -7 * want.abs() + 4e-6 * float(z.abs().max() * sc.abs().max())
+        bad = err > tol
+        i = int(err.argmax())
+        assert not bool(bad.any()), (eye, int(bad.sum()), float(err.reshape(-1)[i]), float(want.reshape(-1)[i]), float(have.reshape(-1)[i]))
+        assert float((err == 0).double().mean()) > 0.98, float((err == 0).double().mean())
+    rel = float((fused - split).norm() / split.norm())
+    print(f"fused bf16 stem vs fp32 stem + pool ({preset}): relative L2 of the heatmaps {rel:.2e}")
+    assert rel < 1e-2

@@ -17,6 +17,9 @@ r = torch.from_numpy(synth_input("probe_r", (4, 3, S, S), -2.0, 2.0)).cuda().rep
 nets = [hm_net(w, preset=preset, hm=hm)[0] for w in ("pos", "rot")]
 for n in nets:
     n.set_precision(mode)
+if len(sys.argv) > 4 and sys.argv[4] == "split":        # round 2's two-kernel stem + max-pool (A/B against the fused bf16 kernel)
+    from egotap_amd import lib
+    lib.check(lib.load().egotap_debug_stem_split(1))
 for _ in range(2):
     for n in nets:
         n(l, r)
