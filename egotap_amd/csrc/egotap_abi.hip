@@ -31,6 +31,7 @@
 #include "attention_bf16s2.h"
 #include "conv_bf16s.h"
 #include "stem_bf16s.h"
+#include "conv64_bf16s.h"
 
 // The library is ONE source compiled as four translation units in parallel (egotap_amd/build.py: -DEGOTAP_PART=0 core and
 // inference, 1 lifting-head training operators, 2 heatmap-estimator training operators, 3 bf16-storage operators); every exported function belongs to one
@@ -1073,6 +1074,7 @@ extern "C" int egotap_hm_intermediate(egotap_handle h, int B, const char* name, 
     auto sq = [](int64_t v) { return v * v; };
     if (!strcmp(name, "layer0")) { *offset = w.L0; *numel = N2 * 64 * sq(S0 / 2); }
     else if (!strcmp(name, "pool0")) { *offset = w.P0; *numel = N2 * 64 * sq(S0 / 4); }      // stem + max-pool: fp32 NCHW, or (bf16 mode) bf16 [B * (S0/4)^2, 2 x 64]
+    else if (!strcmp(name, "layer1_bf16")) { *offset = w.S[0][0]; *numel = N2 * 64 * sq(S0 / 4); }      // bf16 mode: bf16 [B * (S0/4)^2, 2 x 64]
     else if (!strcmp(name, "layer1")) { *offset = w.S[0][3]; *numel = N2 * 64 * sq(S0 / 4); }
     else if (!strcmp(name, "layer2")) { *offset = w.S[1][3]; *numel = N2 * 128 * sq(S0 / 8); }
     else if (!strcmp(name, "layer3")) { *offset = w.S[2][3]; *numel = N2 * 256 * sq(S0 / 16); }
@@ -1091,9 +1093,11 @@ extern "C" int egotap_hm_intermediate(egotap_handle h, int B, const char* name, 
 
 // HeatMap_UnrealEgo_Shared.forward(left, right) (model/net_architecture.py:32-36, 45-51, 75-85, 139-173), eval mode.
 #if EGOTAP_IN(0)
-static int g_stem_split = 0;   // egotap_debug_stem_split: 1 = the bf16 estimators run stem and max-pool as two kernels (round 2's form; A/B timing, tests)
-extern "C" int egotap_debug_stem_split(int on) {
-    g_stem_split = on ? 1 : 0;
+static int g_stem_split = 0;   // egotap_debug_stem_split bit 0: the bf16 estimators run stem and max-pool as two kernels (round 2's form; A/B timing, tests)
+static int g_conv64_gemm = 0;  // ... bit 1: layer1's 64 -> 64 convolutions on the implicit-GEMM kernel instead of conv64_bf16s.h
+extern "C" int egotap_debug_stem_split(int mask) {
+    g_stem_split = mask & 1;
+    g_conv64_gemm = (mask >> 1) & 1;
     return EGOTAP_OK;
 }
 #endif
@@ -1191,6 +1195,8 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
             hipLaunchKernelGGL(bn_fold_bf16s_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, bn.g, bn.b, bn.m, bn.v, SC, SH, c, Np);
             const long M = (long)N2 * side * side;
             GemmTimer t(h, s, role, taps == 9 ? "gemm_bf16s_kernel<XConvE,3x3>" : "gemm_bf16s_kernel<XConvE,1x1>", 2.0 * M * c * taps * (double)cin);
+            if (taps == 9 && stride == 1 && cin == 64 && c == 64 && !g_conv64_gemm)      // [r3] layer1: the direct kernel (conv64_bf16s.h)
+                return conv64_direct_bf16s_launch(in, ZP, WP, SC, SH, res, o, ilog2(side), N2, relu, cus, s);
             const XConvE xl{in, ZP, cin, ilog2(side), stride, taps};
             const SEpiBnBf16<false> ep{SC, SH, res, o, c, ilog2(side), relu};
             if (Np == 64 && c == 64) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 1>(xl, WP, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);

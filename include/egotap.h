@@ -124,10 +124,14 @@ int egotap_debug_pu_drop_workgroups(egotap_handle h, int n);
 /* Test / measurement hook (process wide): which generation of the bf16 attention kernels egotap_bf16_attention_fwd / _bwd (and the
  * training step built on them) launch: 2 = DMA-staged kernels (default), 1 = round 2's register-staged kernels. */
 int egotap_debug_attention_gen(int gen);
-/* Test / measurement hook (process wide): 1 = the bf16 estimators (egotap_hm_forward under EGOTAP_PREC_BF16) run the ResNet stem and the
- * max-pool as two kernels (fp32-MFMA stem writing bf16 channels-last, then the pool: round 2's form); 0 (default) = one fused kernel on
- * the bf16 matrix cores (csrc/stem_bf16s.h; reference: net_architecture.py:69-70, torchvision resnet18 conv1 / bn1 / relu / maxpool). */
-int egotap_debug_stem_split(int on);
+/* Test / measurement hook (process wide), a bit mask over the round-3 kernels of the bf16 estimators (egotap_hm_forward under
+ * EGOTAP_PREC_BF16); 0 (default) = all of them on.
+ *   bit 0: the ResNet stem and the max-pool run as two kernels (fp32-MFMA stem writing bf16 channels-last, then the pool: round 2's form)
+ *          instead of one fused kernel on the bf16 matrix cores (csrc/stem_bf16s.h; reference: net_architecture.py:69-70, torchvision
+ *          resnet18 conv1 / bn1 / relu / maxpool);
+ *   bit 1: layer1's four 64 -> 64 3x3 convolutions run on the implicit-GEMM kernel (csrc/conv_bf16s.h, 64-column tile) instead of the
+ *          direct halo-tile kernel (csrc/conv64_bf16s.h). */
+int egotap_debug_stem_split(int mask);
 /* EGOTAP_PREC_BF16 only: caller-owned device scratch (16-byte aligned) into which a GEMM's weight matrix is rounded to bf16 right
  * before the launch (stream ordered; nothing is cached, the live fp32 parameters stay the source of truth).  Halves the W operand's
  * vector-memory bytes, which bound that mode.  bytes >= 2 * the largest N*K (67 MB for fc1 of the position encoder); NULL = off. */

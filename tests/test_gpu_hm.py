@@ -206,3 +206,45 @@ def test_bf16_fused_stem_and_maxpool_kernel(preset, hm, B):
     rel = float((fused - split).norm() / split.norm())
     print(f"fused bf16 stem vs fp32 stem + pool ({preset}): relative L2 of the heatmaps {rel:.2e}")
     assert rel < 1e-2
+
+
+@pytest.mark.parametrize("preset,hm,B", [("UnrealEgo", 64, 3), ("EgoCap", 128, 1)])
+def test_bf16_direct_conv64_kernel_equals_the_implicit_gemm(preset, hm, B):
+    """csrc/conv64_bf16s.h (layer1's four 3x3 convolutions 64 -> 64 with BatchNorm, residual and ReLU: halo tile in LDS, weights in
+    registers) against the implicit-GEMM kernel it replaces (egotap_debug_stem_split bit 1), same bf16 inputs, same fp32 epilogue
+    formula: layer1's output equal up to one bf16 ulp where the order of the 576-term fp32 sum decides a rounding (two blocks deep: a
+    flipped rounding of the first block moves the second block's input), image borders and tile seams included; bit-reproducible."""
+    import ctypes as C
+    from gpu_util import hm_net
+    from egotap_amd import lib
+    L = lib.load()
+    net, _ = hm_net("rot", preset=preset, hm=hm)
+    S = 4 * hm
+    left = torch.from_numpy(synth_input(f"rgbL_c64_{hm}", (B, 3, S, S), -2.0, 2.0)).cuda()
+    right = torch.from_numpy(synth_input(f"rgbR_c64_{hm}", (B, 3, S, S), -2.0, 2.0)).cuda()
+
+    def layer1():
+        off, n = C.c_size_t(), C.c_int64()
+        lib.check(L.egotap_hm_intermediate(net._ensure_handle(), B, b"layer1_bf16", C.byref(off), C.byref(n)))
+        return net._ws[off.value: off.value + 2 * n.value].view(torch.bfloat16).clone()
+    try:
+        net.set_precision("bf16")
+        y_new = net(left, right)
+        l_new = layer1()
+        y_again = net(left, right)
+        assert torch.equal(l_new, layer1()) and torch.equal(y_new, y_again)
+        lib.check(L.egotap_debug_stem_split(2))
+        y_old = net(left, right)
+        l_old = layer1()
+    finally:
+        lib.check(L.egotap_debug_stem_split(0))
+        net.set_precision("f32")
+    a, b = l_new.double().cpu(), l_old.double().cpu()
+    err = (a - b).abs()
+    scale = float(b.abs().max())
+    assert float(err.max()) <= 2.0 ** -6 * scale, (float(err.max()), scale)             # a few ulps of the largest values at worst
+    assert float((err == 0).double().mean()) > 0.97, float((err == 0).double().mean())
+    rel = float((y_new - y_old).norm() / y_old.norm())
+    print(f"direct conv64 vs implicit GEMM ({preset}): layer1 equal on {float((err == 0).double().mean()) * 100:.2f} % of the elements, max |diff| {float(err.max()):.3e} "
+          f"(max |value| {scale:.2f}); heatmaps relative L2 {rel:.2e}")
+    assert rel < 5e-3
