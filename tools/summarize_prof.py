@@ -59,7 +59,8 @@ def main():
     SRC = os.path.join(REPO, "gpurun_out", "prof_hm")
     if os.path.isdir(SRC):
         one(tag + "_estimators_bf16", "python3 tools/hm_bf16_probe.py 256 64 bf16", "both heatmap estimators, 256 stereo frames of 256x256 RGB, EGOTAP_PREC_BF16: "
-            "stem (fp32 MFMA) -> max-pool -> ResNet-18 stages and U-Net decoder as implicit GEMMs on bf16 channels-last tensors (conv_bf16s.h); "
+            "fused stem + max-pool on the bf16 matrix cores (stem_bf16s.h) -> layer1 on the direct halo-tile kernel (conv64_bf16s.h) -> layers 2-4 and the "
+            "U-Net decoder as implicit GEMMs on bf16 channels-last tensors (conv_bf16s.h); "
             "2 warm-up + 3 timed passes x 2 nets", traffic_json=False)
     SRC = os.path.join(REPO, "gpurun_out", "prof_all")
     if os.path.isdir(SRC):
