@@ -1034,8 +1034,64 @@ static hipError_t conv_any(Handle* h, const char* role, int taps, int stride, in
 }
 
 struct HmWs {
-    size_t L0, P0, S[4][4] /* per stage: Ta, Tb, Td, L */, U4, CAT3, X3, CAT2, X2, CAT1, X1, WPACK, total;
+    size_t L0, P0, S[4][4] /* per stage: Ta, Tb, Td, L */, U4, CAT3, X3, CAT2, X2, CAT1, X1, WPACK, WALL, total;
 };
+// [r3] every convolution's packed bf16 weights (+ padded bias) and every BatchNorm's folded scale / shift of one estimator, in the order
+// the bf16 forward uses them; p == nullptr: sizes only.  Returns the bytes of the region; fills T (segment table of pack_all_bf16s_kernel).
+static size_t hm_pack_plan(const HmParams* p, PackTable* T) {
+    size_t o = 0;
+    int nw = 0, nb = 0, blk = 0;
+    auto al = [&](size_t n) { size_t r = o; o = (o + n + 255) & ~(size_t)255; return r; };
+    auto wseg = [&](const float* w, const float* b, int Cout, int Cin, int Cp, int Np, int taps) {
+        PackSeg sg{};
+        sg.w = w; sg.b = b; sg.Cout = Cout; sg.Cin = Cin; sg.Cp = Cp; sg.Np = Np; sg.taps = taps;
+        sg.dst_w = al((size_t)Np * taps * Cp * 2);
+        sg.dst_b = al((size_t)Np * 4);
+        sg.first_block = blk;
+        const long items = taps == 9 ? (long)Np * 9 * (Cp / 8) : (long)Np * (Cin / 8);
+        blk += (int)((items + 255) / 256);
+        if (T && nw < PackTable::MAXW) T->w[nw] = sg;
+        ++nw;
+    };
+    struct Pending { HmParams::Bn bn; int C, Np; } pend[PackTable::MAXB];
+    auto bseg = [&](const HmParams::Bn& bn, int C, int Np) { if (nb < PackTable::MAXB) pend[nb] = Pending{bn, C, Np}; ++nb; };
+    static const HmParams::Bn nobn{nullptr, nullptr, nullptr, nullptr};
+    auto npad = [](int c) { return c <= 64 ? 64 : c <= 128 ? 128 : (c + 255) / 256 * 256; };
+    int cin = 64;
+    for (int i = 0; i < 4; ++i) {
+        const int c = HM_CH[i];
+        for (int bk = 0; bk < 2; ++bk) {
+            const int bc = bk == 0 ? cin : c;
+            const bool down = p ? p->blk[i][bk].wd != nullptr : (bk == 0 && i > 0);
+            wseg(p ? p->blk[i][bk].w1 : nullptr, nullptr, c, bc, bc, npad(c), 9); bseg(p ? p->blk[i][bk].bn1 : nobn, c, npad(c));
+            if (down) { wseg(p ? p->blk[i][bk].wd : nullptr, nullptr, c, bc, bc, npad(c), 1); bseg(p ? p->blk[i][bk].bnd : nobn, c, npad(c)); }
+            wseg(p ? p->blk[i][bk].w2 : nullptr, nullptr, c, c, c, npad(c), 9); bseg(p ? p->blk[i][bk].bn2 : nobn, c, npad(c));
+        }
+        cin = c;
+    }
+    auto cv = [&](int which, int k) -> HmParams::Cv { return p ? (which == 0 ? p->l1x1[k] : which == 1 ? p->up[k] : p->head) : HmParams::Cv{nullptr, nullptr}; };
+    wseg(cv(0, 3).w, cv(0, 3).b, 1024, 1024, 1024, 1024, 1);
+    wseg(cv(0, 2).w, cv(0, 2).b, 516, 512, 512, 768, 1);
+    wseg(cv(1, 2).w, nullptr, 1024, 1540, 1568, 1024, 9);
+    wseg(cv(0, 1).w, cv(0, 1).b, 256, 256, 256, 256, 1);
+    wseg(cv(1, 1).w, nullptr, 512, 1280, 1280, 512, 9);
+    wseg(cv(0, 0).w, cv(0, 0).b, 128, 128, 128, 256, 1);
+    wseg(cv(1, 0).w, nullptr, 512, 640, 640, 512, 9);
+    wseg(cv(2, 0).w, cv(2, 0).b, p ? p->n_out : 30, 512, 512, 256, 1);
+    const int blocks_w = blk;
+    for (int k = 0; k < nb && k < PackTable::MAXB; ++k) {
+        BnSeg bs{};
+        bs.g = pend[k].bn.g; bs.b = pend[k].bn.b; bs.m = pend[k].bn.m; bs.v = pend[k].bn.v;
+        bs.C = pend[k].C; bs.Np = pend[k].Np;
+        bs.dst_sc = al((size_t)bs.Np * 4);
+        bs.dst_sh = al((size_t)bs.Np * 4);
+        bs.first_block = blk;
+        blk += (bs.Np + 255) / 256;
+        if (T) T->bn[k] = bs;
+    }
+    if (T) { T->nw = nw; T->nb = nb; T->blocks_w = blocks_w; T->blocks = blk; }
+    return (nw <= PackTable::MAXW && nb <= PackTable::MAXB) ? o : 0;
+}
 static HmWs hm_ws(const Handle* h, int B) {
     HmWs w;
     const size_t N2 = 2 * (size_t)B, S0 = (size_t)h->cfg.hm_size * 4;   // RGB side
@@ -1053,6 +1109,7 @@ static HmWs hm_ws(const Handle* h, int B) {
     w.CAT2 = take((size_t)B * 1280 * s32 * s32); w.X2 = take((size_t)B * 512 * s32 * s32);
     w.CAT1 = take((size_t)B * 640 * s64 * s64);  w.X1 = take((size_t)B * 512 * s64 * s64);
     w.WPACK = take(conv_bf16_pack_bytes(1024, 1540) / 4);      // largest conv (conv_up3) repacked for the bf16 kernels
+    w.WALL = take(hm_pack_plan(nullptr, nullptr) / 4 + 64);    // [r3] bf16 mode: every layer's packed weights at once (one pack launch per forward)
     w.total = o;
     return w;
 }
@@ -1141,13 +1198,19 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
         auto Hb = [&](size_t off) { return (__bf16*)(base + off); };
         __bf16 *A1 = Hb(w.S[0][0]), *A2 = Hb(w.S[1][0]), *A3 = Hb(w.S[2][0]), *A4 = Hb(w.S[3][0]);
         __bf16 *T4 = Hb(w.U4), *C3 = Hb(w.CAT3), *Y3 = Hb(w.X3), *C2 = Hb(w.CAT2), *Y2 = Hb(w.X2), *C1 = Hb(w.CAT1), *Y1 = Hb(w.X1);
-        __bf16* WP = Hb(w.WPACK);                                                   // packed weights of the running layer (<= 29 MB)
-        float* BP = (float*)(base + w.WPACK + ((size_t)40 << 20));                  // its bias, padded to the GEMM's N
         __bf16* ZP = (__bf16*)(base + w.WPACK + ((size_t)40 << 20) + 32768);        // 256 bytes of zeros (taps outside the image)
         const int cus = device_cu_count();
         const long p8 = (long)s8 * s8, p16 = (long)s16 * s16, p32 = (long)s32 * s32, p64 = (long)s64 * s64;
         auto ilog2 = [](long v) { int l = 0; while ((1L << l) < v) ++l; return l; };
         EGO_HIP(zero_fill(ZP, 256, s));
+        // [r3] all 27 weight repacks and 19 BatchNorm folds of this forward in ONE launch (conv_bf16s.h, pack_all_bf16s_kernel): the
+        // parameters stay the caller's live fp32 tensors, nothing is kept between calls
+        PackTable PT;
+        EGO_CHECK(hm_pack_plan(&p, &PT) != 0, "egotap_hm_forward: the estimator has more layers than the pack table holds");
+        char* reg = base + w.WALL;
+        hipLaunchKernelGGL(pack_all_bf16s_kernel, dim3(PT.blocks), dim3(256), 0, s, PT, reg);
+        EGO_HIP(hipGetLastError());
+        int li = 0, bi = 0;
         auto up2 = [&](const __bf16* in, __bf16* o, int C, int hin, long ld) {
             const long total = (long)B * 4 * hin * hin * (C / 8);
             hipLaunchKernelGGL(upsample2x_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, o, C, hin, ld, total);
@@ -1156,19 +1219,21 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
         // 1x1 convrelu: rows = pixels; the output goes to columns [0, Cout) of o (row stride ld)
         auto conv1 = [&](const char* role, const __bf16* in, long M, const HmParams::Cv& cv, int Cin, int Cout, __bf16* o, long ld) {
             const int Np = (Cout + 255) / 256 * 256;
-            const long items = (long)Np * (Cin / 8);
-            hipLaunchKernelGGL(pack_conv1x1_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, cv.w, cv.b, WP, BP, Cout, Cin, Np);
+            const PackSeg& sg = PT.w[li++];
+            if (sg.w != cv.w || sg.Np != Np || sg.Cin != Cin) return hipErrorInvalidValue;      // the plan and the forward walk the layers in one order
+            const __bf16* WPl = (const __bf16*)(reg + sg.dst_w);
+            const float* BPl = (const float*)(reg + sg.dst_b);
             GemmTimer t(h, s, role, "gemm_bf16s_kernel<XPlain,conv1x1>", 2.0 * M * Cout * Cin);
-            if (Np == Cout) return gemm_bf16s_launch(XPlain{in, Cin}, WP, (long)Cin, SEpiConvBf16<false>{BP, o, ld, Np, 1}, (int)M, Np, Cin, cus, s);
-            return gemm_bf16s_launch(XPlain{in, Cin}, WP, (long)Cin, SEpiConvBf16<true>{BP, o, ld, (Cout + 7) / 8 * 8, 1}, (int)M, Np, Cin, cus, s);
+            if (Np == Cout) return gemm_bf16s_launch(XPlain{in, Cin}, WPl, (long)Cin, SEpiConvBf16<false>{BPl, o, ld, Np, 1}, (int)M, Np, Cin, cus, s);
+            return gemm_bf16s_launch(XPlain{in, Cin}, WPl, (long)Cin, SEpiConvBf16<true>{BPl, o, ld, (Cout + 7) / 8 * 8, 1}, (int)M, Np, Cin, cus, s);
         };
         // 3x3 convrelu on a concat buffer of Cp channels per pixel (Cp a multiple of 32; channels past Cin are zero)
         auto conv3 = [&](const char* role, const __bf16* in, long M, int side, const HmParams::Cv& cv, int Cin, int Cp, int Cout, __bf16* o) {
-            const long items = (long)Cout * 9 * (Cp / 8);
-            hipLaunchKernelGGL(pack_conv3x3_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, cv.w, WP, Cout, Cin, Cp, Cout);
+            const PackSeg& sg = PT.w[li++];
+            if (sg.w != cv.w || sg.Cp != Cp || sg.Np != Cout) return hipErrorInvalidValue;
             GemmTimer t(h, s, role, "gemm_bf16s_kernel<XConv3>", 2.0 * M * Cout * 9.0 * Cin);
             const XConv3 xl{in, ZP, Cp, ilog2(side)};
-            return gemm_bf16s_launch(xl, WP, 9L * Cp, SEpiConvBf16<false>{cv.b, o, (long)Cout, Cout, 1}, (int)M, Cout, 9 * Cp, cus, s);
+            return gemm_bf16s_launch(xl, (const __bf16*)(reg + sg.dst_w), 9L * Cp, SEpiConvBf16<false>{cv.b, o, (long)Cout, Cout, 1}, (int)M, Cout, 9 * Cp, cus, s);
         };
         // E2: max-pool of the stem's bf16 [B * (2 s64)^2, 2 x 64] -> [B * s64^2, 2 x 64]; E3: the four stages on the same GEMM kernel (eye-interleaved rows, see conv_bf16s.h)
         __bf16* P0 = Hb(w.P0);
@@ -1179,30 +1244,25 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
             hipLaunchKernelGGL(maxpool3s2_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const __bf16*)F(w.L0), P0, 128, S0 / 2, total);
             EGO_HIP(hipGetLastError());
         }
-        float *SC = BP + 1024, *SH = BP + 2048;                                    // folded BatchNorm scale / shift of the running conv
         auto bconv = [&](const char* role, const __bf16* in, int cin, int c, int taps, int stride, int side, const float* wgt,
                          const HmParams::Bn& bn, const __bf16* res, int relu, __bf16* o) {
             // [r3] Cout = 64 / 128 run on the 64- / 128-column tile (256 x 64 NI, gemm_bf16s.h) instead of N = 256 with a column guard
             const int Np = c <= 64 ? 64 : c <= 128 ? 128 : (c + 255) / 256 * 256;
-            if (taps == 9) {
-                const long items = (long)Np * 9 * (cin / 8);
-                hipLaunchKernelGGL(pack_conv3x3_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, wgt, WP, c, cin, cin, Np);
-            } else {
-                const long items = (long)Np * (cin / 8);
-                hipLaunchKernelGGL(pack_conv1x1_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, wgt, (const float*)nullptr, WP,
-                                   (float*)nullptr, c, cin, Np);
-            }
-            hipLaunchKernelGGL(bn_fold_bf16s_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, bn.g, bn.b, bn.m, bn.v, SC, SH, c, Np);
+            const PackSeg& sg = PT.w[li++];
+            const BnSeg& bs = PT.bn[bi++];
+            if (sg.w != wgt || sg.Np != Np || sg.taps != taps || bs.g != bn.g) return hipErrorInvalidValue;
+            const __bf16* WPl = (const __bf16*)(reg + sg.dst_w);
+            const float *SC = (const float*)(reg + bs.dst_sc), *SH = (const float*)(reg + bs.dst_sh);
             const long M = (long)N2 * side * side;
             GemmTimer t(h, s, role, taps == 9 ? "gemm_bf16s_kernel<XConvE,3x3>" : "gemm_bf16s_kernel<XConvE,1x1>", 2.0 * M * c * taps * (double)cin);
             if (taps == 9 && stride == 1 && cin == 64 && c == 64 && !g_conv64_gemm)      // [r3] layer1: the direct kernel (conv64_bf16s.h)
-                return conv64_direct_bf16s_launch(in, ZP, WP, SC, SH, res, o, ilog2(side), N2, relu, cus, s);
+                return conv64_direct_bf16s_launch(in, ZP, WPl, SC, SH, res, o, ilog2(side), N2, relu, cus, s);
             const XConvE xl{in, ZP, cin, ilog2(side), stride, taps};
             const SEpiBnBf16<false> ep{SC, SH, res, o, c, ilog2(side), relu};
-            if (Np == 64 && c == 64) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 1>(xl, WP, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
-            if (Np == 128 && c == 128) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 2>(xl, WP, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
-            if (Np == c) return gemm_bf16s_launch(xl, WP, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
-            return gemm_bf16s_launch(xl, WP, (long)taps * cin, SEpiBnBf16<true>{SC, SH, res, o, c, ilog2(side), relu}, (int)M, Np, taps * cin, cus, s);
+            if (Np == 64 && c == 64) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 1>(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
+            if (Np == 128 && c == 128) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 2>(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
+            if (Np == c) return gemm_bf16s_launch(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
+            return gemm_bf16s_launch(xl, WPl, (long)taps * cin, SEpiBnBf16<true>{SC, SH, res, o, c, ilog2(side), relu}, (int)M, Np, taps * cin, cus, s);
         };
         {
             static const char* r1[4][2] = {{"hm.l1.0.conv1", "hm.l1.1.conv1"}, {"hm.l2.0.conv1", "hm.l2.1.conv1"}, {"hm.l3.0.conv1", "hm.l3.1.conv1"}, {"hm.l4.0.conv1", "hm.l4.1.conv1"}};
@@ -1243,10 +1303,11 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
         EGO_HIP(conv1("hm.layer1_1x1", A1, B * p64, p.l1x1[0], 128, 128, C1 + 512, 640));
         EGO_HIP(conv3("hm.conv_up1", C1, B * p64, s64, p.up[0], 640, 640, 512, Y1));
         {   // conv_heatmap: fp32 NCHW into the caller's channel slice
-            const long items = (long)256 * (512 / 8);
-            hipLaunchKernelGGL(pack_conv1x1_bf16s_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p.head.w, p.head.b, WP, BP, p.n_out, 512, 256);
+            const PackSeg& sg = PT.w[li++];
+            EGO_CHECK(sg.w == p.head.w && li == PT.nw && bi == PT.nb, "egotap_hm_forward: pack plan out of step with the forward");
             GemmTimer t(h, s, "hm.conv_heatmap", "gemm_bf16s_kernel<XPlain,heatmap>", 2.0 * B * p64 * p.n_out * 512);
-            EGO_HIP(gemm_bf16s_launch(XPlain{Y1, 512}, WP, 512L, SEpiHeatNCHW{BP, out, (long)out_image_stride, p.n_out, ilog2(p64)}, (int)(B * p64), 256, 512, cus, s));
+            EGO_HIP(gemm_bf16s_launch(XPlain{Y1, 512}, (const __bf16*)(reg + sg.dst_w), 512L,
+                                      SEpiHeatNCHW{(const float*)(reg + sg.dst_b), out, (long)out_image_stride, p.n_out, ilog2(p64)}, (int)(B * p64), 256, 512, cus, s));
         }
         return EGOTAP_OK;
     }
