@@ -318,8 +318,8 @@ def bench_full(args, p, dev, rank, world, barrier, lib, L, mode="f32"):
                            "achieved_algorithmic": round(conv_tf, 2), "achieved": round(3 * conv_tf, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(3 * conv_tf / PEAK_BF16_MFMA_TFLOPS, 4),
                            "conv_share_of_step_time": round(tot_ms * 1e-3 / elapsed, 4)} if mode == "bf16x3" else
-                          {"bound": "mfma", "kernel": "conv kernels (decoder: gemm_bf16s_kernel implicit GEMMs on bf16 channels-last tensors; "
-                                                      "backbone: conv_bf16_kernel / conv_f32_kernel on fp32 NCHW tensors), algorithmic FLOPs",
+                          {"bound": "mfma", "kernel": "conv kernels on bf16 channels-last tensors (layers 2-4 and decoder: gemm_bf16s_kernel implicit GEMMs; "
+                                                      "layer1: conv64_direct_bf16s_kernel; the fused stem + max-pool kernel is not in this sum), algorithmic FLOPs",
                            "achieved": round(conv_tf, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(conv_tf / PEAK_BF16_MFMA_TFLOPS, 4), "conv_share_of_step_time": round(tot_ms * 1e-3 / elapsed, 4)}),
         "by_role": {k: {"kernel": v["kernel"], "avg_ms": round(v["ms"] / v["launches"], 4),

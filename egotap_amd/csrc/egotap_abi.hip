@@ -1254,8 +1254,10 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
             const __bf16* WPl = (const __bf16*)(reg + sg.dst_w);
             const float *SC = (const float*)(reg + bs.dst_sc), *SH = (const float*)(reg + bs.dst_sh);
             const long M = (long)N2 * side * side;
-            GemmTimer t(h, s, role, taps == 9 ? "gemm_bf16s_kernel<XConvE,3x3>" : "gemm_bf16s_kernel<XConvE,1x1>", 2.0 * M * c * taps * (double)cin);
-            if (taps == 9 && stride == 1 && cin == 64 && c == 64 && !g_conv64_gemm)      // [r3] layer1: the direct kernel (conv64_bf16s.h)
+            const bool direct = taps == 9 && stride == 1 && cin == 64 && c == 64 && !g_conv64_gemm;      // [r3] layer1: the direct kernel (conv64_bf16s.h)
+            GemmTimer t(h, s, role, direct ? "conv64_direct_bf16s_kernel" : taps == 9 ? "gemm_bf16s_kernel<XConvE,3x3>" : "gemm_bf16s_kernel<XConvE,1x1>",
+                        2.0 * M * c * taps * (double)cin);
+            if (direct)
                 return conv64_direct_bf16s_launch(in, ZP, WPl, SC, SH, res, o, ilog2(side), N2, relu, cus, s);
             const XConvE xl{in, ZP, cin, ilog2(side), stride, taps};
             const SEpiBnBf16<false> ep{SC, SH, res, o, c, ilog2(side), relu};
