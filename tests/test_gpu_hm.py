@@ -208,20 +208,27 @@ def test_bf16_fused_stem_and_maxpool_kernel(preset, hm, B):
     assert rel < 1e-2
 
 
-@pytest.mark.parametrize("preset,hm,B", [("UnrealEgo", 64, 3), ("EgoCap", 128, 1)])
+@pytest.mark.parametrize("preset,hm,B", [("UnrealEgo", 64, 3), ("EgoCap", 128, 1), ("UnrealEgo", 64, 40)])
 def test_bf16_direct_conv64_kernel_equals_the_implicit_gemm(preset, hm, B):
     """csrc/conv64_bf16s.h (layer1's four 3x3 convolutions 64 -> 64 with BatchNorm, residual and ReLU: halo tile in LDS, weights in
     registers) against the implicit-GEMM kernel it replaces (egotap_debug_stem_split bit 1), same bf16 inputs, same fp32 epilogue
     formula: layer1's output equal up to one bf16 ulp where the order of the 576-term fp32 sum decides a rounding (two blocks deep: a
-    flipped rounding of the first block moves the second block's input), image borders and tile seams included; bit-reproducible."""
+    flipped rounding of the first block moves the second block's input), image borders and tile seams included; bit-reproducible.
+    B = 40: 1280 tiles on 256 persistent workgroups (five tiles each: the halo double buffer, the counted wait that leaves the previous
+    tile's stores in flight) and, in the stem in front, 640 row-group runs on 512 workgroups."""
     import ctypes as C
     from gpu_util import hm_net
     from egotap_amd import lib
     L = lib.load()
     net, _ = hm_net("rot", preset=preset, hm=hm)
     S = 4 * hm
-    left = torch.from_numpy(synth_input(f"rgbL_c64_{hm}", (B, 3, S, S), -2.0, 2.0)).cuda()
-    right = torch.from_numpy(synth_input(f"rgbR_c64_{hm}", (B, 3, S, S), -2.0, 2.0)).cuda()
+    nb = min(B, 8)          # distinct frames (the hash generator is slow): larger batches cycle through them with a per-frame scale
+    left = torch.from_numpy(synth_input(f"rgbL_c64_{hm}", (nb, 3, S, S), -2.0, 2.0)).cuda()
+    right = torch.from_numpy(synth_input(f"rgbR_c64_{hm}", (nb, 3, S, S), -2.0, 2.0)).cuda()
+    if B > nb:
+        idx = torch.arange(B, device="cuda") % nb
+        gain = (1.0 + 0.01 * torch.arange(B, device="cuda", dtype=torch.float32)).view(B, 1, 1, 1)
+        left, right = (left[idx] * gain).contiguous(), (right[idx] * gain).contiguous()
 
     def layer1():
         off, n = C.c_size_t(), C.c_int64()
@@ -248,3 +255,53 @@ def test_bf16_direct_conv64_kernel_equals_the_implicit_gemm(preset, hm, B):
     print(f"direct conv64 vs implicit GEMM ({preset}): layer1 equal on {float((err == 0).double().mean()) * 100:.2f} % of the elements, max |diff| {float(err.max()):.3e} "
           f"(max |value| {scale:.2f}); heatmaps relative L2 {rel:.2e}")
     assert rel < 5e-3
+
+
+def test_bf16_fused_stem_many_runs_per_workgroup():
+    """the fused stem at 40 stereo frames: 640 (image, row group) runs on 512 persistent workgroups, so some workgroups walk two runs
+    (patch restaging, carry buffers and the pooling ring reused across runs).  Every image against the two-kernel form (fp32 stem,
+    separate pool: bf16-sized differences only), three images (first, one in the second round of runs, last) against float64 on
+    the same bf16 operands."""
+    import ctypes as C
+    from gpu_util import hm_net
+    from egotap_amd import lib
+    L = lib.load()
+    net, sd_np = hm_net("pos")
+    B, hm, S = 40, 64, 256
+    base_l = torch.from_numpy(synth_input("rgbL_stem_many", (4, 3, S, S), -2.0, 2.0)).cuda()
+    base_r = torch.from_numpy(synth_input("rgbR_stem_many", (4, 3, S, S), -2.0, 2.0)).cuda()
+    idx = torch.arange(B, device="cuda") % 4
+    gain = (1.0 + 0.02 * torch.arange(B, device="cuda", dtype=torch.float32)).view(B, 1, 1, 1)
+    left, right = (base_l[idx] * gain).contiguous(), (base_r[idx] * gain).contiguous()
+
+    def pool0():
+        off, n = C.c_size_t(), C.c_int64()
+        lib.check(L.egotap_hm_intermediate(net._ensure_handle(), B, b"pool0", C.byref(off), C.byref(n)))
+        return net._ws[off.value: off.value + 2 * n.value].view(torch.bfloat16).reshape(B, hm, hm, 2, 64).double().cpu()
+    try:
+        net.set_precision("bf16")
+        net(left, right)
+        fused = pool0()
+        lib.check(L.egotap_debug_stem_split(1))
+        net(left, right)
+        split = pool0()
+    finally:
+        lib.check(L.egotap_debug_stem_split(0))
+        net.set_precision("f32")
+    for b in range(B):
+        rel = float((fused[b] - split[b]).norm() / split[b].norm())
+        assert rel < 1.5e-2, (b, rel)
+    rb = lambda t: t.float().bfloat16().double()
+    w = rb(torch.from_numpy(sd_np["backbone.backbone.backbone.conv1.weight"]))
+    bn = {k: torch.from_numpy(sd_np["backbone.backbone.backbone.bn1." + k]) for k in ("weight", "bias", "running_mean", "running_var")}
+    sc = (bn["weight"] / torch.sqrt(bn["running_var"] + 1e-5))
+    sh = (bn["bias"] - bn["running_mean"] * sc).double()
+    sc = sc.double()
+    for b in (0, 33, B - 1):
+        for eye, img in enumerate((left, right)):
+            z = torch.nn.functional.conv2d(rb(img[b:b + 1].cpu()), w, stride=2, padding=3)
+            y = rb(torch.relu(z * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))
+            want = torch.nn.functional.max_pool2d(y, 3, 2, 1).permute(0, 2, 3, 1)[0]
+            err = (fused[b, :, :, eye] - want).abs()
+            tol = 2.0 ** -7 * want.abs() + 4e-6 * float(z.abs().max() * sc.abs().max())
+            assert not bool((err > tol).any()), (b, eye, float(err.max()))
