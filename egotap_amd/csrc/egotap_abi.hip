@@ -1150,9 +1150,9 @@ extern "C" int egotap_hm_intermediate(egotap_handle h, int B, const char* name, 
 
 // HeatMap_UnrealEgo_Shared.forward(left, right) (model/net_architecture.py:32-36, 45-51, 75-85, 139-173), eval mode.
 #if EGOTAP_IN(0)
-static int g_stem_split = 0;   // egotap_debug_stem_split bit 0: the bf16 estimators run stem and max-pool as two kernels (round 2's form; A/B timing, tests)
+static int g_stem_split = 0;   // egotap_debug_hm_r2_kernels bit 0: the bf16 estimators run stem and max-pool as two kernels (round 2's form; A/B timing, tests)
 static int g_conv64_gemm = 0;  // ... bit 1: layer1's 64 -> 64 convolutions on the implicit-GEMM kernel instead of conv64_bf16s.h
-extern "C" int egotap_debug_stem_split(int mask) {
+extern "C" int egotap_debug_hm_r2_kernels(int mask) {
     g_stem_split = mask & 1;
     g_conv64_gemm = (mask >> 1) & 1;
     return EGOTAP_OK;
@@ -1186,7 +1186,7 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
     // E1: stem conv7x7/2 + BN + ReLU on image n = 2b + eye (the L/R channel concat of every pyramid level is then a view); in the
     // bf16 mode it writes bf16 channels-last itself (half the bytes, and the layout the max-pool and the stages read)
     // [r3] ... bf16 mode: stem, BatchNorm, ReLU AND the max-pool in one kernel on the bf16 matrix cores (stem_bf16s.h): the 128 x 128 x 64
-    // map never reaches HBM.  h->stem_split (egotap_debug_stem_split, tests / A-B timing) keeps the two-kernel form: fp32-MFMA stem
+    // map never reaches HBM.  g_stem_split (egotap_debug_hm_r2_kernels bit 0, tests / A-B timing) keeps the two-kernel form: fp32-MFMA stem
     // writing bf16 channels-last, then the channels-last max-pool.
     const bool fused_stem = h->precision == EGOTAP_PREC_BF16 && !g_stem_split;
     if (!fused_stem)

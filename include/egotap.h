@@ -131,7 +131,7 @@ int egotap_debug_attention_gen(int gen);
  *          resnet18 conv1 / bn1 / relu / maxpool);
  *   bit 1: layer1's four 64 -> 64 3x3 convolutions run on the implicit-GEMM kernel (csrc/conv_bf16s.h, 64-column tile) instead of the
  *          direct halo-tile kernel (csrc/conv64_bf16s.h). */
-int egotap_debug_stem_split(int mask);
+int egotap_debug_hm_r2_kernels(int mask);
 /* EGOTAP_PREC_BF16 only: caller-owned device scratch (16-byte aligned) into which a GEMM's weight matrix is rounded to bf16 right
  * before the launch (stream ordered; nothing is cached, the live fp32 parameters stay the source of truth).  Halves the W operand's
  * vector-memory bytes, which bound that mode.  bytes >= 2 * the largest N*K (67 MB for fc1 of the position encoder); NULL = off. */

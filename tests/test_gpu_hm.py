@@ -166,7 +166,7 @@ def test_bf16_fused_stem_and_maxpool_kernel(preset, hm, B):
     read back from the workspace (bf16 [B * hm * hm, 2 x 64], eye-interleaved) against float64 arithmetic on the SAME bf16-rounded
     inputs and weights, rounded to bf16 once at the same place: equal up to one bf16 ulp where the fp32 accumulation order decides a
     rounding; image borders (max-pool padding, zero halo), both eyes, the segment seams and, at 512 x 512, four segments per row.
-    Then the two-kernel form (egotap_debug_stem_split: fp32 stem, separate pool) must give the same heatmaps to bf16 accuracy."""
+    Then the two-kernel form (egotap_debug_hm_r2_kernels: fp32 stem, separate pool) must give the same heatmaps to bf16 accuracy."""
     import ctypes as C
     from gpu_util import hm_net
     from egotap_amd import lib
@@ -181,10 +181,10 @@ def test_bf16_fused_stem_and_maxpool_kernel(preset, hm, B):
         off, n = C.c_size_t(), C.c_int64()
         lib.check(L.egotap_hm_intermediate(net._ensure_handle(), B, b"pool0", C.byref(off), C.byref(n)))
         got = net._ws[off.value: off.value + 2 * n.value].view(torch.bfloat16).reshape(B, hm, hm, 2, 64).double().cpu()
-        lib.check(L.egotap_debug_stem_split(1))
+        lib.check(L.egotap_debug_hm_r2_kernels(1))
         split = net(left.cuda(), right.cuda())
     finally:
-        lib.check(L.egotap_debug_stem_split(0))
+        lib.check(L.egotap_debug_hm_r2_kernels(0))
         net.set_precision("f32")
     rb = lambda t: t.float().bfloat16().double()
     w = rb(torch.from_numpy(sd_np["backbone.backbone.backbone.conv1.weight"]))
@@ -211,7 +211,7 @@ def test_bf16_fused_stem_and_maxpool_kernel(preset, hm, B):
 @pytest.mark.parametrize("preset,hm,B", [("UnrealEgo", 64, 3), ("EgoCap", 128, 1), ("UnrealEgo", 64, 40)])
 def test_bf16_direct_conv64_kernel_equals_the_implicit_gemm(preset, hm, B):
     """csrc/conv64_bf16s.h (layer1's four 3x3 convolutions 64 -> 64 with BatchNorm, residual and ReLU: halo tile in LDS, weights in
-    registers) against the implicit-GEMM kernel it replaces (egotap_debug_stem_split bit 1), same bf16 inputs, same fp32 epilogue
+    registers) against the implicit-GEMM kernel it replaces (egotap_debug_hm_r2_kernels bit 1), same bf16 inputs, same fp32 epilogue
     formula: layer1's output equal up to one bf16 ulp where the order of the 576-term fp32 sum decides a rounding (two blocks deep: a
     flipped rounding of the first block moves the second block's input), image borders and tile seams included; bit-reproducible.
     B = 40: 1280 tiles on 256 persistent workgroups (five tiles each: the halo double buffer, the counted wait that leaves the previous
@@ -240,11 +240,11 @@ def test_bf16_direct_conv64_kernel_equals_the_implicit_gemm(preset, hm, B):
         l_new = layer1()
         y_again = net(left, right)
         assert torch.equal(l_new, layer1()) and torch.equal(y_new, y_again)
-        lib.check(L.egotap_debug_stem_split(2))
+        lib.check(L.egotap_debug_hm_r2_kernels(2))
         y_old = net(left, right)
         l_old = layer1()
     finally:
-        lib.check(L.egotap_debug_stem_split(0))
+        lib.check(L.egotap_debug_hm_r2_kernels(0))
         net.set_precision("f32")
     a, b = l_new.double().cpu(), l_old.double().cpu()
     err = (a - b).abs()
@@ -282,11 +282,11 @@ def test_bf16_fused_stem_many_runs_per_workgroup():
         net.set_precision("bf16")
         net(left, right)
         fused = pool0()
-        lib.check(L.egotap_debug_stem_split(1))
+        lib.check(L.egotap_debug_hm_r2_kernels(1))
         net(left, right)
         split = pool0()
     finally:
-        lib.check(L.egotap_debug_stem_split(0))
+        lib.check(L.egotap_debug_hm_r2_kernels(0))
         net.set_precision("f32")
     for b in range(B):
         rel = float((fused[b] - split[b]).norm() / split[b].norm())
