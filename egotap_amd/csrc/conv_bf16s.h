@@ -282,16 +282,18 @@ static __global__ __launch_bounds__(256) void maxpool3s2_nhwc_bf16s_kernel(const
 // every layer's packed copy.  The segment table travels as a kernel argument (2.6 KB): no device-side table to allocate or upload.
 struct PackSeg {
     const float *w, *b;              // [Cout][Cin][taps] weights, bias (1x1 with bias) or null
-    unsigned long dst_w, dst_b;      // byte offsets into the region: packed bf16 weights, padded fp32 bias
-    int Cout, Cin, Cp, Np, taps, first_block;
+    unsigned dst_w, dst_b;           // byte offsets into the region: packed bf16 weights, padded fp32 bias
+    unsigned short Cout, Cin, Cp, Np;
+    int taps, first_block;
 };
 struct BnSeg {
     const float *g, *b, *m, *v;
-    unsigned long dst_sc, dst_sh;
-    int C, Np, first_block, pad_;
+    unsigned dst_sc, dst_sh;
+    unsigned short C, Np;
+    int first_block;
 };
 struct PackTable {
-    static constexpr int MAXW = 28, MAXB = 20;
+    static constexpr int MAXW = 44, MAXB = 36;        // resnet34: 32 + 3 + 8 convolutions, 35 BatchNorms
     PackSeg w[MAXW];
     BnSeg bn[MAXB];
     int nw, nb, blocks_w, blocks;

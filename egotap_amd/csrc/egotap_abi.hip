@@ -119,7 +119,8 @@ struct LiftParams {   // resolved raw pointers of net_AutoEncoder
 struct HmParams {   // resolved raw pointers of one heatmap estimator (net_HeatMap / net_RotHeatMap)
     struct Bn { const float *g, *b, *m, *v; };
     const float* stem_w; Bn stem_bn;
-    struct Block { const float *w1, *w2, *wd; Bn bn1, bn2, bnd; } blk[4][2];
+    struct Block { const float *w1, *w2, *wd; Bn bn1, bn2, bnd; } blk[4][6];
+    int nblk[4];        // BasicBlocks per stage (resnet18: 2,2,2,2; resnet34: 3,4,6,3)
     struct Cv { const float *w, *b; } l1x1[4], up[3], head;   // layerK_1x1 (K=1..4), conv_up1..3, conv_heatmap
     int n_out;   // output channels of conv_heatmap (2 * heatmaps per eye)
 };
@@ -206,6 +207,12 @@ static void lift_expect(Handle* h) {
 }
 
 static const int HM_CH[4] = {64, 128, 256, 512};
+// timing-hook role names of the backbone convolutions (static strings: the hook keeps the pointers)
+#define HM_ROLE_ROW(L, S) {"hm.l" #L ".0." S, "hm.l" #L ".1." S, "hm.l" #L ".2." S, "hm.l" #L ".3." S, "hm.l" #L ".4." S, "hm.l" #L ".5." S}
+static const char* const HM_R1[4][6] = {HM_ROLE_ROW(1, "conv1"), HM_ROLE_ROW(2, "conv1"), HM_ROLE_ROW(3, "conv1"), HM_ROLE_ROW(4, "conv1")};
+static const char* const HM_R2[4][6] = {HM_ROLE_ROW(1, "conv2"), HM_ROLE_ROW(2, "conv2"), HM_ROLE_ROW(3, "conv2"), HM_ROLE_ROW(4, "conv2")};
+static const char* const HM_RD[4] = {"", "hm.l2.down", "hm.l3.down", "hm.l4.down"};
+static inline int hm_nblk(const Handle* h, int i) { return h->cfg.hm_blocks[i] > 0 ? h->cfg.hm_blocks[i] : 2; }
 
 static void hm_expect(Handle* h, int net, int n_out) {
     auto& e = h->expect[net];
@@ -218,7 +225,7 @@ static void hm_expect(Handle* h, int net, int n_out) {
     int cin = 64;
     for (int i = 0; i < 4; ++i) {
         const int c = HM_CH[i];
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < hm_nblk(h, i); ++b) {
             const std::string p = bb + "layer" + std::to_string(i + 1) + "." + std::to_string(b);
             const int bc = b == 0 ? cin : c;
             e[p + ".conv1.weight"] = (int64_t)c * bc * 9; bn(p + ".bn1", c);
@@ -245,6 +252,7 @@ extern "C" int egotap_create(const egotap_config* cfg, egotap_handle* out) {
     EGO_CHECK(cfg->vit_dim == 1024 && cfg->vit_heads == 8, "ViT hidden size / heads are fixed at 1024 / 8 (net_architecture.py:340-348)");
     EGO_CHECK(cfg->vit_layers >= 1 && cfg->vit_layers <= 8, "vit_layers out of range");
     EGO_CHECK(cfg->pu_hidden == 512 && cfg->hidden == 128, "hidden sizes are fixed at ae_hidden_size 128 / PU 512 in this build");
+    for (int i = 0; i < 4; ++i) EGO_CHECK(cfg->hm_blocks[i] >= 0 && cfg->hm_blocks[i] <= 6, "hm_blocks: at most 6 BasicBlocks per ResNet stage (resnet18 / resnet34)");
     Handle* h = new Handle();
     h->cfg = *cfg;
     h->J = cfg->n_joints_hm;
@@ -931,8 +939,9 @@ static int hm_resolve(Handle* h, int net) {
     };
     p.stem_w = P(h, net, bb + "conv1.weight", ok);
     p.stem_bn = bn(bb + "bn1");
+    for (int i = 0; i < 4; ++i) p.nblk[i] = hm_nblk(h, i);
     for (int i = 0; i < 4; ++i)
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < p.nblk[i]; ++b) {
             const std::string k = bb + "layer" + std::to_string(i + 1) + "." + std::to_string(b);
             auto& B = p.blk[i][b];
             B.w1 = P(h, net, k + ".conv1.weight", ok); B.bn1 = bn(k + ".bn1");
@@ -1038,7 +1047,7 @@ struct HmWs {
 };
 // [r3] every convolution's packed bf16 weights (+ padded bias) and every BatchNorm's folded scale / shift of one estimator, in the order
 // the bf16 forward uses them; p == nullptr: sizes only.  Returns the bytes of the region; fills T (segment table of pack_all_bf16s_kernel).
-static size_t hm_pack_plan(const HmParams* p, PackTable* T) {
+static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T) {
     size_t o = 0;
     int nw = 0, nb = 0, blk = 0;
     auto al = [&](size_t n) { size_t r = o; o = (o + n + 255) & ~(size_t)255; return r; };
@@ -1060,7 +1069,7 @@ static size_t hm_pack_plan(const HmParams* p, PackTable* T) {
     int cin = 64;
     for (int i = 0; i < 4; ++i) {
         const int c = HM_CH[i];
-        for (int bk = 0; bk < 2; ++bk) {
+        for (int bk = 0; bk < nblk[i]; ++bk) {
             const int bc = bk == 0 ? cin : c;
             const bool down = p ? p->blk[i][bk].wd != nullptr : (bk == 0 && i > 0);
             wseg(p ? p->blk[i][bk].w1 : nullptr, nullptr, c, bc, bc, npad(c), 9); bseg(p ? p->blk[i][bk].bn1 : nobn, c, npad(c));
@@ -1109,7 +1118,8 @@ static HmWs hm_ws(const Handle* h, int B) {
     w.CAT2 = take((size_t)B * 1280 * s32 * s32); w.X2 = take((size_t)B * 512 * s32 * s32);
     w.CAT1 = take((size_t)B * 640 * s64 * s64);  w.X1 = take((size_t)B * 512 * s64 * s64);
     w.WPACK = take(conv_bf16_pack_bytes(1024, 1540) / 4);      // largest conv (conv_up3) repacked for the bf16 kernels
-    w.WALL = take(hm_pack_plan(nullptr, nullptr) / 4 + 64);    // [r3] bf16 mode: every layer's packed weights at once (one pack launch per forward)
+    const int nblk_[4] = {hm_nblk(h, 0), hm_nblk(h, 1), hm_nblk(h, 2), hm_nblk(h, 3)};
+    w.WALL = take(hm_pack_plan(nullptr, nblk_, nullptr) / 4 + 64);    // [r3] bf16 mode: every layer's packed weights at once (one pack launch per forward)
     w.total = o;
     return w;
 }
@@ -1206,7 +1216,7 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
         // [r3] all 27 weight repacks and 19 BatchNorm folds of this forward in ONE launch (conv_bf16s.h, pack_all_bf16s_kernel): the
         // parameters stay the caller's live fp32 tensors, nothing is kept between calls
         PackTable PT;
-        EGO_CHECK(hm_pack_plan(&p, &PT) != 0, "egotap_hm_forward: the estimator has more layers than the pack table holds");
+        EGO_CHECK(hm_pack_plan(&p, p.nblk, &PT) != 0, "egotap_hm_forward: the estimator has more layers than the pack table holds");
         char* reg = base + w.WALL;
         hipLaunchKernelGGL(pack_all_bf16s_kernel, dim3(PT.blocks), dim3(256), 0, s, PT, reg);
         EGO_HIP(hipGetLastError());
@@ -1267,27 +1277,28 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
             return gemm_bf16s_launch(xl, WPl, (long)taps * cin, SEpiBnBf16<true>{SC, SH, res, o, c, ilog2(side), relu}, (int)M, Np, taps * cin, cus, s);
         };
         {
-            static const char* r1[4][2] = {{"hm.l1.0.conv1", "hm.l1.1.conv1"}, {"hm.l2.0.conv1", "hm.l2.1.conv1"}, {"hm.l3.0.conv1", "hm.l3.1.conv1"}, {"hm.l4.0.conv1", "hm.l4.1.conv1"}};
-            static const char* r2[4][2] = {{"hm.l1.0.conv2", "hm.l1.1.conv2"}, {"hm.l2.0.conv2", "hm.l2.1.conv2"}, {"hm.l3.0.conv2", "hm.l3.1.conv2"}, {"hm.l4.0.conv2", "hm.l4.1.conv2"}};
-            static const char* rd[4] = {"", "hm.l2.down", "hm.l3.down", "hm.l4.down"};
             const int sides[4] = {s64, s32, s16, s8};
             __bf16* Ls[4] = {A1, A2, A3, A4};                                       // stage outputs = pyramid levels = the decoder's operands
             const __bf16* x = P0;
             int cin = 64;
             for (int i = 0; i < 4; ++i) {
-                const int c = HM_CH[i], side = sides[i];
+                const int c = HM_CH[i], side = sides[i], nb = p.nblk[i];
                 __bf16 *Ta = Hb(w.S[i][1]), *Tb = Hb(w.S[i][2]), *Td = Hb(w.S[i][3]);   // S[i][0] is the level itself (A1..A4)
-                for (int bk = 0; bk < 2; ++bk) {
+                const __bf16* xin = x;
+                for (int bk = 0; bk < nb; ++bk) {
                     const auto& K = p.blk[i][bk];
-                    const __bf16* xin = bk == 0 ? x : Tb;
                     const int stride = (bk == 0 && i > 0) ? 2 : 1, bc = bk == 0 ? cin : c;
-                    EGO_HIP(bconv(r1[i][bk], xin, bc, c, 9, stride, side, K.w1, K.bn1, nullptr, 1, Ta));
+                    // block outputs alternate between Tb and the level so that the last block writes the level (a block never writes
+                    // the buffer it reads its identity from)
+                    __bf16* y = ((nb - 1 - bk) & 1) ? Tb : Ls[i];
+                    EGO_HIP(bconv(HM_R1[i][bk], xin, bc, c, 9, stride, side, K.w1, K.bn1, nullptr, 1, Ta));
                     const __bf16* idt = xin;
                     if (K.wd) {
-                        EGO_HIP(bconv(rd[i], xin, bc, c, 1, 2, side, K.wd, K.bnd, nullptr, 0, Td));
+                        EGO_HIP(bconv(HM_RD[i], xin, bc, c, 1, 2, side, K.wd, K.bnd, nullptr, 0, Td));
                         idt = Td;
                     }
-                    EGO_HIP(bconv(r2[i][bk], Ta, c, c, 9, 1, side, K.w2, K.bn2, idt, 1, bk == 0 ? Tb : Ls[i]));
+                    EGO_HIP(bconv(HM_R2[i][bk], Ta, c, c, 9, 1, side, K.w2, K.bn2, idt, 1, y));
+                    xin = y;
                 }
                 x = Ls[i];
                 cin = c;
@@ -1320,33 +1331,32 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
     const float* x = F(w.P0);
     int cin = 64;
     const int sides[4] = {s64, s32, s16, s8};
-    static const char* r1[4][2] = {{"hm.l1.0.conv1", "hm.l1.1.conv1"}, {"hm.l2.0.conv1", "hm.l2.1.conv1"}, {"hm.l3.0.conv1", "hm.l3.1.conv1"}, {"hm.l4.0.conv1", "hm.l4.1.conv1"}};
-    static const char* r2[4][2] = {{"hm.l1.0.conv2", "hm.l1.1.conv2"}, {"hm.l2.0.conv2", "hm.l2.1.conv2"}, {"hm.l3.0.conv2", "hm.l3.1.conv2"}, {"hm.l4.0.conv2", "hm.l4.1.conv2"}};
-    static const char* rd[4] = {"", "hm.l2.down", "hm.l3.down", "hm.l4.down"};
     for (int i = 0; i < 4; ++i) {
-        const int c = HM_CH[i], side = sides[i];
+        const int c = HM_CH[i], side = sides[i], nb = p.nblk[i];
         const long ist_in = (long)cin * (i == 0 ? side : 2 * side) * (i == 0 ? side : 2 * side);
         const long ist = (long)c * side * side;
         float *Ta = F(w.S[i][0]), *Tb = F(w.S[i][1]), *Td = F(w.S[i][2]), *L = F(w.S[i][3]);
-        for (int b = 0; b < 2; ++b) {
+        const float* xin = x;
+        long xin_ist = ist_in;
+        for (int b = 0; b < nb; ++b) {
             const auto& K = p.blk[i][b];
-            const float* xin = b == 0 ? x : Tb;
             const int stride = (b == 0 && i > 0) ? 2 : 1;
             const int bc = b == 0 ? cin : c;
-            const long xin_ist = b == 0 ? ist_in : ist;
             ConvArgs a1{xin, K.w1, Ta, nullptr, K.bn1.g, K.bn1.b, K.bn1.m, K.bn1.v, nullptr, xin_ist, ist, 0, N2, bc, c, 1, 0, 0};
-            EGO_HIP(conv_any(h, r1[i][b], 9, stride, side, a1, s));
+            EGO_HIP(conv_any(h, HM_R1[i][b], 9, stride, side, a1, s));
             const float* idt = xin;
             long idt_ist = xin_ist;
             if (K.wd) {
                 ConvArgs ad{xin, K.wd, Td, nullptr, K.bnd.g, K.bnd.b, K.bnd.m, K.bnd.v, nullptr, xin_ist, ist, 0, N2, bc, c, 0, 0, 0};
-                EGO_HIP(conv_any(h, rd[i], 1, 2, side, ad, s));
+                EGO_HIP(conv_any(h, HM_RD[i], 1, 2, side, ad, s));
                 idt = Td;
                 idt_ist = ist;
             }
-            float* y = b == 0 ? Tb : L;
+            float* y = ((nb - 1 - b) & 1) ? Tb : L;       // outputs alternate so that the last block writes the level
             ConvArgs a2{Ta, K.w2, y, idt, K.bn2.g, K.bn2.b, K.bn2.m, K.bn2.v, nullptr, ist, ist, idt_ist, N2, c, c, 1, 0, 0};
-            EGO_HIP(conv_any(h, r2[i][b], 9, 1, side, a2, s));
+            EGO_HIP(conv_any(h, HM_R2[i][b], 9, 1, side, a2, s));
+            xin = y;
+            xin_ist = ist;
         }
         x = L;
         cin = c;

@@ -68,7 +68,7 @@ class HmTrainFn(torch.autograd.Function):
             x, cin, side = p0, 64, S0 // 4
             blocks, pyr = [], []
             for i, (c, st) in enumerate(STAGES, start=1):
-                for b in range(2):
+                for b in range(net.blocks[i - 1]):
                     k = f"{BB}layer{i}.{b}."
                     stride = st if b == 0 else 1
                     so = side // stride
@@ -86,7 +86,7 @@ class HmTrainFn(torch.autograd.Function):
                     z2, y2 = new(N2, c, so, so), new(N2, c, so, so)
                     H.conv_fwd(h, y1, P[k + "conv2.weight"], z2, taps=9, stride=1)
                     m2 = _bn_fwd(z2, y2, P, buf, k + "bn2", B, res=idt)
-                    rec.update(z2=z2, y2=y2, m2=m2)
+                    rec.update(z2=z2, y2=y2, m2=m2, level=i - 1 if b == net.blocks[i - 1] - 1 else None)
                     blocks.append(rec)
                     x, cin, side = y2, c, so
                 pyr.append(x)
@@ -192,8 +192,8 @@ class HmTrainFn(torch.autograd.Function):
             for bi in range(len(blocks) - 1, -1, -1):
                 r = blocks[bi]
                 k, c, cin, stride = r["k"], r["c"], r["cin"], r["stride"]
-                if bi % 2 == 1:                       # output of a stage = pyramid level bi // 2
-                    share = dL[bi // 2].view(N2, c, r["y2"].shape[2], r["y2"].shape[3])
+                if r["level"] is not None:            # output of a stage = a pyramid level
+                    share = dL[r["level"]].view(N2, c, r["y2"].shape[2], r["y2"].shape[3])
                     if dy is None:
                         dy = share
                     else:

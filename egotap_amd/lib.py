@@ -16,7 +16,7 @@ PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}      # egotap.h EGOTAP_PREC_*
 class EgotapConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_bytes", "n_joints_hm", "estimate_head", "hm_size", "hidden", "vit_dim", "vit_heads", "vit_layers",
-        "patch", "pu_hidden")]
+        "patch", "pu_hidden")] + [("hm_blocks", C.c_int32 * 4)]      # zeros = resnet18's (2, 2, 2, 2)
 
 
 class EgotapError(RuntimeError):

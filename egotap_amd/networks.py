@@ -319,8 +319,8 @@ class HeatMap_UnrealEgo_Shared(nn.Module):
 
     def __init__(self, opt, model_name: str = "resnet18", input_channel_scale: int = 2):
         super().__init__()
-        if model_name != "resnet18":
-            raise NotImplementedError("only the resnet18 backbone (the shipped configuration) is built")
+        self.model_name = model_name
+        self.blocks = _spec.hm_blocks(model_name)         # resnet18 / resnet34; raises for the Bottleneck ResNets
         if input_channel_scale != 2:
             raise NotImplementedError("only the stereo presets are built")
         limb = {"none": 0, "sin": 2, "limb": 1}[getattr(opt, "heatmap_type", "none")]
@@ -335,7 +335,7 @@ class HeatMap_UnrealEgo_Shared(nn.Module):
             self._net = _lib.NET_HM_ROT
         else:
             raise ValueError("heatmap estimator must be the position net (num_rot_heatmap=0) or the sin/cos net (num_heatmap=0)")
-        entries = _spec.hm_state_spec(self.num_heatmap)
+        entries = _spec.hm_state_spec(self.num_heatmap, model_name)
         _build_tree(self, [(k, s) for k, s, a in entries if a is None])
         for k, s, a in entries:                      # aliases: same Parameter / buffer object under a second path
             if a is None:
@@ -376,7 +376,7 @@ class HeatMap_UnrealEgo_Shared(nn.Module):
         if self._handle is None:
             p = self.preset
             cfg = _lib.EgotapConfig(C.sizeof(_lib.EgotapConfig), p.n_joints_hm, int(p.estimate_head), p.hm_size, p.hidden,
-                                    p.vit_dim, p.vit_heads, p.vit_layers, p.patch, p.pu_hidden)
+                                    p.vit_dim, p.vit_heads, p.vit_layers, p.patch, p.pu_hidden, (C.c_int32 * 4)(*self.blocks))
             h = C.c_void_p()
             _lib.check(_lib.load().egotap_create(C.byref(cfg), C.byref(h)))
             self._handle = h

@@ -134,12 +134,23 @@ def _bn2d(pre, c):
             (pre + ".running_var", (c,)), (pre + ".num_batches_tracked", ())]
 
 
-def resnet18_spec():
-    """[(key, shape)] of torchvision.models.resnet18().state_dict() (public architecture; 122 entries)."""
+HM_BLOCKS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}      # BasicBlock ResNets of torchvision (net_architecture.py:57-60)
+
+
+def hm_blocks(model_name: str = "resnet18"):
+    """BasicBlocks per stage; resnet50 / resnet101 (Bottleneck blocks, feature_scale 4: net_architecture.py:61-64, 108-111) are not built"""
+    if model_name not in HM_BLOCKS:
+        raise NotImplementedError(f"backbone {model_name!r}: only the BasicBlock ResNets are built ({', '.join(HM_BLOCKS)}; the shipped scripts use resnet18)")
+    return HM_BLOCKS[model_name]
+
+
+def resnet18_spec(model_name: str = "resnet18"):
+    """[(key, shape)] of torchvision.models.resnet18().state_dict() (public architecture; 122 entries) -- or resnet34's (218 entries)."""
     s = [("conv1.weight", (64, 3, 7, 7))] + _bn2d("bn1", 64)
     cin = 64
+    blocks = hm_blocks(model_name)
     for i, (c, stride) in enumerate(HM_STAGES, start=1):
-        for b in range(2):
+        for b in range(blocks[i - 1]):
             pre = f"layer{i}.{b}"
             bc_in = cin if b == 0 else c
             s += [(pre + ".conv1.weight", (c, bc_in, 3, 3))] + _bn2d(pre + ".bn1", c)
@@ -151,14 +162,14 @@ def resnet18_spec():
     return s
 
 
-def hm_state_spec(n_hm_per_eye: int):
+def hm_state_spec(n_hm_per_eye: int, model_name: str = "resnet18"):
     """[(key, shape, alias_of)] of HeatMap_UnrealEgo_Shared(resnet18, stereo).state_dict() in the reference's order.
 
     Encoder_Block registers the ResNet and, again, its slices layer0..layer4 (net_architecture.py:58, 68-73), so
     every backbone tensor appears under two keys; alias_of names the canonical key of the shared tensor.
     n_hm_per_eye = num_heatmap + 2 * num_rot_heatmap of that net (15 for the position net, 30 for the sin/cos net).
     """
-    rs = resnet18_spec()
+    rs = resnet18_spec(model_name)
     root = "backbone.backbone."
     out = [(root + "backbone." + k, shp, None) for k, shp in rs]
 

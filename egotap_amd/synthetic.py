@@ -114,12 +114,12 @@ def synth_input(name: str, shape, lo: float = 0.0, hi: float = 1.0) -> np.ndarra
     return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
 
 
-def synth_hm_state_dict(n_hm_per_eye: int, salt: str):
+def synth_hm_state_dict(n_hm_per_eye: int, salt: str, model_name: str = "resnet18"):
     """Hash-RNG state_dict of a heatmap estimator.  Backbone tensors appear under two keys in the reference's
     state_dict (spec.hm_state_spec); load_state_dict writes them in key order, so the value that survives is the one
     generated from the LATER (alias) key -- reproduced here so weights equal what tools/make_golden.py loaded."""
     from . import spec
-    entries = spec.hm_state_spec(n_hm_per_eye)
+    entries = spec.hm_state_spec(n_hm_per_eye, model_name)
     last_key_of = {}
     for key, shape, alias in entries:
         last_key_of[alias or key] = key

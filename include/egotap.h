@@ -47,6 +47,8 @@ typedef struct egotap_config {
     int32_t vit_layers;     /* 3 */
     int32_t patch;          /* 16 */
     int32_t pu_hidden;      /* 512 */
+    int32_t hm_blocks[4];   /* BasicBlocks per ResNet stage of the heatmap estimators (--model_name, net_architecture.py:57-64):
+                             * {2,2,2,2} resnet18 (all zeros mean this), {3,4,6,3} resnet34; at most 6 per stage */
 } egotap_config;
 
 typedef struct egotap_handle_s* egotap_handle;

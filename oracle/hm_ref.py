@@ -47,7 +47,7 @@ class ResNet18Holder(nn.Module):
     """Module with torchvision.models.resnet18's children order and state_dict names (conv1, bn1, relu, maxpool,
     layer1..4, avgpool, fc), which is all Encoder_Block relies on (net_architecture.py:68-73)."""
 
-    def __init__(self):
+    def __init__(self, blocks=(2, 2, 2, 2)):
         super().__init__()
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -55,7 +55,7 @@ class ResNet18Holder(nn.Module):
         self.maxpool = nn.MaxPool2d(3, 2, 1)
         cin = 64
         for i, (c, s) in enumerate(STAGES, start=1):
-            setattr(self, f"layer{i}", nn.Sequential(_BasicBlock(cin, c, s), _BasicBlock(c, c, 1)))
+            setattr(self, f"layer{i}", nn.Sequential(_BasicBlock(cin, c, s), *[_BasicBlock(c, c, 1) for _ in range(blocks[i - 1] - 1)]))
             cin = c
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
         self.fc = nn.Linear(512, 1000)
@@ -99,8 +99,10 @@ def resnet18_pyramid(x, sd, pre="backbone.backbone.backbone."):
     y = F.max_pool2d(l0, 3, 2, 1)
     outs = [l0]
     for i, (c, s) in enumerate(STAGES, start=1):
-        y = _block(y, sd, f"{pre}layer{i}.0", s)
-        y = _block(y, sd, f"{pre}layer{i}.1", 1)
+        b = 0
+        while f"{pre}layer{i}.{b}.conv1.weight" in sd:      # 2 BasicBlocks per stage in resnet18, (3, 4, 6, 3) in resnet34 (torchvision)
+            y = _block(y, sd, f"{pre}layer{i}.{b}", s if b == 0 else 1)
+            b += 1
         outs.append(y)
     return outs
 

@@ -28,18 +28,18 @@ def lift_net(preset="UnrealEgo", hm=64, device="cuda"):
     return _cache[key]
 
 
-def hm_net(which="pos", device="cuda", preset="UnrealEgo", hm=64):
+def hm_net(which="pos", device="cuda", preset="UnrealEgo", hm=64, model_name="resnet18"):
     """HeatMap_UnrealEgo_Shared (position or sin/cos net) with hash-RNG weights on the GPU, eval mode."""
     from egotap_amd.synthetic import synth_hm_state_dict
-    key = ("hm", which, device, preset, hm)
+    key = ("hm", which, device, preset, hm, model_name)
     if key not in _cache:
         opt = make_opt(preset, hm)
         if which == "pos":
             opt.num_rot_heatmap = 0
         else:
             opt.num_heatmap = 0
-        net = networks.HeatMap_UnrealEgo_Shared(opt, "resnet18", input_channel_scale=2)
-        sd_np = synth_hm_state_dict(net.num_heatmap, f"hm_{which}.")
+        net = networks.HeatMap_UnrealEgo_Shared(opt, model_name, input_channel_scale=2)
+        sd_np = synth_hm_state_dict(net.num_heatmap, f"hm_{which}.", model_name)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
         net = net.to(device).eval()
         _cache[key] = (net, sd_np)

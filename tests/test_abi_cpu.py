@@ -135,3 +135,42 @@ def test_host_side_argument_checks_of_the_newer_entry_points():
         L.pose_metrics(torch.zeros(2, 16, 3), torch.zeros(2, 16, 3))
     assert L.KINEMATIC_PARENTS == R.KINEMATIC_PARENTS and len(L.KINEMATIC_PARENTS["EgoCap"]) == 18
     assert sorted(L.PRECISIONS) == ["bf16", "bf16x3", "f32"]
+
+
+def test_resnet34_backbone_spec_module_and_handle():
+    """--model_name resnet34 (net_architecture.py:59-60, 104-105: torchvision resnet34, feature_scale 1): BasicBlocks (3, 4, 6, 3) per
+    stage under torchvision's key names, the same decoder; the Bottleneck ResNets (resnet50 / 101) are refused, not approximated."""
+    import torch
+    from egotap_amd import networks, spec
+    from egotap_amd.options import preset_defaults
+    rs = spec.resnet18_spec("resnet34")
+    assert len(rs) == 218 and len(spec.resnet18_spec()) == 122                     # torchvision's state_dict sizes
+    keys = [k for k, _ in rs]
+    assert "layer3.5.conv2.weight" in keys and "layer3.6.conv1.weight" not in keys and "layer1.2.bn2.running_var" in keys
+    assert [k for k in keys if "downsample.0" in k] == [f"layer{i}.0.downsample.0.weight" for i in (2, 3, 4)]
+    assert dict(rs)["layer2.0.conv1.weight"] == (128, 64, 3, 3) and dict(rs)["layer2.3.conv1.weight"] == (128, 128, 3, 3)
+    opt = preset_defaults("UnrealEgo")
+    opt.num_rot_heatmap = 0
+    net = networks.HeatMap_UnrealEgo_Shared(opt, "resnet34", input_channel_scale=2)
+    want = [k for k, _, _ in spec.hm_state_spec(15, "resnet34")]
+    assert list(net.state_dict().keys()) == want
+    sd = net.state_dict(keep_vars=True)
+    assert sd["backbone.backbone.layer3.5.conv2.weight"] is sd["backbone.backbone.backbone.layer3.5.conv2.weight"]      # the reference's aliases
+    with pytest.raises(NotImplementedError):
+        networks.HeatMap_UnrealEgo_Shared(opt, "resnet50", input_channel_scale=2)
+    lib = L.load()
+    counts = {}
+    for name, blocks in (("resnet18", (0, 0, 0, 0)), ("resnet34", (3, 4, 6, 3))):
+        cfg = _cfg()
+        for i in range(4):
+            cfg.hm_blocks[i] = blocks[i]
+        h, n = C.c_void_p(), C.c_int()
+        assert lib.egotap_create(C.byref(cfg), C.byref(h)) == 0
+        assert lib.egotap_unbound_count(h, L.NET_HM_POS, C.byref(n)) == 0
+        counts[name] = n.value
+        lib.egotap_destroy(h)
+    assert counts["resnet34"] - counts["resnet18"] == 8 * 2 * 5                    # eight more blocks: two convolutions + two BatchNorms (4 tensors) each
+    bad = _cfg()
+    bad.hm_blocks[2] = 7
+    h = C.c_void_p()
+    assert lib.egotap_create(C.byref(bad), C.byref(h)) == 1 and b"hm_blocks" in lib.egotap_last_error()

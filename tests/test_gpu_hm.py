@@ -39,11 +39,12 @@ def test_hm_forward_matches_golden(which, n_hm):
         np.testing.assert_allclose(right_eye[::997].numpy(), g[f"pyr{i}_sample"], atol=2e-4, rtol=1e-4, err_msg=f"layer{i}")
 
 
-@pytest.mark.parametrize("which,B", [("pos", 3), ("rot", 2)])
-def test_hm_forward_matches_oracle(which, B):
+@pytest.mark.parametrize("which,B,model_name", [("pos", 3, "resnet18"), ("rot", 2, "resnet18"), ("rot", 3, "resnet34")])
+def test_hm_forward_matches_oracle(which, B, model_name):
+    """resnet34 (--model_name, net_architecture.py:59-60): BasicBlocks (3, 4, 6, 3) per stage, same decoder (feature_scale 1)"""
     from gpu_util import hm_net
     from oracle import hm_ref as H
-    net, sd_np = hm_net(which)
+    net, sd_np = hm_net(which, model_name=model_name)
     left, right = _rgb(f"rgbL_{which}_{B}", B), _rgb(f"rgbR_{which}_{B}", B)
     sd = H.to_torch_sd(sd_np, torch.float64)
     with torch.no_grad():
@@ -109,8 +110,9 @@ def test_hm_forward_bf16x3_mode_matches_oracle(which, B):
     assert torch.equal(fast, again) and torch.equal(back, exact) and not torch.equal(fast, exact)
 
 
-@pytest.mark.parametrize("which,preset,hm,B", [("pos", "UnrealEgo", 64, 3), ("rot", "UnrealEgo", 64, 2), ("rot", "EgoCap", 128, 1)])
-def test_hm_forward_bf16_channels_last_decoder_against_float64_oracle(which, preset, hm, B):
+@pytest.mark.parametrize("which,preset,hm,B,model_name", [("pos", "UnrealEgo", 64, 3, "resnet18"), ("rot", "UnrealEgo", 64, 2, "resnet18"),
+                                                          ("rot", "EgoCap", 128, 1, "resnet18"), ("pos", "UnrealEgo", 64, 2, "resnet34")])
+def test_hm_forward_bf16_channels_last_decoder_against_float64_oracle(which, preset, hm, B, model_name):
     """EGOTAP_PREC_BF16: the decoder runs on bf16 channels-last activations, every convolution as an implicit GEMM on the bf16-storage
     GEMM kernel (conv_bf16s.h: 3x3 taps through a loader with a zero page for the padding, 1x1 lateral convs with padded N, the
     concat buffers' channel slices written in place, conv_heatmap back to fp32 NCHW).  Against the FLOAT64 ORACLE: relative L2 below
@@ -118,7 +120,7 @@ def test_hm_forward_bf16_channels_last_decoder_against_float64_oracle(which, pre
     result does not depend on the batch it is in."""
     from gpu_util import hm_net
     from oracle import hm_ref as H
-    net, sd_np = hm_net(which, preset=preset, hm=hm)
+    net, sd_np = hm_net(which, preset=preset, hm=hm, model_name=model_name)
     S = 4 * hm
     left = torch.from_numpy(synth_input(f"rgbL_cl_{which}{hm}", (B, 3, S, S), -2.0, 2.0))
     right = torch.from_numpy(synth_input(f"rgbR_cl_{which}{hm}", (B, 3, S, S), -2.0, 2.0))
@@ -135,9 +137,9 @@ def test_hm_forward_bf16_channels_last_decoder_against_float64_oracle(which, pre
     low = low.double().cpu()
     assert tuple(low.shape) == tuple(ref.shape)
     rels = [float((low[b] - ref[b]).norm() / ref[b].norm()) for b in range(B)]
-    print(f"bf16 estimator ({which}, {preset}, {hm}): relative L2 against the float64 oracle per frame {['%.2e' % r for r in rels]}")
+    print(f"bf16 estimator ({which}, {preset}, {hm}, {model_name}): relative L2 against the float64 oracle per frame {['%.2e' % r for r in rels]}")
     for b, rel in enumerate(rels):
-        assert 1e-5 < rel < 2e-2, (b, rel)
+        assert 1e-5 < rel < (2e-2 if model_name == "resnet18" else 3e-2), (b, rel)         # resnet34: twice the backbone depth
 
 
 def test_hm_forward_bf16_mode_against_float64_oracle():

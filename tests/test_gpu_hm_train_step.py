@@ -10,7 +10,7 @@ from egotap_amd.synthetic import synth_input
 pytestmark = pytest.mark.gpu
 
 
-def _net(which):
+def _net(which, model_name="resnet18"):
     from egotap_amd import networks
     from egotap_amd.options import preset_defaults
     from egotap_amd.synthetic import synth_hm_state_dict
@@ -19,17 +19,18 @@ def _net(which):
         opt.num_rot_heatmap = 0
     else:
         opt.num_heatmap = 0
-    net = networks.HeatMap_UnrealEgo_Shared(opt, "resnet18", input_channel_scale=2)
-    sd_np = synth_hm_state_dict(net.num_heatmap, f"hm_{which}.")
+    net = networks.HeatMap_UnrealEgo_Shared(opt, model_name, input_channel_scale=2)
+    sd_np = synth_hm_state_dict(net.num_heatmap, f"hm_{which}.", model_name)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
     return net.cuda(), sd_np
 
 
-@pytest.mark.parametrize("which", ["pos", "rot"])
-def test_hm_train_forward_backward_matches_oracle(which):
+@pytest.mark.parametrize("which,model_name", [("pos", "resnet18"), ("rot", "resnet18"), ("pos", "resnet34")])
+def test_hm_train_forward_backward_matches_oracle(which, model_name):
+    """resnet34 (--model_name, net_architecture.py:59-60): the same BasicBlocks, (3, 4, 6, 3) per stage"""
     from egotap_amd import hm_ops as H
     from oracle import hm_ref as R
-    net, sd_np = _net(which)
+    net, sd_np = _net(which, model_name)
     net.train()
     B, n2 = 2, 2 * net.num_heatmap
     left = torch.from_numpy(synth_input(f"tr_rgbL_{which}", (B, 3, 256, 256), -2.0, 2.0))
@@ -69,11 +70,13 @@ def test_hm_train_forward_backward_matches_oracle(which):
         nrm = float(gref.norm()) + 1e-300
         rel = float((g.cpu().double() - gref).norm()) / nrm
         rel32 = float((grads32[k].double() - gref).norm()) / nrm
-        assert rel <= 2.5 * rel32 + 2e-3, f"{k}: relative L2 error {rel:.3e}, CPU fp32 oracle {rel32:.3e}"
+        # resnet34 is twice as deep: more ReLU inputs within rounding of zero between any two fp32 evaluations
+        lim = 2.5 * rel32 + 2e-3 if model_name == "resnet18" else 4.0 * rel32 + 5e-3
+        assert rel <= lim, f"{k}: relative L2 error {rel:.3e}, CPU fp32 oracle {rel32:.3e}"
         cos = float((g.cpu().double().flatten() @ gref.flatten()) / (g.cpu().double().norm() * gref.norm() + 1e-300))
         assert cos > 0.999 or float(gref.norm()) < 1e-9, f"{k}: cos {cos}"
         checked += 1
-    assert checked >= 60
+    assert checked >= (60 if model_name == "resnet18" else 108)
     bufs = dict(net.named_buffers())
     for k, v in stats_ref.items():
         np.testing.assert_allclose(bufs[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
