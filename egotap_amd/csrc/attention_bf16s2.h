@@ -407,6 +407,153 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_bf16s2_kernel(const __bf
     }
 }
 
+// ------------------------------------------------------------------------------------------------- forward, 32-key steps, three workgroups per CU
+// [r3] At N = 576 a (batch, head) pair is 4.5 workgroups of 9 steps each and the per-block cost (dispatch, Q load, first tile's round trip,
+// output store) is worth 5.4 steps (measured: 0.67 PF at N = 576 against 0.93 PF at N = 2304 on the same kernel).  With two workgroups per
+// CU there is one partner to run under it.  The forward needs 160 VGPRs, so three waves per SIMD fit; what held it at two was LDS
+// (64 KB of images, a 68 KB output patch).  This variant steps 32 keys at a time (32 KB of images) and stores its output through a
+// half-width patch in two passes (35 KB): three workgroups per CU.  Same arithmetic and summation order as the 64-key kernel.
+namespace att2 {
+__device__ __forceinline__ void store_rows_bf16_2pass(const f32x16 (&o)[4], float mul, float* patch, __bf16* out, long ld, int lane) {
+    constexpr int PLD = 68;
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = o[2 * half + dd][4 * g + c] * mul;
+                *(f32x4*)(patch + l31 * PLD + dd * 32 + 8 * g + 4 * lh) = v;
+            }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3), c8 = lane & 7;
+            const f32x4 a = *(const f32x4*)(patch + row * PLD + c8 * 8), b = *(const f32x4*)(patch + row * PLD + c8 * 8 + 4);
+            float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            store_bf16x8(out + (long)row * ld + half * 64 + c8 * 8, v);
+        }
+    }
+}
+}  // namespace att2
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 3) void attention_bf16s3_kernel(const __bf16* __restrict__ QKV, __bf16* __restrict__ CTX, int N, int heads,
+                                                                     int qgroups, float scale_log2e, float* __restrict__ LSE) {
+    using namespace att2;
+    static_assert(NW >= 2 && NW <= 4, "the workgroup's waves share the 8 + 8 DMA pieces of a 32-key step");
+    constexpr unsigned KVBUF = 2 * TILEB;                      // K image | V image
+    constexpr float RESC = 6.0f;
+    extern __shared__ __attribute__((aligned(16))) char sm3[];
+    const int lin = xcd_lin(blockIdx.x, gridDim.x);
+    const int bh = lin / qgroups, qg = lin - bh * qgroups;
+    const int b = bh / heads, h = bh - b * heads;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
+    const int D = heads * DH;
+    const int ld3 = 3 * D;
+    const __bf16* qkv = QKV + (long)b * N * ld3 + h * DH;
+    const int qb = qg * NW + wid;
+    const bool valid = qb * 32 < N;
+    const int q0 = min(qb * 32, N - 32);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sm3;
+    constexpr int PPW = (8 + NW - 1) / NW;                     // pieces per wave: wave w takes pieces w, w + NW, ... < 8 of the K and of the V image
+    int ok[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) ok[i] = D + dma_src(min(wid + i * NW, 7), lane, ld3);
+    auto issue = [&](int kt, unsigned boff) __attribute__((always_inline)) {
+        const __bf16* src = qkv + (long)(kt * 32) * ld3;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (wid + i * NW < 8) {                             // wave-uniform
+                const unsigned a = lds0 + boff + 1024 * (wid + i * NW);
+                dma16(src + ok[i], a);
+                dma16(src + ok[i] + D, a + TILEB);
+            }
+        }
+    };
+    issue(0, 0);
+    Frags<1> qf;
+    attns::load_row_frags(qf, qkv + (long)(q0 + l31) * ld3, lh);
+    const LaneAddr la = lane_addr(lane);
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntiles = N / 32;
+    auto step = [&](int kt, unsigned boff) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < ntiles) issue(kt + 1, boff ^ KVBUF);
+        if (!valid) return;
+        f32x16 s = rows_x_frags(sm3 + boff, la, qf);
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
+        const bool raise = mx > m_run + RESC;
+        if (__builtin_amdgcn_ballot_w64(raise) != 0) {
+            const float m_new = raise ? mx : m_run;
+            const float alpha = exp2f(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_run));
+            psum += s[r];
+        }
+        l_run += psum;
+        imgT_x_p(o, sm3 + boff + TILEB, la, s);
+    };
+    for (int kt = 0; kt < ntiles; kt += 2) {
+        step(kt, 0);
+        if (kt + 1 < ntiles) step(kt + 1, KVBUF);
+    }
+    __syncthreads();
+    if (valid) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        if (LSE != nullptr && lh == 0) LSE[(long)bh * N + q0 + l31] = m_run * 0.6931471805599453f + logf(l_tot);
+        store_rows_bf16_2pass(o, 1.0f / l_tot, (float*)sm3 + wid * 32 * 68, CTX + ((long)b * N + q0) * D + h * DH, D, lane);
+    }
+}
+
+template <int NW>
+static hipError_t attention_bf16s3_fwd_launch_t(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream) {
+    using namespace att2;
+    constexpr size_t img = 2 * 2 * (size_t)TILEB, patch = (size_t)NW * 32 * 68 * 4;
+    constexpr size_t lds = img > patch ? img : patch;
+    static_assert(NW == 2 || (12 / NW) * lds <= 160 * 1024, "twelve waves (three per SIMD) per CU (two-wave workgroups: five per CU, ten waves)");
+    auto kern = attention_bf16s3_kernel<NW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int groups = (N / 32 + NW - 1) / NW;
+    hipLaunchKernelGGL(kern, dim3(B * heads * groups), dim3(64 * NW), lds, stream, QKV, CTX, N, heads, groups, 1.4426950408889634f / sqrtf(128.0f), LSE);
+    return hipGetLastError();
+}
+static int g_attn3_nw = 0;          // A/B: waves per workgroup of the 32-key forward (0 = choose by N)
+static hipError_t attention_bf16s3_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream) {
+    // four waves per workgroup: three-wave workgroups (no idle wave at N = 576: 18 query blocks = 6 x 3) measured equal at N = 576 and
+    // 7 % slower at N = 2304, two-wave ones 20 % slower (each workgroup streams the pair's whole K and V)
+    const int nw = g_attn3_nw ? g_attn3_nw : 4;
+    if (nw == 3) return attention_bf16s3_fwd_launch_t<3>(QKV, CTX, LSE, B, N, heads, stream);
+    if (nw == 2) return attention_bf16s3_fwd_launch_t<2>(QKV, CTX, LSE, B, N, heads, stream);
+    return attention_bf16s3_fwd_launch_t<4>(QKV, CTX, LSE, B, N, heads, stream);
+}
+
 static hipError_t attention_bf16s2_dq_launch(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
                                              int heads, hipStream_t stream, float* colpart) {
     using namespace att2;

@@ -2525,9 +2525,12 @@ extern "C" int egotap_bf16_from_f32(const float* src, void* dst, int64_t n, void
 #endif
 
 #if EGOTAP_IN(3)
-static int g_attn_gen = 2;     // egotap_debug_attention_gen: 2 = the DMA-staged kernels of attention_bf16s2.h (default), 1 = round 2's (A/B timing, tests)
+static int g_attn_gen = 3;     // egotap_debug_attention_gen: 3 (default) = 2 with the forward on 32-key steps / three workgroups per CU, 2 = the DMA-staged
+                               // kernels of attention_bf16s2.h, 1 = round 2's (A/B timing, tests)
 extern "C" int egotap_debug_attention_gen(int gen) {
-    EGO_CHECK(gen == 1 || gen == 2, "egotap_debug_attention_gen: 1 or 2");
+    EGO_CHECK((gen >= 1 && gen <= 3) || (gen >= 32 && gen <= 34), "egotap_debug_attention_gen: 1, 2, 3 (or 32..34: generation 3 with 2..4 waves per workgroup)");
+    g_attn3_nw = gen >= 32 ? gen - 30 : 0;
+    if (gen >= 32) gen = 3;
     g_attn_gen = gen;
     return EGOTAP_OK;
 }

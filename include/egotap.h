@@ -124,7 +124,9 @@ int egotap_pu_chain_status(egotap_handle h, int* enabled, int* faults);
  * shared device does. */
 int egotap_debug_pu_drop_workgroups(egotap_handle h, int n);
 /* Test / measurement hook (process wide): which generation of the bf16 attention kernels egotap_bf16_attention_fwd / _bwd (and the
- * training step built on them) launch: 2 = DMA-staged kernels (default), 1 = round 2's register-staged kernels. */
+ * training step built on them) launch: 3 (default) = DMA-staged kernels, the forward stepping 32 keys at a time with three workgroups
+ * per CU; 2 = the same with the 64-key forward; 1 = round 2's register-staged kernels; 32..34 = 3 with 2..4 waves per forward
+ * workgroup.  All generations produce the same bits. */
 int egotap_debug_attention_gen(int gen);
 /* Test / measurement hook (process wide), a bit mask over the round-3 kernels of the bf16 estimators (egotap_hm_forward under
  * EGOTAP_PREC_BF16); 0 (default) = all of them on.

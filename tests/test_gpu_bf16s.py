@@ -210,7 +210,7 @@ def test_attention_backward_bias_sums_from_the_epilogues_equal_a_column_sum_pass
     dctx = (torch.randn(B * N, D, device="cuda") * 0.1).bfloat16()
     ctx, lse = bf16s.attention_fwd(qkv, B, N, heads)
     outs = {}
-    for gen in (2, 1):
+    for gen in (2, 1, 3):
         lib.check(L.egotap_debug_attention_gen(gen))
         try:
             gb = tuple(torch.full((D,), float("nan"), device="cuda") for _ in range(3))
@@ -218,7 +218,7 @@ def test_attention_backward_bias_sums_from_the_epilogues_equal_a_column_sum_pass
             torch.cuda.synchronize()
             outs[gen] = (dqkv.clone(), [t.clone() for t in gb])
         finally:
-            lib.check(L.egotap_debug_attention_gen(2))
+            lib.check(L.egotap_debug_attention_gen(3))
     assert torch.equal(outs[1][0], outs[2][0])
     ref = outs[2][0].double().sum(0)
     for gen in (1, 2):
@@ -226,3 +226,26 @@ def test_attention_backward_bias_sums_from_the_epilogues_equal_a_column_sum_pass
             got = outs[gen][1][q].double()
             want = ref[q * D:(q + 1) * D]
             assert float((got - want).abs().max()) <= 2e-6 * float(outs[2][0].double().abs().sum(0)[q * D:(q + 1) * D].max()) + 1e-9, (gen, q)
+
+
+@pytest.mark.parametrize("B,N", [(3, 576), (2, 2304), (5, 96), (1, 32)])
+def test_attention_forward_generations_give_the_same_bits(B, N):
+    """egotap_debug_attention_gen: the 32-key forward with three workgroups per CU (generation 3, the default; 2 to 4 waves per
+    workgroup: 32..34) against the 64-key DMA-staged forward (2, N % 64 == 0 only) and round 2's register-staged one (1): context and
+    log-sum-exp bit-identical (same products, same summation order per query row), N = 96 / 32: a single partly filled workgroup."""
+    from egotap_amd import bf16s, lib
+    L = lib.load()
+    torch.manual_seed(N)
+    qkv = (torch.randn(B * N, 3072, device="cuda") * 0.7).bfloat16()
+    outs = {}
+    try:
+        for gen in (3, 1, 2, 32, 33, 34):
+            lib.check(L.egotap_debug_attention_gen(gen))
+            ctx, lse = bf16s.attention_fwd(qkv, B, N, 8)
+            torch.cuda.synchronize()
+            outs[gen] = (ctx.clone(), lse.clone())
+    finally:
+        lib.check(L.egotap_debug_attention_gen(3))
+    assert torch.isfinite(outs[3][0].float()).all() and torch.isfinite(outs[3][1]).all()
+    for gen in (1, 2, 32, 33, 34):
+        assert torch.equal(outs[gen][0], outs[3][0]) and torch.equal(outs[gen][1], outs[3][1]), gen

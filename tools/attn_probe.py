@@ -49,7 +49,7 @@ def main():
                           "bwd_tf_7products": round(3.5 * fl / tb / 1e9, 1)}))
     d = (outs[1] - outs[2]).abs().max().item()
     print("max |dqkv gen1 - gen2| =", d, " (scale", outs[1].abs().max().item(), ")")
-    lib.check(L.egotap_debug_attention_gen(2))
+    lib.check(L.egotap_debug_attention_gen(3))
 
 
 if __name__ == "__main__":
