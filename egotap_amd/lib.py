@@ -142,7 +142,15 @@ def load(build_if_missing: bool = True):
     import torch  # noqa: F401
     path = _build.LIB
     if build_if_missing and not os.path.exists(path):
-        path = _build.build()
+        # several ranks of one node may get here together (torch.distributed.run): one builds, the others wait on the lock
+        import fcntl
+        with open(path + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if not os.path.exists(path):
+                    path = _build.build()
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     if not os.path.exists(path):
         raise EgotapError(f"{path} is missing: build it with `python -m egotap_amd.build` (hipcc, gfx950)")
     lib = C.CDLL(path)
