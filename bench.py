@@ -702,6 +702,8 @@ def main():
             train["stage1_heatmap_estimator"] = leg(bench_stage1, args, p, dev, rank, world, barrier)
             if not args.no_fast_mode:
                 train["stage1_heatmap_estimator"]["bf16x3"] = leg(bench_stage1, args, p, dev, rank, world, barrier, mode="bf16x3")
+                # opt.amp_precision_heatmap = "bf16": one bf16 product per multiply on fp32 tensors (bf16-grade gradients: tests/test_gpu_hm_train_step.py)
+                train["stage1_heatmap_estimator"]["bf16"] = leg(bench_stage1, args, p, dev, rank, world, barrier, mode="bf16")
 
     latency = None
     if rank == 0 and world == 1 and not args.lift_only:

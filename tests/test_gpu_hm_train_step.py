@@ -164,6 +164,40 @@ def test_hm_train_bf16x3_mode_tracks_fp32_step():
         assert float((a - b).norm() / b.norm()) < 5e-2 and float(a @ b / (a.norm() * b.norm())) > 0.999, k
 
 
+def test_hm_train_plain_bf16_mode_is_bf16_grade():
+    """opt.amp_precision_heatmap = "bf16" (opt-in; --use_amp alone selects bf16x3 for stage 1): one bf16 product per multiply in the
+    convolutions, fp32 tensors and accumulation.  Forward within 2 % of the exact-fp32 step; gradients bf16-grade on this
+    ill-conditioned random-weight network (train-mode BatchNorm2d over 4 images): measured median relative L2 0.19, worst 0.35, cosine
+    0.94 -- the regime of the lifting head's bf16-storage step, an order of magnitude from bf16x3 (0.017 / 0.9999).
+    The gates are sanity bounds, not a precision claim: a wiring mistake in the mode's routing gives cosine ~0."""
+    from egotap_amd import hm_ops as H
+    outs = {}
+    for mode in ("f32", "bf16"):
+        net, _ = _net("pos")
+        net.train()
+        net.set_precision(mode)
+        left = torch.from_numpy(synth_input("tr_rgbL_pos", (2, 3, 256, 256), -2.0, 2.0)).cuda()
+        right = torch.from_numpy(synth_input("tr_rgbR_pos", (2, 3, 256, 256), -2.0, 2.0)).cuda()
+        gt = torch.from_numpy(synth_input("tr_gt_pos", (2, 30, 64, 64), 0.0, 1.0)).cuda()
+        pred = net(left, right)
+        loss, dpred = H.mse(pred.detach().contiguous(), gt, None, 1.0)
+        pred.backward(dpred)
+        torch.cuda.synchronize()
+        outs[mode] = (pred.detach().clone(), float(loss), {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None})
+    rel = float((outs["bf16"][0] - outs["f32"][0]).norm() / outs["f32"][0].norm())
+    assert 1e-4 < rel < 2e-2, rel
+    np.testing.assert_allclose(outs["bf16"][1], outs["f32"][1], rtol=5e-3)
+    rels, coss = [], []
+    for k, g in outs["f32"][2].items():
+        a, b = outs["bf16"][2][k].double().flatten(), g.double().flatten()
+        if float(b.norm()) < 1e-9:
+            continue
+        rels.append(float((a - b).norm() / b.norm()))
+        coss.append(float(a @ b / (a.norm() * b.norm())))
+    print(f"stage-1 plain bf16 vs fp32: forward relative L2 {rel:.2e}; gradients median relative L2 {np.median(rels):.3f}, worst {max(rels):.3f}, worst cosine {min(coss):.4f}")
+    assert max(rels) < 0.6 and min(coss) > 0.85 and np.median(rels) < 0.3
+
+
 def test_wrapper_stage1_step_b8_against_the_references_float64_step():
     """The better-conditioned pin of the stage-1 step: B = 8 (BatchNorm statistics over 16 images) against ONE optimize_parameters() of
     the reference's own HeatmapSharedModel computed in FLOAT64 (tests/golden/hm_train_step_pos_b8.npz, tools/make_golden.py
