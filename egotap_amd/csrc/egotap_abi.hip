@@ -1047,6 +1047,8 @@ struct HmWs {
 };
 // [r3] every convolution's packed bf16 weights (+ padded bias) and every BatchNorm's folded scale / shift of one estimator, in the order
 // the bf16 forward uses them; p == nullptr: sizes only.  Returns the bytes of the region; fills T (segment table of pack_all_bf16s_kernel).
+// conv_heatmap's GEMM N: 30 / 34 / 60 / 68 heatmap channels padded to the 64- or 128-column tile (256 before: 4-8 x the MFMAs)
+static inline int hm_head_np(int n_out) { return n_out <= 64 ? 64 : n_out <= 128 ? 128 : 256; }
 static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T) {
     size_t o = 0;
     int nw = 0, nb = 0, blk = 0;
@@ -1086,7 +1088,7 @@ static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T) {
     wseg(cv(1, 1).w, nullptr, 512, 1280, 1280, 512, 9);
     wseg(cv(0, 0).w, cv(0, 0).b, 128, 128, 128, 256, 1);
     wseg(cv(1, 0).w, nullptr, 512, 640, 640, 512, 9);
-    wseg(cv(2, 0).w, cv(2, 0).b, p ? p->n_out : 30, 512, 512, 256, 1);
+    wseg(cv(2, 0).w, cv(2, 0).b, p ? p->n_out : 30, 512, 512, p ? hm_head_np(p->n_out) : 256, 1);      // (sizes-only: the largest padding)
     const int blocks_w = blk;
     for (int k = 0; k < nb && k < PackTable::MAXB; ++k) {
         BnSeg bs{};
@@ -1319,8 +1321,12 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
             const PackSeg& sg = PT.w[li++];
             EGO_CHECK(sg.w == p.head.w && li == PT.nw && bi == PT.nb, "egotap_hm_forward: pack plan out of step with the forward");
             GemmTimer t(h, s, "hm.conv_heatmap", "gemm_bf16s_kernel<XPlain,heatmap>", 2.0 * B * p64 * p.n_out * 512);
-            EGO_HIP(gemm_bf16s_launch(XPlain{Y1, 512}, (const __bf16*)(reg + sg.dst_w), 512L,
-                                      SEpiHeatNCHW{(const float*)(reg + sg.dst_b), out, (long)out_image_stride, p.n_out, ilog2(p64)}, (int)(B * p64), 256, 512, cus, s));
+            const SEpiHeatNCHW he{(const float*)(reg + sg.dst_b), out, (long)out_image_stride, p.n_out, ilog2(p64)};
+            const __bf16* hw = (const __bf16*)(reg + sg.dst_w);
+            const int hn = hm_head_np(p.n_out);
+            if (hn == 64) EGO_HIP((gemm_bf16s_launch<XPlain, SEpiHeatNCHW, 1>(XPlain{Y1, 512}, hw, 512L, he, (int)(B * p64), 64, 512, cus, s)));
+            else if (hn == 128) EGO_HIP((gemm_bf16s_launch<XPlain, SEpiHeatNCHW, 2>(XPlain{Y1, 512}, hw, 512L, he, (int)(B * p64), 128, 512, cus, s)));
+            else EGO_HIP(gemm_bf16s_launch(XPlain{Y1, 512}, hw, 512L, he, (int)(B * p64), 256, 512, cus, s));
         }
         return EGOTAP_OK;
     }
