@@ -352,7 +352,7 @@ static hipError_t attention_bf16s_fwd_launch_t(const __bf16* QKV, __bf16* CTX, f
 }
 static hipError_t attention_bf16s2_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream);      // attention_bf16s2.h
 static hipError_t attention_bf16s3_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream);      // attention_bf16s2.h
-static hipError_t attention_bf16s_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream, int gen = 2) {
+static hipError_t attention_bf16s_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream, int gen = 3) {
     if (B <= 0) return hipSuccess;
     if (N % 32 != 0) return hipErrorInvalidValue;
     if (gen == 3) return attention_bf16s3_fwd_launch(QKV, CTX, LSE, B, N, heads, stream);      // 32-key steps, three workgroups per CU

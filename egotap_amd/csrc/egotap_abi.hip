@@ -825,7 +825,11 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
         {
             const int K1 = h->ppd * h->ppd * D;
             prep(p.pos_fc[0].w, Wb, 2048, K1);
-            EGO_HIP(gemm_bf16s_launch(XTokens{Yb, h->T, D, h->seq, h->side, h->ppd, h->grid}, Wb, (long)K1, bnf(p.pos_fc[0], Z1), BT, 2048, K1, cu, s));
+            // [r3] few encoder rows (EgoCap at 128 x 128 heatmaps, B = 32: 1088 rows = 40 tiles for 256 CUs, K = 65536): split K over the chip
+            const XTokens xt{Yb, h->T, D, h->seq, h->side, h->ppd, h->grid};
+            const int sp = gemm_bf16s_ksplit(BT, 2048, K1, cu, SPLITK_FLOATS);
+            if (sp > 1) EGO_HIP(gemm_bf16s_splitk_launch(xt, Wb, (long)K1, bnf(p.pos_fc[0], Z1), SPK, sp, BT, 2048, K1, cu, s));
+            else EGO_HIP(gemm_bf16s_launch(xt, Wb, (long)K1, bnf(p.pos_fc[0], Z1), BT, 2048, K1, cu, s));
             EGO_HIP((fc_gemm(h, "pos_fc2", ALoadPlain{Z1, 2048}, segmat1(p.pos_fc[1].w, 512, 2048), bn(p.pos_fc[1]), Z2, 512, BT, 512, 2048, SPK, s)));
             EGO_HIP((fc_gemm(h, "pos_fc3", ALoadPlain{Z2, 512}, segmat1(p.pos_fc[2].w, hid, 512), bn(p.pos_fc[2]), POSZ, hid, BT, hid, 512, SPK, s)));
         }
@@ -835,7 +839,10 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
             hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, hm, hmb, n8);
             prep(p.rot_fc[0].w, Wb, 2048, 2 * HW);
             EGO_HIP(hipGetLastError());
-            EGO_HIP(gemm_bf16s_launch(XRot{hmb, h->C, J, HW}, Wb, 2L * HW, bnf(p.rot_fc[0], Z1), BT, 2048, 2 * HW, cu, s));
+            const XRot xr{hmb, h->C, J, HW};
+            const int sp = gemm_bf16s_ksplit(BT, 2048, 2 * HW, cu, SPLITK_FLOATS);
+            if (sp > 1) EGO_HIP(gemm_bf16s_splitk_launch(xr, Wb, 2L * HW, bnf(p.rot_fc[0], Z1), SPK, sp, BT, 2048, 2 * HW, cu, s));
+            else EGO_HIP(gemm_bf16s_launch(xr, Wb, 2L * HW, bnf(p.rot_fc[0], Z1), BT, 2048, 2 * HW, cu, s));
             EGO_HIP((fc_gemm(h, "rot_fc2", ALoadPlain{Z1, 2048}, segmat1(p.rot_fc[1].w, 512, 2048), bn(p.rot_fc[1]), Z2, 512, BT, 512, 2048, SPK, s)));
             EGO_HIP((fc_gemm(h, "rot_fc3", ALoadPlain{Z2, 512}, segmat1(p.rot_fc[2].w, hid, 512), bn(p.rot_fc[2]), ROTZ, hid, BT, hid, 512, SPK, s)));
         }

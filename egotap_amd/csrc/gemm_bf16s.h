@@ -159,6 +159,18 @@ struct SEpiF32 {             // out f32 = acc + bias  (fc1: the BatchNorm statis
         *(f32x4*)(out + (long)m * ld + n) = o;
     }
 };
+struct SEpiRawF32 {          // out f32 = acc   (split-K partial sums: slab [M][ksplit * N])
+    static constexpr int W = 4, STORES = 1;
+    float* out;
+    long ld;
+    typedef SNoAux Col;
+    typedef SNoAux Aux;
+    __device__ __forceinline__ Col col(int n) const { return Col{}; }
+    __device__ __forceinline__ Aux fetch(int m, int n) const { return Aux{}; }
+    __device__ __forceinline__ void emit(float* v, const Col&, const Aux&, int m, int n) const {
+        *(f32x4*)(out + (long)m * ld + n) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+};
 struct SEpiGeluSave {        // z = acc + bias -> Z (bf16, kept for the backward); H = GELU(z) (bf16)
     static constexpr int W = 8, STORES = 2;
     const float* bias;
@@ -274,8 +286,12 @@ struct SEpiScatterTokens {
 // part of a stage shrinks to 64 NI rows, a phase to 4 NI MFMAs per wave; ring, barriers and X traffic are unchanged.
 template <class XL, class Epi, int NI = 4>
 __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, const __bf16* __restrict__ Wb, long ldw, Epi epi, int M, int N, int K,
-                                                                       int tiles_m, int tiles_n) {
+                                                                       int tiles_m, int tiles_n_real, int ksplit) {
+    // [r3] ksplit > 1: split-K for few-row GEMMs (fc1 of the encoders below a full chip of tiles).  The launch is the GEMM
+    // [M, ksplit * N] with K = the per-split depth: column tile tnx = (split, tn) reads W rows tn at k offset split * K and X at the
+    // same k offset, and its output columns are tnx * BN .. of a [M][ksplit * N] fp32 slab that splitk_rows_reduce_kernel folds.
     using Cfg = SCfg;
+    const int tiles_n = tiles_n_real * ksplit;
     static_assert(NI == 4 || NI == 2 || NI == 1, "n-tiles per wave");
     constexpr int BM = Cfg::BM, BN = 64 * NI, BK = Cfg::BK, NS = Cfg::NS, ROWB = Cfg::ROWB, PART = Cfg::PART, STAGE = Cfg::STAGE;
     constexpr int NWI = NI == 4 ? 2 : 1;             // W-part DMA instructions per wave and K-tile (NI = 1: waves w and w + 4 fetch the same block)
@@ -315,18 +331,22 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
     typename XL::Row xr0, xr1;
     const __bf16 *pw0, *pw1;
     int lx_tile = 0, lx_kt = 0, lw_tile = 0, lw_kt = 0;       // position of the X / W issue streams (the W stream runs one phase ahead)
+    int xkb = 0;                                               // k offset of the X stream's tile (split * K; 0 without split-K)
     auto set_x = [&](int i) __attribute__((always_inline)) {
         int tm, tn;
         tile_of(i, tm, tn);
         xr0 = xl.row(min(tm * BM + wid * 16 + drow, M - 1));
         xr1 = xl.row(min(tm * BM + (wid + 8) * 16 + drow, M - 1));
+        xkb = ksplit > 1 ? (tn / tiles_n_real) * K : 0;
     };
     auto set_w = [&](int i) __attribute__((always_inline)) {
         int tm, tn;
         tile_of(i, tm, tn);
+        long koff = 0;
+        if (ksplit > 1) { const int sp = tn / tiles_n_real; tn -= sp * tiles_n_real; koff = (long)sp * K; }
         constexpr int WBLK = BN / 16;                // 16-row blocks of the W part
-        pw0 = Wb + (long)(tn * BN + (wid % WBLK) * 16 + drow) * ldw + dchunk * 8;
-        pw1 = NI == 4 ? Wb + (long)(tn * BN + (wid + 8) * 16 + drow) * ldw + dchunk * 8 : pw0;
+        pw0 = Wb + (long)(tn * BN + (wid % WBLK) * 16 + drow) * ldw + koff + dchunk * 8;
+        pw1 = NI == 4 ? Wb + (long)(tn * BN + (wid + 8) * 16 + drow) * ldw + koff + dchunk * 8 : pw0;
     };
     set_x(0);
     set_w(0);
@@ -349,7 +369,7 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
     };
     auto issue_x = [&](int st) __attribute__((always_inline)) {
         const unsigned sa = lds0 + st * STAGE + wid * 1024;
-        const int k0 = lx_kt * BK;
+        const int k0 = lx_kt * BK + xkb;
         dma1(xl.ptr(xr0, k0, dchunk * 8), sa);
         dma1(xl.ptr(xr1, k0, dchunk * 8), sa + 8 * 1024);
         if (lx_tile < my_n && ++lx_kt == KT) {
@@ -561,6 +581,55 @@ static hipError_t gemm_bf16s_launch(const XL& xl, const __bf16* Wb, long ldw, co
     const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / BN;
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < num_cu ? ntiles : num_cu;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xl, Wb, ldw, epi, M, N, K, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xl, Wb, ldw, epi, M, N, K, tiles_m, tiles_n, 1);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------- split-K for few-row GEMMs
+// out = epi(sum over splits of slab[m][split * N + n]) in a fixed order (bitwise reproducible); Epi is one of the W = 4 (fp32 output)
+// epilogues above, used through col() / emit() exactly as the GEMM's own epilogue would
+template <class Epi>
+static __global__ __launch_bounds__(256) void splitk_rows_reduce_kernel(const float* __restrict__ slab, Epi epi, int M, int N, int ksplit) {
+    static_assert(Epi::W == 4, "fp32-output epilogues");
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n4 = N / 4;
+    if (i >= (long)M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+    const float* p = slab + (long)m * N * ksplit + n;
+    f32x4 acc = *(const f32x4*)p;
+    for (int sp = 1; sp < ksplit; ++sp) acc += *(const f32x4*)(p + (long)sp * N);
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    epi.emit(v, epi.col(n), typename Epi::Aux{}, m, n);
+}
+// chooses the split count: enough column tiles to fill the chip, at least 8 K-tiles per split, the slab within slab_floats; 1 = not worth it
+static inline int gemm_bf16s_ksplit(int M, int N, int K, int num_cu, size_t slab_floats) {
+    const int tiles = ((M + SCfg::BM - 1) / SCfg::BM) * (N / 256);
+    if (tiles * 2 > num_cu) return 1;
+    int sp = num_cu / tiles;
+    while (sp > 1 && (K % (sp * SCfg::BK) != 0 || K / sp < 8 * SCfg::BK || (size_t)M * N * sp > slab_floats)) --sp;
+    return sp;
+}
+template <class XL, class Epi>
+static hipError_t gemm_bf16s_splitk_launch(const XL& xl, const __bf16* Wb, long ldw, const Epi& epi, float* slab, int ksplit, int M, int N, int K, int num_cu,
+                                           hipStream_t stream) {
+    using Cfg = SCfg;
+    if (M <= 0) return hipSuccess;
+    if (N % 256 != 0 || ksplit < 2 || K % (ksplit * Cfg::BK) != 0 || ldw % 8 != 0) return hipErrorInvalidValue;
+    auto kern = gemm_bf16s_kernel<XL, SEpiRawF32, 4>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / 256;
+    const int ntiles = tiles_m * tiles_n * ksplit;
+    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xl, Wb, ldw, SEpiRawF32{slab, (long)N * ksplit}, M, N * ksplit, K / ksplit,
+                       tiles_m, tiles_n, ksplit);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long items = (long)M * (N / 4);
+    hipLaunchKernelGGL(splitk_rows_reduce_kernel<Epi>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, (const float*)slab, epi, M, N, ksplit);
     return hipGetLastError();
 }

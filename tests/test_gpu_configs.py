@@ -362,3 +362,26 @@ def test_frozen_estimators_batchnorm_flag_reproduces_the_reference_train_mode(tm
             want = hm_train_forward_nograd(ref.net_HeatMap, m.input_rgb_left.float().contiguous(), m.input_rgb_right.float().contiguous())
             assert torch.equal(cats[True][:, :2 * J], want)
     assert not torch.equal(cats[False], cats[True])
+
+
+def test_bf16_inference_split_k_fc1_equals_the_unsplit_rows():
+    """bf16-storage inference with few encoder rows: fc1 of both encoders (K = 16384 / 8192, N = 2048) splits K over the chip when its
+    row tiles would leave most CUs idle (B = 8: 240 rows = 8 tiles -> 32 splits) and sums the fp32 partial slabs in a fixed order.  Rows
+    are batch independent in eval, so the same frames inside a batch of 256 (240 tiles: no split) must give the same poses up to the
+    fp32 summation order of that one product; run to run bit-identical."""
+    from gpu_util import lift_net
+    net, _, p = lift_net("UnrealEgo")
+    hm = torch.from_numpy(synth_input("hm_splitk", (8, p.in_channels, 64, 64))).cuda()
+    big = hm.repeat(32, 1, 1, 1).contiguous()
+    try:
+        net.set_precision("bf16")
+        small = net.predict_pose(hm).clone()
+        again = net.predict_pose(hm).clone()
+        full = net.predict_pose(big)[:8].clone()
+    finally:
+        net.set_precision("f32")
+    assert torch.equal(small, again)
+    scale = float(full.abs().max())
+    err = float((small - full).abs().max())
+    print(f"split-K fc1 (B = 8) vs unsplit rows (B = 256): max |diff| {err:.3e} at pose scale {scale:.3f}")
+    assert err < 2e-4 * scale
