@@ -604,7 +604,11 @@ static constexpr int SKINNY_ROWS = 1024;       // encoder rows (30 or 34 per fra
 template <class AL, class Epi>
 static hipError_t fc_gemm(Handle* h, const char* role, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc, int M, int N, int K,
                           float* P, hipStream_t s) {
-    if (M >= SKINNY_ROWS || N % 128 != 0 || K % 32 != 0) return gemm<TileA>(h, role, al, W, epi, C, ldc, M, N, K, s);
+    // [r3] bf16 mode only (the fp32 routing, and with it the fp32 bits per batch size, stays as it was): also above the row threshold
+    // while the 128 x 128 tiles fill less than half the chip (EgoCap at 128 x 128 heatmaps, B = 32 / 64: 36 / 68 tiles of fc2)
+    const bool few_tiles = h && h->precision == EGOTAP_PREC_BF16 && 2L * ((M + 127) / 128) * (N / 128) <= device_cu_count() &&
+                           (size_t)M * N * 8 <= SPLITK_FLOATS;
+    if ((M >= SKINNY_ROWS && !few_tiles) || N % 128 != 0 || K % 32 != 0) return gemm<TileA>(h, role, al, W, epi, C, ldc, M, N, K, s);
     static const std::string kname = std::string("gemm_f32_splitk_kernel<128x128x32,") + AlName<AL>::v + ">+splitk_reduce_kernel<" + EpiName<Epi>::v + ">";
     GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
     return gemm_f32_splitk_launch<TileA>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s);
