@@ -1070,7 +1070,7 @@ static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T) {
         sg.dst_w = al((size_t)Np * taps * Cp * 2);
         sg.dst_b = al((size_t)Np * 4);
         sg.first_block = blk;
-        const long items = taps == 9 ? (long)Np * 9 * (Cp / 8) : (long)Np * (Cin / 8);
+        const long items = taps == 9 ? (long)Np * (Cp / 8) : (long)Np * (Cin / 8);       // 3x3: one thread per (co, 8 input channels), all taps
         blk += (int)((items + 255) / 256);
         if (T && nw < PackTable::MAXW) T->w[nw] = sg;
         ++nw;
