@@ -1234,6 +1234,8 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
         hipLaunchKernelGGL(pack_all_bf16s_kernel, dim3(PT.blocks), dim3(256), 0, s, PT, reg);
         EGO_HIP(hipGetLastError());
         int li = 0, bi = 0;
+        float* split_slab = F(w.L0);                                               // the fp32 stem map's slot: unused (fused stem) or dead after the max-pool
+        const size_t split_floats = (size_t)N2 * 64 * (S0 / 2) * (S0 / 2);
         auto up2 = [&](const __bf16* in, __bf16* o, int C, int hin, long ld) {
             const long total = (long)B * 4 * hin * hin * (C / 8);
             hipLaunchKernelGGL(upsample2x_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, o, C, hin, ld, total);
@@ -1286,7 +1288,13 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
             const SEpiBnBf16<false> ep{SC, SH, res, o, c, ilog2(side), relu};
             if (Np == 64 && c == 64) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 1>(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
             if (Np == 128 && c == 128) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 2>(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
-            if (Np == c) return gemm_bf16s_launch(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
+            if (Np == c) {
+                // [r3] few pixels (layer3 / layer4 at small batches: 512 x 512 RGB at B = 32 leaves layer4 128 tiles for 256 CUs): split K,
+                // partial sums in the (by now free) slot of the stem's map, BatchNorm / residual / ReLU in the fixed-order reduce
+                const int sp = gemm_bf16s_ksplit((int)M, Np, taps * cin, cus, split_floats);
+                if (sp > 1) return gemm_bf16s_splitk_launch(xl, WPl, (long)taps * cin, ep, split_slab, sp, (int)M, Np, taps * cin, cus, s);
+                return gemm_bf16s_launch(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
+            }
             return gemm_bf16s_launch(xl, WPl, (long)taps * cin, SEpiBnBf16<true>{SC, SH, res, o, c, ilog2(side), relu}, (int)M, Np, taps * cin, cus, s);
         };
         {

@@ -590,19 +590,25 @@ static hipError_t gemm_bf16s_launch(const XL& xl, const __bf16* Wb, long ldw, co
 // epilogues above, used through col() / emit() exactly as the GEMM's own epilogue would
 template <class Epi>
 static __global__ __launch_bounds__(256) void splitk_rows_reduce_kernel(const float* __restrict__ slab, Epi epi, int M, int N, int ksplit) {
-    static_assert(Epi::W == 4, "fp32-output epilogues");
+    constexpr int W = Epi::W;                     // columns per thread: 4 (fp32 outputs) or 8 (bf16 outputs), as in the GEMM's own epilogue
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int n4 = N / 4;
-    if (i >= (long)M * n4) return;
-    const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+    const int nw = N / W;
+    if (i >= (long)M * nw) return;
+    const int m = (int)(i / nw), n = (int)(i - (long)m * nw) * W;
     const float* p = slab + (long)m * N * ksplit + n;
-    f32x4 acc = *(const f32x4*)p;
-    for (int sp = 1; sp < ksplit; ++sp) acc += *(const f32x4*)(p + (long)sp * N);
-    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    epi.emit(v, epi.col(n), typename Epi::Aux{}, m, n);
+    float v[W];
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) {
+        f32x4 acc = *(const f32x4*)(p + 4 * q);
+        for (int sp = 1; sp < ksplit; ++sp) acc += *(const f32x4*)(p + (long)sp * N + 4 * q);
+        v[4 * q] = acc[0]; v[4 * q + 1] = acc[1]; v[4 * q + 2] = acc[2]; v[4 * q + 3] = acc[3];
+    }
+    const typename Epi::Aux ax = epi.fetch(m, n);
+    epi.emit(v, epi.col(n), ax, m, n);
 }
 // chooses the split count: enough column tiles to fill the chip, at least 8 K-tiles per split, the slab within slab_floats; 1 = not worth it
 static inline int gemm_bf16s_ksplit(int M, int N, int K, int num_cu, size_t slab_floats) {
+    if (N % 256 != 0 || M <= 0) return 1;
     const int tiles = ((M + SCfg::BM - 1) / SCfg::BM) * (N / 256);
     if (tiles * 2 > num_cu) return 1;
     int sp = num_cu / tiles;
@@ -629,7 +635,7 @@ static hipError_t gemm_bf16s_splitk_launch(const XL& xl, const __bf16* Wb, long 
                        tiles_m, tiles_n, ksplit);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const long items = (long)M * (N / 4);
+    const long items = (long)M * (N / Epi::W);
     hipLaunchKernelGGL(splitk_rows_reduce_kernel<Epi>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, (const float*)slab, epi, M, N, ksplit);
     return hipGetLastError();
 }
