@@ -255,3 +255,58 @@ def test_wrapper_stage1_step_b8_against_the_references_float64_step():
     for es, d, k in rows:
         assert es <= 8e-2, (k, es, d)
     assert float(np.median([r[0] for r in rows])) < 1.5e-2
+
+
+def test_wrappers_with_model_name_resnet34(tmp_path):
+    """--model_name resnet34 through create_model (options/base_options.py model_name; net_architecture.py:59-60): the stage-1 wrapper
+    trains (loss falls over a few steps on one batch), save_networks / load_networks round-trip the 218 + alias keys bit-exactly, and the
+    stage-2 wrapper's evaluation forward runs both resnet34 estimators into the head (finite pose; the bf16 mode tracks fp32)."""
+    from egotap_amd import models
+    from egotap_amd.options import preset_defaults
+    from egotap_amd.synthetic import synth_hm_state_dict
+    opt = preset_defaults("UnrealEgo")
+    opt.model, opt.isTrain, opt.num_rot_heatmap, opt.model_name = "heatmap_shared", True, 0, "resnet34"
+    opt.lr, opt.weight_decay, opt.lambda_heatmap = 2e-5, 0.0, 1.0      # (hash-RNG weights are no trained optimum: Adam at 1e-3 blows the first steps up)
+    opt.log_dir, opt.experiment_name = str(tmp_path), "r34"
+    m = models.create_model(opt)
+    assert m.net_HeatMap.blocks == (3, 4, 6, 3)
+    m.net_HeatMap.load_state_dict({k: torch.from_numpy(v) for k, v in synth_hm_state_dict(15, "hm_pos.", "resnet34").items()})
+    B = 4
+    data = {"input_rgb_left": torch.from_numpy(synth_input("r34_l", (B, 3, 256, 256), -2.0, 2.0)),
+            "input_rgb_right": torch.from_numpy(synth_input("r34_r", (B, 3, 256, 256), -2.0, 2.0)),
+            "gt_heatmap_left": torch.from_numpy(synth_input("r34_gl", (B, 15, 64, 64), 0.0, 1.0)),
+            "gt_heatmap_right": torch.from_numpy(synth_input("r34_gr", (B, 15, 64, 64), 0.0, 1.0))}
+    m.set_input(data)
+    losses = []
+    for _ in range(6):
+        m.optimize_parameters()
+        e = m.get_current_errors()
+        losses.append(e["heatmap_left"] + e["heatmap_right"])
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    m.save_networks("latest")
+    before = {k: v.detach().clone() for k, v in m.net_HeatMap.state_dict().items()}
+    m2 = models.create_model(opt)
+    m2.load_networks("latest")
+    after = m2.net_HeatMap.state_dict()
+    assert list(after.keys()) == list(before.keys()) and len(after) > 400
+    for k in before:
+        assert torch.equal(before[k].cpu(), after[k].cpu()), k
+    # stage 2, evaluation forward from RGB with resnet34 estimators
+    opt2 = preset_defaults("UnrealEgo")
+    opt2.model_name, opt2.gpu_ids = "resnet34", [0]
+    mm = models.create_model(opt2)
+    assert mm.net_HeatMap.blocks == (3, 4, 6, 3) and mm.net_RotHeatMap.blocks == (3, 4, 6, 3)
+    mm.net_HeatMap.load_state_dict(m.net_HeatMap.state_dict())
+    mm.set_input({"input_rgb_left": data["input_rgb_left"], "input_rgb_right": data["input_rgb_right"]})
+    mm.set_eval_mode()
+    poses = {}
+    for mode in ("f32", "bf16"):
+        mm.set_precision(mode)
+        with torch.no_grad():
+            mm.forward(evaluate=True)
+        torch.cuda.synchronize()
+        poses[mode] = mm.pred_pose.detach().clone()
+    mm.set_precision("f32")
+    assert torch.isfinite(poses["f32"]).all() and tuple(poses["f32"].shape) == (B, 16, 3)
+    # a sanity bound only: the head and the sin / cos estimator are freshly initialised here (kaiming), not a conditioned network
+    assert float((poses["bf16"] - poses["f32"]).abs().max()) < 0.25 * float(poses["f32"].abs().max())
