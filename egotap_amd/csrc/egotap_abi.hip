@@ -2550,6 +2550,12 @@ extern "C" int egotap_bf16_from_f32(const float* src, void* dst, int64_t n, void
 #endif
 
 #if EGOTAP_IN(3)
+extern "C" int egotap_debug_tn_sync(int on) {
+    g_tn_sync = on ? 1 : 0;
+    return EGOTAP_OK;
+}
+#endif
+#if EGOTAP_IN(3)
 static int g_attn_gen = 3;     // egotap_debug_attention_gen: 3 (default) = 2 with the forward on 32-key steps / three workgroups per CU, 2 = the DMA-staged
                                // kernels of attention_bf16s2.h, 1 = round 2's (A/B timing, tests)
 extern "C" int egotap_debug_attention_gen(int gen) {

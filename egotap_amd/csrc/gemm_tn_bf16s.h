@@ -58,7 +58,7 @@ struct TXRot {               // rows gathered as XRot (fc1 of the rotation encod
 template <class XL>
 __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const __bf16* __restrict__ dY, long ldy, XL xl, const __bf16* __restrict__ zeros,
                                                                             float* __restrict__ slabs, int M, int N, int K, int tiles_n, int splits,
-                                                                            int rows_per) {
+                                                                            int rows_per, int* __restrict__ sync) {
     using Cfg = TnSCfg;
     constexpr int BN = Cfg::BN, BK = Cfg::BK, BKM = Cfg::BKM, ROWB = Cfg::ROWB, PART = Cfg::PART, STAGE = Cfg::STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem_t[];
@@ -93,6 +93,19 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
         }
     }
     const int n0 = tn * BN, k0 = tk * BK;
+    // [r3] The workgroups of one XCD that work on one split stream the same dY / X slabs and share them through that XCD's L2 only
+    // while they stay within ~20 steps of each other (4 MB over 12 slab streams of 16 KB per step).  Nothing kept them there: measured
+    // 1.2 x the algorithmic bytes at 37 k rows, 1.35 x at 147 k, 2.6 x at 590 k (tools/tn_prof.sh).  Every SYNC_STEPS steps wave 0 of each
+    // of them checks in at a counter and waits (bounded: a missing partner costs 60 us, never a hang) until all have; the other waves
+    // wait for it at the phase's barrier as they always do.  sync == nullptr: off.
+    constexpr int SYNC_STEPS = 128;
+    int sync_size = 0, sync_slot = 0;
+    if (sync != nullptr && (gridDim.x & 7) == 0) {
+        const int chunk_sz = gridDim.x >> 3, chunk = bid / chunk_sz;
+        const int lo = max(chunk * chunk_sz, split * tiles), hi = min((chunk + 1) * chunk_sz, (split + 1) * tiles);
+        sync_size = hi - lo;
+        sync_slot = chunk * splits + split;
+    }
     const int m_lo = split * rows_per, m_hi = min(M, m_lo + rows_per);
     const int total = m_hi > m_lo ? (m_hi - m_lo + BKM - 1) / BKM : 0;      // 32-row steps of this split
     float* out = slabs + (long)split * N * K;
@@ -164,6 +177,17 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
         for (int T = 0; T < total; ++T) {
             const char* sa = smem_t + st * STAGE;
             const int st3 = (st + 3) & 3;
+            if (sync_size > 1 && T > 0 && (T & (SYNC_STEPS - 1)) == 0 && wid == 0) {        // wave-uniform
+                if (lane == 0) {
+                    __hip_atomic_fetch_add(sync + sync_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int target = sync_size * (T / SYNC_STEPS);
+                    for (int it = 0; it < 256; ++it) {
+                        if (__hip_atomic_load(sync + sync_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the counter traffic must not sit in the in-order vmcnt count of the DMA waits
+            }
             // ---------------- phase 2T: k half 0 of this wave
             issue_y(st3);
 #pragma unroll
@@ -216,6 +240,11 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
         }
 }
 
+static int g_tn_sync = 1;          // A/B switch (egotap_debug_tn_sync)
+static inline long total_steps_hint(int M, int splits) { return (long)M / splits / TnSCfg::BKM; }
+static __global__ void zero_ints_kernel(int* p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+}
 // dY bf16 [M, N] (row stride ldy), X through xl, zeros: >= 512 bytes of zeros (16-byte aligned), dW fp32 [N, K]
 template <class XL>
 static hipError_t gemm_tn_bf16s_launch(const __bf16* dY, long ldy, const XL& xl, const __bf16* zeros, float* dW, float* slabs, size_t slab_bytes,
@@ -239,8 +268,15 @@ static hipError_t gemm_tn_bf16s_launch(const __bf16* dY, long ldy, const XL& xl,
         if (e != hipSuccess) return e;
         attr_done = true;
     }
+    // check-in counters of the L2-sharing groups (8 XCD chunks x splits) behind the slabs, cleared per launch
+    int* sync = nullptr;
+    const size_t sync_off = ((size_t)splits * N * K * 4 + 255) & ~(size_t)255;
+    if (g_tn_sync && !direct && slabs != nullptr && sync_off + (size_t)8 * splits * 4 <= slab_bytes && (long)total_steps_hint(M, splits) > 256) {
+        sync = (int*)((char*)slabs + sync_off);
+        hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, stream, sync, 8 * splits);
+    }
     hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, dY, ldy, xl, zeros, direct ? dW : slabs, M, N, K,
-                       tiles_n, splits, rows_per);
+                       tiles_n, splits, rows_per, sync);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || direct) return e;
     const long n = (long)N * K;

@@ -41,6 +41,7 @@ _PROTOS = {
     "egotap_pu_chain_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "egotap_debug_pu_drop_workgroups": (C.c_int, [C.c_void_p, C.c_int]),
     "egotap_debug_attention_gen": (C.c_int, [C.c_int]),
+    "egotap_debug_tn_sync": (C.c_int, [C.c_int]),
     "egotap_debug_hm_r2_kernels": (C.c_int, [C.c_int]),
     "egotap_set_weight_scratch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "egotap_set_act_scratch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

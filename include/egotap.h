@@ -128,6 +128,9 @@ int egotap_debug_pu_drop_workgroups(egotap_handle h, int n);
  * per CU; 2 = the same with the 64-key forward; 1 = round 2's register-staged kernels; 32..34 = 3 with 2..4 waves per forward
  * workgroup.  All generations produce the same bits. */
 int egotap_debug_attention_gen(int gen);
+/* Test / measurement hook (process wide): 0 = the bf16 weight-gradient GEMM (csrc/gemm_tn_bf16s.h) without the periodic check-in that keeps
+ * the workgroups sharing operand slabs through one L2 within reach of each other; 1 (default) = with it.  Same bits either way. */
+int egotap_debug_tn_sync(int on);
 /* Test / measurement hook (process wide), a bit mask over the round-3 kernels of the bf16 estimators (egotap_hm_forward under
  * EGOTAP_PREC_BF16); 0 (default) = all of them on.
  *   bit 0: the ResNet stem and the max-pool run as two kernels (fp32-MFMA stem writing bf16 channels-last, then the pool: round 2's form)
