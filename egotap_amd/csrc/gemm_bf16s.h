@@ -259,6 +259,7 @@ struct SEpiGeluGradCS : SEpiGeluGrad {
 template <class E> struct s_epi_colsum { static constexpr bool value = false; };
 template <class E> struct s_epi_stagger { static constexpr bool value = false; };
 template <> struct s_epi_stagger<SEpiResF32> { static constexpr bool value = true; };
+// (the same staggered start on the two GELU epilogues of the training step: 199.3 / 199.8 ms against 199.5 / 199.3 ms per config-3 step, same box: not adopted)
 template <> struct s_epi_colsum<SEpiGeluGradCS> { static constexpr bool value = true; };
 // input gradient of fc1 of the position encoder, scattered back to token order: row (b, i), column (s, c) -> token
 // (b, patch s of heatmap i), channel c.  The gather of XTokens is a bijection onto the non-dummy tokens (dummy rows stay zero:
