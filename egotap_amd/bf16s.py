@@ -67,7 +67,7 @@ def gemm_tn(dy, x, dw, accumulate=False):
     _bf(dy, "dy"); _bf(x, "x")
     M, N = dy.shape
     K = x.shape[1]
-    ws = _scratch.get(max(64 << 20, 4 * N * K * 8), dy.device)
+    ws = _scratch.get(max(64 << 20, 4 * N * K * 8) + 8192, dy.device)      # + the check-in counters behind the slabs
     _lib.check(_lib.load().egotap_bf16_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), M, N, K, int(accumulate), _p(zero_page(dy.device)),
                                                _p(ws), ws.numel(), _s()))
     return dw

@@ -178,14 +178,20 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
             const char* sa = smem_t + st * STAGE;
             const int st3 = (st + 3) & 3;
             if (sync_size > 1 && T > 0 && (T & (SYNC_STEPS - 1)) == 0 && wid == 0) {        // wave-uniform
+                int met = 1;
                 if (lane == 0) {
                     __hip_atomic_fetch_add(sync + sync_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int target = sync_size * (T / SYNC_STEPS);
-                    for (int it = 0; it < 256; ++it) {
-                        if (__hip_atomic_load(sync + sync_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-                        __builtin_amdgcn_s_sleep(8);
+                    met = 0;
+                    for (int it = 0; it < 256 && !met; ++it) {
+                        met = __hip_atomic_load(sync + sync_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+                        if (!met) __builtin_amdgcn_s_sleep(8);
                     }
                 }
+                // a partner that is not resident (other kernels on the device: a collective overlapped with the backward, a shared GPU)
+                // costs this workgroup ONE bounded wait: after a miss it stops checking in (the counter then runs behind for its
+                // partners, which give up the same way)
+                if (!__builtin_amdgcn_readfirstlane(met)) sync_size = 0;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the counter traffic must not sit in the in-order vmcnt count of the DMA waits
             }
             // ---------------- phase 2T: k half 0 of this wave
