@@ -10,12 +10,8 @@
 //   O^T += V_tile^T P^T : four 32(d) x 32(q) MFMA tiles, A operand = V read row-wise from LDS.
 // The MFMA k index is permuted like in gemm_f32.h so Q lives in 64 registers loaded as float4 and
 // each K fragment is one ds_read_b128 (K rows padded to 132 floats: conflict free).
-#pragma once
-#include "common.h"
+// round 2's fp32 attention forward (K and V staged together in 64 registers: 7 VGPRs spilled), kept for A/B builds
 #include <math.h>
-#ifdef EGOTAP_ATTN_F32_OLD      // A/B builds (EGOTAP_CXXFLAGS=-DEGOTAP_ATTN_F32_OLD): round 2's kernel, both operands staged in 64 registers
-#include "../../tools/experiments/attention_f32_r2.h"
-#else
 
 template <int NW>
 struct AttnCfg {
@@ -66,43 +62,36 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // K / V tiles go global -> registers -> LDS in two steps (cdna_hip_programming.md T14), and [r3] the two operands take turns in
-    // ONE set of staging registers: K(t + 1) is requested under tile t's P V MFMAs of the PREVIOUS iteration and written right behind the
-    // barrier that ends tile t's score MFMAs (the last readers of K(t)); V(t + 1) is then requested into the same registers, flies under
-    // the softmax and the P V MFMAs, and is written behind the barrier that ends them.  Still two barriers per tile, half the staging
-    // registers (32 instead of 64): the kernel no longer spills (7 VGPRs before, whose scratch reloads waited -- vmcnt is one in-order
-    // counter -- for the K / V loads in flight).
+    // K / V tiles go global -> registers -> LDS in two steps (cdna_hip_programming.md T14): the NEXT tile's loads are issued right
+    // after this tile's score MFMAs and fly during its softmax and its P V MFMAs; the registers are written to LDS after the barrier
+    // that retires this tile's reads.  Before: both loads of a tile were waited for on the spot, two exposed round trips per tile
+    // with the workgroup's MFMAs idle (MFMA busy 0.77).
     constexpr int PER = KT * (DH / 4) / THREADS;
-    f32x4 stg[PER];
-    auto tile_req = [&](int kt, int vpart) __attribute__((always_inline)) {      // vpart: 0 = K rows, 1 = V rows of key tile kt
-        const float* kp = base + (long)(kt * KT) * ld + D + vpart * D;
+    f32x4 stk[PER], stv[PER];
+    auto tile_load = [&](int kt) __attribute__((always_inline)) {
+        const float* kp = base + (long)(kt * KT) * ld + D;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
-            stg[i] = *(const f32x4*)(kp + (size_t)(unsigned)(row * (int)ld + c4 * 4));
-        }
-    };
-    auto tile_put = [&](int vpart) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
-            if (vpart) *(f32x4*)(Vs + row * DH + c4 * 4) = stg[i];
-            else *(f32x4*)(Ks + row * KLD + c4 * 4) = stg[i];
+            stk[i] = *(const f32x4*)(kp + (size_t)(unsigned)(row * (int)ld + c4 * 4));
+            stv[i] = *(const f32x4*)(kp + D + (size_t)(unsigned)(row * (int)ld + c4 * 4));
         }
     };
     const int ntiles = N / KT;
-    // prologue: K(0) and V(0) into LDS, K(1) into the staging registers
-    tile_req(0, 0);
-    tile_put(0);
-    tile_req(0, 1);
-    tile_put(1);
-    if (ntiles > 1) tile_req(1, 0);
-    __syncthreads();
+    tile_load(0);
     // The running maximum is raised (and the output rescaled) only when a query's scores exceed it by more than 2^RESC in the
     // softmax's base-2 units (T13): probabilities stay below 2^RESC -- harmless in fp32 -- and the 64 multiplies per tile vanish
     // from almost every tile.
     constexpr float RESC = 8.0f;
     for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();   // every wave is done with the previous tile
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
+            *(f32x4*)(Ks + row * KLD + c4 * 4) = stk[i];
+            *(f32x4*)(Vs + row * DH + c4 * 4) = stv[i];
+        }
+        __syncthreads();
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -115,11 +104,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
                 for (int u = 0; u < 4; ++u) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], qreg[4 * t + u], s, 0, 0, 0);
             }
         }
-        __syncthreads();   // A: every wave has read K(kt)
-        if (kt + 1 < ntiles) {
-            tile_put(0);                      // K(kt + 1)
-            tile_req(kt + 1, 1);              // V(kt + 1) flies under the softmax and the P V MFMAs
-        }
+        if (kt + 1 < ntiles) tile_load(kt + 1);
         if (valid) {
             // online softmax; the 32 keys of this tile sit in 16 registers x 2 lane halves
             float mx = s[0];
@@ -152,11 +137,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
                 for (int dt = 0; dt < 4; ++dt)
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[dt * 32], s[r], o[dt], 0, 0, 0);
             }
-        }
-        __syncthreads();   // B: every wave has read V(kt)
-        if (kt + 1 < ntiles) {
-            tile_put(1);                      // V(kt + 1)
-            if (kt + 2 < ntiles) tile_req(kt + 2, 0);      // K(kt + 2) flies under the next tile's score MFMAs
         }
     }
     __syncthreads();   // K/V tiles are dead: reuse the LDS to turn O^T into row-major rows
@@ -199,4 +179,3 @@ static hipError_t attention_f32_launch(const float* QKV, float* CTX, int B, int 
                        qgroups, scale_log2e, LSE);
     return hipGetLastError();
 }
-#endif
