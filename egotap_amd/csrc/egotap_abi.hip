@@ -784,18 +784,28 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     const int S = h->cfg.hm_size, HW = S * S;
     using Tile = TileA;
 
-    // H1+H2: tile -> patch embed -> mask token -> + position embeddings
-    {
-        ALoadPatch al{hm, h->C, S, h->seq, h->side, h->ppd, h->grid, h->T};
-        EpiPatch ep{p.patch_b, p.mask_tok, p.pos_emb, D, h->seq, h->side, h->ppd, h->grid, h->T};
-        EGO_HIP((gemm_small(h, "patch_embed", al, segmat1(p.patch_w, D, 256), ep, X, D, M, D, 256, SPK, s)));
-    }
-    if (h->debug_stop == 1) return EGOTAP_OK;
     // EGOTAP_PREC_BF16 at a batch that fills the chip: bf16 ACTIVATION STORAGE (the same workspace slices hold bf16): LayerNorm, the
     // GEMM epilogues and attention write bf16, every GEMM reads bf16 operands through the LDS DMA (gemm_bf16s.h); weights are rounded
     // into the caller's weight scratch right before each launch (nothing cached: the fp32 parameters stay the source of truth)
     const bool bf16s = h->precision == EGOTAP_PREC_BF16 && D == 1024 && M >= 4096 && h->wscratch != nullptr &&
                        h->wscratch_bytes >= (size_t)2 * 2048 * (size_t)(h->ppd * h->ppd * D);
+    // H1+H2: tile -> patch embed -> mask token -> + position embeddings
+    if (bf16s) {
+        // [r3] on the bf16-storage GEMM: the heatmaps' bf16 copy in the (still free) MLP buffer, by LDS DMA; zeros for the dummy cells in SPK
+        __bf16* hmb0 = (__bf16*)HID;
+        const long n8 = (long)B * h->C * HW / 8;
+        hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, hm, hmb0, n8);
+        hipLaunchKernelGGL(prep_weight_kernel, dim3((256 + 63) / 64, (D + 63) / 64), dim3(256), 0, s, p.patch_w, h->wscratch, (__bf16*)nullptr, D, 256, (long)D);
+        EGO_HIP(zero_fill(SPK, 256, s));
+        const XPatch xl{hmb0, (const __bf16*)SPK, h->C, S, h->seq, h->side, h->ppd, h->grid, h->T};
+        const SEpiPatchF32 ep{p.patch_b, p.mask_tok, p.pos_emb, X, D, h->seq, h->side, h->ppd, h->grid, h->T};
+        EGO_HIP(gemm_bf16s_launch(xl, h->wscratch, 256L, ep, M, D, 256, device_cu_count(), s));
+    } else {
+        ALoadPatch al{hm, h->C, S, h->seq, h->side, h->ppd, h->grid, h->T};
+        EpiPatch ep{p.patch_b, p.mask_tok, p.pos_emb, D, h->seq, h->side, h->ppd, h->grid, h->T};
+        EGO_HIP((gemm_small(h, "patch_embed", al, segmat1(p.patch_w, D, 256), ep, X, D, M, D, 256, SPK, s)));
+    }
+    if (h->debug_stop == 1) return EGOTAP_OK;
     if (bf16s) {
         __bf16 *Yb = (__bf16*)Y, *QKVb = (__bf16*)QKV, *CTXb = (__bf16*)CTX, *HIDb = (__bf16*)HID, *Wb = h->wscratch;
         float* bias3 = SPK;
@@ -2621,6 +2631,20 @@ extern "C" int egotap_bf16_attention_bwd_bias(const void* qkv, const void* ctx, 
 // fc1 of the two heatmap encoders on bf16 operands, the gathers folded into the loaders (net_architecture.py:388-406, 690-694):
 //   which 0: rows = per-heatmap patch tokens gathered from tokens bf16 [B*seq, D];  1: rows = [cos | sin] maps from hm bf16 [B, C, S, S]
 #if EGOTAP_IN(3)
+// [r3] patch embedding of the bf16-storage step on the bf16-storage GEMM: hmb = bf16 copy of the heatmaps [B, C, S, S], w = bf16 copy of
+// projection.weight [D, 256] (egotap_bf16_prep_weight), zeros >= 16 bytes of zeros; x fp32 [B * seq, D] = the embeddings
+// (net_architecture.py:326-336, modeling_vit.py:137-153).  Replaces the fp32-operand kernel of the opt-in modes (VALU conversion per element).
+extern "C" int egotap_bf16_patch_fwd(egotap_handle h, const void* hmb, const void* w, const float* bias, const float* mask_tok, const float* pos,
+                                     const void* zeros, float* x, int B, void* stream) {
+    EGO_CHECK(h && hmb && w && bias && mask_tok && pos && zeros && x && B > 0, "egotap_bf16_patch_fwd: bad argument");
+    const int S = h->cfg.hm_size, D = h->D, M = B * h->seq;
+    const XPatch xl{(const __bf16*)hmb, (const __bf16*)zeros, h->C, S, h->seq, h->side, h->ppd, h->grid, h->T};
+    const SEpiPatchF32 ep{bias, mask_tok, pos, x, D, h->seq, h->side, h->ppd, h->grid, h->T};
+    EGO_HIP(gemm_bf16s_launch(xl, (const __bf16*)w, 256L, ep, M, D, 256, device_cu_count(), (hipStream_t)stream));
+    return EGOTAP_OK;
+}
+#endif
+#if EGOTAP_IN(3)
 extern "C" int egotap_bf16_fc1_fwd(egotap_handle h, int which, const void* src, const void* w, const float* bias, float* z, int B, void* stream) {
     EGO_CHECK(h && src && w && bias && z && (which == 0 || which == 1), "egotap_bf16_fc1_fwd: bad argument");
     const int BT = B * h->T, S = h->cfg.hm_size, K = which == 0 ? h->ppd * h->ppd * h->D : 2 * S * S;
@@ -2850,7 +2874,13 @@ static int lift_forward_train16(Handle* h, const float* hm, int B, float* pose, 
     EGO_RC(egotap_bf16_prep_weight(p.pos_fc[0].w, Hb(t.w_fc1p), Hb(t.w_fc1p_t), 2048, K1, 2048, stream));
     EGO_RC(egotap_bf16_prep_weight(p.rot_fc[0].w, Hb(t.w_fc1r), nullptr, 2048, K1r, 2048, stream));
     EGO_RC(egotap_bf16_from_f32(hm, Hb(t.hmb), (int64_t)B * h->C * h->cfg.hm_size * h->cfg.hm_size, stream));
-    EGO_RC(egotap_train_patch_fwd(h, hm, B, p.patch_w, p.patch_b, p.mask_tok, p.pos_emb, S(t.X[0]), stream));
+    {   // [r3] patch embedding on the bf16-storage GEMM (bf16 heatmaps by LDS DMA); its bf16 weight copy (512 KB) and a page of zeros live in
+        // the step's scratch for the duration of the launch (the weight gradient still reads the fp32 heatmaps: egotap_lift_backward)
+        char* pscr = (char*)ws + w.scr;
+        EGO_HIP(zero_fill(pscr, 256, s));
+        EGO_RC(egotap_bf16_prep_weight(p.patch_w, pscr + 256, nullptr, D, 256, D, stream));
+        EGO_RC(egotap_bf16_patch_fwd(h, Hb(t.hmb), pscr + 256, p.patch_b, p.mask_tok, p.pos_emb, pscr, S(t.X[0]), B, stream));
+    }
     for (int i = 0; i < L; ++i) {
         const auto& P_ = p.layer[i];
         const auto& l = t.layer[i];

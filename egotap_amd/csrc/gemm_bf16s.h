@@ -81,6 +81,27 @@ struct XRot {
     }
 };
 
+// [r3] patch embedding (modeling_vit.py:137-153 over the tiled heatmap image, net_architecture.py:326-336): row (b, token) = the 16 x 16
+// patch of heatmap `cell` the token covers, k = (py, px) -- 8 consecutive k are 8 consecutive pixels of one patch row: one 16-byte piece of
+// the bf16 heatmaps [B, C, S, S].  Dummy cells (cell >= T) read a page of zeros; SEpiPatchF32 puts the mask token there.
+struct XPatch {
+    const __bf16* hm;
+    const __bf16* zero;
+    int C, S, seq, side, ppd, grid, T;
+    struct Row { const __bf16* p; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int b = m / seq, tok = m - b * seq;
+        const int pr = tok / side, pc = tok - pr * side;
+        const int cell = (pr / ppd) * grid + pc / ppd;
+        if (cell >= T) return Row{nullptr};
+        return Row{hm + ((long)(b * C + cell) * S + (pr % ppd) * 16) * S + (pc % ppd) * 16};
+    }
+    __device__ __forceinline__ const __bf16* ptr(const Row& r, int k0, int ko) const {
+        const int k = k0 + ko;
+        return r.p ? r.p + (k >> 4) * S + (k & 15) : zero + ko;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------- epilogues
 // W = elements per lane and call: 4 for fp32 outputs (16 lanes cover a 256-byte row segment), 8 for bf16 outputs (8 lanes cover
 // 128 bytes).  col(n): per-column constants of the lane's W columns (loaded once per tile); fetch(m, n): per-element operands from
@@ -157,6 +178,27 @@ struct SEpiF32 {             // out f32 = acc + bias  (fc1: the BatchNorm statis
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = v[i] + c[i];
         *(f32x4*)(out + (long)m * ld + n) = o;
+    }
+};
+struct SPatch4 { f32x4 b, mt; };
+__device__ __forceinline__ void s_keep(const SPatch4& c) { asm volatile("" ::"v"(c.b), "v"(c.mt)); }
+struct SEpiPatchF32 {        // out f32 = (dummy cell ? mask_token : acc + bias) + position_embeddings[token]   (EpiPatch of gemm_f32.h)
+    static constexpr int W = 4, STORES = 1;
+    const float *bias, *mask_tok, *pos;
+    float* out;
+    int D, seq, side, ppd, grid, T;
+    typedef SPatch4 Col;
+    typedef f32x4 Aux;
+    __device__ __forceinline__ Col col(int n) const { return Col{*(const f32x4*)(bias + n), *(const f32x4*)(mask_tok + n)}; }
+    __device__ __forceinline__ Aux fetch(int m, int n) const { return *(const f32x4*)(pos + (long)(m % seq) * D + n); }
+    __device__ __forceinline__ void emit(float* v, const Col& c, const Aux& pe, int m, int n) const {
+        const int tok = m % seq;
+        const int pr = tok / side, pc = tok - pr * side;
+        const bool dummy = (pr / ppd) * grid + pc / ppd >= T;
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (dummy ? c.mt[i] : v[i] + c.b[i]) + pe[i];
+        *(f32x4*)(out + (long)m * D + n) = o;
     }
 };
 struct SEpiRawF32 {          // out f32 = acc   (split-K partial sums: slab [M][ksplit * N])

@@ -422,9 +422,13 @@ class LiftTrainBf16Fn(torch.autograd.Function):
         hm_b = S.from_f32(hm)                                       # bf16 copy of the input heatmaps: the rotation encoder's fc1 operand
         saved = {"hm": hm, "hm_b": hm_b}
         x = torch.empty((M, D), dtype=torch.float32, device=dev)
-        _lib.check(lib.egotap_train_patch_fwd(h, T._p(hm), B, T._p(P[v + "embeddings.patch_embeddings.projection.weight"]),
-                                              T._p(P[v + "embeddings.patch_embeddings.projection.bias"]), T._p(P[v + "embeddings.mask_token"]),
-                                              T._p(P[v + "embeddings.position_embeddings"]), T._p(x), st()))
+        # patch embedding on the bf16-storage GEMM: bf16 heatmaps, a per-step bf16 copy of the projection weight (as the one-call ABI does)
+        pw = P[v + "embeddings.patch_embeddings.projection.weight"]
+        pwb = torch.empty((D, 256), dtype=torch.bfloat16, device=dev)
+        S.prep_weight(pw.detach().reshape(D, 256), pwb)
+        _lib.check(lib.egotap_bf16_patch_fwd(h, T._p(hm_b), T._p(pwb), T._p(P[v + "embeddings.patch_embeddings.projection.bias"]),
+                                             T._p(P[v + "embeddings.mask_token"]), T._p(P[v + "embeddings.position_embeddings"]),
+                                             T._p(S.zero_page(dev)), T._p(x), B, st()))
         layers = []
         for i in range(p.vit_layers):
             l = f"{v}encoder.layer.{i}."

@@ -346,6 +346,11 @@ int egotap_bf16_attention_bwd_bias(const void* qkv, const void* ctx, const void*
  * 1: rotation encoder, src = the head's input heatmaps as bf16 [B, 6J, S, S]); z fp32 [B*T, 2048] = x w^T + bias.
  * wgrad: dw fp32 [2048, K1] = dz^T x;  dgrad_tokens (position encoder): dtok bf16 [B*seq, D] = scatter(dz wt^T), wt bf16 [K1, 2048] */
 int egotap_bf16_fc1_fwd(egotap_handle h, int which, const void* src, const void* w, const float* bias, float* z, int B, void* stream);
+/* Patch embedding of the position heatmaps on bf16 operands (ViTPatchEmbeddings + mask token + position embeddings over the tiled heatmap
+ * image: net_architecture.py:326-336, modeling_vit.py:137-153): hmb = the head's input heatmaps as bf16 [B, 6J, S, S], w = bf16 copy of
+ * projection.weight [D, 256], zeros >= 16 bytes of zeros (dummy cells); x fp32 [B*seq, D]. */
+int egotap_bf16_patch_fwd(egotap_handle h, const void* hmb, const void* w, const float* bias, const float* mask_tok, const float* pos,
+                          const void* zeros, float* x, int B, void* stream);
 int egotap_bf16_fc1_wgrad(egotap_handle h, int which, const void* dz, const void* src, float* dw, int B, const void* zeros, void* ws, size_t ws_bytes,
                           void* stream);
 int egotap_bf16_fc1_dgrad_tokens(egotap_handle h, const void* dz, const void* wt, void* dtok, int B, void* stream);

@@ -249,3 +249,47 @@ def test_attention_forward_generations_give_the_same_bits(B, N):
     assert torch.isfinite(outs[3][0].float()).all() and torch.isfinite(outs[3][1]).all()
     for gen in (1, 2, 32, 33, 34):
         assert torch.equal(outs[gen][0], outs[3][0]) and torch.equal(outs[gen][1], outs[3][1]), gen
+
+
+@pytest.mark.parametrize("preset,hm,B", [("UnrealEgo", 64, 3), ("EgoCap", 128, 1)])
+def test_patch_embedding_on_the_bf16_storage_gemm(preset, hm, B):
+    """egotap_bf16_patch_fwd: ViTPatchEmbeddings + mask token + position embeddings over the tiled heatmap image (net_architecture.py:326-336,
+    modeling_vit.py:137-153) with the bf16 heatmaps fetched patch row by patch row through the LDS DMA (XPatch) -- against float64
+    arithmetic on the same bf16-rounded heatmaps and weights (oracle.vit_embed's tiling): real cells, dummy cells (mask token), every
+    token of every frame; bit-reproducible."""
+    import ctypes as C
+    from egotap_amd import bf16s, lib, spec
+    from egotap_amd.synthetic import synth_input
+    from gpu_util import lift_net
+    from oracle import lift_ref as O
+    L = lib.load()
+    net, sd_np, p = lift_net(preset, hm)
+    h = net._ensure_handle()
+    D, seq, J = p.vit_dim, p.seq, p.n_joints_hm
+    hm_t = torch.from_numpy(synth_input(f"hm_patch_{hm}", (B, p.in_channels, hm, hm)))
+    v = "pos_heatmap_encoder.vit.embeddings."
+    w = torch.from_numpy(sd_np[v + "patch_embeddings.projection.weight"]).reshape(D, 256)
+    b, mt, pos = (torch.from_numpy(sd_np[v + k]).reshape(-1) for k in ("patch_embeddings.projection.bias", "mask_token", "position_embeddings"))
+    hm_dev = hm_t.cuda()
+    hmb = bf16s.from_f32(hm_dev)
+    wb = torch.empty((D, 256), dtype=torch.bfloat16, device="cuda")
+    wc, bc, mc, pc = w.cuda(), b.cuda(), mt.cuda(), pos.cuda()          # (kept alive: the call takes raw pointers)
+    bf16s.prep_weight(wc, wb)
+    torch.cuda.synchronize()
+    zp = bf16s.zero_page(torch.device("cuda", torch.cuda.current_device()))
+    outs = []
+    for _ in range(2):
+        x = torch.full((B * seq, D), float("nan"), device="cuda")
+        lib.check(L.egotap_bf16_patch_fwd(h, C.c_void_p(hmb.data_ptr()), C.c_void_p(wb.data_ptr()), C.c_void_p(bc.data_ptr()), C.c_void_p(mc.data_ptr()),
+                                          C.c_void_p(pc.data_ptr()), C.c_void_p(zp.data_ptr()), C.c_void_p(x.data_ptr()), B,
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        outs.append(x.clone())
+    assert torch.equal(outs[0], outs[1])
+    rb = lambda t: t.float().bfloat16().double()
+    patches, dummy = O.tile_to_patches(rb(hm_t[:, : 2 * J]), p)
+    emb = patches @ rb(w).T + b.double()
+    emb = torch.where(dummy.view(1, -1, 1), mt.double().view(1, 1, D), emb) + pos.double().view(1, -1, D)[:, -seq:]
+    got = outs[0].double().cpu().view(B, seq, D)
+    err = float((got - emb).abs().max())
+    assert err < 2e-5 * float(emb.abs().max()) + 1e-6, err
