@@ -205,7 +205,8 @@ def test_pu_chain_and_pose_head_backward():
     _close(pose, pose_ref.detach(), 3e-6)
     dposz, dhs1, drotz = torch.empty_like(pc), torch.empty(J * B * H, device="cuda"), torch.empty_like(rc)
     g = {k: torch.zeros_like(net.state_dict()[k]) for k in keys}
-    L.check(lib.egotap_train_pose_head_bwd(h, T._p(pc), T._p(hs1), T._p(dpose.cuda()), B, T._p(dposz), T._p(dhs1),
+    dpose_dev = dpose.cuda()                  # (kept alive: the call takes a raw pointer)
+    L.check(lib.egotap_train_pose_head_bwd(h, T._p(pc), T._p(hs1), T._p(dpose_dev), B, T._p(dposz), T._p(dhs1),
                                            T._p(g["pose_mlp.pose_fcs.0.weight"]), T._p(g["pose_mlp.pose_fcs.0.bias"]),
                                            T._p(g["global_mlp.pose_fcs.0.weight"]), T._p(g["global_mlp.pose_fcs.0.bias"]), 0, st))
     wsb = C.c_size_t()
