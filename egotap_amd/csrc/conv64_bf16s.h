@@ -131,20 +131,34 @@ static __global__ __launch_bounds__(Conv64Cfg::THREADS, 1) void conv64_direct_bf
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         const char* hb = c64_sm + buf * Cfg::HALO_BYTES;
+        // 36 k-steps (tap, c2) in 18 groups of two: the fragment reads of group g + 1 are issued before the MFMAs of group g (one wave per
+        // SIMD: nobody else hides the LDS latency); the scheduling barrier per group keeps the compiler from hoisting the whole tile's reads
+        // above the first MFMA (it then spills the weights)
+        auto frag = [&](int step, int i) __attribute__((always_inline)) {
+            const int tap = step >> 2, c2 = step & 3;
+            return *(const bf16x8*)(hb + (RPW * rg + tap / 3 + i) * (HC * 128) + boff[tap % 3][c2]);
+        };
+        bf16x8 bq[2][2][RPW];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
-            const char* r0 = hb + (RPW * rg + dy) * (HC * 128);
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int c2 = 0; c2 < 4; ++c2) {
-                bf16x8 b[RPW];
+            for (int i = 0; i < RPW; ++i) bq[0][u][i] = frag(u, i);
 #pragma unroll
-                for (int i = 0; i < RPW; ++i) b[i] = *(const bf16x8*)(r0 + i * (HC * 128) + boff[dx][c2]);
+        for (int g = 0; g < 18; ++g) {
+            if (g + 1 < 18) {
 #pragma unroll
-                for (int i = 0; i < RPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap][c2 >> 1][c2 & 1], b[i], acc[i], 0, 0, 0);
-                // keep the scheduler from hoisting every fragment read of the tile above the first MFMA (it then spills the weights)
-                if (c2 & 1) __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) bq[(g + 1) & 1][u][i] = frag(2 * (g + 1) + u, i);
             }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int step = 2 * g + u, tap = step >> 2, c2 = step & 3;
+#pragma unroll
+                for (int i = 0; i < RPW; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap][c2 >> 1][c2 & 1], bq[g & 1][u][i], acc[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- accumulators -> fp32 patch [pixel][64 channels], BatchNorm applied; 16-byte chunk ch of pixel (row, x) at ch ^ (x & 15)
 #pragma unroll
