@@ -2358,11 +2358,14 @@ extern "C" int egotap_hmtrain_conv_wgrad(const float* dy, const float* x, float*
                                          int64_t dy_istride, int64_t x_istride, int accumulate, int precision, void* ws, size_t ws_bytes,
                                          void* stream) {
     EGO_CHECK(dy && x && dw && ws, "egotap_hmtrain_conv_wgrad: null argument");
-    WgArgs a{dy, x, (float*)ws, dy_istride, x_istride, Nimg, Cin, Cout, 0, 0, 1};
+    WgArgs a{dy, x, (float*)ws, dy_istride, x_istride, Nimg, Cin, Cout, 0, 0, 1, 0};
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipErrorInvalidValue;
     if (ks == 3 && stride == 1 && precision != EGOTAP_PREC_F32 && (wout == 64 || wout == 32 || wout == 16))
         e = precision == EGOTAP_PREC_BF16X3 ? wgrad_bf<3>(wout, a, dw, ws_bytes, accumulate, s) : wgrad_bf<1>(wout, a, dw, ws_bytes, accumulate, s);
+    // [r3] at most 64 output channels on 64 x 64 maps (layer1, conv_heatmap): 2 x 2 waves over 64 co x 2 ci groups instead of four waves over 128 co
+    else if (ks == 3 && stride == 1 && wout == 64 && Cout <= 64) e = conv_wgrad_launch<WgCfg<3, 1, 6, 64, 64, 32>>(a, dw, ws_bytes, device_cu_count(), accumulate, s);
+    else if (ks == 1 && stride == 1 && wout == 64 && Cout <= 64) e = conv_wgrad_launch<WgCfg<1, 1, 6, 192, 64, 96>>(a, dw, ws_bytes, device_cu_count(), accumulate, s);
     else if (ks == 3 && stride == 1) e = wgrad_w<3, 1, 32>(wout, a, dw, ws_bytes, accumulate, s);
     else if (ks == 3 && stride == 2) e = wgrad_w<3, 2, 32>(wout, a, dw, ws_bytes, accumulate, s);
     else if (ks == 1 && stride == 1) e = wgrad_w<1, 1, 96>(wout, a, dw, ws_bytes, accumulate, s);
@@ -2391,7 +2394,13 @@ extern "C" int egotap_hmtrain_relu_bwd(const float* y, const float* dy, float* d
 extern "C" int egotap_hmtrain_maxpool_bwd(const float* x, const float* dy, float* dx, int64_t planes, int HIN, void* stream) {
     EGO_CHECK(x && dy && dx && planes > 0 && HIN % 2 == 0, "egotap_hmtrain_maxpool_bwd: bad argument");
     const long total = planes * HIN * HIN;
-    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)planes, HIN);
+    constexpr int RI = 16;
+    const size_t lds = ((size_t)(RI + 3) * HIN + 2 * (size_t)(RI / 2 + 1) * (HIN / 2)) * 4;
+    const long strips = planes * ((HIN + RI - 1) / RI);
+    if (HIN % 4 == 0 && lds <= 60 * 1024 && strips < (1L << 31))
+        hipLaunchKernelGGL(maxpool3s2_bwd_strip_kernel<RI>, dim3((unsigned)strips), dim3(256), lds, (hipStream_t)stream, x, dy, dx, (long)planes, HIN);
+    else
+        hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)planes, HIN);
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;
 }

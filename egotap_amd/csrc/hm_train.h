@@ -16,12 +16,16 @@
 #include "gemm_tn_f32.h"
 
 // ------------------------------------------------------------------------------------------------- weight gradient
-template <int KS_, int STRIDE_, int LOG2W_, int CI_T_, int CO_T_ = 128>
+// [r3] CIW input channels per wave: a block is (CO_T / 32) x (CI_T / CIW) waves, wave (wco, wci) owns 32 output channels x CIW input channels x
+// all taps (CIW = CI_T: the round-2 layout, four waves side by side over 128 output channels; 64-channel layers use 2 x 2 waves over 64 co x 64 ci,
+// so that no wave multiplies rows that do not exist)
+template <int KS_, int STRIDE_, int LOG2W_, int CI_T_, int CO_T_ = 128, int CIW_ = CI_T_>
 struct WgCfg {
-    static constexpr int KS = KS_, TAPS = KS_ * KS_, PAD = (KS_ - 1) / 2, STRIDE = STRIDE_, W = 1 << LOG2W_, CI_T = CI_T_;
-    static constexpr int WIN = W * STRIDE, CO_T = CO_T_, WAVES = CO_T_ / 32, THREADS = 64 * WAVES;   // wave w owns output channels 32w..32w+31
-    static constexpr int NCOL = CI_T * TAPS;                         // product columns of a block: (ci_local, tap)
-    static constexpr int NT = (NCOL + 31) / 32, NT_W = NT;           // 32-column tiles: every wave takes all of them
+    static constexpr int KS = KS_, TAPS = KS_ * KS_, PAD = (KS_ - 1) / 2, STRIDE = STRIDE_, W = 1 << LOG2W_, CI_T = CI_T_, CIW = CIW_;
+    static constexpr int WIN = W * STRIDE, CO_T = CO_T_, WCO = CO_T_ / 32, WCI = CI_T_ / CIW_, WAVES = WCO * WCI, THREADS = 64 * WAVES;
+    static constexpr int NCOL = CIW * TAPS;                          // product columns of a wave: (ci_local, tap)
+    static constexpr int NT = (NCOL + 31) / 32, NT_W = NT;           // 32-column tiles: every wave takes all of its own
+    static_assert(CI_T_ % CIW_ == 0 && CO_T_ % 32 == 0, "wave grid");
     static constexpr int ALD = W + 1;                                // dY row stride in LDS (floats): conflict-free b32
     static constexpr int ROWW = WIN + 2 * PAD + 1, CHS = KS * ROWW;  // staged input row / floats per channel
     static constexpr int A_FLOATS = CO_T * ALD, B_FLOATS = CI_T * CHS;
@@ -36,6 +40,7 @@ struct WgArgs {
     float* slabs;         // [splits][Cout][Cin * TAPS]
     long dy_istride, x_istride;
     int Nimg, Cin, Cout, tiles_co, tiles_ci, splits;
+    int per;              // [r3] slabs (output rows of an image) per split: the split unit is the row, not the image
 };
 
 template <class Cfg>
@@ -43,14 +48,15 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgArgs a) {
     constexpr int KS = Cfg::KS, TAPS = Cfg::TAPS, PAD = Cfg::PAD, STRIDE = Cfg::STRIDE, W = Cfg::W, WIN = Cfg::WIN;
     constexpr int CI_T = Cfg::CI_T, CO_T = Cfg::CO_T, THREADS = Cfg::THREADS, NCOL = Cfg::NCOL, NT_W = Cfg::NT_W;
     constexpr int ALD = Cfg::ALD, ROWW = Cfg::ROWW, CHS = Cfg::CHS, A_FLOATS = Cfg::A_FLOATS, STAGE = Cfg::A_FLOATS + Cfg::B_FLOATS;
+    constexpr int CIW = Cfg::CIW, WCO = Cfg::WCO;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int wco = wid % WCO, wci = wid / WCO;
     const int split = blockIdx.x % a.splits, tile = blockIdx.x / a.splits;
     const int tco = tile % a.tiles_co, tci = tile / a.tiles_co;
     const int co0 = tco * CO_T, ci0 = tci * CI_T;
-    const int per = (a.Nimg + a.splits - 1) / a.splits;
-    const int n_lo = split * per, n_hi = min(a.Nimg, n_lo + per);
-    const int nslab = max(0, n_hi - n_lo) * W;            // one slab = one output row of one image
+    const int s_lo = split * a.per, s_hi = min(a.Nimg * W, s_lo + a.per);
+    const int nslab = max(0, s_hi - s_lo);                // one slab = one output row of one image
 
     // zero both input stages once: the x halo columns are never written again
     for (int i = tid; i < Cfg::B_FLOATS; i += THREADS) {
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgArgs a) {
     constexpr int A_IT = (A_V4 + THREADS - 1) / THREADS, B_IT = (B_V4 + THREADS - 1) / THREADS;
     f32x4 pa[A_IT], pb[B_IT];
     auto gload = [&](int s) __attribute__((always_inline)) {
-        const int n = n_lo + s / W, y = s - (s / W) * W;
+        const int n = (s_lo + s) / W, y = (s_lo + s) - n * W;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int idx = tid + it * THREADS, row = idx / (W / 4), c4 = idx - row * (W / 4);
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgArgs a) {
         const int ncol = t * 32 + l31;
         bok[t] = ncol < NCOL;
         const int cl = min(ncol, NCOL - 1) / TAPS, tap = min(ncol, NCOL - 1) - cl * TAPS;
-        boff[t] = cl * CHS + (tap / KS) * ROWW + (tap % KS) + lh * STRIDE;
+        boff[t] = (wci * CIW + cl) * CHS + (tap / KS) * ROWW + (tap % KS) + lh * STRIDE;
     }
     f32x16 acc[NT_W];
 #pragma unroll
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgArgs a) {
     for (int s = 0; s < nslab; ++s) {
         const int buf = s & 1;
         if (s + 1 < nslab) gload(s + 1);
-        const float* As = wsm + buf * STAGE + (wid * 32 + l31) * ALD + lh;
+        const float* As = wsm + buf * STAGE + (wco * 32 + l31) * ALD + lh;
         const float* Bs = wsm + buf * STAGE + A_FLOATS;
 #pragma unroll 4
         for (int x0 = 0; x0 < W; x0 += 2) {                 // MFMA k = 2 pixels: lane half h takes pixel x0 + h
@@ -140,15 +146,41 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int t = 0; t < NT_W; ++t) {
         const int ncol = t * 32 + l31;
-        const int cl = ncol / TAPS;
+        const int cl = wci * CIW + ncol / TAPS;
         if (ncol >= NCOL || ci0 + cl >= a.Cin) continue;
-        const long col = (long)ci0 * TAPS + ncol;
+        const long col = (long)(ci0 + wci * CIW) * TAPS + ncol;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (co < a.Cout) out[(long)co * ldw + col] = acc[t][r];
         }
     }
+}
+
+// [r3] How many splits: workgroups go to the CUs round-robin, so a launch takes ceil(tiles * S / CUs) workgroups in a row on the busiest CU, each
+// ceil(slabs / S) slabs long plus a fixed part (LDS zeroing, first loads, the slab store), and the reduction reads S slabs afterwards.  Round 2
+// took S = 2 CUs / tiles over whole images: 560 workgroups of 5 images on 256 CUs for conv_up1 (three rounds for 2.2 rounds of work), 128
+// workgroups for the 64-channel layers (half the chip idle).  Times in microseconds; only their ratios matter.
+// Two workgroups fit on a CU where the LDS allows (the registers never allow more): they share the matrix pipe, and one's staging and barriers
+// hide under the other's MFMAs.
+static int wgrad_pick_splits(int tiles, long slabs, long n_floats, size_t slab_bytes, int num_cu, int lds_bytes, double slab_us, double fixed_us, int* per_out) {
+    const int wpc = 2 * lds_bytes <= 160 * 1024 ? 2 : 1;
+    long max_s = (long)(slab_bytes / ((size_t)n_floats * 4));
+    if (max_s < 1) return 0;
+    if (max_s > slabs) max_s = slabs;
+    if (max_s > 4096) max_s = 4096;
+    double best = 1e30;
+    int best_s = 1;
+    for (long s = 1; s <= max_s; ++s) {
+        const long per = (slabs + s - 1) / s, s_eff = (slabs + per - 1) / per;
+        if (s_eff != s) continue;                           // the same launch as a smaller S
+        const long in_a_row = ((long)tiles * s + num_cu - 1) / num_cu;
+        const double alone_us = wpc == 2 && in_a_row >= 2 ? 0.0 : 0.25;      // a slab's barrier and LDS stores, exposed when nobody shares the CU
+        const double t = in_a_row * per * (slab_us + alone_us) + (in_a_row + wpc - 1) / wpc * fixed_us + (double)s * n_floats * 4.0 / 3.0e6 + 0.02 * s;
+        if (t < best * 0.995) { best = t; best_s = (int)s; }
+    }
+    *per_out = (int)((slabs + best_s - 1) / best_s);
+    return best_s;
 }
 
 template <class Cfg>
@@ -158,11 +190,9 @@ static hipError_t conv_wgrad_launch(WgArgs a, float* dw, size_t slab_bytes, int 
     a.tiles_ci = (a.Cin + Cfg::CI_T - 1) / Cfg::CI_T;
     const int tiles = a.tiles_co * a.tiles_ci;
     const long n = (long)a.Cout * a.Cin * Cfg::TAPS;
-    int splits = (2 * num_cu + tiles - 1) / tiles;          // ~2 blocks of 4 waves per CU where the LDS allows
-    if (splits > a.Nimg) splits = a.Nimg;
-    if (splits < 1) splits = 1;
-    while ((size_t)splits * n * 4 > slab_bytes && splits > 1) --splits;
-    if ((size_t)splits * n * 4 > slab_bytes) return hipErrorOutOfMemory;
+    // a slab of a wave: W / 2 k-steps x NT MFMAs of 64 cycles
+    const int splits = wgrad_pick_splits(tiles, (long)a.Nimg * Cfg::W, n, slab_bytes, num_cu, Cfg::LDS_BYTES, Cfg::W / 2 * Cfg::NT * 64 / 2400.0, 4.0, &a.per);
+    if (splits < 1) return hipErrorOutOfMemory;
     a.splits = splits;
     auto kern = conv_wgrad_kernel<Cfg>;
     static bool attr_done = false;
@@ -383,6 +413,59 @@ static __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float*
     dX[i] = acc;
 }
 
+// [r3] strip form of the same: a workgroup owns RI input rows of one plane.  It stages rows y0 - 1 .. y0 + RI + 1 in LDS, finds the first
+// maximum of each of the (RI / 2 + 1) x HO windows that touch its rows ONCE (position and dy kept in LDS), and every input pixel then looks
+// at its (up to four) windows.  Same scan order and same order of the sum as the per-pixel kernel above (which recomputes four 3 x 3
+// scans per pixel from global memory: 1.33 ms for the 64 x 64 x 128^2 planes of a 32-frame step, against 0.6 GB of traffic).
+template <int RI>
+static __global__ __launch_bounds__(256) void maxpool3s2_bwd_strip_kernel(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ dX,
+                                                                          long planes, int HIN) {
+    extern __shared__ __attribute__((aligned(16))) float mp_sm[];
+    const int HO = HIN / 2, strips = (HIN + RI - 1) / RI, tid = threadIdx.x;
+    const long pl = blockIdx.x / strips;
+    const int y0 = (int)(blockIdx.x % strips) * RI, oy0 = y0 / 2;
+    float* xs = mp_sm;                                          // [RI + 3][HIN]: row r = input row y0 - 1 + r
+    int* wpos = (int*)(xs + (RI + 3) * HIN);                    // [RI / 2 + 1][HO]: yy * HIN + xx of the window's first maximum
+    float* wdy = (float*)(wpos + (RI / 2 + 1) * HO);
+    const float* xp = X + pl * HIN * HIN;
+    const float* gp = dY + pl * HO * HO;
+    for (int i = tid * 4; i < (RI + 3) * HIN; i += 1024) {
+        const int r = i / HIN, c = i - r * HIN, yy = y0 - 1 + r;
+        if (yy >= 0 && yy < HIN) *(f32x4*)(xs + i) = *(const f32x4*)(xp + (long)yy * HIN + c);
+    }
+    __syncthreads();
+    for (int w = tid; w < (RI / 2 + 1) * HO; w += 256) {
+        const int oyl = w / HO, ox = w - oyl * HO, oy = oy0 + oyl;
+        int pos = -1;
+        float g = 0.f;
+        if (oy < HO) {
+            float m = -INFINITY;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = 2 * oy + dy, xx = 2 * ox + dx;
+                    if (yy < 0 || yy >= HIN || xx < 0 || xx >= HIN) continue;
+                    const float v = xs[(yy - y0 + 1) * HIN + xx];
+                    if (v > m) { m = v; pos = yy * HIN + xx; }
+                }
+            g = gp[(long)oy * HO + ox];
+        }
+        wpos[w] = pos;
+        wdy[w] = g;
+    }
+    __syncthreads();
+    for (int i = tid; i < RI * HIN; i += 256) {
+        const int yl = i / HIN, x = i - yl * HIN, y = y0 + yl;
+        if (y >= HIN) break;
+        float acc = 0.f;
+        for (int oy = y / 2; oy <= min(HO - 1, (y + 1) / 2); ++oy)
+            for (int ox = x / 2; ox <= min(HO - 1, (x + 1) / 2); ++ox) {
+                const int w = (oy - oy0) * HO + ox;
+                if (wpos[w] == y * HIN + x) acc += wdy[w];
+            }
+        dX[pl * HIN * HIN + (long)y * HIN + x] = acc;
+    }
+}
+
 // adjoint of nn.Upsample(scale 2, bilinear, align_corners=True): gather form, one thread per INPUT pixel
 static __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dY, float* __restrict__ dX, int N, int C, int HIN,
                                                              long dy_istride, long dx_istride) {
@@ -485,13 +568,12 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_bf16_kernel(WgArgs a)
     const int split = blockIdx.x % a.splits, tile = blockIdx.x / a.splits;
     const int tco = tile % a.tiles_co, tci = tile / a.tiles_co;
     const int co0 = tco * CO_T, ci0 = tci * CI_T;
-    const int per = (a.Nimg + a.splits - 1) / a.splits;
-    const int n_lo = split * per, n_hi = min(a.Nimg, n_lo + per);
-    const int nslab = max(0, n_hi - n_lo) * W;
+    const int s_lo = split * a.per, s_hi = min(a.Nimg * W, s_lo + a.per);
+    const int nslab = max(0, s_hi - s_lo);
 
     f32x4 pa[A_IT][2], pb[B_IT][2];
     auto gload = [&](int s) __attribute__((always_inline)) {
-        const int n = n_lo + s / W, y = s - (s / W) * W;
+        const int n = (s_lo + s) / W, y = (s_lo + s) - n * W;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int idx = tid + it * THREADS, row = idx / CPR, ch = idx - row * CPR;
@@ -630,11 +712,10 @@ static hipError_t conv_wgrad_bf16_launch(WgArgs a, float* dw, size_t slab_bytes,
     a.tiles_ci = (a.Cin + Cfg::CI_T - 1) / Cfg::CI_T;
     const int tiles = a.tiles_co * a.tiles_ci;
     const long n = (long)a.Cout * a.Cin * 9;
-    int splits = (num_cu + tiles - 1) / tiles;
-    if (splits > a.Nimg) splits = a.Nimg;
-    if (splits < 1) splits = 1;
-    while ((size_t)splits * n * 4 > slab_bytes && splits > 1) --splits;
-    if ((size_t)splits * n * 4 > slab_bytes) return hipErrorOutOfMemory;
+    // a slab: W / 16 k-steps x NT tiles x NP MFMAs of 32 cycles per wave, or the staging of (128 + 48) fp32 rows through L2 -- whichever is longer
+    const double mfma_us = Cfg::W / 16 * Cfg::NT * Cfg::NP * 32 / 2400.0, stage_us = (Cfg::CO_T + 3 * Cfg::CI_T) * Cfg::W * 4 / 24.0e3;
+    const int splits = wgrad_pick_splits(tiles, (long)a.Nimg * Cfg::W, n, slab_bytes, num_cu, Cfg::LDS_BYTES, mfma_us > stage_us ? mfma_us : stage_us, 4.0, &a.per);
+    if (splits < 1) return hipErrorOutOfMemory;
     a.splits = splits;
     auto kern = conv_wgrad_bf16_kernel<Cfg>;
     static bool attr_done = false;

@@ -43,6 +43,21 @@ def _param_items(net):
     return [(k, p) for k, p in net.named_parameters()]
 
 
+def _grad_arena(net, P):
+    """views of the estimator's flat gradient arena, one per trainable tensor in named_parameters() order (allocated once per module and device)"""
+    dev = next(iter(P.values())).device
+    ga = getattr(net, "_hm_grad_arena", None)
+    sig = tuple((k, v.numel()) for k, v in P.items())
+    if ga is None or ga["flat"].device != dev or ga["sig"] != sig:
+        offs, o = {}, 0
+        for k, v in P.items():
+            offs[k] = o
+            o += (v.numel() + 63) // 64 * 64                  # 256-byte aligned slices
+        ga = dict(flat=torch.empty(o, dtype=torch.float32, device=dev), offs=offs, sig=sig)
+        net._hm_grad_arena = ga
+    return {k: ga["flat"][ga["offs"][k]: ga["offs"][k] + v.numel()].view(v.shape) for k, v in P.items()}
+
+
 class HmTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, left, right, *params):
@@ -125,12 +140,18 @@ class HmTrainFn(torch.autograd.Function):
         B = sv["B"]
         N2 = 2 * B
         dev = dout.device
+        # [r3] the gradients are views of ONE flat arena kept on the module and handed to the parameters directly (.grad), as the lifting head's
+        # backward does: autograd's accumulation copies every tensor it cannot steal, and the optimizer updates a group whose gradients share an
+        # allocation in one launch (EgotapAdamW / egotap_train_adamw_multi) instead of 76 launches.
+        from .training import _held_grads, _publish_grads
+        GA = _grad_arena(net, P)
+        held = _held_grads(P, GA)
         G = {}
         dout = dout.detach().float().contiguous()
 
         def grad_of(key):
             if key not in G:
-                G[key] = torch.empty_like(P[key])
+                G[key] = GA[key]
             return G[key]
 
         def bias_conv_bwd(name, dy_view, x_view, taps, want_dx=True, dx=None):
@@ -224,7 +245,8 @@ class HmTrainFn(torch.autograd.Function):
             _bn_bwd(sv["z0"], sv["l0"], dl0, P, BB + "bn1", sv["m0"], dz0, grad_of, B)
             H.conv_wgrad(dz0, sv["x0"], grad_of(BB + "conv1.weight"), ks=7, stride=2)
         ctx.sv = None
-        return (None, None, None) + tuple(G.get(k) for k in keys)
+        _publish_grads({k: P[k] for k in G}, GA, held)
+        return (None, None, None) + (None,) * len(keys)
 
 
 def hm_train_forward(net, left, right):
