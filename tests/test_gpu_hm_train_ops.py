@@ -32,6 +32,9 @@ CONVS = [  # (ks, stride, Cin, Cout, Wout, N)
     (3, 2, 64, 128, 32, 2), (3, 2, 128, 256, 16, 3), (3, 2, 256, 512, 8, 2),
     (1, 1, 128, 128, 64, 2), (1, 1, 256, 260, 32, 2), (1, 1, 512, 516, 16, 3), (1, 1, 1024, 1024, 8, 2),
     (1, 2, 64, 128, 32, 2), (1, 2, 128, 256, 16, 2), (1, 2, 256, 512, 8, 2),
+    # [r3] the 2 x 2 wave layout of the layers with at most 64 output channels (ragged on both sides), odd image counts for the row splits,
+    # the stem
+    (3, 1, 70, 50, 64, 3), (1, 1, 512, 30, 64, 3), (1, 1, 100, 64, 64, 1), (3, 1, 640, 512, 64, 1), (7, 2, 3, 64, 128, 3),
 ]
 
 
@@ -55,6 +58,8 @@ def test_conv_wgrad_and_dgrad(ks, stride, Cin, Cout, W, N):
     again = torch.empty_like(dw)
     H.conv_wgrad(dy.cuda(), x.cuda(), again, ks=ks, stride=stride)
     assert torch.equal(first, again)
+    if ks == 7:
+        return                                     # the stem has no input gradient (the images are data)
     dx = torch.full((N, Cin, W * stride, W * stride), 7.0, device="cuda")
     H.conv_dgrad(h, dy.cuda(), w.cuda(), dx, taps=ks * ks, stride=stride)
     _close(dx, xr.grad, atol=2e-4 * float(xr.grad.abs().mean()) + 1e-5, msg="dx")
@@ -119,6 +124,17 @@ def test_pointwise_backward_ops():
     dx = torch.empty_like(x, device="cuda")
     H.maxpool_bwd(x.cuda(), dy.cuda(), dx)
     _close(dx, xr.grad, 1e-6)
+    # [r3] strip kernel: a last strip that is not full (24 rows = 16 + 8), the training size (128) and one plane row per strip element
+    for side, seed in ((24, 5), (128, 6), (8, 7)):
+        x = _rand((3, 5, side, side), seed)
+        x[1, 2, 2:7, 1:6] = 0.25
+        xr = x.double().requires_grad_(True)
+        dy = _rand((3, 5, side // 2, side // 2), seed + 10)
+        F.max_pool2d(xr, 3, 2, 1).backward(dy.double())
+        dx = torch.full_like(x, 9.0, device="cuda")
+        H.maxpool_bwd(x.cuda(), dy.cuda(), dx)
+        torch.cuda.synchronize()
+        _close(dx, xr.grad, 1e-6, msg=f"maxpool backward, side {side}")
     # bilinear x2 upsample, align_corners=True, into / out of channel slices of wider buffers
     src = _rand((3, 6, 8, 8), 3).double().requires_grad_(True)
     dup = _rand((3, 10, 16, 16), 4)
