@@ -2229,6 +2229,28 @@ extern "C" int egotap_hmtrain_conv_fwd(egotap_handle h, const float* x, const fl
 }
 #endif
 
+// [r3] Eval-mode building blocks for the backbones the one-call forward does not cover (the Bottleneck ResNets of --model_name resnet50 /
+// resnet101, net_architecture.py:61-64): y = [relu](BatchNorm_eval(conv(x, w)) [+ res]) on the fp32 convolution kernels, BatchNorm folded
+// in the epilogue exactly as egotap_hm_forward folds it (gamma / sqrt(var + 1e-5)), and the stem with its BatchNorm + ReLU.
+#if EGOTAP_IN(2)
+extern "C" int egotap_hm_conv_bn_fwd(egotap_handle h, const float* x, const float* w, const float* gamma, const float* beta, const float* mean,
+                                     const float* var, const float* res, float* y, int Nimg, int Cin, int Cout, int wout, int taps, int stride,
+                                     int relu, int64_t in_istride, int64_t out_istride, int64_t res_istride, void* stream) {
+    EGO_CHECK(h && x && w && gamma && beta && mean && var && y, "egotap_hm_conv_bn_fwd: null argument");
+    ConvArgs a{x, w, y, res, gamma, beta, mean, var, nullptr, in_istride, out_istride, res_istride, Nimg, Cin, Cout, relu, 0, 0};
+    hipError_t e = conv_any(h, "hm.conv_bn", taps, stride, wout, a, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) { egotap_set_error("egotap_hm_conv_bn_fwd: unsupported conv taps=%d stride=%d wout=%d Cin=%d Cout=%d", taps, stride, wout, Cin, Cout); return EGOTAP_ERR_INVALID; }
+    EGO_HIP(e);
+    return EGOTAP_OK;
+}
+extern "C" int egotap_hm_stem_bn_fwd(const float* left, const float* right, const float* w, const float* gamma, const float* beta, const float* mean,
+                                     const float* var, float* y, int B, int S0, void* stream) {
+    EGO_CHECK(left && right && w && gamma && beta && mean && var && y && B > 0 && S0 % 32 == 0, "egotap_hm_stem_bn_fwd: bad argument");
+    EGO_HIP(stem_conv7_launch(left, right, w, gamma, beta, mean, var, y, S0, 2 * B, device_cu_count(), (hipStream_t)stream));
+    return EGOTAP_OK;
+}
+#endif
+
 // conv 7x7 / 2 of the ResNet stem without BatchNorm: z [2B, 64, S0/2, S0/2], image n = 2b + eye
 #if EGOTAP_IN(2)
 extern "C" int egotap_hmtrain_stem_fwd(const float* left, const float* right, const float* w, float* z, int B, int S0, void* stream) {

@@ -61,6 +61,23 @@ def conv_fwd(h, x, w, y, bias=None, res=None, taps=9, stride=1, relu=False):
                                                    stride, int(relu), x.istride, y.istride, res.istride if res is not None else 0, _s()))
 
 
+def conv_bn_fwd(h, x, w, bn, y, res=None, taps=9, stride=1, relu=True):
+    """y = [relu](BatchNorm_eval(conv(x, w)) [+ res]); bn = (gamma, beta, running_mean, running_var); x, y, res Views"""
+    x, y = V(x), V(y)
+    res = V(res) if res is not None else None
+    Cout, Cin = w.shape[0], w.shape[1]
+    assert x.C == Cin and y.C == Cout and y.N == x.N and y.W * stride == x.W
+    _lib.check(_lib.load().egotap_hm_conv_bn_fwd(h, x.ptr, _p(w), _p(bn[0]), _p(bn[1]), _p(bn[2]), _p(bn[3]), res.ptr if res is not None else None, y.ptr,
+                                                 x.N, Cin, Cout, y.W, taps, stride, int(relu), x.istride, y.istride,
+                                                 res.istride if res is not None else 0, _s()))
+
+
+def stem_bn_fwd(left, right, w, bn, y):
+    """y [2B, 64, S0/2, S0/2] = relu(BatchNorm_eval(conv7x7/2(image n = 2b + eye)))"""
+    _lib.check(_lib.load().egotap_hm_stem_bn_fwd(_p(left), _p(right), _p(w), _p(bn[0]), _p(bn[1]), _p(bn[2]), _p(bn[3]), _p(y), left.shape[0],
+                                                 left.shape[2], _s()))
+
+
 def conv_dgrad(h, dy, w, dx, taps=9, stride=1, accumulate=False):
     """dx (+)= d/dx of conv(x, w): the forward kernels on flipped / channel-swapped weights (stride 2: dY spread over the even pixels)"""
     dy, dx = V(dy), V(dx)

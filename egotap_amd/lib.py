@@ -112,6 +112,8 @@ _PROTOS = {
                                       C.c_void_p, C.c_int, C.c_void_p]),
     # ---- heatmap-estimator training operators
     "egotap_hmtrain_conv_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_int64] * 3 + [C.c_void_p]),
+    "egotap_hm_conv_bn_fwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 7 + [C.c_int64] * 3 + [C.c_void_p]),
+    "egotap_hm_stem_bn_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p]),
     "egotap_hmtrain_set_pack_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "egotap_hmtrain_pack_bytes": (C.c_size_t, []),
     "egotap_hmtrain_stem_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),

@@ -136,7 +136,7 @@ class EgoTAPAutoEncoderModel(nn.Module):
                 # eval-mode estimators treat frames independently: walk a large batch in chunks so that the U-Net scratch stays at
                 # the chunk's size (B = 1024 from RGB, BASELINE config 3); one scratch shared by both estimators
                 chunk = min(B, int(getattr(self.opt, "hm_chunk", 256)))
-                ws = self.net_HeatMap._workspace(chunk, left.device)
+                ws = None if self.net_HeatMap.bottleneck else self.net_HeatMap._workspace(chunk, left.device)   # (Bottleneck nets allocate per call)
                 for lo in range(0, B, chunk):
                     hi = min(B, lo + chunk)
                     self.net_HeatMap.forward_into(left[lo:hi], right[lo:hi], cat[lo:hi], 0, workspace=ws)
@@ -187,6 +187,8 @@ class EgoTAPAutoEncoderModel(nn.Module):
             # autocast spans the frozen estimators' forward too (egotap_autoencoder_model.py:219).  The requested mode is set
             # explicitly: whatever a caller (or evaluate()) left on the networks, the step runs in opt.amp_precision.
             for n in (self.net_AutoEncoder, self.net_HeatMap, self.net_RotHeatMap):
+                if getattr(n, "bottleneck", False):
+                    continue                                     # resnet50 / resnet101 estimators run in fp32 only (frozen here anyway)
                 if getattr(n, "precision", "f32") != self.amp_precision:
                     n.set_precision(self.amp_precision)
         for o in self.optimizers:
@@ -201,6 +203,8 @@ class EgoTAPAutoEncoderModel(nn.Module):
     def set_precision(self, mode: str = "f32"):
         """f32 (default) | bf16x3 | bf16 for the three networks (the reference's analogous switch is --use_amp)"""
         for n in (self.net_HeatMap, self.net_RotHeatMap, self.net_AutoEncoder):
+            if getattr(n, "bottleneck", False) and mode != "f32":
+                continue                                         # resnet50 / resnet101 estimators: fp32 only
             n.set_precision(mode)
         return self
 
@@ -318,6 +322,9 @@ class HeatmapSharedModel(nn.Module):
         self.visual_names, self.visual_pose_names = ["input_rgb_left", "input_rgb_right"], []
         self.eval_key, self.cm2mm = "mse_heatmap", 10
         self.net_HeatMap = networks.HeatMap_UnrealEgo_Shared(opt, getattr(opt, "model_name", "resnet18"), 2)
+        if self.isTrain and self.net_HeatMap.bottleneck:
+            raise NotImplementedError(f"stage-1 training of a {self.net_HeatMap.model_name} estimator is not built (resnet18 / resnet34 are); "
+                                      "its checkpoints load and run in evaluation and as frozen estimators of stage 2")
         self.optimizers, self.schedulers = [], []
         self.to(self.device)
         # --use_amp (heatmap_shared_model.py:17, 99, 111: fp16 autocast + GradScaler): the reduced-precision HIP mode of the

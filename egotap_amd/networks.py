@@ -320,7 +320,10 @@ class HeatMap_UnrealEgo_Shared(nn.Module):
     def __init__(self, opt, model_name: str = "resnet18", input_channel_scale: int = 2):
         super().__init__()
         self.model_name = model_name
-        self.blocks = _spec.hm_blocks(model_name)         # resnet18 / resnet34; raises for the Bottleneck ResNets
+        # resnet18 / resnet34 (BasicBlocks: one-call C forward, bf16 modes, stage-1 training) or resnet50 / resnet101 (Bottleneck blocks,
+        # feature_scale 4: fp32 eval forward composed from the operator entry points, _forward_bottleneck)
+        self.bottleneck = _spec.hm_is_bottleneck(model_name)
+        self.blocks = _spec.hm_all_blocks(model_name)
         if input_channel_scale != 2:
             raise NotImplementedError("only the stereo presets are built")
         limb = {"none": 0, "sin": 2, "limb": 1}[getattr(opt, "heatmap_type", "none")]
@@ -361,6 +364,8 @@ class HeatMap_UnrealEgo_Shared(nn.Module):
         "bf16x3" split operands, "bf16" rounded operands; everything else stays fp32 (egotap.h egotap_set_precision)."""
         if mode not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
+        if self.bottleneck and mode != "f32":
+            raise NotImplementedError(f"backbone {self.model_name!r} runs in fp32 only (the bf16 modes cover resnet18 / resnet34)")
         _lib.check(_lib.load().egotap_set_precision(self._ensure_handle(), _lib.PRECISIONS[mode]))
         self.precision = mode
         return self
@@ -375,8 +380,10 @@ class HeatMap_UnrealEgo_Shared(nn.Module):
     def _ensure_handle(self):
         if self._handle is None:
             p = self.preset
+            # Bottleneck nets never bind to the handle's one-call forward (it only carries the operator calls): default block counts
             cfg = _lib.EgotapConfig(C.sizeof(_lib.EgotapConfig), p.n_joints_hm, int(p.estimate_head), p.hm_size, p.hidden,
-                                    p.vit_dim, p.vit_heads, p.vit_layers, p.patch, p.pu_hidden, (C.c_int32 * 4)(*self.blocks))
+                                    p.vit_dim, p.vit_heads, p.vit_layers, p.patch, p.pu_hidden,
+                                    (C.c_int32 * 4)(*((2, 2, 2, 2) if self.bottleneck else self.blocks)))
             h = C.c_void_p()
             _lib.check(_lib.load().egotap_create(C.byref(cfg), C.byref(h)))
             self._handle = h
@@ -438,6 +445,10 @@ class HeatMap_UnrealEgo_Shared(nn.Module):
         if B == 0:
             return out
         dev = left.device
+        if self.bottleneck:
+            with torch.cuda.device(dev):
+                self._forward_bottleneck(left, right, out, channel_offset)
+            return out
         with torch.cuda.device(dev):
             self._bind(dev)
             ws = workspace if workspace is not None else self._workspace(B, dev)
@@ -449,11 +460,88 @@ class HeatMap_UnrealEgo_Shared(nn.Module):
                 ws.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return out
 
+    @torch.no_grad()
+    def _forward_bottleneck(self, left, right, out, channel_offset):
+        """Eval forward of the resnet50 / resnet101 estimators (net_architecture.py:45-51 backbone once per eye, :75-85 pyramid, :139-173
+        decoder on the channel-concatenated eyes), composed from the library's operator entry points: every convolution is one
+        conv_f32 kernel launch with its BatchNorm (eval) / bias, residual and ReLU in the epilogue; images n = 2b + eye, so a stage output
+        [2B, C, s, s] IS the stereo concat [B, 2C, s, s]; upsamples and 1x1 skips write channel slices of the concat buffers in place."""
+        from . import hm_ops as H
+        h = self._ensure_handle()
+        sd = {k: v for k, v in self.state_dict(keep_vars=True).items()}
+        for k, t in sd.items():
+            if t.device != left.device or not t.is_contiguous() or t.dtype not in (torch.float32, torch.long):
+                raise _lib.EgotapError(f"parameter {k}: need a contiguous fp32 tensor (or int64 counter) on {left.device}")
+        BB, AB = "backbone.backbone.backbone.", "after_backbone."
+        bn = lambda k: (sd[k + ".weight"], sd[k + ".bias"], sd[k + ".running_mean"], sd[k + ".running_var"])       # noqa: E731
+        B, S0, dev = left.shape[0], left.shape[2], left.device
+        N2 = 2 * B
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)     # noqa: E731
+        l0 = new(N2, 64, S0 // 2, S0 // 2)
+        H.stem_bn_fwd(left, right, sd[BB + "conv1.weight"], bn(BB + "bn1"), l0)
+        x = new(N2, 64, S0 // 4, S0 // 4)
+        H.maxpool_fwd(l0, x)
+        del l0
+        side, pyr = S0 // 4, []
+        for i, (c, st) in enumerate(_spec.HM_STAGES, start=1):
+            for b in range(self.blocks[i - 1]):
+                k = f"{BB}layer{i}.{b}."
+                stride = st if b == 0 else 1
+                so = side // stride
+                t1 = new(N2, c, side, side)
+                H.conv_bn_fwd(h, x, sd[k + "conv1.weight"], bn(k + "bn1"), t1, taps=1)
+                t2 = new(N2, c, so, so)
+                H.conv_bn_fwd(h, t1, sd[k + "conv2.weight"], bn(k + "bn2"), t2, taps=9, stride=stride)
+                idt = x
+                if (k + "downsample.0.weight") in sd:
+                    idt = new(N2, 4 * c, so, so)
+                    H.conv_bn_fwd(h, x, sd[k + "downsample.0.weight"], bn(k + "downsample.1"), idt, taps=1, stride=stride, relu=False)
+                y = new(N2, 4 * c, so, so)
+                H.conv_bn_fwd(h, t2, sd[k + "conv3.weight"], bn(k + "bn3"), y, res=idt, taps=1)
+                x, side = y, so
+            pyr.append(x)
+        L = [t.view(B, 2 * t.shape[1], t.shape[2], t.shape[3]) for t in pyr]
+        f = 2 * _spec.hm_feature_scale(self.model_name)
+        wb = lambda name: (sd[AB + name + ".weight"], sd[AB + name + ".bias"])      # noqa: E731
+        s64, s32, s16, s8 = (t.shape[2] for t in L)
+        w, bias = wb("layer4_1x1.0")
+        u4 = new(B, 512 * f, s8, s8)
+        H.conv_fwd(h, L[3], w, u4, bias=bias, taps=1, relu=True)
+        cat3 = new(B, (512 + 258) * f, s16, s16)
+        H.upsample_fwd(u4, H.View(cat3, 0, 512 * f))
+        w, bias = wb("layer3_1x1.0")
+        H.conv_fwd(h, L[2], w, H.View(cat3, 512 * f, 258 * f), bias=bias, taps=1, relu=True)
+        x3 = new(B, 512 * f, s16, s16)
+        w, bias = wb("conv_up3.0")
+        H.conv_fwd(h, cat3, w, x3, bias=bias, taps=9, relu=True)
+        del cat3, u4
+        cat2 = new(B, (512 + 128) * f, s32, s32)
+        H.upsample_fwd(x3, H.View(cat2, 0, 512 * f))
+        w, bias = wb("layer2_1x1.0")
+        H.conv_fwd(h, L[1], w, H.View(cat2, 512 * f, 128 * f), bias=bias, taps=1, relu=True)
+        x2 = new(B, 256 * f, s32, s32)
+        w, bias = wb("conv_up2.0")
+        H.conv_fwd(h, cat2, w, x2, bias=bias, taps=9, relu=True)
+        del cat2, x3
+        cat1 = new(B, (256 + 64) * f, s64, s64)
+        H.upsample_fwd(x2, H.View(cat1, 0, 256 * f))
+        w, bias = wb("layer1_1x1.0")
+        H.conv_fwd(h, L[0], w, H.View(cat1, 256 * f, 64 * f), bias=bias, taps=1, relu=True)
+        x1 = new(B, 256 * f, s64, s64)
+        w, bias = wb("conv_up1.0")
+        H.conv_fwd(h, cat1, w, x1, bias=bias, taps=9, relu=True)
+        w, bias = wb("conv_heatmap")
+        H.conv_fwd(h, x1, w, H.View(out, channel_offset, 2 * self.num_heatmap), bias=bias, taps=1, relu=False)
+        return out
+
     def forward(self, *inputs):
         if len(inputs) != 2:
             raise NotImplementedError("stereo input (left, right) expected")
         if not inputs[0].is_cuda:
             raise _lib.EgotapError("HeatMap_UnrealEgo_Shared runs on the GPU only (no CPU fallback)")
+        if self.bottleneck and self.training:
+            raise NotImplementedError(f"backbone {self.model_name!r}: the eval forward is built (fp32); train-mode BatchNorm / stage-1 training cover "
+                                      "resnet18 and resnet34 -- call .eval() (the stage-2 wrapper keeps frozen estimators in eval mode)")
         if self.training and torch.is_grad_enabled():
             from .hm_training import hm_train_forward          # train mode: batch-statistics BatchNorm2d, differentiable
             return hm_train_forward(self, inputs[0], inputs[1])

@@ -135,30 +135,56 @@ def _bn2d(pre, c):
 
 
 HM_BLOCKS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}      # BasicBlock ResNets of torchvision (net_architecture.py:57-60)
+HM_BOTTLENECK = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}  # Bottleneck ResNets (net_architecture.py:61-64), expansion 4
 
 
 def hm_blocks(model_name: str = "resnet18"):
-    """BasicBlocks per stage; resnet50 / resnet101 (Bottleneck blocks, feature_scale 4: net_architecture.py:61-64, 108-111) are not built"""
+    """BasicBlocks per stage of the nets the one-call C forward, the bf16 modes and stage-1 training cover; raises for resnet50 / resnet101
+    (Bottleneck blocks: hm_bottleneck_blocks -- fp32 eval forward composed from the operator entry points, networks.py)"""
     if model_name not in HM_BLOCKS:
-        raise NotImplementedError(f"backbone {model_name!r}: only the BasicBlock ResNets are built ({', '.join(HM_BLOCKS)}; the shipped scripts use resnet18)")
+        raise NotImplementedError(f"backbone {model_name!r}: only the BasicBlock ResNets run on this path ({', '.join(HM_BLOCKS)}; the shipped scripts use resnet18)")
     return HM_BLOCKS[model_name]
 
 
+def hm_is_bottleneck(model_name: str) -> bool:
+    return model_name in HM_BOTTLENECK
+
+
+def hm_all_blocks(model_name: str = "resnet18"):
+    if model_name in HM_BOTTLENECK:
+        return HM_BOTTLENECK[model_name]
+    return hm_blocks(model_name)
+
+
+def hm_feature_scale(model_name: str = "resnet18") -> int:
+    """net_architecture.py:104-111: channels of the pyramid levels relative to resnet18 (Bottleneck expansion 4)"""
+    return 4 if model_name in HM_BOTTLENECK else 1
+
+
 def resnet18_spec(model_name: str = "resnet18"):
-    """[(key, shape)] of torchvision.models.resnet18().state_dict() (public architecture; 122 entries) -- or resnet34's (218 entries)."""
+    """[(key, shape)] of torchvision.models.resnet18().state_dict() (public architecture; 122 entries) -- or resnet34's (218 entries),
+    resnet50's (320) and resnet101's (626): Bottleneck = conv1 1x1 -> conv2 3x3 (carries the stride, torchvision's v1.5) -> conv3 1x1 to
+    4 x width, downsample in the first block of every stage (layer1's too: 64 -> 256 channels)."""
     s = [("conv1.weight", (64, 3, 7, 7))] + _bn2d("bn1", 64)
     cin = 64
-    blocks = hm_blocks(model_name)
+    blocks = hm_all_blocks(model_name)
+    bott = hm_is_bottleneck(model_name)
     for i, (c, stride) in enumerate(HM_STAGES, start=1):
+        cout = 4 * c if bott else c
         for b in range(blocks[i - 1]):
             pre = f"layer{i}.{b}"
-            bc_in = cin if b == 0 else c
-            s += [(pre + ".conv1.weight", (c, bc_in, 3, 3))] + _bn2d(pre + ".bn1", c)
-            s += [(pre + ".conv2.weight", (c, c, 3, 3))] + _bn2d(pre + ".bn2", c)
-            if b == 0 and (stride != 1 or cin != c):
-                s += [(pre + ".downsample.0.weight", (c, bc_in, 1, 1))] + _bn2d(pre + ".downsample.1", c)
-        cin = c
-    s += [("fc.weight", (1000, 512)), ("fc.bias", (1000,))]
+            bc_in = cin if b == 0 else cout
+            if bott:
+                s += [(pre + ".conv1.weight", (c, bc_in, 1, 1))] + _bn2d(pre + ".bn1", c)
+                s += [(pre + ".conv2.weight", (c, c, 3, 3))] + _bn2d(pre + ".bn2", c)
+                s += [(pre + ".conv3.weight", (cout, c, 1, 1))] + _bn2d(pre + ".bn3", cout)
+            else:
+                s += [(pre + ".conv1.weight", (c, bc_in, 3, 3))] + _bn2d(pre + ".bn1", c)
+                s += [(pre + ".conv2.weight", (c, c, 3, 3))] + _bn2d(pre + ".bn2", c)
+            if b == 0 and (stride != 1 or cin != cout):
+                s += [(pre + ".downsample.0.weight", (cout, bc_in, 1, 1))] + _bn2d(pre + ".downsample.1", cout)
+        cin = cout
+    s += [("fc.weight", (1000, cin)), ("fc.bias", (1000,))]
     return s
 
 
@@ -189,8 +215,10 @@ def hm_state_spec(n_hm_per_eye: int, model_name: str = "resnet18"):
     def conv(name, cout, cin, k):
         return [(a + name + ".weight", (cout, cin, k, k), None), (a + name + ".bias", (cout,), None)]
 
-    out += conv("layer1_1x1.0", 128, 128, 1) + conv("layer2_1x1.0", 256, 256, 1)
-    out += conv("layer3_1x1.0", 516, 512, 1) + conv("layer4_1x1.0", 1024, 1024, 1)
-    out += conv("conv_up3.0", 1024, 1540, 3) + conv("conv_up2.0", 512, 1280, 3) + conv("conv_up1.0", 512, 640, 3)
-    out += conv("conv_heatmap", 2 * n_hm_per_eye, 512, 1)
+    f = 2 * hm_feature_scale(model_name)            # feature_scale * input_channel_scale (net_architecture.py:113)
+    out += conv("layer1_1x1.0", 64 * f, 64 * f, 1) + conv("layer2_1x1.0", 128 * f, 128 * f, 1)
+    out += conv("layer3_1x1.0", 258 * f, 256 * f, 1) + conv("layer4_1x1.0", 512 * f, 512 * f, 1)
+    out += conv("conv_up3.0", 512 * f, 258 * f + 512 * f, 3) + conv("conv_up2.0", 256 * f, 128 * f + 512 * f, 3)
+    out += conv("conv_up1.0", 256 * f, 64 * f + 256 * f, 3)
+    out += conv("conv_heatmap", 2 * n_hm_per_eye, 256 * f, 1)
     return out

@@ -278,6 +278,16 @@ int egotap_lift_backward(egotap_handle h, const float* hm, const float* dpose, i
 int egotap_hmtrain_conv_fwd(egotap_handle h, const float* x, const float* w, const float* bias, const float* res, float* y, int Nimg, int Cin,
                             int Cout, int wout, int taps, int stride, int relu, int64_t in_istride, int64_t out_istride, int64_t res_istride,
                             void* stream);
+/* [r3] Eval-mode building blocks for the backbones egotap_hm_forward does not cover -- the Bottleneck ResNets behind --model_name resnet50 /
+ * resnet101 (reference: model/net_architecture.py:61-64 torchvision resnet50 / resnet101, :108-111 feature_scale 4).  The host side composes
+ * the forward from them (egotap_amd/networks.py): y = [relu](BatchNorm_eval(conv(x, w)) [+ res]) with the BatchNorm folded in the epilogue as
+ * gamma / sqrt(var + 1e-5) (what egotap_hm_forward does for the BasicBlock nets), and the 7x7 / 2 stem with its BatchNorm + ReLU
+ * (y [2B, 64, S0/2, S0/2], image n = 2b + eye).  fp32 only. */
+int egotap_hm_conv_bn_fwd(egotap_handle h, const float* x, const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                          const float* res, float* y, int Nimg, int Cin, int Cout, int wout, int taps, int stride, int relu, int64_t in_istride,
+                          int64_t out_istride, int64_t res_istride, void* stream);
+int egotap_hm_stem_bn_fwd(const float* left, const float* right, const float* w, const float* gamma, const float* beta, const float* mean,
+                          const float* var, float* y, int B, int S0, void* stream);
 /* bf16 precision modes: the 3x3 stride-1 convolutions (forward and input gradient) of the training step run on conv_bf16 once a
  * scratch buffer for their repacked weights is set (egotap_hmtrain_pack_bytes() bytes, caller-owned, 16-byte aligned) */
 int egotap_hmtrain_set_pack_buffer(egotap_handle h, void* buf, size_t bytes);

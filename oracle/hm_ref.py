@@ -88,6 +88,14 @@ def _block(x, sd, pre, stride):
     idt = x
     if (pre + ".downsample.0.weight") in sd:
         idt = _bn(F.conv2d(x, sd[pre + ".downsample.0.weight"], None, stride), sd, pre + ".downsample.1")
+    if (pre + ".conv3.weight") in sd:
+        # torchvision's Bottleneck (resnet50 / resnet101, net_architecture.py:61-64), public definition: 1x1 -> 3x3 carrying the stride
+        # ("ResNet v1.5") -> 1x1 to 4 x width, each followed by BatchNorm; ReLU after the first two and after the residual sum.  UNPINNED
+        # like the BasicBlock (torchvision is not installed here).
+        y = F.relu(_bn(F.conv2d(x, sd[pre + ".conv1.weight"]), sd, pre + ".bn1"))
+        y = F.relu(_bn(F.conv2d(y, sd[pre + ".conv2.weight"], None, stride, 1), sd, pre + ".bn2"))
+        y = _bn(F.conv2d(y, sd[pre + ".conv3.weight"]), sd, pre + ".bn3")
+        return F.relu(y + idt)
     y = F.relu(_bn(F.conv2d(x, sd[pre + ".conv1.weight"], None, stride, 1), sd, pre + ".bn1"))
     y = _bn(F.conv2d(y, sd[pre + ".conv2.weight"], None, 1, 1), sd, pre + ".bn2")
     return F.relu(y + idt)
@@ -100,7 +108,7 @@ def resnet18_pyramid(x, sd, pre="backbone.backbone.backbone."):
     outs = [l0]
     for i, (c, s) in enumerate(STAGES, start=1):
         b = 0
-        while f"{pre}layer{i}.{b}.conv1.weight" in sd:      # 2 BasicBlocks per stage in resnet18, (3, 4, 6, 3) in resnet34 (torchvision)
+        while f"{pre}layer{i}.{b}.conv1.weight" in sd:      # 2 BasicBlocks per stage in resnet18, (3, 4, 6, 3) in resnet34; Bottlenecks: resnet50 (3, 4, 6, 3), resnet101 (3, 4, 23, 3)
             y = _block(y, sd, f"{pre}layer{i}.{b}", s if b == 0 else 1)
             b += 1
         outs.append(y)

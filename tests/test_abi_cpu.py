@@ -137,6 +137,44 @@ def test_host_side_argument_checks_of_the_newer_entry_points():
     assert sorted(L.PRECISIONS) == ["bf16", "bf16x3", "f32"]
 
 
+def test_bottleneck_backbones_spec_and_module():
+    """--model_name resnet50 / resnet101 (net_architecture.py:61-64, 108-111: torchvision Bottleneck ResNets, feature_scale 4): torchvision's
+    key names and shapes (320 / 626 state_dict entries, 25.56 M / 44.55 M parameters), decoder widths x 4, the reference's aliases; fp32 eval
+    only -- the bf16 modes and stage-1 training refuse them by name."""
+    import math
+    import torch
+    from egotap_amd import networks, spec
+    from egotap_amd.options import preset_defaults
+    for name, n_entries, n_params in (("resnet50", 320, 25557032), ("resnet101", 626, 44549160)):
+        rs = spec.resnet18_spec(name)
+        assert len(rs) == n_entries
+        assert sum(math.prod(shp) for k, shp in rs if "running" not in k and "num_batches" not in k) == n_params
+    d = dict(spec.resnet18_spec("resnet50"))
+    assert d["layer1.0.conv1.weight"] == (64, 64, 1, 1) and d["layer1.0.conv3.weight"] == (256, 64, 1, 1) and d["layer1.0.downsample.0.weight"] == (256, 64, 1, 1)
+    assert d["layer2.0.conv1.weight"] == (128, 256, 1, 1) and d["layer2.0.conv2.weight"] == (128, 128, 3, 3) and d["layer4.2.conv3.weight"] == (2048, 512, 1, 1)
+    assert "layer3.22.conv3.weight" in dict(spec.resnet18_spec("resnet101")) and d["fc.weight"] == (1000, 2048)
+    hs = {k: shp for k, shp, _ in spec.hm_state_spec(15, "resnet50")}
+    assert hs["after_backbone.conv_up3.0.weight"] == (4096, 6160, 3, 3) and hs["after_backbone.layer3_1x1.0.weight"] == (2064, 2048, 1, 1)
+    assert hs["after_backbone.conv_up1.0.weight"] == (2048, 2560, 3, 3) and hs["after_backbone.conv_heatmap.weight"] == (30, 2048, 1, 1)
+    # the module: keys in the reference's order, aliases are the same objects (built on the meta device: 1.7 GB of decoder weights otherwise)
+    opt = preset_defaults("UnrealEgo")
+    opt.num_rot_heatmap = 0
+    with torch.device("meta"):
+        net = networks.HeatMap_UnrealEgo_Shared(opt, "resnet50", input_channel_scale=2)
+    assert list(net.state_dict().keys()) == [k for k, _, _ in spec.hm_state_spec(15, "resnet50")]
+    sd = net.state_dict(keep_vars=True)
+    assert sd["backbone.backbone.layer3.5.conv3.weight"] is sd["backbone.backbone.backbone.layer3.5.conv3.weight"]
+    assert net.bottleneck and net.blocks == (3, 4, 6, 3)
+    with pytest.raises(NotImplementedError, match="fp32 only"):
+        net.set_precision("bf16")
+    net.train()
+    with pytest.raises(L.EgotapError):
+        net(torch.zeros(1, 3, 256, 256), torch.zeros(1, 3, 256, 256))          # GPU only, as every net
+    assert spec.hm_feature_scale("resnet101") == 4 and spec.hm_feature_scale("resnet34") == 1
+    with pytest.raises(NotImplementedError):
+        spec.hm_blocks("resnet50")                                               # the BasicBlock-only paths (one-call C forward, bf16, training)
+
+
 def test_resnet34_backbone_spec_module_and_handle():
     """--model_name resnet34 (net_architecture.py:59-60, 104-105: torchvision resnet34, feature_scale 1): BasicBlocks (3, 4, 6, 3) per
     stage under torchvision's key names, the same decoder; the Bottleneck ResNets (resnet50 / 101) are refused, not approximated."""
@@ -157,7 +195,7 @@ def test_resnet34_backbone_spec_module_and_handle():
     sd = net.state_dict(keep_vars=True)
     assert sd["backbone.backbone.layer3.5.conv2.weight"] is sd["backbone.backbone.backbone.layer3.5.conv2.weight"]      # the reference's aliases
     with pytest.raises(NotImplementedError):
-        networks.HeatMap_UnrealEgo_Shared(opt, "resnet50", input_channel_scale=2)
+        networks.HeatMap_UnrealEgo_Shared(opt, "resnet152", input_channel_scale=2)
     lib = L.load()
     counts = {}
     for name, blocks in (("resnet18", (0, 0, 0, 0)), ("resnet34", (3, 4, 6, 3))):

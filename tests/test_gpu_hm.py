@@ -39,9 +39,12 @@ def test_hm_forward_matches_golden(which, n_hm):
         np.testing.assert_allclose(right_eye[::997].numpy(), g[f"pyr{i}_sample"], atol=2e-4, rtol=1e-4, err_msg=f"layer{i}")
 
 
-@pytest.mark.parametrize("which,B,model_name", [("pos", 3, "resnet18"), ("rot", 2, "resnet18"), ("rot", 3, "resnet34")])
+@pytest.mark.parametrize("which,B,model_name", [("pos", 3, "resnet18"), ("rot", 2, "resnet18"), ("rot", 3, "resnet34"),
+                                                ("pos", 2, "resnet50"), ("rot", 1, "resnet101")])
 def test_hm_forward_matches_oracle(which, B, model_name):
-    """resnet34 (--model_name, net_architecture.py:59-60): BasicBlocks (3, 4, 6, 3) per stage, same decoder (feature_scale 1)"""
+    """resnet34 (--model_name, net_architecture.py:59-60): BasicBlocks (3, 4, 6, 3) per stage, same decoder (feature_scale 1);
+    resnet50 / resnet101 (:61-64, 108-111): Bottleneck blocks, every decoder width x 4 (conv_up3: 6160 -> 4096 channels) -- the forward is
+    composed from the operator entry points (egotap_hm_conv_bn_fwd ...), fp32, eval mode"""
     from gpu_util import hm_net
     from oracle import hm_ref as H
     net, sd_np = hm_net(which, model_name=model_name)

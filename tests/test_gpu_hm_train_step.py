@@ -310,3 +310,49 @@ def test_wrappers_with_model_name_resnet34(tmp_path):
     assert torch.isfinite(poses["f32"]).all() and tuple(poses["f32"].shape) == (B, 16, 3)
     # a sanity bound only: the head and the sin / cos estimator are freshly initialised here (kaiming), not a conditioned network
     assert float((poses["bf16"] - poses["f32"]).abs().max()) < 0.25 * float(poses["f32"].abs().max())
+
+
+def test_wrappers_with_model_name_resnet50(tmp_path):
+    """--model_name resnet50 (net_architecture.py:61-62, 108-109: Bottleneck backbone, feature_scale 4) through create_model: the stage-1
+    wrapper refuses to TRAIN it by name but evaluates it and round-trips its checkpoint (654 keys); the stage-2 wrapper's evaluation forward
+    runs both resnet50 estimators into the head, and its precision switch leaves them in fp32 (the head alone goes to bf16)."""
+    from egotap_amd import models
+    from egotap_amd.options import preset_defaults
+    from egotap_amd.synthetic import synth_hm_state_dict
+    opt = preset_defaults("UnrealEgo")
+    opt.model, opt.isTrain, opt.num_rot_heatmap, opt.model_name = "heatmap_shared", True, 0, "resnet50"
+    opt.log_dir, opt.experiment_name = str(tmp_path), "r50"
+    with pytest.raises(NotImplementedError, match="stage-1 training"):
+        models.create_model(opt)
+    opt.isTrain = False
+    m = models.create_model(opt)
+    assert m.net_HeatMap.bottleneck and m.net_HeatMap.blocks == (3, 4, 6, 3)
+    sd_np = synth_hm_state_dict(15, "hm_pos.", "resnet50")
+    m.net_HeatMap.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    B = 2
+    data = {"input_rgb_left": torch.from_numpy(synth_input("r50_l", (B, 3, 256, 256), -2.0, 2.0)),
+            "input_rgb_right": torch.from_numpy(synth_input("r50_r", (B, 3, 256, 256), -2.0, 2.0))}
+    m.save_networks("latest")
+    m2 = models.create_model(opt)
+    m2.load_networks("latest")
+    a, b = m.net_HeatMap.state_dict(), m2.net_HeatMap.state_dict()
+    assert list(a.keys()) == list(b.keys()) and len(a) == 654
+    for k in a:
+        assert torch.equal(a[k].cpu(), b[k].cpu()), k
+    m2.net_HeatMap.eval()
+    alone = m2.net_HeatMap(data["input_rgb_left"].cuda(), data["input_rgb_right"].cuda())
+    # stage 2, evaluation forward from RGB
+    opt2 = preset_defaults("UnrealEgo")
+    opt2.model_name, opt2.gpu_ids = "resnet50", [0]
+    mm = models.create_model(opt2)
+    mm.net_HeatMap.load_state_dict(m.net_HeatMap.state_dict())
+    mm.set_input(data)
+    mm.set_eval_mode()
+    mm.set_precision("bf16")
+    assert getattr(mm.net_HeatMap, "precision", "f32") == "f32" and mm.net_AutoEncoder.precision == "bf16"
+    with torch.no_grad():
+        mm.forward(evaluate=True)
+    torch.cuda.synchronize()
+    mm.set_precision("f32")
+    assert torch.isfinite(mm.pred_pose).all() and tuple(mm.pred_pose.shape) == (B, 16, 3)
+    assert torch.equal(mm.pred_heatmap_cat[:, :30], alone)          # the position estimator's slice of the head's input, written in place
