@@ -1665,6 +1665,11 @@ extern "C" int egotap_train_patch_fwd(egotap_handle h, const float* hm, int B, c
 }
 #endif
 
+// EGOTAP_TN_F32_DMA=0 in the environment: the register-staged fp32 weight-gradient kernel for every operand (A/B timing; read once per process)
+static bool tn_f32_dma_enabled() {
+    static const bool on = [] { const char* e = getenv("EGOTAP_TN_F32_DMA"); return !(e && e[0] == '0'); }();
+    return on;
+}
 template <class XL>
 static hipError_t tn_any(Handle* h, const float* dy, const XL& xl, float* dw, float* ws, size_t ws_bytes, int M, int N, int K, int acc, hipStream_t s,
                          long ldy = 0) {
@@ -1673,6 +1678,10 @@ static hipError_t tn_any(Handle* h, const float* dy, const XL& xl, float* dw, fl
         return gemm_tn_bf16_launch<TnBfCfg<3>, XL>(dy, ldy, xl, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
     if (N % 256 == 0 && K % 256 == 0 && M >= 1024 && h->precision == EGOTAP_PREC_BF16)
         return gemm_tn_bf16_launch<TnBfCfg<1>, XL>(dy, ldy, xl, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
+    if constexpr (std::is_same<XL, ALoadPlain>::value) {      // [r3] plain operands: the DMA-staged kernel (gemm_tn_f32.h), same summation order per element
+        if (tn_f32_dma_enabled() && M >= 1024 && gemm_tn_f32_dma_ok(dy, ldy, xl.A, xl.lda, M, N, K))
+            return gemm_tn_f32_dma_launch(dy, ldy, xl.A, xl.lda, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
+    }
     if (N % 256 == 0 && K % 256 == 0) return gemm_tn_f32_launch<TnBig, XL>(dy, ldy, xl, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
     if (N % 128 == 0 && K % 128 == 0) return gemm_tn_f32_launch<TnSmall, XL>(dy, ldy, xl, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
     return hipErrorInvalidValue;

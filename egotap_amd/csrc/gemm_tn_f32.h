@@ -203,6 +203,156 @@ static hipError_t gemm_tn_f32_launch(const float* dY, long ldy, const XLoad& xl,
     return hipGetLastError();
 }
 
+// [r3] How many splits of a weight-gradient launch (the convolution weight gradients of hm_train.h and the DMA-staged GEMM below; a slab = the
+// rows staged between two barriers): workgroups go to the CUs round-robin, so a launch takes ceil(tiles * S / CUs) workgroups in a row on the busiest CU, each
+// ceil(slabs / S) slabs long plus a fixed part (LDS zeroing, first loads, the slab store), and the reduction reads S slabs afterwards.  Round 2
+// took S = 2 CUs / tiles over whole images: 560 workgroups of 5 images on 256 CUs for conv_up1 (three rounds for 2.2 rounds of work), 128
+// workgroups for the 64-channel layers (half the chip idle).  Times in microseconds; only their ratios matter.
+// Two workgroups fit on a CU where the LDS allows (the registers never allow more): they share the matrix pipe, and one's staging and barriers
+// hide under the other's MFMAs.
+static int wgrad_pick_splits(int tiles, long slabs, long n_floats, size_t slab_bytes, int num_cu, int lds_bytes, double slab_us, double fixed_us, int* per_out) {
+    const int wpc = 2 * lds_bytes <= 160 * 1024 ? 2 : 1;
+    long max_s = (long)(slab_bytes / ((size_t)n_floats * 4));
+    if (max_s < 1) return 0;
+    if (max_s > slabs) max_s = slabs;
+    if (max_s > 4096) max_s = 4096;
+    double best = 1e30;
+    int best_s = 1;
+    for (long s = 1; s <= max_s; ++s) {
+        const long per = (slabs + s - 1) / s, s_eff = (slabs + per - 1) / per;
+        if (s_eff != s) continue;                           // the same launch as a smaller S
+        const long in_a_row = ((long)tiles * s + num_cu - 1) / num_cu;
+        const double alone_us = wpc == 2 && in_a_row >= 2 ? 0.0 : 0.25;      // a slab's barrier and LDS stores, exposed when nobody shares the CU
+        const double t = in_a_row * per * (slab_us + alone_us) + (in_a_row + wpc - 1) / wpc * fixed_us + (double)s * n_floats * 4.0 / 3.0e6 + 0.02 * s;
+        if (t < best * 0.995) { best = t; best_s = (int)s; }
+    }
+    *per_out = (int)((slabs + best_s - 1) / best_s);
+    return best_s;
+}
+
+// [r3] The same weight-gradient GEMM with global -> LDS DMA staging, for operands that are plain row-major matrices (every weight gradient of
+// the ViT layers and fc2 / fc3: 83 of the fp32 training step's 324 ms).  A slab is 32 rows of dY and 32 rows of X as they lie in memory: one
+// 1 KiB row segment per DMA instruction (lane = 16 bytes), written to the padded LDS rows of the register-staged kernel above, so fragment
+// addressing, MFMA order and the summation order per output element are unchanged.  Two stages: the slab after the current one is in
+// flight during the current one's 128 MFMAs per wave; no staging registers, no ds_write, half the barriers (32-row slabs).
+// Needs M % 32 == 0 (every slab full: the DMA cannot write the zero rows of a ragged tail) and 16-byte aligned rows.
+struct TnDmaCfg {
+    static constexpr int BN = 256, BK = 256, BKM = 32, WN = 4, WK = 2, THREADS = 512, TN = 2, TK = 4, NS = 2;
+    static constexpr int LDA = BN + 4, LDB = BK + 4;
+    static constexpr int STAGE_FLOATS = BKM * (LDA + LDB);
+    static constexpr int LDS_BYTES = NS * STAGE_FLOATS * 4;             // 133 120
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+static __global__ __launch_bounds__(TnDmaCfg::THREADS) void gemm_tn_f32_dma_kernel(const float* __restrict__ dY, long ldy, const float* __restrict__ X,
+                                                                                  long ldx, float* __restrict__ slabs, int M, int N, int K,
+                                                                                  int tiles_n, int tiles_k, int splits, int rows_per) {
+    using Cfg = TnDmaCfg;
+    constexpr int BN = Cfg::BN, BK = Cfg::BK, BKM = Cfg::BKM, LDA = Cfg::LDA, LDB = Cfg::LDB, TN = Cfg::TN, TK = Cfg::TK, SF = Cfg::STAGE_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float smem_tnd[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wn = wid / Cfg::WK, wk = wid % Cfg::WK;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int bid = blockIdx.x;
+    const int split = bid % splits, tile = bid / splits;
+    const int tn = tile % tiles_n, tk = tile / tiles_n;
+    const int n0 = tn * BN, k0 = tk * BK;
+    const int m_lo = split * rows_per, m_hi = min(M, m_lo + rows_per);
+    const int nslab = m_hi > m_lo ? (m_hi - m_lo) / BKM : 0;        // rows_per % BKM == 0 and M % BKM == 0: every slab is full
+
+    // the DMA goes through inline asm and vmcnt is waited for by hand (see gemm_f32_dma.h for why)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_tnd;
+    auto dma1 = [&](const float* g, unsigned lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+    };
+    // wave w stages rows w, w + 8, w + 16, w + 24 of both operands: 8 DMA instructions per wave and slab
+    const float* ga = dY + (long)(m_lo + wid) * ldy + n0 + lane * 4;
+    const float* gb = X + (long)(m_lo + wid) * ldx + k0 + lane * 4;
+    auto dma_slab = [&](int s, int buf) __attribute__((always_inline)) {
+        const unsigned sa = lds0 + (unsigned)(buf * SF + wid * LDA) * 4u, sb = lds0 + (unsigned)(buf * SF + BKM * LDA + wid * LDB) * 4u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dma1(ga + ((long)s * BKM + 8 * q) * ldy, sa + (unsigned)(8 * q * LDA) * 4u);
+            dma1(gb + ((long)s * BKM + 8 * q) * ldx, sb + (unsigned)(8 * q * LDB) * 4u);
+        }
+    };
+
+    f32x16 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nslab > 0) dma_slab(0, 0);
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's rows of slab s have landed ...
+        __syncthreads();                                          // ... everybody's have, and nobody reads the other stage any more
+        if (s + 1 < nslab) dma_slab(s + 1, buf ^ 1);
+        const float* Ab = smem_tnd + buf * SF + lh * LDA + wn * (TN * 32) + l31;
+        const float* Bb = smem_tnd + buf * SF + BKM * LDA + lh * LDB + wk * (TK * 32) + l31;
+#pragma unroll
+        for (int p = 0; p < BKM / 2; ++p) {
+            float a[TN], b[TK];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) a[i] = Ab[2 * p * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TK; ++j) b[j] = Bb[2 * p * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* out = slabs + (long)split * N * K;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+            const int kk = k0 + wk * (TK * 32) + j * 32 + l31;
+            const int nb = n0 + wn * (TN * 32) + i * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nb + (r & 3) + 8 * (r >> 2);
+                out[(long)n * K + kk] = acc[i][j][r];
+            }
+        }
+}
+
+static inline bool gemm_tn_f32_dma_ok(const float* dY, long ldy, const float* X, long ldx, int M, int N, int K) {
+    return M % TnDmaCfg::BKM == 0 && N % TnDmaCfg::BN == 0 && K % TnDmaCfg::BK == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)dY & 15) == 0 &&
+           ((uintptr_t)X & 15) == 0;
+}
+static hipError_t gemm_tn_f32_dma_launch(const float* dY, long ldy, const float* X, long ldx, float* dW, float* slabs, size_t slab_bytes, int M, int N,
+                                         int K, int num_cu, int accumulate, hipStream_t stream) {
+    using Cfg = TnDmaCfg;
+    if (!gemm_tn_f32_dma_ok(dY, ldy, X, ldx, M, N, K)) return hipErrorInvalidValue;
+    const int tiles_n = N / Cfg::BN, tiles_k = K / Cfg::BK, tiles = tiles_n * tiles_k;
+    // split count from the model shared with the convolution weight gradients: the q | k | v gradient (48 tiles) took 11 splits = 528 workgroups =
+    // three rounds for 2.06 rounds of work under the "two blocks per CU" rule; 16 splits are three full rounds
+    int per = 0;
+    int splits = wgrad_pick_splits(tiles, M / Cfg::BKM, (long)N * K, slab_bytes, num_cu, Cfg::LDS_BYTES, Cfg::BKM / 2 * Cfg::TN * Cfg::TK * 64 / 2400.0, 6.0, &per);
+    if (splits < 1) { splits = 1; per = M / Cfg::BKM; }
+    const bool direct = splits == 1 && !accumulate;
+    if (!direct && (size_t)splits * N * K * 4 > slab_bytes) return hipErrorOutOfMemory;
+    const int rows_per = per * Cfg::BKM;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_f32_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_f32_dma_kernel, dim3(tiles * splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, dY, ldy, X, ldx, direct ? dW : slabs, M, N,
+                       K, tiles_n, tiles_k, splits, rows_per);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || direct) return e;
+    const long n = (long)N * K;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, slabs, dW, n, splits, accumulate);
+    return hipGetLastError();
+}
+
 static hipError_t colsum_f32_launch(const float* Y, long ldy, float* out, float* part, size_t part_bytes, int M, int N,
                                     int accumulate, hipStream_t stream) {
     if (N % 4 != 0) return hipErrorInvalidValue;

@@ -157,32 +157,6 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(WgArgs a) {
     }
 }
 
-// [r3] How many splits: workgroups go to the CUs round-robin, so a launch takes ceil(tiles * S / CUs) workgroups in a row on the busiest CU, each
-// ceil(slabs / S) slabs long plus a fixed part (LDS zeroing, first loads, the slab store), and the reduction reads S slabs afterwards.  Round 2
-// took S = 2 CUs / tiles over whole images: 560 workgroups of 5 images on 256 CUs for conv_up1 (three rounds for 2.2 rounds of work), 128
-// workgroups for the 64-channel layers (half the chip idle).  Times in microseconds; only their ratios matter.
-// Two workgroups fit on a CU where the LDS allows (the registers never allow more): they share the matrix pipe, and one's staging and barriers
-// hide under the other's MFMAs.
-static int wgrad_pick_splits(int tiles, long slabs, long n_floats, size_t slab_bytes, int num_cu, int lds_bytes, double slab_us, double fixed_us, int* per_out) {
-    const int wpc = 2 * lds_bytes <= 160 * 1024 ? 2 : 1;
-    long max_s = (long)(slab_bytes / ((size_t)n_floats * 4));
-    if (max_s < 1) return 0;
-    if (max_s > slabs) max_s = slabs;
-    if (max_s > 4096) max_s = 4096;
-    double best = 1e30;
-    int best_s = 1;
-    for (long s = 1; s <= max_s; ++s) {
-        const long per = (slabs + s - 1) / s, s_eff = (slabs + per - 1) / per;
-        if (s_eff != s) continue;                           // the same launch as a smaller S
-        const long in_a_row = ((long)tiles * s + num_cu - 1) / num_cu;
-        const double alone_us = wpc == 2 && in_a_row >= 2 ? 0.0 : 0.25;      // a slab's barrier and LDS stores, exposed when nobody shares the CU
-        const double t = in_a_row * per * (slab_us + alone_us) + (in_a_row + wpc - 1) / wpc * fixed_us + (double)s * n_floats * 4.0 / 3.0e6 + 0.02 * s;
-        if (t < best * 0.995) { best = t; best_s = (int)s; }
-    }
-    *per_out = (int)((slabs + best_s - 1) / best_s);
-    return best_s;
-}
-
 template <class Cfg>
 static hipError_t conv_wgrad_launch(WgArgs a, float* dw, size_t slab_bytes, int num_cu, int accumulate, hipStream_t stream) {
     if (a.Nimg <= 0) return hipSuccess;
