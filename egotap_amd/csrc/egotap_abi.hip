@@ -1723,6 +1723,27 @@ extern "C" int egotap_train_colsum(const float* y, int64_t ldy, float* out, int 
 }
 #endif
 
+// [r3] dW[N,K] (+)= dY^T X and db[N] (+)= column sums of dY in one call: weight and bias gradient of a Linear layer with a plain input.  In fp32,
+// when the DMA-staged kernel applies, the workgroups that stage dY for the product also sum its columns (no second pass over dY: 5.4 GB per
+// ViT layer at B = 256); otherwise the two operators one after the other.
+#if EGOTAP_IN(1)
+extern "C" int egotap_train_gemm_tn_bias(egotap_handle h, const float* dy, int64_t ldy, const float* x, float* dw, float* db, int M, int N, int K,
+                                         int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(h && dy && x && dw && db && ws, "egotap_train_gemm_tn_bias: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (ldy <= 0) ldy = N;
+    if (h->precision == EGOTAP_PREC_F32 && tn_f32_dma_enabled() && M >= 1024 && gemm_tn_f32_dma_ok(dy, ldy, x, K, M, N, K)) {
+        hipError_t e = gemm_tn_f32_dma_launch(dy, ldy, x, K, dw, (float*)ws, ws_bytes, M, N, K, device_cu_count(), accumulate, s, db);
+        if (e == hipErrorOutOfMemory) { egotap_set_error("egotap_train_gemm_tn_bias: workspace too small (%zu bytes) for N*K=%ld", ws_bytes, (long)N * K); return EGOTAP_ERR_WORKSPACE; }
+        EGO_HIP(e);
+        return EGOTAP_OK;
+    }
+    int rc = egotap_train_gemm_tn(h, 0, dy, ldy, x, nullptr, dw, M, N, K, accumulate, 0, ws, ws_bytes, stream);
+    if (rc != EGOTAP_OK) return rc;
+    return egotap_train_colsum(dy, ldy, db, M, N, accumulate, ws, ws_bytes, stream);
+}
+#endif
+
 #if EGOTAP_IN(1)
 extern "C" int egotap_train_transpose(const float* in, float* out, int R, int C, int64_t ldo, void* stream) {
     EGO_CHECK(in && out, "egotap_train_transpose: null argument");
@@ -3184,21 +3205,19 @@ extern "C" int egotap_lift_backward(egotap_handle h, const float* hm, const floa
         const auto& G_ = g.layer[i];
         const auto& l = t.layer[i];
         // output.dense.bias of layer i closes the bucket of layer i + 1 (or of the head, for the last layer)
-        EGO_RC(egotap_train_colsum(dx, 0, G(G_.dn_b), M, D, 0, scr, scrb, stream));
+        // [r3] every bias gradient of the layer comes out of the weight-gradient GEMM that stages the same dY (egotap_train_gemm_tn_bias)
+        EGO_RC(egotap_train_gemm_tn_bias(h, dx, 0, S(l.hid), G(G_.dn_w), G(G_.dn_b), M, D, 4 * D, 0, scr, scrb, stream));
         EGO_RC(bucket_done());
         // MLP
-        EGO_RC(egotap_train_gemm_tn(h, 0, dx, 0, S(l.hid), nullptr, G(G_.dn_w), M, D, 4 * D, 0, 0, scr, scrb, stream));
         EGO_RC(egotap_train_transpose(P_.dn_w, WT, D, 4 * D, 0, stream));
         EGO_RC(egotap_train_gemm_nt(h, 0, dx, 0, nullptr, WT, nullptr, A4, M, 4 * D, D, 5, S(l.z), nullptr, 0, stream));          // dz
-        EGO_RC(egotap_train_gemm_tn(h, 0, A4, 0, S(l.y2), nullptr, G(G_.up_w), M, 4 * D, D, 0, 0, scr, scrb, stream));
-        EGO_RC(egotap_train_colsum(A4, 0, G(G_.up_b), M, 4 * D, 0, scr, scrb, stream));
+        EGO_RC(egotap_train_gemm_tn_bias(h, A4, 0, S(l.y2), G(G_.up_w), G(G_.up_b), M, 4 * D, D, 0, scr, scrb, stream));
         EGO_RC(egotap_train_transpose(P_.up_w, WT, 4 * D, D, 0, stream));
         EGO_RC(egotap_train_gemm_nt(h, 0, A4, 0, nullptr, WT, nullptr, R0, M, D, 4 * D, 0, nullptr, nullptr, 0, stream));          // dy2
         EGO_RC(egotap_train_layernorm_bwd(S(l.xm), R0, P_.ln2_g, S(l.m2), S(l.r2), dx, R2, G(G_.ln2_g), G(G_.ln2_b), M, 0, scr, scrb, stream));
         float* dxm = R2;
         // attention
-        EGO_RC(egotap_train_gemm_tn(h, 0, dxm, 0, S(l.ctx), nullptr, G(G_.o_w), M, D, D, 0, 0, scr, scrb, stream));
-        EGO_RC(egotap_train_colsum(dxm, 0, G(G_.o_b), M, D, 0, scr, scrb, stream));
+        EGO_RC(egotap_train_gemm_tn_bias(h, dxm, 0, S(l.ctx), G(G_.o_w), G(G_.o_b), M, D, D, 0, scr, scrb, stream));
         EGO_RC(egotap_train_transpose(P_.o_w, WT, D, D, 0, stream));
         EGO_RC(egotap_train_gemm_nt(h, 0, dxm, 0, nullptr, WT, nullptr, R0, M, D, D, 0, nullptr, nullptr, 0, stream));             // dctx
         EGO_RC(egotap_train_attention_bwd(S(l.qkv), S(l.ctx), R0, S(l.lse), W(w.delta), A3, B, h->seq, heads, prec, stream));   // dqkv
@@ -3206,8 +3225,7 @@ extern "C" int egotap_lift_backward(egotap_handle h, const float* hm, const floa
         float* gw[3] = {G(G_.q_w), G(G_.k_w), G(G_.v_w)};
         float* gb[3] = {G(G_.q_b), G(G_.k_b), G(G_.v_b)};
         for (int q = 0; q < 3; ++q) {
-            EGO_RC(egotap_train_gemm_tn(h, 0, A3 + (size_t)q * D, 3 * D, S(l.y1), nullptr, gw[q], M, D, D, 0, 0, scr, scrb, stream));
-            EGO_RC(egotap_train_colsum(A3 + (size_t)q * D, 3 * D, gb[q], M, D, 0, scr, scrb, stream));
+            EGO_RC(egotap_train_gemm_tn_bias(h, A3 + (size_t)q * D, 3 * D, S(l.y1), gw[q], gb[q], M, D, D, 0, scr, scrb, stream));
             EGO_RC(egotap_train_transpose(pw[q], WT + (size_t)q * D, D, D, 3 * D, stream));                                         // [Wq^T | Wk^T | Wv^T]
         }
         EGO_RC(egotap_train_gemm_nt(h, 0, A3, 0, nullptr, WT, nullptr, R0, M, D, 3 * D, 0, nullptr, nullptr, 0, stream));          // dy1

@@ -246,7 +246,8 @@ struct TnDmaCfg {
 
 static __global__ __launch_bounds__(TnDmaCfg::THREADS) void gemm_tn_f32_dma_kernel(const float* __restrict__ dY, long ldy, const float* __restrict__ X,
                                                                                   long ldx, float* __restrict__ slabs, int M, int N, int K,
-                                                                                  int tiles_n, int tiles_k, int splits, int rows_per) {
+                                                                                  int tiles_n, int tiles_k, int splits, int rows_per,
+                                                                                  float* __restrict__ csum) {
     using Cfg = TnDmaCfg;
     constexpr int BN = Cfg::BN, BK = Cfg::BK, BKM = Cfg::BKM, LDA = Cfg::LDA, LDB = Cfg::LDB, TN = Cfg::TN, TK = Cfg::TK, SF = Cfg::STAGE_FLOATS;
     extern __shared__ __attribute__((aligned(16))) float smem_tnd[];
@@ -285,12 +286,22 @@ static __global__ __launch_bounds__(TnDmaCfg::THREADS) void gemm_tn_f32_dma_kern
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // csum != nullptr: the workgroups of the first k-tile column also sum the dY rows they stage anyway -- csum[split][N] = column sums of dY over
+    // the split's rows = the bias gradient of the same Linear layer, which used to be a pass of its own over dY (thread = column tid & 255, rows
+    // 16 (tid >> 8) .. + 15 of every slab, fixed order)
+    const bool do_cs = csum != nullptr && tk == 0;
+    float cs = 0.f;
     if (nslab > 0) dma_slab(0, 0);
     for (int s = 0; s < nslab; ++s) {
         const int buf = s & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's rows of slab s have landed ...
         __syncthreads();                                          // ... everybody's have, and nobody reads the other stage any more
         if (s + 1 < nslab) dma_slab(s + 1, buf ^ 1);
+        if (do_cs) {
+            const float* cp = smem_tnd + buf * SF + (tid >> 8) * 16 * LDA + (tid & 255);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs += cp[r * LDA];
+        }
         const float* Ab = smem_tnd + buf * SF + lh * LDA + wn * (TN * 32) + l31;
         const float* Bb = smem_tnd + buf * SF + BKM * LDA + lh * LDB + wk * (TK * 32) + l31;
 #pragma unroll
@@ -319,25 +330,36 @@ static __global__ __launch_bounds__(TnDmaCfg::THREADS) void gemm_tn_f32_dma_kern
                 out[(long)n * K + kk] = acc[i][j][r];
             }
         }
+    if (do_cs) {                     // (uniform over the workgroup)
+        __syncthreads();             // everybody is done with the stages: the first 2 KB become the hand-over of the two row halves
+        if (tid >= 256) smem_tnd[tid & 255] = cs;
+        __syncthreads();
+        if (tid < 256) csum[(long)split * N + n0 + tid] = cs + smem_tnd[tid];
+    }
 }
 
 static inline bool gemm_tn_f32_dma_ok(const float* dY, long ldy, const float* X, long ldx, int M, int N, int K) {
     return M % TnDmaCfg::BKM == 0 && N % TnDmaCfg::BN == 0 && K % TnDmaCfg::BK == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)dY & 15) == 0 &&
            ((uintptr_t)X & 15) == 0;
 }
+// db != nullptr: also db[N] (+)= column sums of dY (the layer's bias gradient), summed by the workgroups that stage dY anyway
 static hipError_t gemm_tn_f32_dma_launch(const float* dY, long ldy, const float* X, long ldx, float* dW, float* slabs, size_t slab_bytes, int M, int N,
-                                         int K, int num_cu, int accumulate, hipStream_t stream) {
+                                         int K, int num_cu, int accumulate, hipStream_t stream, float* db = nullptr) {
     using Cfg = TnDmaCfg;
     if (!gemm_tn_f32_dma_ok(dY, ldy, X, ldx, M, N, K)) return hipErrorInvalidValue;
     const int tiles_n = N / Cfg::BN, tiles_k = K / Cfg::BK, tiles = tiles_n * tiles_k;
     // split count from the model shared with the convolution weight gradients: the q | k | v gradient (48 tiles) took 11 splits = 528 workgroups =
     // three rounds for 2.06 rounds of work under the "two blocks per CU" rule; 16 splits are three full rounds
     int per = 0;
-    int splits = wgrad_pick_splits(tiles, M / Cfg::BKM, (long)N * K, slab_bytes, num_cu, Cfg::LDS_BYTES, Cfg::BKM / 2 * Cfg::TN * Cfg::TK * 64 / 2400.0, 6.0, &per);
+    // with db every split needs N more floats (its column-sum partial row) behind its N x K slab
+    const size_t avail = db ? slab_bytes / (size_t)(K + 1) * (size_t)K : slab_bytes;
+    int splits = wgrad_pick_splits(tiles, M / Cfg::BKM, (long)N * K, avail, num_cu, Cfg::LDS_BYTES, Cfg::BKM / 2 * Cfg::TN * Cfg::TK * 64 / 2400.0, 6.0, &per);
     if (splits < 1) { splits = 1; per = M / Cfg::BKM; }
     const bool direct = splits == 1 && !accumulate;
-    if (!direct && (size_t)splits * N * K * 4 > slab_bytes) return hipErrorOutOfMemory;
+    const size_t slab_floats = direct ? 0 : (size_t)splits * N * K;
+    if ((slab_floats + (db ? (size_t)splits * N : 0)) * 4 > slab_bytes) return hipErrorOutOfMemory;
     const int rows_per = per * Cfg::BKM;
+    float* csum = db ? slabs + slab_floats : nullptr;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_f32_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
@@ -345,9 +367,11 @@ static hipError_t gemm_tn_f32_dma_launch(const float* dY, long ldy, const float*
         attr_done = true;
     }
     hipLaunchKernelGGL(gemm_tn_f32_dma_kernel, dim3(tiles * splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, dY, ldy, X, ldx, direct ? dW : slabs, M, N,
-                       K, tiles_n, tiles_k, splits, rows_per);
+                       K, tiles_n, tiles_k, splits, rows_per, csum);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || direct) return e;
+    if (e != hipSuccess) return e;
+    if (db) hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((N / 4 + 255) / 256)), dim3(256), 0, stream, (const float*)csum, db, (long)N, splits, accumulate);
+    if (direct) return hipGetLastError();
     const long n = (long)N * K;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, slabs, dW, n, splits, accumulate);
     return hipGetLastError();

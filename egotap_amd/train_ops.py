@@ -53,6 +53,13 @@ def gemm_tn(h, dy, x, dw, M, N, K, loader=LD_PLAIN, accumulate=False, aux=None, 
     return dw
 
 
+def gemm_tn_bias(h, dy, x, dw, db, M, N, K, accumulate=False, ldy=0):
+    """dw[N,K] (+)= dy[M,N]^T @ x[M,K] and db[N] (+)= column sums of dy: weight and bias gradient of a Linear layer in one call"""
+    ws = _scratch.get(max(64 << 20, 4 * N * (K + 1) * 20), dy.device)       # room for 20 partial slabs: never what limits the split count
+    _lib.check(_lib.load().egotap_train_gemm_tn_bias(h, _p(dy), ldy, _p(x), _p(dw), _p(db), M, N, K, int(accumulate), _p(ws), ws.numel(), _s()))
+    return dw, db
+
+
 def colsum(y, out, M, N, accumulate=False, ldy=0):
     ws = _scratch.get(64 << 20, y.device)
     _lib.check(_lib.load().egotap_train_colsum(_p(y), ldy, _p(out), M, N, int(accumulate), _p(ws), ws.numel(), _s()))

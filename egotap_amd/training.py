@@ -325,30 +325,27 @@ class LiftTrainFn(torch.autograd.Function):
         for i in reversed(range(p.vit_layers)):
             # the bias gradient of output.dense of layer i belongs to the bucket that closes after layer i + 1 (arena layout shared
             # with the bf16 path, where it comes out of a LayerNorm backward): compute it first, then close that bucket
-            T.colsum(dx, G[f"{v}encoder.layer.{i}.output.dense.bias"], M, D)
-            red.bucket_ready(ga["bounds"][p.vit_layers - 1 - i], ga["bounds"][p.vit_layers - i])
+            # [r3] (every Linear's weight and bias gradient in one call: the weight-gradient GEMM sums the columns of the dY rows it stages)
             L = S["layers"][i]
             l = f"{v}encoder.layer.{i}."
             a = l + "attention.attention."
+            T.gemm_tn_bias(h, dx, L["hid"], G[l + "output.dense.weight"], G[l + "output.dense.bias"], M, D, 4 * D)
+            red.bucket_ready(ga["bounds"][p.vit_layers - 1 - i], ga["bounds"][p.vit_layers - i])
             # MLP
-            T.gemm_tn(h, dx, L["hid"], G[l + "output.dense.weight"], M, D, 4 * D)
             dz = T.gemm_nt(h, dx, T.transpose(P[l + "output.dense.weight"]), None, M, 4 * D, D, epi=T.TE_GELU_GRAD, r=L["z"])
-            T.gemm_tn(h, dz, L["y2"], G[l + "intermediate.dense.weight"], M, 4 * D, D)
-            T.colsum(dz, G[l + "intermediate.dense.bias"], M, 4 * D)
+            T.gemm_tn_bias(h, dz, L["y2"], G[l + "intermediate.dense.weight"], G[l + "intermediate.dense.bias"], M, 4 * D, D)
             dy2 = T.gemm_nt(h, dz, T.transpose(P[l + "intermediate.dense.weight"]), None, M, D, 4 * D, epi=T.TE_NONE)
             del dz
             dxm = T.layernorm_bwd(L["xm"], dy2, P[l + "layernorm_after.weight"], L["m2"], L["r2"], G[l + "layernorm_after.weight"],
                                   G[l + "layernorm_after.bias"], dres=dx)
             # attention
-            T.gemm_tn(h, dxm, L["ctx"], G[l + "attention.output.dense.weight"], M, D, D)
-            T.colsum(dxm, G[l + "attention.output.dense.bias"], M, D)
+            T.gemm_tn_bias(h, dxm, L["ctx"], G[l + "attention.output.dense.weight"], G[l + "attention.output.dense.bias"], M, D, D)
             dctx = T.gemm_nt(h, dxm, T.transpose(P[l + "attention.output.dense.weight"]), None, M, D, D, epi=T.TE_NONE)
             dqkv = T.attention_bwd(L["qkv"], L["ctx"], dctx, L["lse"], B, seq, heads, prec)
             del dctx
             wt = torch.empty((D, 3 * D), dtype=torch.float32, device=dev)      # [Wq^T | Wk^T | Wv^T]
             for s, nme in enumerate(("query", "key", "value")):
-                T.gemm_tn(h, dqkv[:, s * D:], L["y1"], G[a + nme + ".weight"], M, D, D, ldy=3 * D)
-                T.colsum(dqkv[:, s * D:], G[a + nme + ".bias"], M, D, ldy=3 * D)
+                T.gemm_tn_bias(h, dqkv[:, s * D:], L["y1"], G[a + nme + ".weight"], G[a + nme + ".bias"], M, D, D, ldy=3 * D)
                 T.transpose(P[a + nme + ".weight"], out=wt[:, s * D:], ldo=3 * D)
             dy1 = T.gemm_nt(h, dqkv, wt, None, M, D, 3 * D, epi=T.TE_NONE)
             del dqkv

@@ -201,6 +201,11 @@ int egotap_train_gemm_nt(egotap_handle h, int loader, const float* x, int64_t ld
 int egotap_train_gemm_tn(egotap_handle h, int loader, const float* dy, int64_t ldy, const float* x, const float* aux, float* dw, int M,
                          int N, int K, int accumulate, int Bsz, void* ws, size_t ws_bytes, void* stream);
 int egotap_train_colsum(const float* y, int64_t ldy, float* out, int M, int N, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* [r3] weight and bias gradient of one nn.Linear with a plain input in one call: dw[N,K] (+)= dy^T x, db[N] (+)= column sums of dy (autograd of
+ * the ViT layers' Linear modules, model/modeling_vit.py:226-230, 271, 319-344).  fp32 with M % 32 == 0: the workgroups that stage dy for the
+ * product also sum its columns (one pass over dy); otherwise egotap_train_gemm_tn followed by egotap_train_colsum. */
+int egotap_train_gemm_tn_bias(egotap_handle h, const float* dy, int64_t ldy, const float* x, float* dw, float* db, int M, int N, int K,
+                              int accumulate, void* ws, size_t ws_bytes, void* stream);
 int egotap_train_transpose(const float* in, float* out, int R, int C, int64_t ldo, void* stream);
 int egotap_train_add_inplace(float* out, const float* in, int64_t n, void* stream);
 int egotap_train_patch_fwd(egotap_handle h, const float* hm, int B, const float* w, const float* b, const float* mask_tok,

@@ -41,6 +41,35 @@ def test_gemm_tn(M, N, K):
     _close(dw, 2 * ref, atol=4e-5 * math.sqrt(M))
 
 
+@pytest.mark.parametrize("M,N,K,strided", [(1024, 256, 256, False), (4128, 512, 1024, False), (2080, 256, 512, True), (8192, 1024, 256, False),
+                                             (700, 256, 256, False), (1200, 256, 512, True)])
+def test_gemm_tn_bias_one_call(M, N, K, strided):
+    """[r3] weight + bias gradient in one call (egotap_train_gemm_tn_bias).  M % 32 == 0 and M >= 1024: the DMA-staged kernel, whose first k-tile
+    column of workgroups sums the dY rows it stages; the last two shapes fall back to the two operators.  Against float64; accumulate; the
+    same bits on a second run (fixed summation order); the plain weight-gradient entry takes the same kernel and gives the same dW."""
+    from egotap_amd import train_ops as T
+    h, _, _ = _handle()
+    ld = 3 * N if strided else N
+    dyf, x = _rand((M, ld), 11), _rand((M, K), 12)
+    dyc = dyf.cuda()
+    dy_view = dyc[:, N:] if strided else dyc
+    dy_ref = (dyf[:, N:2 * N] if strided else dyf).double()
+    dw, db = torch.full((N, K), 3.0, device="cuda"), torch.full((N,), -2.0, device="cuda")
+    T.gemm_tn_bias(h, dy_view, x.cuda(), dw, db, M, N, K, ldy=ld if strided else 0)
+    ref_w, ref_b = dy_ref.T @ x.double(), dy_ref.sum(0)
+    _close(dw, ref_w, atol=2e-5 * math.sqrt(M), msg="dw")
+    _close(db, ref_b, atol=2e-5 * math.sqrt(M), msg="db")
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+    T.gemm_tn_bias(h, dy_view, x.cuda(), dw2, db2, M, N, K, ldy=ld if strided else 0)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    dw3 = torch.empty_like(dw)
+    T.gemm_tn(h, dy_view, x.cuda(), dw3, M, N, K, ldy=ld if strided else 0)
+    assert torch.equal(dw, dw3)
+    T.gemm_tn_bias(h, dy_view, x.cuda(), dw, db, M, N, K, accumulate=True, ldy=ld if strided else 0)
+    _close(dw, 2 * ref_w, atol=4e-5 * math.sqrt(M), msg="dw accumulate")
+    _close(db, 2 * ref_b, atol=4e-5 * math.sqrt(M), msg="db accumulate")
+
+
 def test_gemm_tn_strided_dy_and_colsum_transpose():
     from egotap_amd import train_ops as T
     h, _, _ = _handle()
