@@ -802,6 +802,12 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
         EGO_HIP(gemm_bf16s_launch(xl, h->wscratch, 256L, ep, M, D, 256, device_cu_count(), s));
     } else {
         ALoadPatch al{hm, h->C, S, h->seq, h->side, h->ppd, h->grid, h->T};
+        // [r3] fp32 at a batch that fills the chip: a zero page for the dummy cells (the head of the PU chain's ZERO slice, which is cleared as a
+        // whole further down and not read before) makes the loader pure address math -> the LDS-DMA kernel instead of the register-staged one
+        if (h->precision == EGOTAP_PREC_F32 && (long)((M + 255) / 256) * (D / 256) >= 160 && (size_t)B * H * 4 >= 1024) {
+            EGO_HIP(zero_fill(ZERO, 1024, s));
+            al.zeros = ZERO;
+        }
         EpiPatch ep{p.patch_b, p.mask_tok, p.pos_emb, D, h->seq, h->side, h->ppd, h->grid, h->T};
         EGO_HIP((gemm_small(h, "patch_embed", al, segmat1(p.patch_w, D, 256), ep, X, D, M, D, 256, SPK, s)));
     }

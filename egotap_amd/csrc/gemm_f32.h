@@ -38,8 +38,13 @@ struct ALoadPlain {
 struct ALoadPatch {
     const float* hm;   // [B, C, S, S] heatmaps, position channels first
     int C, S, seq, side, ppd, grid, T;
-    static constexpr bool HAS_PTR = false;      // dummy cells are zeros, not memory
+    // [r3] zeros != nullptr: 256 zero floats (16-byte aligned) that stand in for the dummy cells, so that the loader is pure address math and can
+    // feed the global -> LDS DMA (gemm_f32_dma.h); nullptr (the default): the register-staged kernels, as before
+    const float* zeros = nullptr;
     struct Row { const float* p; };   // nullptr: dummy cell (zeros)
+    static constexpr bool HAS_PTR = true;
+    __device__ __forceinline__ const float* ptr(const Row& r, int k) const { return r.p ? r.p + (k >> 4) * S + (k & 15) : zeros + k; }
+    __host__ bool dma_ok() const { return zeros != nullptr && S % 4 == 0 && ((uintptr_t)hm & 15) == 0 && ((uintptr_t)zeros & 15) == 0; }
     __device__ __forceinline__ Row row(int m) const {
         const int b = m / seq, tok = m - b * seq;
         const int pr = tok / side, pc = tok - pr * side;
