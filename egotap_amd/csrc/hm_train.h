@@ -5,8 +5,9 @@
 //                         implicit GEMM on the fp32 matrix cores: the contraction index is the PIXEL; a slab is one output row
 //                         of one image: dY rows and the raw input rows (+ halo) are staged as they lie in memory and every
 //                         (ci, tap) column of the product is a fixed LDS offset per lane.  Tile 128 co x (32 ci x 9 taps): wave w
-//                         owns 32 output channels and all nine 32-column tiles (one dY read feeds nine MFMAs).  Split over images, partial
-//                         slabs summed in a fixed order (reduce_slabs_kernel): no float atomics, bitwise reproducible.
+//                         owns 32 output channels and all nine 32-column tiles (one dY read feeds nine MFMAs); layers with at most 64 output
+//                         channels: 2 x 2 waves over 64 co x 64 ci.  Split over output rows ([r3]: the count comes from wgrad_pick_splits,
+//                         gemm_tn_f32.h), partial slabs summed in a fixed order (reduce_slabs_kernel): no float atomics, bitwise reproducible.
 //   * input gradients need no kernel of their own: dX = conv(dY, W^T flipped) runs on the forward kernels after
 //     conv_wt_kernel (flip + channel swap); stride-2 layers first spread dY over the even pixels (zero_upsample2_kernel).
 //   * BatchNorm2d in train mode (batch statistics over N*H*W, running-stat update, fused residual add and ReLU) forward
