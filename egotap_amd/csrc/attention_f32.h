@@ -26,7 +26,7 @@ struct AttnCfg {
 };
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) void attention_f32_kernel(const float* __restrict__ QKV,
+__global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* __restrict__ QKV,
                                                                  float* __restrict__ CTX, int N, int heads,
                                                                  int qgroups, float scale_log2e, float* __restrict__ LSE) {
     using Cfg = AttnCfg<NW>;
@@ -186,24 +186,17 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) void attention_f32_kernel
     }
 }
 
-static int device_cu_count();      // egotap_abi.hip
-template <int NW>
-static hipError_t attention_f32_launch_nw(const float* QKV, float* CTX, int B, int N, int heads, hipStream_t stream, float* LSE) {
+static hipError_t attention_f32_launch(const float* QKV, float* CTX, int B, int N, int heads, hipStream_t stream,
+                                       float* LSE = nullptr) {
+    constexpr int NW = 2;
     using Cfg = AttnCfg<NW>;
+    if (B <= 0) return hipSuccess;
+    if (N % 32 != 0) return hipErrorInvalidValue;
     auto kern = attention_f32_kernel<NW>;
     const int qgroups = (N / 32 + NW - 1) / NW;
     const float scale_log2e = 1.4426950408889634f / sqrtf(128.0f);
     hipLaunchKernelGGL(kern, dim3(B * heads * qgroups), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, QKV, CTX, N, heads,
                        qgroups, scale_log2e, LSE);
     return hipGetLastError();
-}
-static hipError_t attention_f32_launch(const float* QKV, float* CTX, int B, int N, int heads, hipStream_t stream,
-                                       float* LSE = nullptr) {
-    if (B <= 0) return hipSuccess;
-    if (N % 32 != 0) return hipErrorInvalidValue;
-    // [r3] serving batches: with two query blocks per workgroup B = 1 is 72 workgroups for 256 CUs; one wave per workgroup doubles the
-    // workgroups (same arithmetic per query row: same bits).  From two full rounds of two-wave workgroups on, sharing the K / V tiles wins.
-    if ((long)B * heads * ((N / 32 + 1) / 2) < 2L * device_cu_count()) return attention_f32_launch_nw<1>(QKV, CTX, B, N, heads, stream, LSE);
-    return attention_f32_launch_nw<2>(QKV, CTX, B, N, heads, stream, LSE);
 }
 #endif
