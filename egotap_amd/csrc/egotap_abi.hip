@@ -1744,6 +1744,15 @@ extern "C" int egotap_train_gemm_tn_bias(egotap_handle h, const float* dy, int64
         EGO_HIP(e);
         return EGOTAP_OK;
     }
+    if (h->precision != EGOTAP_PREC_F32 && N % 256 == 0 && K % 256 == 0 && M >= 1024 && ldy % 4 == 0) {      // bf16x3 / bf16 products: the same, on fp32 dY before the rounding
+        const ALoadPlain xl{x, K};
+        hipError_t e = h->precision == EGOTAP_PREC_BF16X3
+                           ? gemm_tn_bf16_launch<TnBfCfg<3>, ALoadPlain>(dy, ldy, xl, dw, (float*)ws, ws_bytes, M, N, K, device_cu_count(), accumulate, s, db)
+                           : gemm_tn_bf16_launch<TnBfCfg<1>, ALoadPlain>(dy, ldy, xl, dw, (float*)ws, ws_bytes, M, N, K, device_cu_count(), accumulate, s, db);
+        if (e == hipErrorOutOfMemory) { egotap_set_error("egotap_train_gemm_tn_bias: workspace too small (%zu bytes) for N*K=%ld", ws_bytes, (long)N * K); return EGOTAP_ERR_WORKSPACE; }
+        EGO_HIP(e);
+        return EGOTAP_OK;
+    }
     int rc = egotap_train_gemm_tn(h, 0, dy, ldy, x, nullptr, dw, M, N, K, accumulate, 0, ws, ws_bytes, stream);
     if (rc != EGOTAP_OK) return rc;
     return egotap_train_colsum(dy, ldy, db, M, N, accumulate, ws, ws_bytes, stream);

@@ -36,7 +36,7 @@ struct TnBfCfg {
 template <class Cfg, class XLoad>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void gemm_tn_bf16_kernel(const float* __restrict__ dY, long ldy, XLoad xl,
                                                                          float* __restrict__ slabs, int M, int N, int K,
-                                                                         int tiles_n, int tiles_k, int splits) {
+                                                                         int tiles_n, int tiles_k, int splits, float* __restrict__ csum) {
     constexpr int BN = Cfg::BN, BK = Cfg::BK, BKM = Cfg::BKM, STR = Cfg::STR, IMG = Cfg::IMG, NIMG = Cfg::NIMG, NP = Cfg::NP;
     constexpr int TN = Cfg::TN, TK = Cfg::TK, V4 = Cfg::V4, THREADS = Cfg::THREADS;
     extern __shared__ __attribute__((aligned(16))) __bf16 simg[];
@@ -82,10 +82,15 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void gemm_tn_bf16_kernel(const flo
         *(bf16x4*)(hi_img + off) = h;
         if (NP == 3) *(bf16x4*)(lo_img + off) = l;
     };
+    // [r3] csum != nullptr: the workgroups of the first k-tile column also sum the fp32 dY values they stage (before the rounding): csum[split][N]
+    // = the layer's bias gradient over the split's rows, fixed order (a thread always stages the same four columns: 512 % 64 == 0)
+    const bool do_cs = csum != nullptr && tk == 0;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     auto lstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < V4; ++i) {
             const int idx = tid + i * THREADS, r = idx / C4, c = idx - r * C4;
+            if (do_cs) cs += pa[i];
             put(pa[i], img(buf, 0, 0), img(buf, 0, NIMG - 1), r * STR + c * 4);
             put(pb[i], img(buf, 1, 0), img(buf, 1, NIMG - 1), r * STR + c * 4);
         }
@@ -161,11 +166,23 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void gemm_tn_bf16_kernel(const flo
                 if (n < N && kk < K) out[(long)n * K + kk] = acc[i][j][r];
             }
         }
+    if (do_cs) {                                   // (uniform over the workgroup; the loop above ended with a barrier: the images are free)
+        f32x4* red = (f32x4*)simg;
+        red[tid] = cs;                             // [wave][lane = float4 column]
+        __syncthreads();
+        if (wid == 0) {
+            f32x4 t = red[lane];
+#pragma unroll
+            for (int w = 1; w < THREADS / 64; ++w) t += red[w * 64 + lane];
+            *(f32x4*)(csum + (long)split * N + n0 + lane * 4) = t;
+        }
+    }
 }
 
+// db != nullptr: also db[N] (+)= column sums of dY (the bias gradient of the same Linear layer)
 template <class Cfg, class XLoad>
 static hipError_t gemm_tn_bf16_launch(const float* dY, long ldy, const XLoad& xl, float* dW, float* slabs, size_t slab_bytes,
-                                      int M, int N, int K, int num_cu, int accumulate, hipStream_t stream) {
+                                      int M, int N, int K, int num_cu, int accumulate, hipStream_t stream, float* db = nullptr) {
     if (N % Cfg::BN != 0 || K % Cfg::BK != 0) return hipErrorInvalidValue;
     const int tiles_n = N / Cfg::BN, tiles_k = K / Cfg::BK;
     const int tiles = tiles_n * tiles_k;
@@ -173,9 +190,11 @@ static hipError_t gemm_tn_bf16_launch(const float* dY, long ldy, const XLoad& xl
     const int max_by_rows = (M + 4 * Cfg::BKM - 1) / (4 * Cfg::BKM);
     if (splits > max_by_rows) splits = max_by_rows;
     if (splits < 1) splits = 1;
-    while ((size_t)splits * N * K * 4 > slab_bytes && splits > 1) --splits;
+    const size_t per_split = ((size_t)N * K + (db ? (size_t)N : 0)) * 4;      // with db: the split's column-sum row behind the slabs
+    while ((size_t)splits * per_split > slab_bytes && splits > 1) --splits;
     const bool direct = splits == 1 && !accumulate;              // a single slab that is not added to anything IS the gradient
-    if (!direct && (size_t)splits * N * K * 4 > slab_bytes) return hipErrorOutOfMemory;
+    if ((direct ? (db ? (size_t)N * 4 : 0) : (size_t)splits * per_split) > slab_bytes) return hipErrorOutOfMemory;
+    float* csum = db ? slabs + (direct ? 0 : (size_t)splits * N * K) : nullptr;
     auto kern = gemm_tn_bf16_kernel<Cfg, XLoad>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -184,9 +203,11 @@ static hipError_t gemm_tn_bf16_launch(const float* dY, long ldy, const XLoad& xl
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, dY, ldy, xl, direct ? dW : slabs, M, N, K,
-                       tiles_n, tiles_k, splits);
+                       tiles_n, tiles_k, splits, csum);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || direct) return e;
+    if (e != hipSuccess) return e;
+    if (db) hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((N / 4 + 255) / 256)), dim3(256), 0, stream, (const float*)csum, db, (long)N, splits, accumulate);
+    if (direct) return hipGetLastError();
     const long n = (long)N * K;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, slabs, dW, n, splits,
                        accumulate);

@@ -70,6 +70,31 @@ def test_gemm_tn_bias_one_call(M, N, K, strided):
     _close(db, 2 * ref_b, atol=4e-5 * math.sqrt(M), msg="db accumulate")
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_gemm_tn_bias_bf16_modes(mode):
+    """[r3] the same call in the bf16 product modes: dW on the bf16 matrix cores (hi + lo split or plain rounding), db summed from the fp32 dY values
+    the kernel stages (before the rounding: fp32-grade in both modes); equal to the two separate operators' dW bit for bit"""
+    from egotap_amd import lib as L
+    from egotap_amd import train_ops as T
+    h, _, _ = _handle()
+    M, N, K = 2048, 512, 256
+    dyf, x = _rand((M, 3 * N), 21), _rand((M, K), 22)
+    dyc = dyf.cuda()
+    L.check(L.load().egotap_set_precision(h, L.PRECISIONS[mode]))
+    try:
+        dw, db = torch.empty((N, K), device="cuda"), torch.empty((N,), device="cuda")
+        T.gemm_tn_bias(h, dyc[:, N:], x.cuda(), dw, db, M, N, K, ldy=3 * N)
+        dw2 = torch.empty_like(dw)
+        T.gemm_tn(h, dyc[:, N:], x.cuda(), dw2, M, N, K, ldy=3 * N)
+        torch.cuda.synchronize()
+    finally:
+        L.check(L.load().egotap_set_precision(h, L.PRECISIONS["f32"]))
+    ref_w, ref_b = dyf[:, N:2 * N].double().T @ x.double(), dyf[:, N:2 * N].double().sum(0)
+    _close(db, ref_b, atol=2e-5 * math.sqrt(M), msg="db")
+    _close(dw, ref_w, atol=(2e-4 if mode == "bf16x3" else 2e-2) * math.sqrt(M), msg="dw")
+    assert torch.equal(dw, dw2)
+
+
 def test_gemm_tn_strided_dy_and_colsum_transpose():
     from egotap_amd import train_ops as T
     h, _, _ = _handle()
