@@ -216,6 +216,18 @@ static int wgrad_pick_splits(int tiles, long slabs, long n_floats, size_t slab_b
     if (max_s < 1) return 0;
     if (max_s > slabs) max_s = slabs;
     if (max_s > 4096) max_s = 4096;
+    // a training step asks the same few questions every time: remember the last answers (per host thread; the scan below is up to 4096 candidates)
+    struct Memo { int tiles; long slabs, n_floats, max_s; int num_cu, wpc; double slab_us, fixed_us; int s, per; };
+    static thread_local Memo memo[32];
+    static thread_local int memo_n = 0, memo_next = 0;
+    for (int i = 0; i < memo_n; ++i) {
+        const Memo& m = memo[i];
+        if (m.tiles == tiles && m.slabs == slabs && m.n_floats == n_floats && m.max_s == max_s && m.num_cu == num_cu && m.wpc == wpc && m.slab_us == slab_us &&
+            m.fixed_us == fixed_us) {
+            *per_out = m.per;
+            return m.s;
+        }
+    }
     double best = 1e30;
     int best_s = 1;
     for (long s = 1; s <= max_s; ++s) {
@@ -227,6 +239,9 @@ static int wgrad_pick_splits(int tiles, long slabs, long n_floats, size_t slab_b
         if (t < best * 0.995) { best = t; best_s = (int)s; }
     }
     *per_out = (int)((slabs + best_s - 1) / best_s);
+    memo[memo_next] = Memo{tiles, slabs, n_floats, max_s, num_cu, wpc, slab_us, fixed_us, best_s, *per_out};
+    memo_next = (memo_next + 1) % 32;
+    if (memo_n < 32) ++memo_n;
     return best_s;
 }
 
