@@ -1729,6 +1729,17 @@ extern "C" int egotap_train_colsum(const float* y, int64_t ldy, float* out, int 
 }
 #endif
 
+// (test aid, host only) the split count the weight-gradient launches choose: wgrad_pick_splits of gemm_tn_f32.h
+#if EGOTAP_IN(1)
+extern "C" int egotap_debug_wgrad_splits(int tiles, int64_t slabs, int64_t n_floats, size_t slab_bytes, int num_cu, int lds_bytes, double slab_us,
+                                         double fixed_us, int* per) {
+    int p = 0;
+    const int s = (tiles > 0 && slabs > 0 && n_floats > 0 && num_cu > 0) ? wgrad_pick_splits(tiles, (long)slabs, (long)n_floats, slab_bytes, num_cu, lds_bytes, slab_us, fixed_us, &p) : 0;
+    if (per) *per = p;
+    return s;
+}
+#endif
+
 // [r3] dW[N,K] (+)= dY^T X and db[N] (+)= column sums of dY in one call: weight and bias gradient of a Linear layer with a plain input.  In fp32,
 // when the DMA-staged kernel applies, the workgroups that stage dY for the product also sum its columns (no second pass over dY: 5.4 GB per
 // ViT layer at B = 256); otherwise the two operators one after the other.

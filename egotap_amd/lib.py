@@ -63,6 +63,7 @@ _PROTOS = {
     # ---- training-step operators
     "egotap_train_gemm_nt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "egotap_debug_wgrad_splits": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)]),
     "egotap_train_gemm_tn_bias": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, C.c_size_t, C.c_void_p]),
     "egotap_train_gemm_tn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -201,6 +201,11 @@ int egotap_train_gemm_nt(egotap_handle h, int loader, const float* x, int64_t ld
 int egotap_train_gemm_tn(egotap_handle h, int loader, const float* dy, int64_t ldy, const float* x, const float* aux, float* dw, int M,
                          int N, int K, int accumulate, int Bsz, void* ws, size_t ws_bytes, void* stream);
 int egotap_train_colsum(const float* y, int64_t ldy, float* out, int M, int N, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* (test aid, host only: no device call) the number of partial slabs a weight-gradient launch splits its contraction into, and the slabs per split:
+ * workgroups in a row on the busiest CU x slabs each + a fixed part per workgroup + the traffic of the slab reduction, within slab_bytes of
+ * workspace.  0 when not even one slab of n_floats fits. */
+int egotap_debug_wgrad_splits(int tiles, int64_t slabs, int64_t n_floats, size_t slab_bytes, int num_cu, int lds_bytes, double slab_us, double fixed_us,
+                              int* per);
 /* [r3] weight and bias gradient of one nn.Linear with a plain input in one call: dw[N,K] (+)= dy^T x, db[N] (+)= column sums of dy (autograd of
  * the ViT layers' Linear modules, model/modeling_vit.py:226-230, 271, 319-344).  fp32 with M % 32 == 0: the workgroups that stage dy for the
  * product also sum its columns (one pass over dy); otherwise egotap_train_gemm_tn followed by egotap_train_colsum. */

@@ -212,3 +212,31 @@ def test_resnet34_backbone_spec_module_and_handle():
     bad.hm_blocks[2] = 7
     h = C.c_void_p()
     assert lib.egotap_create(C.byref(bad), C.byref(h)) == 1 and b"hm_blocks" in lib.egotap_last_error()
+
+
+def test_weight_gradient_split_count_host_logic():
+    """[r3] wgrad_pick_splits (csrc/gemm_tn_f32.h), the host-side choice behind every weight-gradient launch: covers the contraction exactly, stays within
+    the workspace, fills whole rounds of the 256 CUs where round 2's rule left a partial third round, and answers the same question the same way."""
+    lib = L.load()
+    per = C.c_int()
+
+    def pick(tiles, slabs, n, mem=256 << 20, cu=256, lds=118016, slab_us=7.68, fixed=4.0):
+        s = lib.egotap_debug_wgrad_splits(tiles, slabs, n, mem, cu, lds, slab_us, fixed, C.byref(per))
+        return s, per.value
+
+    # conv_up1 of a 32-frame stage-1 step: 80 tiles, 32 images x 64 rows; round 2: 7 splits of whole images = 560 workgroups (three rounds for 2.2)
+    s, p = pick(80, 32 * 64, 512 * 640 * 9)
+    assert (s, p) == (16, 128) and (80 * s) % 256 == 0
+    # a 64 -> 64 layer of layer1 with the 2 x 2 wave layout: one tile, 64 images x 64 rows -> every CU gets one workgroup
+    s, p = pick(1, 64 * 64, 64 * 64 * 9, lds=136192)
+    assert s == 256 and p == 16
+    # the ViT's D x D weight gradients at B = 256 (4608 slabs of 32 rows): one full round
+    s, p = pick(16, 4608, 1024 * 1024, mem=512 << 20, lds=133120, slab_us=3.41, fixed=6.0)
+    assert (s, p) == (16, 288)
+    for tiles, slabs, n in ((392, 512, 1024 * 1540 * 9), (3, 100, 4096), (7, 1, 1 << 20), (160, 1024, 512 * 1280 * 9)):
+        s, p = pick(tiles, slabs, n)
+        assert s >= 1 and p >= 1 and (s - 1) * p < slabs <= s * p              # every split is non-empty, together they cover the slabs
+        assert s * n * 4 <= 256 << 20
+        assert pick(tiles, slabs, n) == (s, p)                                 # (second call: the per-thread memo)
+    assert pick(4, 64, 1 << 20, mem=(1 << 22) - 1)[0] == 0                      # not even one slab fits
+    assert pick(4, 64, 1 << 20, mem=3 << 22)[0] <= 3                            # the workspace bounds the count
