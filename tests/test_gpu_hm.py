@@ -70,12 +70,13 @@ def test_hm_writes_into_channel_slice_and_batch_independent():
     assert float((cat[:, 30:] - 7.0).abs().max()) == 0.0              # nothing outside the slice is touched
 
 
-def test_hm_forward_512_rgb_egocap_matches_oracle():
+@pytest.mark.parametrize("model_name", ["resnet18", "resnet50"])
+def test_hm_forward_512_rgb_egocap_matches_oracle(model_name):
     """BASELINE config 5 geometry: EgoCap preset, 512x512 RGB -> 128x128 heatmaps (128-wide conv instantiations,
-    stride-2 convs from 128 to 64)."""
+    stride-2 convs from 128 to 64); [r3] also through the Bottleneck backbone's operator composition (1x1 convolutions on 128 x 128 maps)."""
     from gpu_util import hm_net
     from oracle import hm_ref as H
-    net, sd_np = hm_net("pos", preset="EgoCap", hm=128)
+    net, sd_np = hm_net("pos", preset="EgoCap", hm=128, model_name=model_name)
     left = torch.from_numpy(synth_input("rgbL_ec512", (1, 3, 512, 512), -2.0, 2.0))
     right = torch.from_numpy(synth_input("rgbR_ec512", (1, 3, 512, 512), -2.0, 2.0))
     sd = H.to_torch_sd(sd_np, torch.float64)
