@@ -1002,6 +1002,8 @@ using C3s1_64       = ConvCfg<9, 1, 6, 128, 2, 4, 8>;
 using C3s1_32       = ConvCfg<9, 1, 5, 128, 2, 4, 8>;
 using C3s1_16       = ConvCfg<9, 1, 4, 128, 2, 4, 8>;
 using C3s1_8        = ConvCfg<9, 1, 3, 128, 2, 4, 8>;
+using C3s1_16_co64  = ConvCfg<9, 1, 4,  64, 2, 4, 8>;    // [r3] the same two widths with 64-channel tiles: twice the workgroups where 128-channel
+using C3s1_8_co64   = ConvCfg<9, 1, 3,  64, 2, 4, 8>;    // tiles leave CUs without one (training batches, serving batches); same bits (k order unchanged)
 using C3s2_32       = ConvCfg<9, 2, 5,  64, 2, 4, 8>;
 using C3s2_16       = ConvCfg<9, 2, 4,  64, 2, 4, 8>;
 using C3s2_8        = ConvCfg<9, 2, 3,  64, 2, 4, 8>;
@@ -1047,8 +1049,10 @@ static hipError_t conv_any(Handle* h, const char* role, int taps, int stride, in
         if (wout == 128) return a.Cout <= 64 ? conv<C3s1_128_co64>(h, role, a, s) : conv<C3s1_128>(h, role, a, s);
         if (wout == 64) return a.Cout <= 64 ? conv<C3s1_64_co64>(h, role, a, s) : conv<C3s1_64>(h, role, a, s);
         if (wout == 32) return conv<C3s1_32>(h, role, a, s);
-        if (wout == 16) return conv<C3s1_16>(h, role, a, s);
-        if (wout == 8) return conv<C3s1_8>(h, role, a, s);
+        // layer3 / layer4 at a 32-frame training batch: 128 / 64 workgroups of 128-channel tiles for 256 CUs (MFMA busy 0.21 on the 8 x 8 maps)
+        const long co128 = (a.Cout + 127) / 128;
+        if (wout == 16) return (long)a.Nimg * co128 < device_cu_count() ? conv<C3s1_16_co64>(h, role, a, s) : conv<C3s1_16>(h, role, a, s);
+        if (wout == 8) return (long)((a.Nimg + 3) / 4) * co128 < device_cu_count() ? conv<C3s1_8_co64>(h, role, a, s) : conv<C3s1_8>(h, role, a, s);
     } else if (taps == 9 && stride == 2) {
         if (wout == 64) return conv<C3s2_64>(h, role, a, s);
         if (wout == 32) return conv<C3s2_32>(h, role, a, s);

@@ -2,7 +2,7 @@
 # Runs on the GPU box (through gpurun): rocprofv3 passes, outputs under gpurun_out/prof*/ (scratch); tools/summarize_prof.py digests them
 # into profiles/rNN_*.  Every command gets FOUR separate passes (never combined: PMC + tracing together is refused on this pool):
 #   1 kernel trace + stats (durations)   2 FETCH_SIZE   3 WRITE_SIZE   4 MFMA busy / clock / wave counters
-# usage: tools/profile_bench.sh [headline] [config3] [hm16] [all]     (default: headline config3)
+# usage: tools/profile_bench.sh [headline] [config3] [hm16] [stage1] [all]     (default: headline config3)
 set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -24,6 +24,7 @@ for s in $SETS; do
     headline) passes gpurun_out/prof bench.py --steps 5 --warmup 2 --lift-only --no-fast-mode --no-cpu-baseline --no-kernel-timing ;;
     config3)  passes gpurun_out/prof_c3 tools/train_bf16_probe.py 1024 bf16 ;;
     hm16)     passes gpurun_out/prof_hm tools/hm_bf16_probe.py 256 64 bf16 ;;
+    stage1)   passes gpurun_out/prof_st1 tools/stage1_probe.py 32 f32 ;;
     all)      passes gpurun_out/prof_all bench.py --steps 2 --warmup 1 --full-steps 1 --train-steps 1 --no-cpu-baseline --no-kernel-timing ;;
   esac
 done

@@ -62,6 +62,10 @@ def main():
             "fused stem + max-pool on the bf16 matrix cores (stem_bf16s.h) -> layer1 on the direct halo-tile kernel (conv64_bf16s.h) -> layers 2-4 and the "
             "U-Net decoder as implicit GEMMs on bf16 channels-last tensors (conv_bf16s.h); "
             "2 warm-up + 3 timed passes x 2 nets", traffic_json=False)
+    SRC = os.path.join(REPO, "gpurun_out", "prof_st1")
+    if os.path.isdir(SRC):
+        one(tag + "_stage1_f32", "python3 tools/stage1_probe.py 32 f32", "stage-1 training step of the position heatmap estimator, fp32, B = 32 stereo frames: "
+            "train-mode forward, loss, backward, Adam; 1 warm-up + 2 timed steps", traffic_json=False)
     SRC = os.path.join(REPO, "gpurun_out", "prof_all")
     if os.path.isdir(SRC):
         one(tag + "_all_legs", ALL_CMD, "every leg: fp32 headline, bf16x3 / bf16 fast modes, full pipeline in both modes, EgoCap / 128x128 geometry, "
