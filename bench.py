@@ -353,6 +353,10 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
         opt.log_dir = tmp.name
         opt.path_to_trained_heatmap = os.path.join(tmp.name, "hm", "best_net_HeatMap.pth")
         opt.use_amp, opt.amp_precision = mode != "f32", (mode if mode != "f32" else "bf16")
+        # the benchmark's frozen estimators use folded running-statistics BatchNorm (frames independent, the
+        # bf16 channels-last kernels, chunks of 256 frames).  The wrapper's DEFAULT is the reference's batch-statistics BatchNorm under
+        # model.train() (train.py:91); this leg opts out explicitly and says so in its "input" field.
+        opt.frozen_heatmap_bn_eval = True
     m = models.create_model(opt)
     m.net_AutoEncoder.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
     m.net_AutoEncoder.set_precision(mode)
@@ -408,7 +412,8 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
             "allreduce_op": ("avg (RCCL ReduceOp.AVG, in place on the gradient arena)" if world > 1 and dist_backend() == "nccl" else
                              "sum + 1/world scaling pass (gloo)" if world > 1 else None),
             "per_rank_ms_per_step": per_rank, "device_allocations_in_timed_region": int(dev_allocs),
-            "input": "RGB frames through the two frozen heatmap estimators (eval-mode BatchNorm, --use_amp arithmetic), then the head" if from_rgb
+            "input": "RGB frames through the two frozen heatmap estimators (opt.frozen_heatmap_bn_eval: running-statistics BatchNorm, "
+                     "SURVEY Appendix D.5; --use_amp arithmetic), then the head" if from_rgb
                      else "resident heatmaps (--use_gt_heatmap): the frozen estimators are not run",
             "note": "gradient all-reduce (N > 1) overlapped with the backward, bucket by bucket, in place on a flat arena; the attention "
                     "backward recomputes the scores (two kernels, 7 MFMA products), not counted in flops_per_frame"}

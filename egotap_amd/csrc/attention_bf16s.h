@@ -111,85 +111,6 @@ __device__ __forceinline__ void store_rows_bf16(const f32x16 (&o)[4], float mul,
 // query's scores exceed it by more than 2^RESC in the softmax's base-2 units (cdna_hip_programming.md T13): probabilities then
 // stay below 2^RESC, harmless in fp32 sums and bf16 operands, and the 64 multiplies per sub-tile disappear from almost every tile.
 template <int NW, int SUB>
-__global__ __launch_bounds__(64 * NW, 2) void attention_bf16s_kernel(const __bf16* __restrict__ QKV, __bf16* __restrict__ CTX, int N, int heads,
-                                                                    int qgroups, float scale_log2e, float* __restrict__ LSE) {
-    using namespace attns;
-    constexpr int THREADS = 64 * NW, ROWS = 32 * SUB;
-    constexpr float RESC = 6.0f;
-    extern __shared__ __attribute__((aligned(16))) __bf16 simg_s[];
-    __bf16* Kimg = simg_s;                     // [ROWS][RSTR]
-    __bf16* Vimg = simg_s + SUB * RIMG;        // [ROWS][TSTR]
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int q8 = nblk >> 3, r8 = nblk & 7, x8 = bid & 7;
-    const int lin = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (bid >> 3);
-    const int bh = lin / qgroups, qg = lin - bh * qgroups;
-    const int b = bh / heads, h = bh - b * heads;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int D = heads * DH;
-    const long ld = 3L * D;
-    const __bf16* base = QKV + (long)b * N * ld + h * DH;
-    const int qb = qg * NW + wid;
-    const bool valid = qb * 32 < N;            // invalid waves run on clamped rows (EXEC all ones around the transposing reads) and skip the store
-    const int q0 = min(qb * 32, N - 32);
-    Frags<1> qf;
-    load_row_frags(qf, base + (long)(q0 + l31) * ld, lh);
-    f32x16 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;      // m_run in base-2 units (score * scale_log2e)
-    TileRegs<THREADS, ROWS> tk, tv;
-    tile_load(tk, base + D, ld, tid);
-    tile_load(tv, base + 2 * D, ld, tid);
-    const int ntiles = N / ROWS;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();                       // every wave is done with the previous tile's images
-        tile_store(tk, Kimg, nullptr, tid);
-        tile_store(tv, nullptr, Vimg, tid);
-        __syncthreads();
-        if (kt + 1 < ntiles) {                 // next tile's loads fly during this tile's MFMAs
-            tile_load(tk, base + (long)((kt + 1) * ROWS) * ld + D, ld, tid);
-            tile_load(tv, base + (long)((kt + 1) * ROWS) * ld + 2 * D, ld, tid);
-        }
-#pragma unroll
-        for (int sub = 0; sub < SUB; ++sub) {
-            f32x16 s = tile_x_frags<1>(Kimg + sub * RIMG, qf, l31, lh);     // S^T[key][q]
-            float mx = s[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
-            const bool raise = mx > m_run + RESC;
-            if (__builtin_amdgcn_ballot_w64(raise) != 0) {                   // rare after the first tile: wave-uniform branch
-                const float m_new = raise ? mx : m_run;
-                const float alpha = exp2f(m_run - m_new);
-                l_run *= alpha;
-                m_run = m_new;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-            }
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_run));
-                psum += s[r];
-            }
-            l_run += psum;
-            acc_tile_t_x_p<1>(o, Vimg + sub * TIMG, s, lane);                // O^T[d][q] += V^T P^T
-        }
-    }
-    __syncthreads();
-    if (valid) {
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        if (LSE != nullptr && lh == 0) LSE[(long)bh * N + q0 + l31] = m_run * 0.6931471805599453f + logf(l_tot);
-        store_rows_bf16(o, 1.0f / l_tot, (float*)simg_s + wid * 32 * OLD, CTX + ((long)b * N + q0) * D + h * DH, D, lane);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------- dQ (+ delta)
-template <int NW, int SUB>
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_bf16s_kernel(const __bf16* __restrict__ QKV, const __bf16* __restrict__ O,
                                                                       const __bf16* __restrict__ dO, const float* __restrict__ LSE,
                                                                       __bf16* __restrict__ dQKV, float* __restrict__ DELTA, int N, int heads,
@@ -260,104 +181,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_bf16s_kernel(const __b
 }
 
 // ------------------------------------------------------------------------------------------------- dK and dV
-template <int NW, int SUB>
-__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_bf16s_kernel(const __bf16* __restrict__ QKV, const __bf16* __restrict__ dO,
-                                                                       const float* __restrict__ LSE, const float* __restrict__ DELTA,
-                                                                       __bf16* __restrict__ dQKV, int N, int heads, int kgroups, float scale) {
-    using namespace attns;
-    constexpr int THREADS = 64 * NW;
-    extern __shared__ __attribute__((aligned(16))) __bf16 bsm_s[];
-    constexpr int ROWS = 32 * SUB;
-    __bf16* Qrow = bsm_s;
-    __bf16* Qtr = Qrow + SUB * RIMG;
-    __bf16* Drow = Qtr + SUB * TIMG;
-    __bf16* Dtr = Drow + SUB * RIMG;
-    float* Ls = (float*)(Dtr + SUB * TIMG);    // [ROWS] lse (log2 units), [ROWS] delta
-    __bf16* Vw = (__bf16*)(Ls + 2 * ROWS);     // per wave: row image of the V rows of its 32 keys (registers hold K, dK, dV)
-    const int lin = xcd_lin(blockIdx.x, gridDim.x);          // XCD-aware order: the key blocks of one (batch, head) share Q / dO tiles in one L2
-    const int bh = lin / kgroups, kg = lin - bh * kgroups;
-    const int b = bh / heads, h = bh - b * heads;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int D = heads * DH;
-    const long ld3 = 3L * D;
-    const __bf16* qkv = QKV + (long)b * N * ld3 + h * DH;
-    const int kb = kg * NW + wid;
-    const bool valid = kb * 32 < N;
-    const int k0 = min(kb * 32, N - 32);
-    Frags<1> kf;
-    load_row_frags(kf, qkv + (long)(k0 + l31) * ld3 + D, lh);
-    __bf16* Vmine = Vw + wid * RIMG;
-    stage<64>(Vmine, nullptr, qkv + (long)k0 * ld3 + 2 * D, ld3, lane);
-    const float c2 = scale * 1.4426950408889634f;
-    f32x16 dk[4], dv[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
-    // no register prefetch of the next tile here: dK + dV hold 128 accumulators, the K fragments 32 more, and 16 staging registers
-    // on top spill in the tile loop (measured 5.3 -> 7.2 ms); the CU's second workgroup covers the load latency instead
-    const __bf16* dob = dO + (long)b * N * D + h * DH;
-    const int ntiles = N / ROWS;
-    for (int qt = 0; qt < ntiles; ++qt) {
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < SUB; ++sub) {
-            stage<THREADS>(Qrow + sub * RIMG, Qtr + sub * TIMG, qkv + (long)(qt * ROWS + 32 * sub) * ld3, ld3, tid);
-            stage<THREADS>(Drow + sub * RIMG, Dtr + sub * TIMG, dob + (long)(qt * ROWS + 32 * sub) * D, D, tid);
-        }
-        {
-            const float* lp = LSE + (long)bh * N + qt * ROWS;
-            const float* dp_ = DELTA + (long)bh * N + qt * ROWS;
-            if (tid < ROWS) Ls[tid] = lp[(unsigned)tid] * 1.4426950408889634f;
-            else if (tid < 2 * ROWS) Ls[tid] = dp_[(unsigned)(tid - ROWS)];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < SUB; ++sub) {
-            f32x16 p = tile_x_frags<1>(Qrow + sub * RIMG, kf, l31, lh);              // S[q][key]
-#pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(fmaf(p[r], c2, -Ls[32 * sub + (r & 3) + 8 * (r >> 2) + 4 * lh]));
-            acc_tile_t_x_p<1>(dv, Dtr + sub * TIMG, p, lane);                        // dV^T[d][key] += dO^T P
-            const f32x16 dp = tile_x_tile<1>(Drow + sub * RIMG, Vmine, l31, lh);     // dP[q][key] = dO V^T
-#pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = p[r] * (dp[r] - Ls[ROWS + 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * lh]) * scale;   // dS[q][key]
-            acc_tile_t_x_p<1>(dk, Qtr + sub * TIMG, p, lane);                        // dK^T[d][key] += Q^T dS
-        }
-    }
-    __syncthreads();
-    if (valid) {
-        float* patch = (float*)bsm_s + wid * 32 * OLD;
-        __bf16* dst = dQKV + ((long)b * N + k0) * ld3 + h * DH;
-        store_rows_bf16(dk, 1.0f, patch, dst + D, ld3, lane);
-        store_rows_bf16(dv, 1.0f, patch, dst + 2 * D, ld3, lane);    // same wave, same patch: program order
-    }
-}
-
-template <int SUB>
-static hipError_t attention_bf16s_fwd_launch_t(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream) {
-    using namespace attns;
-    constexpr int NW = 4;
-    constexpr size_t img = (size_t)SUB * (RIMG + TIMG) * 2, patch = (size_t)NW * 32 * OLD * 4;
-    constexpr size_t lds = img > patch ? img : patch;
-    auto kern = attention_bf16s_kernel<NW, SUB>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    const int qgroups = (N / 32 + NW - 1) / NW;
-    hipLaunchKernelGGL(kern, dim3(B * heads * qgroups), dim3(64 * NW), lds, stream, QKV, CTX, N, heads, qgroups, 1.4426950408889634f / sqrtf(128.0f), LSE);
-    return hipGetLastError();
-}
-static hipError_t attention_bf16s2_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream);      // attention_bf16s2.h
 static hipError_t attention_bf16s3_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream);      // attention_bf16s2.h
-static hipError_t attention_bf16s_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream, int gen = 3) {
+static hipError_t attention_bf16s_fwd_launch(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream) {
     if (B <= 0) return hipSuccess;
     if (N % 32 != 0) return hipErrorInvalidValue;
-    if (gen == 3) return attention_bf16s3_fwd_launch(QKV, CTX, LSE, B, N, heads, stream);      // 32-key steps, three workgroups per CU
-    if (gen >= 2 && N % 64 == 0) return attention_bf16s2_fwd_launch(QKV, CTX, LSE, B, N, heads, stream);
-    return N % 64 == 0 ? attention_bf16s_fwd_launch_t<2>(QKV, CTX, LSE, B, N, heads, stream) : attention_bf16s_fwd_launch_t<1>(QKV, CTX, LSE, B, N, heads, stream);
+    return attention_bf16s3_fwd_launch(QKV, CTX, LSE, B, N, heads, stream);      // 32-key steps, three workgroups per CU
 }
 
 static hipError_t attention_bf16s2_dkv_launch(const __bf16* QKV, const __bf16* dO, const float* LSE, const float* DELTA, __bf16* dQKV, int B, int N,
@@ -365,41 +193,33 @@ static hipError_t attention_bf16s2_dkv_launch(const __bf16* QKV, const __bf16* d
 static hipError_t attention_bf16s2_dq_launch(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
                                              int heads, hipStream_t stream, float* colpart);
 
-template <int SUB>
-static hipError_t attention_bf16s_bwd_launch_t(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
-                                               int heads, hipStream_t stream, int gen, float* colpart) {
-    using namespace attns;
-    constexpr int NW = 4;
-    const float scale = 1.0f / sqrtf((float)DH);
-    const int groups = (N / 32 + NW - 1) / NW;
-    constexpr size_t patch = (size_t)NW * 32 * OLD * 4;
-    constexpr int SKV = 1;       // the dK + dV kernel keeps four images + a per-wave V image: 64-row tiles would leave one workgroup per CU
-    constexpr size_t img_q = (size_t)SUB * (2 * RIMG + TIMG) * 2, img_kv = (size_t)SKV * (2 * RIMG + 2 * TIMG) * 2 + SKV * 256 + (size_t)NW * RIMG * 2;
-    constexpr size_t lds_q = img_q > patch ? img_q : patch, lds_kv = img_kv > patch ? img_kv : patch;
-    static_assert(2 * lds_kv <= 160 * 1024 && 2 * lds_q <= 160 * 1024, "two workgroups per CU");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_bf16s_kernel<NW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkv_bf16s_kernel<NW, SKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    if (gen >= 2 && SUB == 2) {       // N % 64 == 0: the DMA-staged dQ kernel walks the keys 64 at a time
-        hipError_t e = attention_bf16s2_dq_launch(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream, colpart);
-        if (e != hipSuccess) return e;
-    } else
-    hipLaunchKernelGGL((attn_bwd_dq_bf16s_kernel<NW, SUB>), dim3(B * heads * groups), dim3(64 * NW), lds_q, stream, QKV, O, dO, LSE, dQKV, DELTA, N, heads, groups, scale);
-    if (gen >= 2) return attention_bf16s2_dkv_launch(QKV, dO, LSE, DELTA, dQKV, B, N, heads, stream, colpart);
-    hipLaunchKernelGGL((attn_bwd_dkv_bf16s_kernel<NW, SKV>), dim3(B * heads * groups), dim3(64 * NW), lds_kv, stream, QKV, dO, LSE, DELTA, dQKV, N, heads, groups, scale);
-    return hipGetLastError();
-}
 static hipError_t attention_bf16s_bwd_launch(const __bf16* QKV, const __bf16* O, const __bf16* dO, const float* LSE, float* DELTA, __bf16* dQKV, int B, int N,
-                                             int heads, hipStream_t stream, int gen = 2, float* colpart = nullptr) {
-    // colpart (generation 2, N % 64 == 0 only; the caller checks with attention_bf16s_bwd_colsums()): fp32 [B * N / 32][3 * heads * 128]
-    // partial column sums of dQKV, one row per 32-row block -- summed over the rows they give the q | k | v bias gradients
+                                             int heads, hipStream_t stream, float* colpart = nullptr) {
+    // colpart (N % 64 == 0 only): fp32 [B * N / 32][3 * heads * 128] partial column sums of dQKV, one row per 32-row block -- summed over
+    // the rows they give the q | k | v bias gradients
+    using namespace attns;
     if (B <= 0) return hipSuccess;
     if (N % 32 != 0) return hipErrorInvalidValue;
-    if (colpart != nullptr && !(gen >= 2 && N % 64 == 0)) return hipErrorInvalidValue;
-    return N % 64 == 0 ? attention_bf16s_bwd_launch_t<2>(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream, gen, colpart)
-                       : attention_bf16s_bwd_launch_t<1>(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream, gen, colpart);
+    if (colpart != nullptr && N % 64 != 0) return hipErrorInvalidValue;
+    if (N % 64 == 0) {       // the DMA-staged dQ kernel walks the keys 64 at a time
+        hipError_t e = attention_bf16s2_dq_launch(QKV, O, dO, LSE, DELTA, dQKV, B, N, heads, stream, colpart);
+        if (e != hipSuccess) return e;
+    } else {                 // other multiples of 32: the register-staged dQ kernel on 32-key tiles
+        constexpr int NW = 4, SUB = 1;
+        const int groups = (N / 32 + NW - 1) / NW;
+        constexpr size_t patch = (size_t)NW * 32 * OLD * 4, img_q = (size_t)SUB * (2 * RIMG + TIMG) * 2;
+        constexpr size_t lds_q = img_q > patch ? img_q : patch;
+        static_assert(2 * lds_q <= 160 * 1024, "two workgroups per CU");
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_bf16s_kernel<NW, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dq_bf16s_kernel<NW, SUB>), dim3(B * heads * groups), dim3(64 * NW), lds_q, stream, QKV, O, dO, LSE, dQKV, DELTA, N, heads, groups,
+                           1.0f / sqrtf((float)DH));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return attention_bf16s2_dkv_launch(QKV, dO, LSE, DELTA, dQKV, B, N, heads, stream, colpart);
 }

@@ -241,40 +241,6 @@ static __global__ __launch_bounds__(256) void bn_fold_bf16s_kernel(const float* 
     shift[c] = sh;
 }
 
-// max-pool 3x3 / 2 (pad 1) of the stem's output, both in the eye-interleaved bf16 layout: [B * HIN * HIN, 2 C] -> [B * HO * HO, 2 C].
-// One thread = 8 channels (16 bytes) of one output pixel: nine 16-byte loads, lanes along the channels (a pixel's 2 C channels are
-// contiguous), max in fp32 (exact on bf16 values).
-static __global__ __launch_bounds__(256) void maxpool3s2_nhwc_bf16s_kernel(const __bf16* __restrict__ in, __bf16* __restrict__ out, int C2, int HIN, long total) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int HO = HIN / 2, c8n = C2 / 8;
-    const int c8 = (int)(i % c8n);
-    const long pp = i / c8n;
-    const int xo = (int)(pp % HO), yo = (int)((pp / HO) % HO);
-    const long b = pp / ((long)HO * HO);
-    const __bf16* p = in + b * (long)HIN * HIN * C2 + c8 * 8;
-    float mx[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) mx[j] = -INFINITY;
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = 2 * yo + dy;
-        if (yy < 0 || yy >= HIN) continue;
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int xx = 2 * xo + dx;
-            if (xx < 0 || xx >= HIN) continue;
-            const bf16x8 v = *(const bf16x8*)(p + ((long)yy * HIN + xx) * C2);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) mx[j] = fmaxf(mx[j], (float)v[j]);
-        }
-    }
-    bf16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (__bf16)mx[j];
-    *(bf16x8*)(out + pp * C2 + c8 * 8) = o;
-}
-
 // ---------------------------------------------------------------------------------------------------- [r3] one launch for all of them
 // An estimator forward repacked its 27 convolution weights and folded its 19 BatchNorms with 46 tiny launches (0.46 ms of a 15 ms
 // forward at B = 256, 5 % at B = 32 and 512 x 512).  The parameters stay the caller's live fp32 tensors and nothing is cached across

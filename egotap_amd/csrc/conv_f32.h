@@ -437,24 +437,19 @@ static __global__ __launch_bounds__(StemCfg::THREADS, 2) void stem_conv7_mfma_ke
     }
 }
 static inline hipError_t stem_conv7_launch(const float* left, const float* right, const float* w, const float* gamma, const float* beta,
-                                           const float* mean, const float* var, float* out, int HIN, int nimg, int num_cu, hipStream_t s,
-                                           bool bf16_nhwc = false) {
+                                           const float* mean, const float* var, float* out, int HIN, int nimg, int num_cu, hipStream_t s) {
     using Cfg = StemCfg;
     const int HO = HIN / 2;
     if (HO % Cfg::XT == 0 && HO % Cfg::RG == 0 && ((uintptr_t)out & 15) == 0) {
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute((const void*)stem_conv7_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_conv7_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
             if (e != hipSuccess) return e;
             attr_done = true;
         }
         const long items = (long)nimg * (HO / Cfg::RG) * (HO / Cfg::XT);
         const int grid = (int)(items < num_cu ? items : num_cu);
-        if (bf16_nhwc) hipLaunchKernelGGL(stem_conv7_mfma_kernel<true>, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, left, right, w, gamma, beta, mean, var, out, HIN, nimg);
-        else hipLaunchKernelGGL(stem_conv7_mfma_kernel<false>, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, left, right, w, gamma, beta, mean, var, out, HIN, nimg);
-    } else if (bf16_nhwc) {
-        return hipErrorInvalidValue;
+        hipLaunchKernelGGL(stem_conv7_mfma_kernel<false>, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, left, right, w, gamma, beta, mean, var, out, HIN, nimg);
     } else {
         hipLaunchKernelGGL(stem_conv7_kernel, dim3(HO / 16, HO / 16, nimg), dim3(256), 0, s, left, right, w, gamma, beta, mean, var, out, HIN);
     }

@@ -1193,15 +1193,6 @@ extern "C" int egotap_hm_intermediate(egotap_handle h, int B, const char* name, 
 
 // HeatMap_UnrealEgo_Shared.forward(left, right) (model/net_architecture.py:32-36, 45-51, 75-85, 139-173), eval mode.
 #if EGOTAP_IN(0)
-static int g_stem_split = 0;   // egotap_debug_hm_r2_kernels bit 0: the bf16 estimators run stem and max-pool as two kernels (round 2's form; A/B timing, tests)
-static int g_conv64_gemm = 0;  // ... bit 1: layer1's 64 -> 64 convolutions on the implicit-GEMM kernel instead of conv64_bf16s.h
-extern "C" int egotap_debug_hm_r2_kernels(int mask) {
-    g_stem_split = mask & 1;
-    g_conv64_gemm = (mask >> 1) & 1;
-    return EGOTAP_OK;
-}
-#endif
-#if EGOTAP_IN(0)
 extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, const float* right, int B, float* out,
                                  int64_t out_image_stride, void* ws, size_t ws_bytes, void* stream) {
     EGO_CHECK(h, "null handle");
@@ -1229,12 +1220,11 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
     // E1: stem conv7x7/2 + BN + ReLU on image n = 2b + eye (the L/R channel concat of every pyramid level is then a view); in the
     // bf16 mode it writes bf16 channels-last itself (half the bytes, and the layout the max-pool and the stages read)
     // [r3] ... bf16 mode: stem, BatchNorm, ReLU AND the max-pool in one kernel on the bf16 matrix cores (stem_bf16s.h): the 128 x 128 x 64
-    // map never reaches HBM.  g_stem_split (egotap_debug_hm_r2_kernels bit 0, tests / A-B timing) keeps the two-kernel form: fp32-MFMA stem
-    // writing bf16 channels-last, then the channels-last max-pool.
-    const bool fused_stem = h->precision == EGOTAP_PREC_BF16 && !g_stem_split;
+    // map never reaches HBM (round 2's two-kernel form -- fp32-MFMA stem writing bf16 channels-last, then a channels-last max-pool: 2.35 ms
+    // against 0.66 per 512 images -- was retired in round 4).
+    const bool fused_stem = h->precision == EGOTAP_PREC_BF16;
     if (!fused_stem)
-        EGO_HIP(stem_conv7_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, F(w.L0), S0, N2, device_cu_count(), s,
-                                  h->precision == EGOTAP_PREC_BF16));
+        EGO_HIP(stem_conv7_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, F(w.L0), S0, N2, device_cu_count(), s));
     if (h->precision == EGOTAP_PREC_BF16) {
         // bf16 mode: everything after the stem on bf16 channels-last activations, every convolution on the bf16-storage GEMM
         // (conv_bf16s.h).  Buffers live in the fp32 path's slots (each at most half as large).
@@ -1282,13 +1272,7 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
         };
         // E2: max-pool of the stem's bf16 [B * (2 s64)^2, 2 x 64] -> [B * s64^2, 2 x 64]; E3: the four stages on the same GEMM kernel (eye-interleaved rows, see conv_bf16s.h)
         __bf16* P0 = Hb(w.P0);
-        if (fused_stem) {
-            EGO_HIP(stem_pool_bf16s_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, P0, S0, N2, cus, s));
-        } else {
-            const long total = (long)B * p64 * (128 / 8);
-            hipLaunchKernelGGL(maxpool3s2_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const __bf16*)F(w.L0), P0, 128, S0 / 2, total);
-            EGO_HIP(hipGetLastError());
-        }
+        EGO_HIP(stem_pool_bf16s_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, P0, S0, N2, cus, s));
         auto bconv = [&](const char* role, const __bf16* in, int cin, int c, int taps, int stride, int side, const float* wgt,
                          const HmParams::Bn& bn, const __bf16* res, int relu, __bf16* o) {
             // [r3] Cout = 64 / 128 run on the 64- / 128-column tile (256 x 64 NI, gemm_bf16s.h) instead of N = 256 with a column guard
@@ -1299,7 +1283,7 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
             const __bf16* WPl = (const __bf16*)(reg + sg.dst_w);
             const float *SC = (const float*)(reg + bs.dst_sc), *SH = (const float*)(reg + bs.dst_sh);
             const long M = (long)N2 * side * side;
-            const bool direct = taps == 9 && stride == 1 && cin == 64 && c == 64 && !g_conv64_gemm;      // [r3] layer1: the direct kernel (conv64_bf16s.h)
+            const bool direct = taps == 9 && stride == 1 && cin == 64 && c == 64;      // [r3] layer1: the direct kernel (conv64_bf16s.h)
             GemmTimer t(h, s, role, direct ? "conv64_direct_bf16s_kernel" : taps == 9 ? "gemm_bf16s_kernel<XConvE,3x3>" : "gemm_bf16s_kernel<XConvE,1x1>",
                         2.0 * M * c * taps * (double)cin);
             if (direct)
@@ -1542,6 +1526,19 @@ extern "C" int egotap_pose_metrics(const float* pred, const float* gt, int B, in
 }
 #endif
 
+// the same metrics as the reference computes them for a batch of 2 or 3 frames (utils/util.py:337 skips its transpose there)
+#if EGOTAP_IN(0)
+extern "C" int egotap_pose_metrics_batch_axes(const float* pred, const float* gt, int B, int J, float* mpjpe, float* pa_mpjpe, float* aligned,
+                                              void* stream) {
+    EGO_CHECK(pred && gt && mpjpe && pa_mpjpe, "egotap_pose_metrics_batch_axes: null argument");
+    EGO_CHECK((B == 2 || B == 3) && J >= 1 && J <= EGOTAP_MAX_JOINTS,
+              "egotap_pose_metrics_batch_axes: the reference takes this branch for batches of 2 or 3 frames only (B=%d J=%d)", B, J);
+    hipLaunchKernelGGL(pose_metrics_batch_axes_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pred, gt, B, J, mpjpe, pa_mpjpe, aligned);
+    EGO_HIP(hipGetLastError());
+    return EGOTAP_OK;
+}
+#endif
+
 // joints -> ground-truth heatmaps in the lifting head's input layout (dataloader/data_loader.py:76-215 with --use_gt_heatmap)
 #if EGOTAP_IN(0)
 extern "C" int egotap_synth_heatmaps(const float* pts2d_left, const float* pts2d_right, const float* pose3d, const int* parents, int B,
@@ -1675,11 +1672,6 @@ extern "C" int egotap_train_patch_fwd(egotap_handle h, const float* hm, int B, c
 }
 #endif
 
-// EGOTAP_TN_F32_DMA=0 in the environment: the register-staged fp32 weight-gradient kernel for every operand (A/B timing; read once per process)
-static bool tn_f32_dma_enabled() {
-    static const bool on = [] { const char* e = getenv("EGOTAP_TN_F32_DMA"); return !(e && e[0] == '0'); }();
-    return on;
-}
 template <class XL>
 static hipError_t tn_any(Handle* h, const float* dy, const XL& xl, float* dw, float* ws, size_t ws_bytes, int M, int N, int K, int acc, hipStream_t s,
                          long ldy = 0) {
@@ -1689,7 +1681,7 @@ static hipError_t tn_any(Handle* h, const float* dy, const XL& xl, float* dw, fl
     if (N % 256 == 0 && K % 256 == 0 && M >= 1024 && h->precision == EGOTAP_PREC_BF16)
         return gemm_tn_bf16_launch<TnBfCfg<1>, XL>(dy, ldy, xl, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
     if constexpr (std::is_same<XL, ALoadPlain>::value) {      // [r3] plain operands: the DMA-staged kernel (gemm_tn_f32.h), same summation order per element
-        if (tn_f32_dma_enabled() && M >= 1024 && gemm_tn_f32_dma_ok(dy, ldy, xl.A, xl.lda, M, N, K))
+        if (M >= 1024 && gemm_tn_f32_dma_ok(dy, ldy, xl.A, xl.lda, M, N, K))
             return gemm_tn_f32_dma_launch(dy, ldy, xl.A, xl.lda, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
     }
     if (N % 256 == 0 && K % 256 == 0) return gemm_tn_f32_launch<TnBig, XL>(dy, ldy, xl, dw, ws, ws_bytes, M, N, K, device_cu_count(), acc, s);
@@ -1753,7 +1745,7 @@ extern "C" int egotap_train_gemm_tn_bias(egotap_handle h, const float* dy, int64
     EGO_CHECK(h && dy && x && dw && db && ws, "egotap_train_gemm_tn_bias: null argument");
     hipStream_t s = (hipStream_t)stream;
     if (ldy <= 0) ldy = N;
-    if (h->precision == EGOTAP_PREC_F32 && tn_f32_dma_enabled() && M >= 1024 && gemm_tn_f32_dma_ok(dy, ldy, x, K, M, N, K)) {
+    if (h->precision == EGOTAP_PREC_F32 && M >= 1024 && gemm_tn_f32_dma_ok(dy, ldy, x, K, M, N, K)) {
         hipError_t e = gemm_tn_f32_dma_launch(dy, ldy, x, K, dw, (float*)ws, ws_bytes, M, N, K, device_cu_count(), accumulate, s, db);
         if (e == hipErrorOutOfMemory) { egotap_set_error("egotap_train_gemm_tn_bias: workspace too small (%zu bytes) for N*K=%ld", ws_bytes, (long)N * K); return EGOTAP_ERR_WORKSPACE; }
         EGO_HIP(e);
@@ -2659,27 +2651,9 @@ extern "C" int egotap_bf16_from_f32(const float* src, void* dst, int64_t n, void
 #endif
 
 #if EGOTAP_IN(3)
-extern "C" int egotap_debug_tn_sync(int on) {
-    g_tn_sync = on ? 1 : 0;
-    return EGOTAP_OK;
-}
-#endif
-#if EGOTAP_IN(3)
-static int g_attn_gen = 3;     // egotap_debug_attention_gen: 3 (default) = 2 with the forward on 32-key steps / three workgroups per CU, 2 = the DMA-staged
-                               // kernels of attention_bf16s2.h, 1 = round 2's (A/B timing, tests)
-extern "C" int egotap_debug_attention_gen(int gen) {
-    EGO_CHECK((gen >= 1 && gen <= 3) || (gen >= 32 && gen <= 34), "egotap_debug_attention_gen: 1, 2, 3 (or 32..34: generation 3 with 2..4 waves per workgroup)");
-    g_attn3_nw = gen >= 32 ? gen - 30 : 0;
-    if (gen >= 32) gen = 3;
-    g_attn_gen = gen;
-    return EGOTAP_OK;
-}
-#endif
-
-#if EGOTAP_IN(3)
 extern "C" int egotap_bf16_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int N, int heads, void* stream) {
     EGO_CHECK(qkv && ctx, "egotap_bf16_attention_fwd: null argument");
-    hipError_t e = attention_bf16s_fwd_launch((const __bf16*)qkv, (__bf16*)ctx, lse, B, N, heads, (hipStream_t)stream, g_attn_gen);
+    hipError_t e = attention_bf16s_fwd_launch((const __bf16*)qkv, (__bf16*)ctx, lse, B, N, heads, (hipStream_t)stream);
     if (e == hipErrorInvalidValue) { egotap_set_error("egotap_bf16_attention_fwd: sequence length %d is not a multiple of 32", N); return EGOTAP_ERR_INVALID; }
     EGO_HIP(e);
     return EGOTAP_OK;
@@ -2690,8 +2664,7 @@ extern "C" int egotap_bf16_attention_fwd(const void* qkv, void* ctx, float* lse,
 extern "C" int egotap_bf16_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv, int B, int N, int heads,
                                          void* stream) {
     EGO_CHECK(qkv && ctx && dctx && lse && delta && dqkv, "egotap_bf16_attention_bwd: null argument");
-    hipError_t e = attention_bf16s_bwd_launch((const __bf16*)qkv, (const __bf16*)ctx, (const __bf16*)dctx, lse, delta, (__bf16*)dqkv, B, N, heads, (hipStream_t)stream,
-                                              g_attn_gen);
+    hipError_t e = attention_bf16s_bwd_launch((const __bf16*)qkv, (const __bf16*)ctx, (const __bf16*)dctx, lse, delta, (__bf16*)dqkv, B, N, heads, (hipStream_t)stream);
     if (e == hipErrorInvalidValue) { egotap_set_error("egotap_bf16_attention_bwd: sequence length %d is not a multiple of 32", N); return EGOTAP_ERR_INVALID; }
     EGO_HIP(e);
     return EGOTAP_OK;
@@ -2700,17 +2673,17 @@ extern "C" int egotap_bf16_attention_bwd(const void* qkv, const void* ctx, const
 
 #if EGOTAP_IN(3)
 // the same, also producing the q | k | v BIAS gradients (column sums of dqkv) without a pass over dqkv: the kernels' epilogues leave
-// per-block partial sums in ws (fp32 [B * N / 32][3 * heads * 128]); three small fp32 column sums finish them.  Shapes or kernel
-// generations without that epilogue (N % 64 != 0, egotap_debug_attention_gen(1)) take the column-sum pass over dqkv instead.
+// per-block partial sums in ws (fp32 [B * N / 32][3 * heads * 128]); three small fp32 column sums finish them.  Shapes
+// without that epilogue (N % 64 != 0) take the column-sum pass over dqkv instead.
 extern "C" int egotap_bf16_attention_bwd_bias(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv, float* dq_bias,
                                               float* dk_bias, float* dv_bias, int B, int N, int heads, void* ws, size_t ws_bytes, void* stream) {
     EGO_CHECK(qkv && ctx && dctx && lse && delta && dqkv && dq_bias && dk_bias && dv_bias && ws, "egotap_bf16_attention_bwd_bias: null argument");
     const int D = heads * 128, M = B * N;
     float* db[3] = {dq_bias, dk_bias, dv_bias};
     const size_t part_bytes = (size_t)B * (N / 32) * 3 * D * 4;
-    const bool fused = g_attn_gen >= 2 && N % 64 == 0 && ws_bytes >= part_bytes + (64u << 20);
+    const bool fused = N % 64 == 0 && ws_bytes >= part_bytes + (64u << 20);
     hipError_t e = attention_bf16s_bwd_launch((const __bf16*)qkv, (const __bf16*)ctx, (const __bf16*)dctx, lse, delta, (__bf16*)dqkv, B, N, heads, (hipStream_t)stream,
-                                              g_attn_gen, fused ? (float*)ws : nullptr);
+                                              fused ? (float*)ws : nullptr);
     if (e == hipErrorInvalidValue) { egotap_set_error("egotap_bf16_attention_bwd_bias: sequence length %d is not a multiple of 32", N); return EGOTAP_ERR_INVALID; }
     EGO_HIP(e);
     for (int q = 0; q < 3; ++q) {

@@ -246,7 +246,6 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
         }
 }
 
-static int g_tn_sync = 1;          // A/B switch (egotap_debug_tn_sync)
 static inline long total_steps_hint(int M, int splits) { return (long)M / splits / TnSCfg::BKM; }
 static __global__ void zero_ints_kernel(int* p, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
@@ -277,7 +276,7 @@ static hipError_t gemm_tn_bf16s_launch(const __bf16* dY, long ldy, const XL& xl,
     // check-in counters of the L2-sharing groups (8 XCD chunks x splits) behind the slabs, cleared per launch
     int* sync = nullptr;
     const size_t sync_off = ((size_t)splits * N * K * 4 + 255) & ~(size_t)255;
-    if (g_tn_sync && !direct && slabs != nullptr && sync_off + (size_t)8 * splits * 4 <= slab_bytes && (long)total_steps_hint(M, splits) > 256) {
+    if (!direct && slabs != nullptr && sync_off + (size_t)8 * splits * 4 <= slab_bytes && (long)total_steps_hint(M, splits) > 256) {
         sync = (int*)((char*)slabs + sync_off);
         hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, stream, sync, 8 * splits);
     }

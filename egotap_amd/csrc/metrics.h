@@ -168,3 +168,107 @@ static __global__ __launch_bounds__(64) void pose_metrics_kernel(const float* __
     }
     pa_mpjpe[b] = (float)(pa / J);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// What the reference computes for a BATCH of 2 or 3 frames.  utils/util.py:337 tests S1.shape[0] against 3 and 2 (meant for
+// unbatched 3 x N / 2 x N point sets) and then skips its transpose: the [B, J, 3] poses are read as J "coordinates" x 3 "points" --
+// means over the three columns, K = X1 X2^T a J x J matrix of rank <= 2, R = V Z U^T from its SVD, no transpose back.  test.py and
+// train_evaluate print these numbers for a ragged last batch of 2 or 3 frames, so the drop-in reproduces them (default; see
+// egotap_pose_metrics_batch_axes in egotap.h).  The J x J SVD reduces exactly to 3 x 3 and 2 x 2 problems: with thin SVDs
+// X1 = Ua Sa Va^T, X2 = Ub Sb Vb^T (J x 2, 2 x 2, 3 x 2: the columns are centred, rank <= 2) and M = Sa Va^T Vb Sb = Um Sm Vm^T,
+//   K = (Ua Um) Sm (Ub Vm)^T,   scale = (sm_0 + sm_1) / |X1|^2     (the sign fix Z lands on a zero singular value),
+//   S1_hat = scale (Ub Vm Um^T Ua^T) X1 + mu2 1^T = scale X2 W + mu2 1^T,   W = Vb Sb^-1 (Vm Um^T) Sa Va^T   (3 x 3)
+// (the null-space terms of R S1 and of t = mu2 - scale R mu1 cancel).  Checked against the reference's own outputs
+// (tests/golden/procrustes_batch_axes.npz) and against the J x J restatement in oracle/lift_ref.py.
+__device__ __forceinline__ void top2_eig3(double G[3][3], double V2[3][2], double s2[2]) {
+    double V[3][3];
+    jacobi_eig3(G, V);
+    const double ev[3] = {G[0][0], G[1][1], G[2][2]};
+    int o0 = 0, o1 = 1, o2 = 2;
+    if (ev[o0] < ev[o1]) { const int t = o0; o0 = o1; o1 = t; }
+    if (ev[o1] < ev[o2]) { const int t = o1; o1 = o2; o2 = t; }
+    if (ev[o0] < ev[o1]) { const int t = o0; o0 = o1; o1 = t; }
+    s2[0] = sqrt(fmax(ev[o0], 0.0));
+    s2[1] = sqrt(fmax(ev[o1], 0.0));
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { V2[r][0] = V[r][o0]; V2[r][1] = V[r][o1]; }
+}
+
+static __global__ __launch_bounds__(64) void pose_metrics_batch_axes_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int B, int J,
+                                                                     float* __restrict__ mpjpe, float* __restrict__ pa_mpjpe,
+                                                                     float* __restrict__ aligned) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* x1 = pred + (long)b * J * 3;
+    const float* x2 = gt + (long)b * J * 3;
+    double G1[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, G2[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, var1 = 0.0, e = 0.0;
+    for (int j = 0; j < J; ++j) {
+        double a[3], g[3], d2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a[c] = x1[3 * j + c]; g[c] = x2[3 * j + c]; d2 += (g[c] - a[c]) * (g[c] - a[c]); }
+        e += sqrt(d2);
+        const double m1 = (a[0] + a[1] + a[2]) / 3.0, m2 = (g[0] + g[1] + g[2]) / 3.0;      // the "mean point" of row j: over the 3 columns
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a[c] -= m1; g[c] -= m2; var1 += a[c] * a[c]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { G1[r][c] += a[r] * a[c]; G2[r][c] += g[r] * g[c]; }
+    }
+    mpjpe[b] = (float)(e / J);
+    double Va[3][2], Vb[3][2], sa[2], sb[2];
+    top2_eig3(G1, Va, sa);
+    top2_eig3(G2, Vb, sb);
+    double M[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) M[i][k] = sa[i] * (Va[0][i] * Vb[0][k] + Va[1][i] * Vb[1][k] + Va[2][i] * Vb[2][k]) * sb[k];
+    // 2 x 2 SVD through the eigenvectors of M^T M: v_i, s_i = |M v_i|, u_i = M v_i / s_i;  T = sum_i v_i u_i^T = Vm Um^T
+    const double p = M[0][0] * M[0][0] + M[1][0] * M[1][0], q = M[0][1] * M[0][1] + M[1][1] * M[1][1], r_ = M[0][0] * M[0][1] + M[1][0] * M[1][1];
+    const double th = 0.5 * atan2(2.0 * r_, p - q), cs = cos(th), sn = sin(th);
+    const double vm[2][2] = {{cs, sn}, {-sn, cs}};               // vm[i] = i-th right singular vector
+    double T[2][2] = {{0, 0}, {0, 0}}, ssum = 0.0;
+    const double tiny = 1e-14 * fmax(sa[0] * sb[0], 1e-300);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double u0 = M[0][0] * vm[i][0] + M[0][1] * vm[i][1], u1 = M[1][0] * vm[i][0] + M[1][1] * vm[i][1];
+        const double s = sqrt(u0 * u0 + u1 * u1);
+        if (s > tiny) {
+            ssum += s;
+            T[0][0] += vm[i][0] * u0 / s; T[0][1] += vm[i][0] * u1 / s;
+            T[1][0] += vm[i][1] * u0 / s; T[1][1] += vm[i][1] * u1 / s;
+        }
+    }
+    const double scale = ssum / var1;
+    // W = Vb Sb^-1 T Sa Va^T
+    double W[3][3];
+    const double isb[2] = {sb[0] > tiny ? 1.0 / sb[0] : 0.0, sb[1] > tiny ? 1.0 / sb[1] : 0.0};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double w = 0.0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) w += Vb[r][i] * isb[i] * T[i][k] * sa[k] * Va[c][k];
+            W[r][c] = w;
+        }
+    double pa = 0.0;
+    for (int j = 0; j < J; ++j) {
+        const double g0 = x2[3 * j], g1 = x2[3 * j + 1], g2 = x2[3 * j + 2];
+        const double m2 = (g0 + g1 + g2) / 3.0;
+        const double y[3] = {g0 - m2, g1 - m2, g2 - m2}, gg[3] = {g0, g1, g2};
+        double d2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double h = scale * (y[0] * W[0][c] + y[1] * W[1][c] + y[2] * W[2][c]) + m2;
+            if (aligned) aligned[((long)b * J + j) * 3 + c] = (float)h;
+            const double d = gg[c] - h;
+            d2 += d * d;
+        }
+        pa += sqrt(d2);
+    }
+    pa_mpjpe[b] = (float)(pa / J);
+}

@@ -71,16 +71,21 @@ class HmTrainFn(torch.autograd.Function):
         N2 = 2 * B
         new = lambda *shape: torch.empty(shape, device=dev)     # noqa: E731
         sv = {"B": B, "S0": S0}
+        # frozen estimators of stage 2 (hm_train_forward_nograd): nothing is kept for a backward, every map is dropped as soon as its
+        # consumer has run -- a 1024-frame batch peaks at a few concat buffers instead of every activation of the network
+        keep = any(ctx.needs_input_grad[3:])
         with torch.no_grad():
-            x0 = torch.stack([left, right], 1).reshape(N2, 3, S0, S0)       # image n = 2b + eye (plumbing copy, needed by the stem wgrad)
+            x0 = torch.stack([left, right], 1).reshape(N2, 3, S0, S0) if keep else None   # image n = 2b + eye (plumbing copy, needed by the stem wgrad)
             z0 = new(N2, 64, S0 // 2, S0 // 2)
             H.stem_fwd(left, right, P[BB + "conv1.weight"], z0)
             l0 = torch.empty_like(z0)
             m0 = _bn_fwd(z0, l0, P, buf, BB + "bn1", B)
             p0 = new(N2, 64, S0 // 4, S0 // 4)
             H.maxpool_fwd(l0, p0)
-            sv.update(x0=x0, z0=z0, l0=l0, m0=m0, p0=p0)
+            if keep:
+                sv.update(x0=x0, z0=z0, l0=l0, m0=m0, p0=p0)
             x, cin, side = p0, 64, S0 // 4
+            del z0, l0, p0
             blocks, pyr = [], []
             for i, (c, st) in enumerate(STAGES, start=1):
                 for b in range(net.blocks[i - 1]):
@@ -102,8 +107,11 @@ class HmTrainFn(torch.autograd.Function):
                     H.conv_fwd(h, y1, P[k + "conv2.weight"], z2, taps=9, stride=1)
                     m2 = _bn_fwd(z2, y2, P, buf, k + "bn2", B, res=idt)
                     rec.update(z2=z2, y2=y2, m2=m2, level=i - 1 if b == net.blocks[i - 1] - 1 else None)
-                    blocks.append(rec)
+                    if keep:
+                        blocks.append(rec)
                     x, cin, side = y2, c, so
+                    del rec, z1, y1, z2, y2, idt
+                    zd = yd = None
                 pyr.append(x)
             # decoder on the channel-concatenated pyramids: [2B, C, s, s] viewed as [B, 2C, s, s]
             L = [t.view(B, 2 * t.shape[1], t.shape[2], t.shape[3]) for t in pyr]
@@ -128,8 +136,9 @@ class HmTrainFn(torch.autograd.Function):
             n_out = P[AB + "conv_heatmap.weight"].shape[0]
             out = new(B, n_out, s64, s64)
             H.conv_fwd(h, x1, P[AB + "conv_heatmap.weight"], out, bias=P[AB + "conv_heatmap.bias"], taps=1)
-            sv.update(blocks=blocks, L=L, u4=u4, cat3=cat3, x3=x3, cat2=cat2, x2=x2, cat1=cat1, x1=x1)
-        ctx.sv, ctx.net, ctx.keys, ctx.P = sv, net, keys, P
+            if keep:
+                sv.update(blocks=blocks, L=L, u4=u4, cat3=cat3, x3=x3, cat2=cat2, x2=x2, cat1=cat1, x1=x1)
+        ctx.sv, ctx.net, ctx.keys, ctx.P = (sv if keep else None), net, keys, P
         return out
 
     @staticmethod

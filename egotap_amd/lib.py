@@ -40,9 +40,6 @@ _PROTOS = {
     "egotap_set_pu_chain": (C.c_int, [C.c_void_p, C.c_int]),
     "egotap_pu_chain_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "egotap_debug_pu_drop_workgroups": (C.c_int, [C.c_void_p, C.c_int]),
-    "egotap_debug_attention_gen": (C.c_int, [C.c_int]),
-    "egotap_debug_tn_sync": (C.c_int, [C.c_int]),
-    "egotap_debug_hm_r2_kernels": (C.c_int, [C.c_int]),
     "egotap_set_weight_scratch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "egotap_set_act_scratch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "egotap_hm_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
@@ -55,6 +52,7 @@ _PROTOS = {
     "egotap_layernorm_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "egotap_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "egotap_pose_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "egotap_pose_metrics_batch_axes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egotap_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "egotap_synth_heatmaps": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egotap_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -165,7 +163,7 @@ def load(build_if_missing: bool = True):
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.egotap_abi_version() != 1:
+    if lib.egotap_abi_version() != 2:
         raise EgotapError("libegotap_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -225,8 +223,10 @@ def linear_bf16_dma(x_bf16, w_bf16, b):
     return y
 
 
-def pose_metrics(pred, gt, want_aligned: bool = False):
-    """per-sample (mpjpe [B], pa_mpjpe [B][, aligned [B,J,3]]) of poses [B,J,3] in the input units (egotap_pose_metrics)"""
+def pose_metrics(pred, gt, want_aligned: bool = False, reference_batch_axes: bool = False):
+    """per-sample (mpjpe [B], pa_mpjpe [B][, aligned [B,J,3]]) of poses [B,J,3] in the input units (egotap_pose_metrics).
+    reference_batch_axes: for a batch of 2 or 3 frames return what utils/util.py:328-379 returns there -- line 337 skips its transpose
+    and aligns the wrong axes (egotap_pose_metrics_batch_axes); other batch sizes are unaffected, as in the reference."""
     import torch
     pred, gt = pred.detach().float().contiguous(), gt.detach().float().contiguous()
     _need_cuda_f32(pred, gt)
@@ -235,7 +235,8 @@ def pose_metrics(pred, gt, want_aligned: bool = False):
     B, J = pred.shape[0], pred.shape[1]
     e, pa = torch.empty(B, device=pred.device), torch.empty(B, device=pred.device)
     al = torch.empty_like(pred) if want_aligned else None
-    check(load().egotap_pose_metrics(_ptr(pred), _ptr(gt), B, J, _ptr(e), _ptr(pa), _ptr(al), _stream()))
+    fn = load().egotap_pose_metrics_batch_axes if reference_batch_axes and B in (2, 3) else load().egotap_pose_metrics
+    check(fn(_ptr(pred), _ptr(gt), B, J, _ptr(e), _ptr(pa), _ptr(al), _stream()))
     return (e, pa, al) if want_aligned else (e, pa)
 
 

@@ -114,7 +114,20 @@ class EgoTAPAutoEncoderModel(nn.Module):
             self._gt_cat = syn["cat"]
 
     # ---- forward -----------------------------------------------------------------------------------------------
-    def forward_heatmap(self, train_bn=False):
+    def _estimator_bn_modes(self):
+        """(position net, limb net) -> True where the estimator normalises with BATCH statistics.  The reference's estimators are plain
+        sub-modules of the wrapper: they run in whatever mode their `.training` flag says.  train.py:91 `model.train()` therefore
+        leaves the FROZEN estimators' BatchNorm2d on batch statistics, running statistics drifting, while the head trains
+        (egotap_autoencoder_model.py:127-129 freezes parameters only), and set_eval_mode() (:325-327) switches net_HeatMap but not
+        net_RotHeatMap.  That is the default here too (pinned by tests/golden/wrapper_step_rgb_ue_b2.npz, the reference wrapper's own
+        run).  opt.frozen_heatmap_bn_eval = True is the opt-out: folded running-statistics BatchNorm in both estimators whatever
+        their mode (what the stage-1 checkpoints were validated with; frames then stay independent and large batches run in chunks on
+        the bf16 channels-last kernels)."""
+        if getattr(self.opt, "frozen_heatmap_bn_eval", False):
+            return False, False
+        return bool(self.net_HeatMap.training), bool(self.net_RotHeatMap.training)
+
+    def forward_heatmap(self):
         p = self.net_AutoEncoder.preset
         J = p.n_joints_hm
         if getattr(self.opt, "use_gt_heatmap", False):
@@ -128,36 +141,33 @@ class EgoTAPAutoEncoderModel(nn.Module):
             right = self.input_rgb_right.float().contiguous()
             B = left.shape[0]
             cat = torch.empty((B, p.in_channels, p.hm_size, p.hm_size), dtype=torch.float32, device=left.device)
-            if train_bn:
-                from .hm_training import hm_train_forward_nograd
-                cat[:, :2 * J] = hm_train_forward_nograd(self.net_HeatMap, left, right)
-                cat[:, 2 * J:] = hm_train_forward_nograd(self.net_RotHeatMap, left, right)
-            else:
-                # eval-mode estimators treat frames independently: walk a large batch in chunks so that the U-Net scratch stays at
-                # the chunk's size (B = 1024 from RGB, BASELINE config 3); one scratch shared by both estimators
-                chunk = min(B, int(getattr(self.opt, "hm_chunk", 256)))
-                ws = None if self.net_HeatMap.bottleneck else self.net_HeatMap._workspace(chunk, left.device)   # (Bottleneck nets allocate per call)
-                for lo in range(0, B, chunk):
-                    hi = min(B, lo + chunk)
-                    self.net_HeatMap.forward_into(left[lo:hi], right[lo:hi], cat[lo:hi], 0, workspace=ws)
-                    self.net_RotHeatMap.forward_into(left[lo:hi], right[lo:hi], cat[lo:hi], 2 * J, workspace=ws)
+            bn_batch = self._estimator_bn_modes()
+            for net, c0, batch_stats in ((self.net_HeatMap, 0, bn_batch[0]), (self.net_RotHeatMap, 2 * J, bn_batch[1])):
+                if batch_stats:
+                    # batch statistics couple the frames of a batch: the whole batch goes through in one piece, per eye
+                    from .hm_training import hm_train_forward_nograd
+                    cat[:, c0:c0 + 2 * J] = hm_train_forward_nograd(net, left, right)
+                else:
+                    # eval-mode estimators treat frames independently: walk a large batch in chunks so that the U-Net scratch stays
+                    # at the chunk's size (B = 1024 from RGB, BASELINE config 3); one scratch shared by both estimators
+                    was = net.training
+                    net.eval()
+                    try:
+                        chunk = min(B, int(getattr(self.opt, "hm_chunk", 256)))
+                        ws = None if net.bottleneck else self.net_HeatMap._workspace(chunk, left.device)   # (Bottleneck nets allocate per call)
+                        for lo in range(0, B, chunk):
+                            hi = min(B, lo + chunk)
+                            net.forward_into(left[lo:hi], right[lo:hi], cat[lo:hi], c0, workspace=ws)
+                    finally:
+                        net.train(was)
         self.pred_heatmap_cat = cat
         self.pred_heatmap_left, self.pred_heatmap_right = cat[:, :J], cat[:, J:2 * J]
         self.pred_limb_heatmap_left, self.pred_limb_heatmap_right = cat[:, 2 * J:4 * J], cat[:, 4 * J:]
 
     def forward(self, evaluate=False):
-        with torch.no_grad():
-            was = (self.net_HeatMap.training, self.net_RotHeatMap.training)
-            # Frozen estimators: the reference's train.py:91 model.train() leaves their BatchNorm2d on batch statistics (and its
-            # running stats drifting) while the head trains.  Default here: folded running-stat BatchNorm (what the checkpoints
-            # were validated with; INTEGRATION.md states the deviation).  opt.frozen_heatmap_bn_train = True reproduces the
-            # reference: train-mode forward of the estimators (batch statistics per eye, running stats updated), no gradient.
-            ref_bn = self.isTrain and not evaluate and getattr(self.opt, "frozen_heatmap_bn_train", False) and was[0]
-            if not ref_bn:
-                self.net_HeatMap.eval(); self.net_RotHeatMap.eval()
-            self.forward_heatmap(train_bn=ref_bn)
-            self.net_HeatMap.train(was[0]); self.net_RotHeatMap.train(was[1])
-        if self.net_AutoEncoder.training and not evaluate:
+        with torch.no_grad():                      # the estimators never train here (egotap_autoencoder_model.py:179 with train_heatmap False)
+            self.forward_heatmap()
+        if self.net_AutoEncoder.training:          # (evaluate only switches autocast off in the reference: egotap_autoencoder_model.py:219)
             from .training import lift_train_forward
             self.pred_pose = lift_train_forward(self.net_AutoEncoder, self.pred_heatmap_cat)
             _, self.pred_rot, self.pred_indep_pos, rec = self.net_AutoEncoder._zero_outputs(self.pred_heatmap_cat.shape[0], self.pred_pose.device)
@@ -209,9 +219,11 @@ class EgoTAPAutoEncoderModel(nn.Module):
         return self
 
     def set_eval_mode(self):
+        """egotap_autoencoder_model.py:325-327: the head and the POSITION estimator; net_RotHeatMap keeps its mode, exactly as in the
+        reference (every caller there runs model.eval() first: utils/evaluate.py:93, 150).  opt.frozen_heatmap_bn_eval makes the
+        estimators' mode irrelevant."""
         self.net_AutoEncoder.eval()
         self.net_HeatMap.eval()
-        self.net_RotHeatMap.eval()
 
     def evaluate(self, runnning_average_dict):
         self.set_eval_mode()
@@ -230,7 +242,11 @@ class EgoTAPAutoEncoderModel(nn.Module):
                         if getattr(n, "precision", "f32") != q:
                             n.set_precision(q)
             from . import lib as _lib                     # one fused launch: per-sample MPJPE + Procrustes-aligned MPJPE
-            err, pa = _lib.pose_metrics(self.pred_pose, self.gt_pose)
+            # batches of 2 or 3 frames: the reference's batch_compute_similarity_transform_torch aligns the wrong axes there
+            # (utils/util.py:337) and test.py prints that number; reproduced by default, opt.pa_mpjpe_reference_batch_axes = False
+            # gives every frame the PA-MPJPE it has in any other batch
+            err, pa = _lib.pose_metrics(self.pred_pose, self.gt_pose,
+                                        reference_batch_axes=bool(getattr(self.opt, "pa_mpjpe_reference_batch_axes", True)))
             err, pa = (err * self.cm2mm).cpu(), (pa * self.cm2mm).cpu()      # one device->host copy, not one per sample
         for i in range(self.pred_pose.shape[0]):
             runnning_average_dict.update(dict(mpjpe=err[i], pa_mpjpe=pa[i]))

@@ -47,9 +47,9 @@ def parse(argv=None, is_train: bool = False) -> types.SimpleNamespace:
             A("--lambda_" + name, type=float, default=dflt)
         A("--stage", action="append", dest="train_stage", default=[]); A("--auto_restart", action="store_true")
         A("--auto_terminate", action="store_true")
-        # additions of this build (not reference flags): reduced-precision mode behind --use_amp, reference BatchNorm behaviour of
-        # the frozen estimators (train.py:91), see INTEGRATION.md
-        A("--amp_precision", default="bf16", choices=["bf16", "bf16x3"]); A("--frozen_heatmap_bn_train", action="store_true")
+        # additions of this build (not reference flags), see INTEGRATION.md: reduced-precision mode behind --use_amp; opt-OUT of the
+        # reference's batch-statistics BatchNorm in the frozen estimators (train.py:91: the default here, as there)
+        A("--amp_precision", default="bf16", choices=["bf16", "bf16x3"]); A("--frozen_heatmap_bn_eval", action="store_true")
     ns = ap.parse_args(argv)
     opt = preset_defaults(ns.joint_preset, ns.load_size_heatmap[0])
     for k, v in vars(ns).items():

@@ -13,6 +13,8 @@
  *   - every function returns 0 on success, an EGOTAP_ERR_* code otherwise; the message is in
  *     egotap_last_error() (thread local).  No C++ exception crosses the ABI.
  *   - a handle is not thread-safe; data parallelism = one process + one handle per GPU.
+ *   - the library reads no environment variable.  Test and measurement hooks (fault injection, partial forward, GEMM event timing)
+ *     are exported too but declared separately, in egotap_debug.h: nothing a deployment calls.
  */
 #ifndef EGOTAP_H
 #define EGOTAP_H
@@ -23,7 +25,8 @@
 extern "C" {
 #endif
 
-#define EGOTAP_ABI_VERSION 1
+/* 2 (round 4): egotap_config grew (hm_blocks, round 3); test / measurement hooks moved to egotap_debug.h; egotap_pose_metrics_batch_axes added */
+#define EGOTAP_ABI_VERSION 2
 
 enum { EGOTAP_OK = 0, EGOTAP_ERR_INVALID = 1, EGOTAP_ERR_HIP = 2, EGOTAP_ERR_UNBOUND = 3, EGOTAP_ERR_WORKSPACE = 4 };
 
@@ -120,25 +123,6 @@ int egotap_set_pu_chain(egotap_handle h, int enable);
 /* *enabled: whether the handle still uses the one-launch recurrence; *faults: chain launches that had to be redone so far (see above).
  * Exact for calls whose stream the caller has synchronised. */
 int egotap_pu_chain_status(egotap_handle h, int* enabled, int* faults);
-/* Test hook: launch the one-launch recurrence with its last `n` workgroups missing (0 = off), which starves a row block exactly as a
- * shared device does. */
-int egotap_debug_pu_drop_workgroups(egotap_handle h, int n);
-/* Test / measurement hook (process wide): which generation of the bf16 attention kernels egotap_bf16_attention_fwd / _bwd (and the
- * training step built on them) launch: 3 (default) = DMA-staged kernels, the forward stepping 32 keys at a time with three workgroups
- * per CU; 2 = the same with the 64-key forward; 1 = round 2's register-staged kernels; 32..34 = 3 with 2..4 waves per forward
- * workgroup.  All generations produce the same bits. */
-int egotap_debug_attention_gen(int gen);
-/* Test / measurement hook (process wide): 0 = the bf16 weight-gradient GEMM (csrc/gemm_tn_bf16s.h) without the periodic check-in that keeps
- * the workgroups sharing operand slabs through one L2 within reach of each other; 1 (default) = with it.  Same bits either way. */
-int egotap_debug_tn_sync(int on);
-/* Test / measurement hook (process wide), a bit mask over the round-3 kernels of the bf16 estimators (egotap_hm_forward under
- * EGOTAP_PREC_BF16); 0 (default) = all of them on.
- *   bit 0: the ResNet stem and the max-pool run as two kernels (fp32-MFMA stem writing bf16 channels-last, then the pool: round 2's form)
- *          instead of one fused kernel on the bf16 matrix cores (csrc/stem_bf16s.h; reference: net_architecture.py:69-70, torchvision
- *          resnet18 conv1 / bn1 / relu / maxpool);
- *   bit 1: layer1's four 64 -> 64 3x3 convolutions run on the implicit-GEMM kernel (csrc/conv_bf16s.h, 64-column tile) instead of the
- *          direct halo-tile kernel (csrc/conv64_bf16s.h). */
-int egotap_debug_hm_r2_kernels(int mask);
 /* EGOTAP_PREC_BF16 only: caller-owned device scratch (16-byte aligned) into which a GEMM's weight matrix is rounded to bf16 right
  * before the launch (stream ordered; nothing is cached, the live fp32 parameters stay the source of truth).  Halves the W operand's
  * vector-memory bytes, which bound that mode.  bytes >= 2 * the largest N*K (67 MB for fc1 of the position encoder); NULL = off. */
@@ -150,9 +134,6 @@ int egotap_set_weight_scratch(egotap_handle h, void* buf, size_t bytes);
  * kernel.  NULL = off. */
 int egotap_set_act_scratch(egotap_handle h, void* buf, size_t bytes);
 
-/* debugging aid for parity tests: 0 = full forward (default); 1 = return after the embeddings;
- * 2+i = return after ViT layer i.  The state is then readable as intermediate "x". */
-int egotap_lift_debug_stop(egotap_handle h, int stage);
 
 /* ---- single operators (same kernels the forward uses; exported for unit tests and reuse) ---- */
 /* y = epi(x W^T + b): nn.Linear (+ residual / exact GELU / BatchNorm1d-eval + LeakyReLU 0.2).
@@ -178,6 +159,13 @@ int egotap_attention(const float* qkv, float* ctx, int B, int N, int heads, int 
  * scale, translation), one launch for the batch instead of the reference's two Python loops.
  *   pred, gt  device f32 [B, J, 3];  mpjpe, pa_mpjpe  device f32 [B] (input units);  aligned  device f32 [B, J, 3] or NULL */
 int egotap_pose_metrics(const float* pred, const float* gt, int B, int J, float* mpjpe, float* pa_mpjpe, float* aligned, void* stream);
+/* The same metrics AS THE REFERENCE COMPUTES THEM FOR A BATCH OF 2 OR 3 FRAMES.  utils/util.py:337 decides whether to transpose its
+ * [B, J, 3] input by testing shape[0] against 3 and 2 (meant for unbatched 3 x N / 2 x N point sets), so for B = 2 or 3 the similarity
+ * transform is solved over the wrong axes (J "coordinates", 3 "points"; a J x J SVD of rank <= 2) and PA-MPJPE of a frame depends on
+ * the size of the batch it arrives in.  test.py / utils/evaluate.py:149-168 print exactly these numbers for a ragged last batch, so the
+ * wrapper's evaluate() calls this entry for B in {2, 3} by default (opt.pa_mpjpe_reference_batch_axes).
+ * B must be 2 or 3; same arguments as egotap_pose_metrics; `aligned` = the reference's S1_hat (not transposed back, as there). */
+int egotap_pose_metrics_batch_axes(const float* pred, const float* gt, int B, int J, float* mpjpe, float* pa_mpjpe, float* aligned, void* stream);
 
 /* Ground-truth heatmaps from joints, written in the lifting head's input layout (the data loader's per-frame CPU work when
  * training with --use_gt_heatmap: dataloader/data_loader.py:76-215, utils/projection.py:263-279 coord2d_to_heatmap,
@@ -201,11 +189,6 @@ int egotap_train_gemm_nt(egotap_handle h, int loader, const float* x, int64_t ld
 int egotap_train_gemm_tn(egotap_handle h, int loader, const float* dy, int64_t ldy, const float* x, const float* aux, float* dw, int M,
                          int N, int K, int accumulate, int Bsz, void* ws, size_t ws_bytes, void* stream);
 int egotap_train_colsum(const float* y, int64_t ldy, float* out, int M, int N, int accumulate, void* ws, size_t ws_bytes, void* stream);
-/* (test aid, host only: no device call) the number of partial slabs a weight-gradient launch splits its contraction into, and the slabs per split:
- * workgroups in a row on the busiest CU x slabs each + a fixed part per workgroup + the traffic of the slab reduction, within slab_bytes of
- * workspace.  0 when not even one slab of n_floats fits. */
-int egotap_debug_wgrad_splits(int tiles, int64_t slabs, int64_t n_floats, size_t slab_bytes, int num_cu, int lds_bytes, double slab_us, double fixed_us,
-                              int* per);
 /* [r3] weight and bias gradient of one nn.Linear with a plain input in one call: dw[N,K] (+)= dy^T x, db[N] (+)= column sums of dy (autograd of
  * the ViT layers' Linear modules, model/modeling_vit.py:226-230, 271, 319-344).  fp32 with M % 32 == 0: the workgroups that stage dy for the
  * product also sum its columns (one pass over dy); otherwise egotap_train_gemm_tn followed by egotap_train_colsum. */
@@ -375,15 +358,6 @@ int egotap_bf16_fc1_wgrad(egotap_handle h, int which, const void* dz, const void
                           void* stream);
 int egotap_bf16_fc1_dgrad_tokens(egotap_handle h, const void* dz, const void* wt, void* dtok, int B, void* stream);
 
-/* ---- measurement hooks (bench.py roofline) ---- */
-/* when enabled, every GEMM launch of the handle is bracketed by HIP events on the caller's stream */
-int egotap_timing_enable(egotap_handle h, int enable);
-/* synchronises the recorded events; returns launches, summed milliseconds and summed algorithmic FLOPs
- * of the fp32 GEMM kernel since the last reset, then resets */
-int egotap_timing_read(egotap_handle h, int* launches, double* total_ms, double* total_flops);
-/* JSON array written by the last egotap_timing_read: one object per GEMM role
- * {"role","kernel","launches","ms","flops"}; the pointer stays valid until the next read */
-const char* egotap_timing_detail(egotap_handle h);
 
 #ifdef __cplusplus
 }

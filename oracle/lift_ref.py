@@ -446,6 +446,24 @@ def procrustes_align(s1, s2):
     return (scale[:, None, None] * (r @ x1) + t).transpose(1, 2)
 
 
+def procrustes_align_batch_axes(s1, s2):
+    """What utils/util.py:328-379 computes for a BATCH of 2 or 3 frames: line 337 tests S1.shape[0] against 3 and 2 (meant for
+    unbatched 3 x N / 2 x N points) and skips the transpose, so s1 [B,J,3] is read as J "coordinates" x 3 "points": means over the
+    three columns, a J x J outer product K of rank <= 2, its SVD, no transpose back.  Restated as written (float64 in the tests)."""
+    mu1, mu2 = s1.mean(-1, keepdim=True), s2.mean(-1, keepdim=True)
+    y1, y2 = s1 - mu1, s2 - mu2
+    var1 = (y1 ** 2).sum(dim=(1, 2))
+    k = y1 @ y2.transpose(1, 2)
+    u, _, vh = torch.linalg.svd(k)
+    v = vh.transpose(1, 2)
+    z = torch.eye(k.shape[1], dtype=s1.dtype).repeat(s1.shape[0], 1, 1)
+    z[:, -1, -1] = torch.sign(torch.det(u @ v.transpose(1, 2)))
+    r = v @ z @ u.transpose(1, 2)
+    scale = torch.diagonal(r @ k, dim1=1, dim2=2).sum(-1) / var1
+    t = mu2 - scale[:, None, None] * (r @ mu1)
+    return scale[:, None, None] * (r @ s1) + t
+
+
 def to_torch_sd(np_sd, dtype=torch.float32):
     out = {}
     for k, v in np_sd.items():

@@ -11,20 +11,32 @@ from egotap_amd import lib as L
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(REPO, "include", "egotap.h")).read()
+def _declared(header="egotap.h"):
+    text = open(os.path.join(REPO, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(egotap_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_library_agree():
     lib = L.load()
-    names = _declared()
-    assert len(names) >= 15
+    boundary, hooks = _declared(), _declared("egotap_debug.h")
+    assert len(boundary) >= 15
+    # the drop-in boundary holds no test / measurement hook, the hook header nothing else
+    assert not [n for n in boundary if "debug" in n or "timing" in n], "hooks belong in egotap_debug.h"
+    assert hooks and all("debug" in n or "timing" in n for n in hooks) and not set(hooks) & set(boundary)
+    names = sorted(boundary + hooks)
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in egotap.h but not exported"
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported"
     assert sorted(L.exported_symbols()) == names
-    assert lib.egotap_abi_version() == 1
+    # and the library exports nothing beyond the two headers
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", L._build.LIB], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r"\b(egotap_[a-z0-9_]+)$", out, flags=re.M)))
+    assert exported == names, sorted(set(exported) ^ set(names))
+    assert lib.egotap_abi_version() == 2
+    # the library reads no environment variable
+    src = "".join(open(os.path.join(REPO, "egotap_amd", "csrc", f)).read() for f in os.listdir(os.path.join(REPO, "egotap_amd", "csrc")))
+    assert "getenv" not in src
 
 
 def _cfg(**kw):

@@ -142,6 +142,7 @@ def test_create_model_with_the_reference_training_flags(tmp_path):
             for k, v in d.items():
                 self.setdefault(k, []).append(float(v))
     avg = Avg()
+    m.eval()                                                       # utils/evaluate.py:150 (every caller of evaluate() in the reference does)
     m.evaluate(avg)
     assert len(avg["mpjpe"]) == B and m.net_AutoEncoder.precision == "bf16"
     # evaluation is fp32 for all three networks: the heatmaps it leaves behind equal an fp32 model's (bit for bit)
@@ -319,12 +320,11 @@ def test_config4_two_rank_wrapper_step_on_one_gpu(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------------------ frozen estimators' BatchNorm
-def test_frozen_estimators_batchnorm_flag_reproduces_the_reference_train_mode(tmp_path):
+def test_frozen_estimators_batchnorm_default_is_the_reference_train_mode_and_the_flag_opts_out(tmp_path):
     """train.py:91 calls model.train() on the wrapper, so the reference's FROZEN estimators normalise with batch statistics and keep
-    updating their running statistics while the head trains (egotap_autoencoder_model.py:127-129 freezes parameters only).  Default
-    here: eval-mode estimators (what the stage-1 checkpoints were validated with); opt.frozen_heatmap_bn_train
-    reproduces the reference: heatmaps = the train-mode forward of hm_training (oracle-checked in test_gpu_hm_train_step.py), running
-    statistics move, parameters do not."""
+    updating their running statistics while the head trains (egotap_autoencoder_model.py:127-129 freezes parameters only).  That is
+    the default here too (pinned against the reference wrapper in test_gpu_wrapper_golden.py); opt.frozen_heatmap_bn_eval opts out:
+    eval-mode estimators (what the stage-1 checkpoints were validated with), running statistics and parameters both untouched."""
     from egotap_amd import models, options, spec
     from egotap_amd.hm_training import hm_train_forward_nograd
     from egotap_amd.synthetic import synth_hm_state_dict
@@ -339,28 +339,33 @@ def test_frozen_estimators_batchnorm_flag_reproduces_the_reference_train_mode(tm
             "gt_local_pose": torch.from_numpy(synth_input("gt_bn", (B, 16, 3), -20.0, 20.0))}
     key = "backbone.backbone.backbone.bn1.running_mean"
     cats = {}
-    for flag in (False, True):
+    for opt_out in (True, False):
         m, p = _model(use_gt_heatmap=False, log_dir=str(tmp_path), path_to_trained_heatmap=str(tmp_path / "hm" / "best_net_HeatMap.pth"),
-                      frozen_heatmap_bn_train=flag)
-        m.train() if hasattr(m, "train") else None
-        m.net_HeatMap.train(); m.net_RotHeatMap.train()                       # what train.py's model.train() does to the sub-modules
+                      frozen_heatmap_bn_eval=opt_out)
+        m.train()                                                             # train.py:91
+        assert m.net_HeatMap.training and m.net_RotHeatMap.training
         before = {k: v.clone() for k, v in m.net_HeatMap.state_dict().items()}
         m.set_input(data)
         m.optimize_parameters()
         after = m.net_HeatMap.state_dict()
         moved = not torch.equal(before[key], after[key])
-        assert moved == flag
+        assert moved == (not opt_out)
+        assert m.net_HeatMap.training and m.net_RotHeatMap.training           # the forward leaves the modes alone
         for k, v in m.net_HeatMap.named_parameters():
             assert torch.equal(before[k], after[k]) and not v.requires_grad      # frozen either way
-        cats[flag] = m.pred_heatmap_cat.clone()
-        if flag:
+        cats[opt_out] = m.pred_heatmap_cat.clone()
+        if not opt_out:
             # the heatmaps the head trained on are the train-mode forward (batch statistics per eye) of the estimators as they were
             ref = models.create_model(m.opt)
             ref.net_HeatMap.load_state_dict(before)
             ref.net_HeatMap.train()
             J = p.n_joints_hm
             want = hm_train_forward_nograd(ref.net_HeatMap, m.input_rgb_left.float().contiguous(), m.input_rgb_right.float().contiguous())
-            assert torch.equal(cats[True][:, :2 * J], want)
+            assert torch.equal(cats[False][:, :2 * J], want)
+        else:
+            m.eval()
+            m.forward()
+            assert torch.equal(m.pred_heatmap_cat, cats[True])                # opted out: model.train() / model.eval() give the same heatmaps
     assert not torch.equal(cats[False], cats[True])
 
 

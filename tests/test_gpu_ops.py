@@ -241,6 +241,32 @@ def test_pose_metrics_matches_reference_golden_and_oracle(B, J):
         np.testing.assert_allclose(al.cpu().numpy(), g["s1_hat"], atol=2e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,J", [(2, 16), (3, 16), (2, 17), (3, 17)])
+def test_pose_metrics_reference_batch_axes_for_batches_of_two_and_three(B, J):
+    """utils/util.py:337: a batch of 2 or 3 frames is aligned over the wrong axes by the reference; egotap_pose_metrics_batch_axes
+    reproduces the reference's own outputs (tests/golden/procrustes_batch_axes.npz) through a 3 x 3 / 2 x 2 reduction of its J x J SVD"""
+    import os
+    from egotap_amd import lib
+    from egotap_amd.synthetic import synth_input
+    from oracle import lift_ref as O
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "procrustes_batch_axes.npz"))
+    a = torch.from_numpy(synth_input(f"procrustes_q1_{B}_{J}", (B, J, 3), -30.0, 30.0))
+    b = torch.from_numpy(synth_input(f"procrustes_q2_{B}_{J}", (B, J, 3), -30.0, 30.0))
+    b[:1] = a[:1] * 1.3 + 0.5 * b[:1]
+    e, pa, al = lib.pose_metrics(a.cuda(), b.cuda(), want_aligned=True, reference_batch_axes=True)
+    np.testing.assert_allclose(al.cpu().numpy(), g[f"s1_hat_b{B}_j{J}"], atol=2e-4, rtol=1e-4)           # the reference itself (fp32 LAPACK)
+    ref = O.procrustes_align_batch_axes(a.double(), b.double())
+    _close(al, ref, atol=2e-5, rtol=1e-6)                                                                # the float64 restatement
+    _close(pa, torch.linalg.norm(b.double() - ref, dim=-1).mean(-1), atol=1e-5)
+    _close(e, torch.linalg.norm(b.double() - a.double(), dim=-1).mean(-1), atol=1e-5)
+    # the switch off, or any other batch size: the 3 x 3 alignment
+    e2, pa2 = lib.pose_metrics(a.cuda(), b.cuda())
+    _close(pa2, torch.linalg.norm(b.double() - O.procrustes_align(a.double(), b.double()), dim=-1).mean(-1), atol=1e-4)
+    a4, b4 = torch.cat([a, a])[:4], torch.cat([b, b])[:4]                  # the same frames inside a batch of 4
+    _, pa4 = lib.pose_metrics(a4.cuda(), b4.cuda(), reference_batch_axes=True)
+    _close(pa4[:B], pa2, atol=1e-6)
+
+
 def test_pose_metrics_reflection_and_identity():
     """gt = mirrored pred needs the det-sign fix (a reflection is not allowed); gt = similarity(pred) aligns to zero error"""
     from egotap_amd import lib

@@ -167,7 +167,8 @@ def test_wrapper_eval_fixture_metrics_and_the_batch_of_two_accident():
     """G7 (the reference wrapper's evaluate()): the oracle's MPJPE / Procrustes restatement reproduces the reference's per-sample
     metrics at B = 4.  For a batch of 2 or 3 frames the reference's batch_compute_similarity_transform_torch skips its transpose
     (utils/util.py:337 tests S1.shape[0] against 3 and 2, meant for unbatched 3 x N input) and aligns the wrong axes: recorded in
-    the fixture, NOT reproduced (the same frames must not score differently because of the batch they arrive in)."""
+    the fixture and REPRODUCED (default of the drop-in since round 4: test.py prints these numbers for a ragged last batch) by
+    oracle.procrustes_align_batch_axes, the restatement of that branch."""
     import os
     from egotap_amd.synthetic import synth_input
     from oracle import lift_ref as O
@@ -183,7 +184,27 @@ def test_wrapper_eval_fixture_metrics_and_the_batch_of_two_accident():
     assert np.all(np.abs(g["quirk_b2_gt_pa_mpjpe"] - g["gt_pa_mpjpe"][:2]) > 50.0)             # the accident: ~100 mm off
     al2 = O.procrustes_align(pose[:2], gt[:2])
     pa2 = [float(torch.linalg.norm(gt[i] - al2[i], dim=-1).mean() * 10) for i in range(2)]
-    np.testing.assert_allclose(pa2, g["gt_pa_mpjpe"][:2], rtol=1e-4)                           # the oracle (and the HIP kernel) are batch independent
+    np.testing.assert_allclose(pa2, g["gt_pa_mpjpe"][:2], rtol=1e-4)                           # the 3 x 3 solve is batch independent ...
+    alq = O.procrustes_align_batch_axes(pose[:2].double(), gt[:2].double())
+    paq = [float(torch.linalg.norm(gt[i].double() - alq[i], dim=-1).mean() * 10) for i in range(2)]
+    np.testing.assert_allclose(paq, g["quirk_b2_gt_pa_mpjpe"], rtol=1e-4)                      # ... and this is what the reference printed
+
+
+def test_procrustes_batch_axes_restatement_matches_the_reference():
+    """utils/util.py:328-379 called with batches of 2 and 3 frames (the no-transpose branch of line 337), 16 and 17 joints:
+    tests/golden/procrustes_batch_axes.npz holds the reference's own outputs"""
+    from egotap_amd.synthetic import synth_input
+    from oracle import lift_ref as O
+    g = _load("procrustes_batch_axes.npz")
+    for B in (2, 3):
+        for J in (16, 17):
+            a = torch.from_numpy(synth_input(f"procrustes_q1_{B}_{J}", (B, J, 3), -30.0, 30.0))
+            b = torch.from_numpy(synth_input(f"procrustes_q2_{B}_{J}", (B, J, 3), -30.0, 30.0))
+            b[:1] = a[:1] * 1.3 + 0.5 * b[:1]
+            got = O.procrustes_align_batch_axes(a.double(), b.double()).numpy()
+            np.testing.assert_allclose(got, g[f"s1_hat_b{B}_j{J}"], atol=2e-4, rtol=1e-4)
+            # and it is NOT the 3 x 3 alignment
+            assert np.abs(got - O.procrustes_align(a.double(), b.double()).numpy()).max() > 1.0
 
 
 def test_bf16_storage_hook_changes_only_what_it_should():

@@ -17,9 +17,6 @@ r = torch.from_numpy(synth_input("probe_r", (4, 3, S, S), -2.0, 2.0)).cuda().rep
 nets = [hm_net(w, preset=preset, hm=hm)[0] for w in ("pos", "rot")]
 for n in nets:
     n.set_precision(mode)
-if len(sys.argv) > 4:        # A/B: egotap_debug_hm_r2_kernels mask (1 = round 2's two-kernel stem + max-pool, 2 = layer1 on the implicit GEMM, 3 = both)
-    from egotap_amd import lib
-    lib.check(lib.load().egotap_debug_hm_r2_kernels(int(sys.argv[4])))
 for _ in range(2):
     for n in nets:
         n(l, r)

@@ -451,6 +451,88 @@ def gen_wrapper():
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+def gen_wrapper_rgb():
+    """G6-rgb wrapper_step_rgb_ue_b2: the path train.py runs WITHOUT --use_gt_heatmap.  The reference's wrapper with the shipped
+    training flags, frozen estimators from <dir>_pos / <dir>_sin, model.train() (train.py:91: the frozen estimators' BatchNorm2d is
+    in batch-statistics mode and its running statistics keep drifting, egotap_autoencoder_model.py:127-129 freezes parameters only),
+    three optimize_parameters() from RGB.  Recorded: pred_heatmap_cat (sample + sums) of steps 1 and 3, losses by key, poses, every
+    head gradient of step 1, EVERY BatchNorm buffer of both estimators after the three steps, then -- as utils/evaluate.py:149-168
+    does between epochs -- model.eval() + evaluate() from RGB on the drifted running statistics, and evaluate() WITHOUT model.eval()
+    (set_eval_mode, egotap_autoencoder_model.py:325-327, forgets net_RotHeatMap: it stays on batch statistics).
+    The backbone is this repo's ResNet-18 restatement standing in for torchvision, as in G7-rgb."""
+    import tempfile
+    from model.egotap_autoencoder_model import EgoTAPAutoEncoderModel
+    from egotap_amd import spec
+    from egotap_amd.synthetic import synth_hm_state_dict, synth_state_dict
+
+    tmp = tempfile.mkdtemp(prefix="egotap_gold_rgb_")
+    sd_lift = {k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(spec.lift_preset("UnrealEgo"))).items()}
+    for sub, nh, salt in (("hm_pos", 15, "hm_pos."), ("hm_sin", 30, "hm_rot.")):
+        os.makedirs(os.path.join(tmp, sub))
+        torch.save({k: torch.from_numpy(v) for k, v in synth_hm_state_dict(nh, salt).items()}, os.path.join(tmp, sub, "best_net_HeatMap.pth"))
+    opt = _wrapper_opt(tmp, True, False)
+    m = EgoTAPAutoEncoderModel()
+    m.initialize(opt)
+    m.net_AutoEncoder.load_state_dict(sd_lift, strict=True)
+    m.train()                                                   # train.py:91
+    out = {"modes_after_train": np.array([int(n.training) for n in (m.net_HeatMap, m.net_RotHeatMap, m.net_AutoEncoder)])}
+    B = 2
+    m.set_input(_wrapper_data(B, "rgbstep"))
+    for step in (1, 2, 3):
+        m.optimize_parameters()
+        errs = m.get_current_errors()
+        out["errors_keys"] = np.array(list(errs.keys()))
+        out[f"errors_step{step}"] = np.array([errs[k] for k in errs], dtype=np.float64)
+        out[f"pred_pose_step{step}"] = m.pred_pose.detach().numpy().copy()
+        out[f"cat_stats_step{step}"] = stats(m.pred_heatmap_cat)
+        out[f"cat_sample_step{step}"] = sample(m.pred_heatmap_cat, 997)
+        if step == 1:
+            names, norms = [], []
+            for k, prm in m.net_AutoEncoder.named_parameters():
+                if prm.grad is None:
+                    continue
+                names.append(k)
+                norms.append(float(prm.grad.double().norm()))
+                out["g:" + k] = prm.grad.reshape(-1)[:: max(1, prm.numel() // 257)].numpy().copy()
+            out["grad_keys"], out["grad_norms"] = np.array(names), np.array(norms)
+            out["cat_requires_grad"] = np.array([int(m.pred_heatmap_cat.requires_grad)])
+        m.update_learning_rate()
+    for tag, net in (("pos", m.net_HeatMap), ("rot", m.net_RotHeatMap)):
+        for k, v in net.state_dict().items():
+            if k.startswith("backbone.backbone.backbone.") and (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked")):
+                out[f"buf_{tag}:" + k] = v.numpy().copy()
+        out[f"frozen_param_sum_{tag}"] = np.array([float(sum(p.double().sum() for p in net.parameters()))])
+
+    class Acc:
+        def __init__(self):
+            self.rows = []
+
+        def update(self, d):
+            self.rows.append({k: float(v.detach()) for k, v in d.items()})
+
+    # validation between epochs (utils/evaluate.py:149-168): model.eval(), evaluate() per batch -- on the DRIFTED running statistics
+    m.eval()
+    m.set_input(_wrapper_data(4, "rgbeval"))
+    acc = Acc()
+    pose, cat, _ = m.evaluate(acc)
+    out["eval_pred_pose"], out["eval_cat_sample"], out["eval_cat_stats"] = pose.detach().numpy().copy(), sample(cat, 997), stats(cat)
+    out["eval_mpjpe"], out["eval_pa_mpjpe"] = np.array([r["mpjpe"] for r in acc.rows]), np.array([r["pa_mpjpe"] for r in acc.rows])
+    m.train()                                                   # utils/evaluate.py:168
+    # evaluate() straight from train mode: set_eval_mode() switches net_AutoEncoder and net_HeatMap only -> the limb estimator
+    # normalises with batch statistics (and moves its running statistics once more); the position estimator uses running statistics
+    acc = Acc()
+    pose, cat, _ = m.evaluate(acc)
+    out["quirk_modes_after_evaluate"] = np.array([int(n.training) for n in (m.net_HeatMap, m.net_RotHeatMap, m.net_AutoEncoder)])
+    out["quirk_pred_pose"], out["quirk_cat_sample"], out["quirk_cat_stats"] = pose.detach().numpy().copy(), sample(cat, 997), stats(cat)
+    k = "backbone.backbone.backbone.bn1.num_batches_tracked"
+    out["quirk_num_batches_tracked"] = np.array([int(m.net_HeatMap.state_dict()[k]), int(m.net_RotHeatMap.state_dict()[k])])
+    np.savez_compressed(os.path.join(GOLD, "wrapper_step_rgb_ue_b2.npz"), **out)
+    print("wrapper_step_rgb:", {s: out[f"errors_step{s}"] for s in (1, 2, 3)}, "modes", out["modes_after_train"], out["quirk_modes_after_evaluate"],
+          "tracked", out["quirk_num_batches_tracked"], "eval mpjpe", out["eval_mpjpe"])
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 def gen_procrustes():
     import utils.util as U
 
@@ -460,6 +542,18 @@ def gen_procrustes():
     out = U.batch_compute_similarity_transform_torch(s1, s2)
     np.savez_compressed(os.path.join(GOLD, "procrustes.npz"), s1_hat=out.numpy())
     print("procrustes ok", tuple(out.shape))
+    # utils/util.py:337: a BATCH of 2 or 3 frames skips the transpose (the test is meant for unbatched 3 x N / 2 x N points), so the
+    # similarity transform is solved over the wrong axes: J "coordinates", 3 "points".  test.py / train_evaluate print exactly these
+    # numbers for a ragged last batch of 2 or 3 frames; the drop-in reproduces them by default.
+    q = {}
+    for B in (2, 3):
+        for J in (16, 17):
+            a = torch.from_numpy(synth_input(f"procrustes_q1_{B}_{J}", (B, J, 3), -30.0, 30.0))
+            b = torch.from_numpy(synth_input(f"procrustes_q2_{B}_{J}", (B, J, 3), -30.0, 30.0))
+            b[:1] = a[:1] * 1.3 + 0.5 * b[:1]
+            q[f"s1_hat_b{B}_j{J}"] = U.batch_compute_similarity_transform_torch(a, b).numpy()
+    np.savez_compressed(os.path.join(GOLD, "procrustes_batch_axes.npz"), **q)
+    print("procrustes batch-axes quirk ok", {k: v.shape for k, v in q.items()})
 
 
 def gen_hm():
@@ -692,7 +786,7 @@ def gen_synth():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="lift,pu,fc,loss,hm,procrustes,train,sched,synth,hmtrain,wrapper")
+    ap.add_argument("--only", default="lift,pu,fc,loss,hm,procrustes,train,sched,synth,hmtrain,wrapper,wrapper_rgb")
     args = ap.parse_args()
     which = set(args.only.split(","))
     os.makedirs(GOLD, exist_ok=True)
@@ -723,6 +817,8 @@ def main():
         gen_hm_train_b8()
     if "wrapper" in which:
         gen_wrapper()
+    if "wrapper_rgb" in which:
+        gen_wrapper_rgb()
 
 
 if __name__ == "__main__":
