@@ -225,7 +225,7 @@ def bench_config5(args, dev, rank, world, barrier, lib, L):
     rgb = [torch.from_numpy(synth_input(f"rgb5_{sd_}_rank{rank}", (4, 3, 512, 512), -2.0, 2.0)).to(dev).repeat(Bf // 4, 1, 1, 1).contiguous()
            for sd_ in ("l", "r")]
     m.set_input({"input_rgb_left": rgb[0], "input_rgb_right": rgb[1]})
-    m.set_eval_mode()
+    m.eval()                                   # test.py -> utils/evaluate.py:93 (set_eval_mode() leaves net_RotHeatMap in its mode, as the reference does)
     flops_full = out["flops_per_frame"] + hm_flops_per_frame(2 * J, 512) + hm_flops_per_frame(4 * J, 512)
     out["full_pipeline_from_rgb_512"] = {"batch_per_gpu": Bf, "flops_per_frame": flops_full}
     for mode in ("f32", "bf16"):
@@ -271,7 +271,7 @@ def bench_full(args, p, dev, rank, world, barrier, lib, L, mode="f32"):
     l = torch.from_numpy(synth_input(f"rgb_l_rank{rank}", (blk, 3, S, S), -2.0, 2.0)).to(dev).repeat((B + blk - 1) // blk, 1, 1, 1)[:B].contiguous()
     r = torch.from_numpy(synth_input(f"rgb_r_rank{rank}", (blk, 3, S, S), -2.0, 2.0)).to(dev).repeat((B + blk - 1) // blk, 1, 1, 1)[:B].contiguous()
     m.set_input({"input_rgb_left": l, "input_rgb_right": r})
-    m.set_eval_mode()
+    m.eval()                                   # test.py -> utils/evaluate.py:93 (set_eval_mode() leaves net_RotHeatMap in its mode, as the reference does)
     m.set_precision(mode)
     h = m.net_HeatMap._ensure_handle()
     with torch.no_grad():
@@ -732,6 +732,18 @@ def main():
             fast16["oracle_pose_scale"] = float(ref.abs().max())
             net.set_precision("f32")
 
+    parity_note = None
+    if rank == 0 and world > 1:
+        # N > 1: no timed CPU baseline (it is a property of the host, measured at N = 1), but the sharded headline still gets its numerical
+        # check: rank 0's shard, first frames, against the oracle on the same inputs (a few seconds of CPU work)
+        from oracle import lift_ref as O
+        n_chk = min(4, B)
+        with torch.no_grad():
+            ref = O.lift_forward(hm[:n_chk].cpu(), O.to_torch_sd(sd_np), p)
+        gpu_vs_oracle = float((net.predict_pose(hm[:n_chk]).cpu() - ref).abs().max())
+        parity_note = f"rank 0's shard, first {n_chk} frames of the timed input, oracle/lift_ref.lift_forward on the host (cpu_baseline itself is timed at N = 1 only)"
+    elif rank == 0 and gpu_vs_oracle is not None:
+        parity_note = f"the cpu_baseline sample (B = {args.cpu_batch})"
     if rank == 0:
         frames = world * B * args.steps
         fps = frames / elapsed
@@ -754,6 +766,7 @@ def main():
                             "legs_at_this_n": "all" if single_gpu_legs or args.lift_only else
                                               "headline + fast modes + data-parallel training legs (single-GPU legs: run with --gpus 1 or --all-legs)"},
             "roofline": roof, "cpu_baseline": cpu, "max_abs_diff_vs_oracle": gpu_vs_oracle,
+            "parity_checked_on": parity_note if parity_note is not None else "not checked in this run (--no-cpu-baseline at N = 1)",
             "fast_mode_bf16x3": fast, "fast_mode_bf16": fast16, "full_pipeline_from_rgb": full, "config5_geometry_egocap_hm128": config5,
             "train_step_lifting_head": train, "small_batch_latency": latency,
         }

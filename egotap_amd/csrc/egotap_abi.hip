@@ -25,6 +25,7 @@
 #include "gemm_tn_bf16.h"
 #include "train_ops.h"
 #include "gemm_bf16s.h"
+#include "gemm_bf16s64.h"
 #include "gemm_tn_bf16s.h"
 #include "bf16s_ops.h"
 #include "attention_bf16s.h"
@@ -828,15 +829,15 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
             prep(L.q_w, Wb, D, D); prep(L.k_w, Wb + (size_t)D * D, D, D); prep(L.v_w, Wb + (size_t)2 * D * D, D, D);
             hipLaunchKernelGGL(concat3_kernel, dim3((D + 255) / 256), dim3(256), 0, s, L.q_b, L.k_b, L.v_b, bias3, D);
             EGO_HIP(hipGetLastError());
-            EGO_HIP(gemm_bf16s_launch(XPlain{Yb, (long)D}, Wb, (long)D, SEpiBf16{bias3, QKVb, 3L * D}, M, 3 * D, D, cu, s));
+            EGO_HIP(gemm_bf16s_plain_launch(XPlain{Yb, (long)D}, Wb, (long)D, SEpiBf16{bias3, QKVb, 3L * D}, M, 3 * D, D, cu, s));
             EGO_HIP(attention_bf16s_fwd_launch(QKVb, CTXb, nullptr, B, h->seq, h->cfg.vit_heads, s));
             prep(L.o_w, Wb, D, D);
-            EGO_HIP(gemm_bf16s_launch(XPlain{CTXb, (long)D}, Wb, (long)D, SEpiResF32{L.o_b, X, X, (long)D}, M, D, D, cu, s));
+            EGO_HIP(gemm_bf16s_plain_launch(XPlain{CTXb, (long)D}, Wb, (long)D, SEpiResF32{L.o_b, X, X, (long)D}, M, D, D, cu, s));
             ln(L.ln2_g, L.ln2_b);
             prep(L.up_w, Wb, 4 * D, D);
-            EGO_HIP(gemm_bf16s_launch(XPlain{Yb, (long)D}, Wb, (long)D, SEpiGelu{L.up_b, HIDb, 4L * D}, M, 4 * D, D, cu, s));
+            EGO_HIP(gemm_bf16s_plain_launch(XPlain{Yb, (long)D}, Wb, (long)D, SEpiGelu{L.up_b, HIDb, 4L * D}, M, 4 * D, D, cu, s));
             prep(L.dn_w, Wb, D, 4 * D);
-            EGO_HIP(gemm_bf16s_launch(XPlain{HIDb, 4L * D}, Wb, 4L * D, SEpiResF32{L.dn_b, X, X, (long)D}, M, D, 4 * D, cu, s));
+            EGO_HIP(gemm_bf16s_plain_launch(XPlain{HIDb, 4L * D}, Wb, 4L * D, SEpiResF32{L.dn_b, X, X, (long)D}, M, D, 4 * D, cu, s));
             if (h->debug_stop == 2 + i) return EGOTAP_OK;
         }
         ln(p.lnf_g, p.lnf_b);                               // tokens (bf16) -> fc1's gathering loader
@@ -2539,6 +2540,14 @@ extern "C" int egotap_hmtrain_upsample_fwd(const float* x, float* y, int N, int 
 // EGOTAP_PREC_BF16 with bf16 tensors in HBM: activations are written as bf16 by their producers, weights are rounded once per
 // step; every GEMM reads bf16 through the LDS DMA (gemm_bf16s.h).  Single operators first (tests, tools), the whole step below.
 #if EGOTAP_IN(3)
+int g_gemm_bf16s_bk = 0;             // the one definition (gemm_bf16s64.h declares it for every part)
+extern "C" int egotap_debug_gemm_bk(int bk) {
+    EGO_CHECK(bk == 0 || bk == 32 || bk == 64, "egotap_debug_gemm_bk: 0 (by shape), 32 or 64");
+    g_gemm_bf16s_bk = bk;
+    return EGOTAP_OK;
+}
+#endif
+#if EGOTAP_IN(3)
 extern "C" int egotap_bf16_gemm_nt(const void* x, int64_t ldx, const void* w, const float* bias, int M, int N, int K, int epi, const void* aux,
                                    void* out0, void* out1, int64_t ldo, void* stream) {
     EGO_CHECK(x && w && out0, "egotap_bf16_gemm_nt: null argument");
@@ -2551,18 +2560,18 @@ extern "C" int egotap_bf16_gemm_nt(const void* x, int64_t ldx, const void* w, co
     const int cu = device_cu_count();
     hipError_t e;
     switch (epi) {
-        case 0: e = gemm_bf16s_launch(xl, wb, (long)K, SEpiBf16{bias, (__bf16*)out0, (long)ldo}, M, N, K, cu, s); break;
+        case 0: e = gemm_bf16s_plain_launch(xl, wb, (long)K, SEpiBf16{bias, (__bf16*)out0, (long)ldo}, M, N, K, cu, s); break;
         case 1: EGO_CHECK(bias && aux, "egotap_bf16_gemm_nt: epi 1 needs bias and residual");
-                e = gemm_bf16s_launch(xl, wb, (long)K, SEpiResF32{bias, (const float*)aux, (float*)out0, (long)ldo}, M, N, K, cu, s); break;
+                e = gemm_bf16s_plain_launch(xl, wb, (long)K, SEpiResF32{bias, (const float*)aux, (float*)out0, (long)ldo}, M, N, K, cu, s); break;
         case 2: EGO_CHECK(bias && out1, "egotap_bf16_gemm_nt: epi 2 needs bias and the second output");
-                e = gemm_bf16s_launch(xl, wb, (long)K, SEpiGeluSave{bias, (__bf16*)out0, (__bf16*)out1, (long)ldo}, M, N, K, cu, s); break;
+                e = gemm_bf16s_plain_launch(xl, wb, (long)K, SEpiGeluSave{bias, (__bf16*)out0, (__bf16*)out1, (long)ldo}, M, N, K, cu, s); break;
         case 3: EGO_CHECK(aux, "egotap_bf16_gemm_nt: epi 3 needs the saved pre-activation");
                 // out1 (optional): fp32 [2 * ceil(M / 256)][N] partial column sums of the stored output, one row per 128-row wave block
-                if (out1) e = gemm_bf16s_launch(xl, wb, (long)K, SEpiGeluGradCS{{(const __bf16*)aux, (__bf16*)out0, (long)ldo}, (float*)out1}, M, N, K, cu, s);
-                else e = gemm_bf16s_launch(xl, wb, (long)K, SEpiGeluGrad{(const __bf16*)aux, (__bf16*)out0, (long)ldo}, M, N, K, cu, s);
+                if (out1) e = gemm_bf16s_plain_launch(xl, wb, (long)K, SEpiGeluGradCS{{(const __bf16*)aux, (__bf16*)out0, (long)ldo}, (float*)out1}, M, N, K, cu, s);
+                else e = gemm_bf16s_plain_launch(xl, wb, (long)K, SEpiGeluGrad{(const __bf16*)aux, (__bf16*)out0, (long)ldo}, M, N, K, cu, s);
                 break;
         case 4: EGO_CHECK(bias, "egotap_bf16_gemm_nt: epi 4 needs bias");
-                e = gemm_bf16s_launch(xl, wb, (long)K, SEpiF32{bias, (float*)out0, (long)ldo}, M, N, K, cu, s); break;
+                e = gemm_bf16s_plain_launch(xl, wb, (long)K, SEpiF32{bias, (float*)out0, (long)ldo}, M, N, K, cu, s); break;
         default: egotap_set_error("egotap_bf16_gemm_nt: unknown epilogue %d", epi); return EGOTAP_ERR_INVALID;
     }
     EGO_HIP(e);

@@ -1,0 +1,343 @@
+// [r4] bf16-STORAGE GEMM, 64-deep K-tiles:  OUT = epi( X[M,K] * W[N,K]^T ), X and W plain row-major bf16 -- the ViT's nn.Linear forward and
+// input-gradient products (modeling_vit.py:226-230, 271, 319-344), which are 95 % of the NT GEMM time of the bf16 training step.  Same
+// tile, wave layout, MFMA shape, accumulator layout, tile walk and epilogue functors as gemm_bf16s_kernel (gemm_bf16s.h); what changed
+// is the operand pipeline (profiles/r03_gemm_ablation.md, column 3: fetching 128-byte row segments instead of 64-byte ones is worth
+// +4-7 % on every shape; the round-3 verdict's item 1a):
+//
+//   * K-tile = 64 k.  An LDS row is the 128 contiguous bytes of one operand row: one global_load_lds_dwordx4 wave instruction moves
+//     8 rows x 128 B (BK = 32: 16 rows x 64 B), i.e. whole 128-byte lines.  The 16-byte chunk c of local row r sits at chunk position
+//     c ^ ((r >> 1) & 7): the 16 lanes a ds_read_b128 serves together (16 consecutive rows, one logical chunk) then touch 16 distinct
+//     16-byte bank groups of the 256-byte bank row.  The permutation is applied on the global side (which chunk a lane fetches); the
+//     DMA itself writes lane i at base + 16 i.
+//   * LDS holds TWO K-tiles of four 16 KB parts each (128 rows x 128 B):
+//        XA0 = rows a0 (the first 64 of each wave group's 128 rows), XA1 = rows a1, WB0 / WB1 = the first / second 32 of each wave's 64 columns.
+//     A K-tile is four PHASES of 16 MFMAs per wave, one output QUADRANT each, over the whole K = 64:
+//        phase 0: a0 x b0   (reads XA0: 8 fragments, WB0: 4)      phase 1: a0 x b1   (reads WB1: 4)
+//        phase 2: a1 x b1   (reads XA1: 8)                        phase 3: a1 x b0   (no reads: b0 stayed in registers)
+//     so every part is read in exactly ONE phase and its region is free again right after it -- with only two K-tiles of LDS a part is
+//     then requested five to six phases ahead of its first use (the BK = 32 ring's distance), not one to three:
+//        phase 4T+0 issues WB1(T+1)    4T+1: XA1(T+1)    4T+2: XA0(T+2)    4T+3: WB0(T+2)
+//     Write-after-read: the regions were last read in phases 4T-3, 4T-2, 4T, 4T -- at least two phases back, what two wave groups one
+//     barrier apart need (gemm_bf16s.h).  Read-after-write: every phase ends [own DMA; own fragment reads; vmcnt(8)] barrier: the four newest
+//     parts may stay in flight, the part read in the NEXT phase was issued five or six phases ago.
+//   * 64 fragment registers (XA: 8 x 4, WB0 / WB1: 4 x 4 each) + 128 accumulators; the X / W operand addresses are a wave-uniform 64-bit
+//     base (scalar unit) + one 32-bit lane offset per row block (global_load_lds ..., s[base] form): no per-lane pointer arithmetic.
+//   * Epilogue, store allowance after an exact epilogue, staggered start: as gemm_bf16s_kernel.
+#pragma once
+#include "gemm_bf16s.h"
+
+struct S64Cfg {
+    static constexpr int BM = 256, BN = 256, BK = 64, THREADS = 512;
+    static constexpr int ROWB = 128;                      // bytes per LDS row (64 bf16)
+    static constexpr int PART = 128 * ROWB;               // 16 KiB
+    static constexpr int KBUF = 4 * PART;                 // one K-tile: XA0 | WB0 | WB1 | XA1
+    static constexpr int O_XA0 = 0, O_WB0 = PART, O_WB1 = 2 * PART, O_XA1 = 3 * PART;
+    static constexpr int EPATCH = 16 * 64 * 4;            // per-wave epilogue patch: 16 rows x 64 fp32
+    static constexpr int LDS_BYTES = 2 * KBUF + (THREADS / 64) * EPATCH;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <class Epi>
+__global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const __bf16* __restrict__ Xb, long ldx, const __bf16* __restrict__ Wb, long ldw, Epi epi,
+                                                                           int M, int N, int K, int tiles_m, int tiles_n) {
+    using Cfg = S64Cfg;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, ROWB = Cfg::ROWB, PART = Cfg::PART, KBUF = Cfg::KBUF;
+    constexpr int VMC = 8;                           // vmcnt allowance: the four newest parts (two DMA instructions per wave each) may stay in flight
+    extern __shared__ __attribute__((aligned(16))) char smem_s64[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2, wc = wid & 3;
+    float* Es = (float*)(smem_s64 + 2 * KBUF + wid * Cfg::EPATCH);
+
+    // tiles of this workgroup: XCD-aware chunk of the grouped tile order (as gemm_bf16s_kernel)
+    const int ntiles = tiles_m * tiles_n, nb = gridDim.x, x8 = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int nbx = (nb >> 3) + (x8 < (nb & 7) ? 1 : 0);
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int lo_t = x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8;
+    const int cnt = q8 + (x8 < r8 ? 1 : 0);
+    const int my_n = cnt > jb ? (cnt - jb + nbx - 1) / nbx : 0;
+    const int KT = K / BK;
+    const int total = my_n * KT;                     // K-tiles of this workgroup's stream
+    if (total == 0) return;
+    auto tile_of = [&](int i, int& tm, int& tn) __attribute__((always_inline)) {
+        const int lin = lo_t + jb + i * nbx;
+        const int per_group = 8 * tiles_n;
+        const int g = lin / per_group, first = g * 8;
+        const int gsz = min(tiles_m - first, 8);
+        const int in = lin - g * per_group;
+        tm = first + in % gsz;
+        tn = in / gsz;
+    };
+
+    // ---- DMA duty of this wave per part: row blocks wid and wid + 8 of the part's 16 (8 rows x 128 B each).  Lane -> row lane >> 3 of
+    // the block, chunk position lane & 7, which holds logical chunk (lane & 7) ^ ((r >> 1) & 7), r = 8 blk + (lane >> 3) the local row:
+    // (r >> 1) & 7 = (4 blk + (lane >> 4)) & 7, the same for blk = wid and wid + 8.
+    const int drow = lane >> 3, dchunk = (lane & 7) ^ ((4 * wid + (lane >> 4)) & 7);
+    // X parts: local row r of XA_a -> tile row (r >> 6) * 128 + a * 64 + (r & 63): block wid is group 0's rows, block wid + 8 group 1's.
+    // W parts: local row r of WB_b -> tile column (r >> 5) * 64 + b * 32 + (r & 31): block wid -> wave column wid >> 2, block wid + 8 -> 2 + (wid >> 2).
+    // Lane offsets in bytes from the wave-uniform base of the part (rows past M re-read row M - 1: their results are never stored).
+    unsigned xo[2][2];                               // [a][g]
+    const unsigned wo = (unsigned)((8 * (wid & 3) + drow) * ldw * 2 + dchunk * 16);
+    struct Stream { int tile, kt; };                 // position of an issue stream: (tile index of this workgroup, K-tile inside it)
+    Stream s_xa[2] = {{0, 0}, {0, 0}}, s_wb[2] = {{0, 0}, {0, 0}};
+    unsigned long long xbase[2], wbase[2];           // wave-uniform bases of the streams' current tiles (bytes)
+    auto uniform64 = [](unsigned long long v) __attribute__((always_inline)) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    auto set_x = [&](int a, int i) __attribute__((always_inline)) {
+        int tm, tn;
+        tile_of(i, tm, tn);
+        const int r0 = tm * BM + a * 64 + 8 * wid + drow;      // group 0's row of this lane; group 1's is 128 further
+        xbase[a] = uniform64((unsigned long long)(size_t)Xb + (unsigned long long)tm * BM * ldx * 2);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) xo[a][g] = (unsigned)((long)(min(r0 + g * 128, M - 1) - tm * BM) * ldx * 2 + dchunk * 16);
+    };
+    auto set_w = [&](int b, int i) __attribute__((always_inline)) {
+        int tm, tn;
+        tile_of(i, tm, tn);
+        wbase[b] = uniform64((unsigned long long)(size_t)Wb + ((unsigned long long)(tn * BN + (wid >> 2) * 64 + b * 32) * ldw) * 2);
+    };
+    set_x(0, 0); set_x(1, 0);
+    set_w(0, 0); set_w(1, 0);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_s64;
+    // inline asm: the compiler's waitcnt pass would drain vmcnt(0) before every LDS read after __builtin_amdgcn_global_load_lds;
+    // the waits are counted by hand below (a constant number of DMA instructions per phase, unconditionally)
+    auto dma1 = [&](unsigned voff, unsigned long long sbase, unsigned lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+    };
+    auto advance = [&](Stream& st, int which, bool is_x) __attribute__((always_inline)) {
+        if (st.tile < my_n && ++st.kt == KT) {
+            st.kt = 0;
+            if (++st.tile < my_n) { if (is_x) set_x(which, st.tile); else set_w(which, st.tile); }
+            else st.kt = KT - 1;                     // stream exhausted: keep re-reading the last K-tile into a region nobody reads
+        }
+    };
+    auto issue_x = [&](int a, int buf) __attribute__((always_inline)) {        // XA_a of the stream's next K-tile -> K-tile buffer buf
+        const unsigned sa = lds0 + buf * KBUF + (a ? Cfg::O_XA1 : Cfg::O_XA0) + wid * 1024;
+        const unsigned long long kb = xbase[a] + (unsigned long long)s_xa[a].kt * (BK * 2);
+        dma1(xo[a][0], kb, sa);
+        dma1(xo[a][1], kb, sa + 8 * 1024);
+        advance(s_xa[a], a, true);
+    };
+    auto issue_w = [&](int b, int buf) __attribute__((always_inline)) {
+        const unsigned sa = lds0 + buf * KBUF + (b ? Cfg::O_WB1 : Cfg::O_WB0) + wid * 1024;
+        const unsigned long long kb = wbase[b] + (unsigned long long)s_wb[b].kt * (BK * 2);
+        dma1(wo, kb, sa);
+        dma1(wo, kb + (unsigned long long)128 * ldw * 2, sa + 8 * 1024);
+        advance(s_wb[b], b, false);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment byte offset of this lane inside a 16-row block: row lane & 15, logical chunk 4 s + (lane >> 4) of k-step s
+    const int l15 = lane & 15;
+    const int foff0 = l15 * ROWB + (((lane >> 4) ^ (l15 >> 1)) << 4);           // k-step 0; k-step 1 is the chunk position xor 4: offset xor 64
+    const int foff1 = foff0 ^ 64;
+    const int xa_base = (grp * 64) * ROWB;            // + i * 16 * ROWB: m-tile i of the half
+    const int wb_base = (wc * 32) * ROWB;             // + j * 16 * ROWB: n-tile j of the half
+
+    int c_tile = 0, c_kt = 0;
+    // vmcnt is ONE in-order counter for DMA, loads and stores: for the first four phases after an exact epilogue the parts a wait
+    // must retire were all issued before the epilogue's NST stores, so the allowance is 8 + NST and the stores stay in flight
+    // (derivation in gemm_bf16s.h); after a ragged tile the plain allowance makes the first wait drain them.
+    constexpr bool CS = s_epi_colsum<Epi>::value;
+    static_assert(!CS || Epi::W == 8, "column sums ride on the bf16-output epilogues");
+    constexpr int IT = Epi::W == 4 ? 4 : 2, NST = 8 * IT * Epi::STORES + (CS ? 2 : 0);
+    constexpr int SLK = s_epi_exact<Epi>::value ? VMC + NST : VMC;
+    static_assert(SLK <= 63, "vmcnt is a 6-bit counter");
+    int slack_ph = 0;
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        int tm, tn;
+        tile_of(c_tile, tm, tn);
+        const int m_wave = tm * BM + grp * 128, n_wave = tn * BN + wc * 64;
+        const int q = lane >> 4;
+        const int er = Epi::W == 4 ? q : (lane >> 3), ecol = Epi::W == 4 ? l15 * 4 : (lane & 7) * 8;
+        const int en = n_wave + ecol;
+        const typename Epi::Col cc = epi.col(en);
+        typename Epi::Aux ax[IT], an[IT];
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < IT; ++it) ax[it] = epi.fetch(min(m_wave + (16 / IT) * it + er, M - 1), en);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            if (mi + 1 < 8) {
+#pragma unroll
+                for (int it = 0; it < IT; ++it) an[it] = epi.fetch(min(m_wave + (mi + 1) * 16 + (16 / IT) * it + er, M - 1), en);
+            }
+            // accumulators -> patch[16 m][64 n] (fp32), 16-byte chunk ch of row r at position ch ^ r
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                *(f32x4*)(Es + l15 * 64 + (((4 * ni + q) ^ l15) << 2)) = acc[mi][ni];
+                acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const int m0 = m_wave + mi * 16;
+            if (mi == 0) s_keep(cc);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int r = (16 / IT) * it + er;
+                s_keep(ax[it]);
+                if constexpr (Epi::W == 4) {
+                    const f32x4 v = *(const f32x4*)(Es + r * 64 + ((l15 ^ r) << 2));
+                    float vv[4] = {v[0], v[1], v[2], v[3]};
+                    if (m0 + r < M) epi.emit(vv, cc, ax[it], m0 + r, en);
+                } else {
+                    const int c2 = lane & 7;
+                    const f32x4 v0 = *(const f32x4*)(Es + r * 64 + (((2 * c2) ^ r) << 2));
+                    const f32x4 v1 = *(const f32x4*)(Es + r * 64 + (((2 * c2 + 1) ^ r) << 2));
+                    float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (m0 + r < M) {
+                        epi.emit(vv, cc, ax[it], m0 + r, en);              // (leaves the values it stored in vv)
+                        if constexpr (CS) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) cs[i] += (float)(__bf16)vv[i];      // the sum of what was STORED (bf16)
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) ax[it] = an[it];
+        }
+        if constexpr (CS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                cs[i] += __shfl_xor(cs[i], 8, 64);
+                cs[i] += __shfl_xor(cs[i], 16, 64);
+                cs[i] += __shfl_xor(cs[i], 32, 64);
+            }
+            if (lane < 8) {
+                float* cp = epi.colpart + (long)(2 * tm + grp) * N + en;
+                *(f32x4*)cp = f32x4{cs[0], cs[1], cs[2], cs[3]};
+                *(f32x4*)(cp + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+            }
+        }
+        slack_ph = (s_epi_exact<Epi>::value && (tm + 1) * BM <= M && KT >= 2) ? 4 : 0;
+    };
+
+    if constexpr (s_epi_stagger<Epi>::value) {       // workgroups start a quarter tile apart (gemm_bf16s.h)
+        for (int i = 0; i < (int)((blockIdx.x >> 3) & 3); ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    // ---- prologue: K-tile 0 complete, then XA0 and WB0 of K-tile 1 -- what the steady-state schedule would have issued by now
+    issue_x(0, 0); issue_w(0, 0); issue_w(1, 0); issue_x(1, 0);
+    issue_x(0, 1); issue_w(0, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         // K-tile 0 has landed (the two parts of K-tile 1 may be in flight) ...
+    __builtin_amdgcn_s_barrier();                          // ... for every wave: phase 0 may read it
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
+
+    bf16x8 xf[4][2], wf0[2][2], wf1[2][2];
+    int buf = 0;
+#define S64_WAIT()                                                                              \
+    do {                                                                                        \
+        if (slack_ph > 0) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLK) : "memory"); --slack_ph; } \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMC) : "memory");                          \
+    } while (0)
+#define S64_PHASE_MFMA(A, WF, B)                                                                  \
+    do {                                                                                        \
+        __builtin_amdgcn_s_barrier();                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
+                _Pragma("unroll") for (int s = 0; s < 2; ++s)                                   \
+                    acc[4 * (A) + i][2 * (B) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j][s], xf[i][s], acc[4 * (A) + i][2 * (B) + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        __builtin_amdgcn_s_barrier();                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    } while (0)
+    for (int T = 0; T < total; ++T) {
+        const char* kb = smem_s64 + buf * KBUF;
+        // ---------------- phase 0: a0 x b0
+        issue_w(1, buf ^ 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wf0[j][0] = *(const bf16x8*)(kb + Cfg::O_WB0 + wb_base + j * 16 * ROWB + foff0);
+            wf0[j][1] = *(const bf16x8*)(kb + Cfg::O_WB0 + wb_base + j * 16 * ROWB + foff1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xf[i][0] = *(const bf16x8*)(kb + Cfg::O_XA0 + xa_base + i * 16 * ROWB + foff0);
+            xf[i][1] = *(const bf16x8*)(kb + Cfg::O_XA0 + xa_base + i * 16 * ROWB + foff1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        S64_WAIT();
+        S64_PHASE_MFMA(0, wf0, 0);
+        // ---------------- phase 1: a0 x b1
+        issue_x(1, buf ^ 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wf1[j][0] = *(const bf16x8*)(kb + Cfg::O_WB1 + wb_base + j * 16 * ROWB + foff0);
+            wf1[j][1] = *(const bf16x8*)(kb + Cfg::O_WB1 + wb_base + j * 16 * ROWB + foff1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        S64_WAIT();
+        S64_PHASE_MFMA(0, wf1, 1);
+        // ---------------- phase 2: a1 x b1
+        issue_x(0, buf);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xf[i][0] = *(const bf16x8*)(kb + Cfg::O_XA1 + xa_base + i * 16 * ROWB + foff0);
+            xf[i][1] = *(const bf16x8*)(kb + Cfg::O_XA1 + xa_base + i * 16 * ROWB + foff1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        S64_WAIT();
+        S64_PHASE_MFMA(1, wf1, 1);
+        // ---------------- phase 3: a1 x b0
+        issue_w(0, buf);
+        __builtin_amdgcn_sched_barrier(0);
+        S64_WAIT();
+        S64_PHASE_MFMA(1, wf0, 0);
+        buf ^= 1;
+        if (++c_kt == KT) {
+            // one extra barrier per tile and group lets the two groups' epilogues run side by side (gemm_bf16s.h)
+            if (grp == 0) __builtin_amdgcn_s_barrier();
+            epilogue();
+            if (grp == 1) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            c_kt = 0;
+            ++c_tile;
+        }
+    }
+#undef S64_WAIT
+#undef S64_PHASE_MFMA
+    if (grp == 0) __builtin_amdgcn_s_barrier();          // matches group 1's extra barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing (dummy) DMAs must not outlive the workgroup's LDS
+}
+
+// shapes this kernel takes; the caller falls back to gemm_bf16s_launch otherwise
+static inline bool gemm_bf16s64_ok(int M, int N, int K, long ldx, long ldw) {
+    return M > 0 && N % 256 == 0 && K % 64 == 0 && K >= 128 && ldx % 8 == 0 && ldw % 8 == 0 && (long)256 * (ldx > ldw ? ldx : ldw) * 2 < (1L << 31);
+}
+template <class Epi>
+static hipError_t gemm_bf16s64_launch(const __bf16* X, long ldx, const __bf16* Wb, long ldw, const Epi& epi, int M, int N, int K, int num_cu, hipStream_t stream) {
+    using Cfg = S64Cfg;
+    if (M <= 0) return hipSuccess;
+    if (!gemm_bf16s64_ok(M, N, K, ldx, ldw)) return hipErrorInvalidValue;
+    auto kern = gemm_bf16s64_kernel<Epi>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
+    const int ntiles = tiles_m * tiles_n;
+    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, X, ldx, Wb, ldw, epi, M, N, K, tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
+// Dispatch of a plain-operand NT product: the 64-deep kernel where its shape rules hold, the 32-deep one otherwise (ragged K, narrow
+// leading dimensions).  g_gemm_bf16s_bk (egotap_debug_gemm_bk, egotap_debug.h; defined once, in part 3 of the library) pins one of the two
+// for same-process A/B timing and for the bit-equality test: both kernels run the same MFMAs in the same k order per output element.
+extern int g_gemm_bf16s_bk;          // 0 = choose by shape (default), 32 / 64 = force
+template <class Epi>
+static hipError_t gemm_bf16s_plain_launch(const XPlain& xl, const __bf16* Wb, long ldw, const Epi& epi, int M, int N, int K, int num_cu, hipStream_t stream) {
+    if (g_gemm_bf16s_bk != 32 && gemm_bf16s64_ok(M, N, K, xl.lda, ldw)) return gemm_bf16s64_launch(xl.A, xl.lda, Wb, ldw, epi, M, N, K, num_cu, stream);
+    if (g_gemm_bf16s_bk == 64) return hipErrorInvalidValue;
+    return gemm_bf16s_launch(xl, Wb, ldw, epi, M, N, K, num_cu, stream);
+}

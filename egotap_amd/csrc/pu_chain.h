@@ -15,10 +15,11 @@
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-static __global__ void fill_u32_kernel(unsigned* p, long n, unsigned v, unsigned* zero_word = nullptr) {
+#define PU_FAULT_WORDS 16      // fault words of one pu_chain_launch: one per row-block chunk (the workspace reserves 64 bytes)
+static __global__ void fill_u32_kernel(unsigned* p, long n, unsigned v, unsigned* zero_words = nullptr) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
-    if (i == 0 && zero_word) *zero_word = 0u;
+    if (i < PU_FAULT_WORDS && zero_words) zero_words[i] = 0u;
 }
 
 // One recurrent step of a PU layer.  The gated state hp_t = sigmoid(F_t[:, 0:H]) * h_{t-1} is produced by the PREVIOUS step's pointwise
@@ -373,7 +374,7 @@ static inline int pu_chain_resident() {
     return per_cu * prop.multiProcessorCount;
 }
 
-// One PU layer over all J steps of B rows (p.HP: (J - 1) * hp_stride floats, armed here; p.fault zeroed here).
+// One PU layer over all J steps of B rows (p.HP: (J - 1) * hp_stride floats, armed here; p.fault: PU_FAULT_WORDS words, zeroed here, one per chunk).
 // resident1/resident2: pu_chain_resident<1/2>().  Returns false when the chain kernel cannot run here (the caller then walks the steps
 // with pu_step_launch).  Every chain launch is followed by its pu_solo_kernel, which does nothing unless the launch faulted.
 static inline bool pu_chain_launch(hipStream_t s, int resident1, int resident2, PuChain p, int B, int debug_drop = 0) {
@@ -389,6 +390,10 @@ static inline bool pu_chain_launch(hipStream_t s, int resident1, int resident2, 
     for (int rb0 = 0; rb0 < nrb; rb0 += chunk_rb) {
         const int nb = min(chunk_rb, nrb - rb0), row0 = rb0 * 16;
         PuChain q = p;
+        // [r4] a fault word per chunk: a chunk whose wait ran out is redone by ITS solo kernel only; the chunks behind it, whose own chain
+        // launches ran cleanly, no longer see a raised word and repeat their work at the ~16 x slower solo rate (B = 1024 is four chunks).
+        // fault_host stays the sticky summary of the whole call.
+        q.fault = p.fault + ((rb0 / chunk_rb) % PU_FAULT_WORDS);
         q.F = p.F + (long)row0 * p.ldf; q.G = p.G + (long)row0 * 4 * p.H; q.HS = p.HS + (long)row0 * p.H; q.HP = p.HP + (long)row0 * p.H;
         if (p.GP) q.GP = p.GP + (long)row0 * 4 * p.H;
         if (p.C) q.C = p.C + (long)row0 * p.H;

@@ -43,19 +43,43 @@ def _param_items(net):
     return [(k, p) for k, p in net.named_parameters()]
 
 
+def hm_arena_order(keys, n_stages=4):
+    """Order of an estimator's trained tensors in its flat gradient arena = the order in which the backward FINISHES them, cut into
+    buckets for the overlapped all-reduce (parallel.GradReducer): bucket 0 = the decoder (after_backbone.*: 2/3 of the
+    parameters, complete before the backbone's backward starts), bucket 1 = layer4, bucket 2 = layer3 .. layer1 and the stem.
+    Returns (keys in arena order, [bucket end index into that list])."""
+    dec = [k for k in keys if k.startswith(AB)]
+    l4 = [k for k in keys if k.startswith(f"{BB}layer{n_stages}.")]
+    rest = [k for k in keys if k.startswith(BB) and k not in set(l4)]
+    order = dec + l4 + rest
+    assert sorted(order) == sorted(keys), "every trained tensor belongs to exactly one bucket"
+    return order, [len(dec), len(dec) + len(l4), len(order)]
+
+
 def _grad_arena(net, P):
-    """views of the estimator's flat gradient arena, one per trainable tensor in named_parameters() order (allocated once per module and device)"""
+    """views of the estimator's flat gradient arena, one per trainable tensor (allocated once per module and device); `bounds` = the
+    bucket boundaries in floats"""
     dev = next(iter(P.values())).device
     ga = getattr(net, "_hm_grad_arena", None)
     sig = tuple((k, v.numel()) for k, v in P.items())
     if ga is None or ga["flat"].device != dev or ga["sig"] != sig:
+        order, ends = hm_arena_order(list(P.keys()))
         offs, o = {}, 0
-        for k, v in P.items():
+        for k in order:
             offs[k] = o
-            o += (v.numel() + 63) // 64 * 64                  # 256-byte aligned slices
-        ga = dict(flat=torch.empty(o, dtype=torch.float32, device=dev), offs=offs, sig=sig)
+            o += (P[k].numel() + 63) // 64 * 64                  # 256-byte aligned slices
+        bounds = [0] + [offs[order[e]] if e < len(order) else o for e in ends]
+        ga = dict(flat=torch.zeros(o, dtype=torch.float32, device=dev), offs=offs, sig=sig, bounds=bounds)   # (zeros: the alignment gaps ride along in the all-reduce)
         net._hm_grad_arena = ga
     return {k: ga["flat"][ga["offs"][k]: ga["offs"][k] + v.numel()].view(v.shape) for k, v in P.items()}
+
+
+def _reducer(net):
+    """the overlapped gradient reducer of this estimator's training Function (a no-op for one rank)"""
+    if getattr(net, "_grad_reducer", None) is None:
+        from .parallel import GradReducer
+        net._grad_reducer = GradReducer()
+    return net._grad_reducer
 
 
 class HmTrainFn(torch.autograd.Function):
@@ -155,6 +179,9 @@ class HmTrainFn(torch.autograd.Function):
         from .training import _held_grads, _publish_grads
         GA = _grad_arena(net, P)
         held = _held_grads(P, GA)
+        ga = net._hm_grad_arena
+        red = _reducer(net)                 # data parallel: the all-reduce of a bucket starts as soon as its kernels are enqueued
+        red.begin(ga["flat"])
         G = {}
         dout = dout.detach().float().contiguous()
 
@@ -216,12 +243,16 @@ class HmTrainFn(torch.autograd.Function):
             dl4 = torch.empty_like(L[3])
             bias_conv_bwd("layer4_1x1.0", dz, L[3], 1, dx=dl4)
             dL[3] = dl4
+            red.bucket_ready(ga["bounds"][0], ga["bounds"][1])          # the decoder's gradients are final
             # backbone, last block first.  dy = gradient of the current block's output (pyramid levels add their decoder share)
             blocks = sv["blocks"]
             dy = None
+            last_stage = f"{BB}layer{len(STAGES)}."
             for bi in range(len(blocks) - 1, -1, -1):
                 r = blocks[bi]
                 k, c, cin, stride = r["k"], r["c"], r["cin"], r["stride"]
+                if not k.startswith(last_stage) and blocks[bi + 1]["k"].startswith(last_stage):
+                    red.bucket_ready(ga["bounds"][1], ga["bounds"][2])  # layer4 is done
                 if r["level"] is not None:            # output of a stage = a pyramid level
                     share = dL[r["level"]].view(N2, c, r["y2"].shape[2], r["y2"].shape[3])
                     if dy is None:
@@ -253,6 +284,8 @@ class HmTrainFn(torch.autograd.Function):
             dz0 = torch.empty_like(sv["z0"])
             _bn_bwd(sv["z0"], sv["l0"], dl0, P, BB + "bn1", sv["m0"], dz0, grad_of, B)
             H.conv_wgrad(dz0, sv["x0"], grad_of(BB + "conv1.weight"), ks=7, stride=2)
+            red.bucket_ready(ga["bounds"][2], ga["bounds"][3])
+            red.finish()                    # the compute stream waits for the outstanding buckets; gradients arrive averaged
         ctx.sv = None
         _publish_grads({k: P[k] for k in G}, GA, held)
         return (None, None, None) + (None,) * len(keys)

@@ -142,11 +142,15 @@ class EgoTAPAutoEncoderModel(nn.Module):
             B = left.shape[0]
             cat = torch.empty((B, p.in_channels, p.hm_size, p.hm_size), dtype=torch.float32, device=left.device)
             bn_batch = self._estimator_bn_modes()
-            for net, c0, batch_stats in ((self.net_HeatMap, 0, bn_batch[0]), (self.net_RotHeatMap, 2 * J, bn_batch[1])):
+            # position net: channels [0, 2J) (left | right), limb net: [2J, 6J) (left cos, sin | right cos, sin)
+            for net, c0, cn, batch_stats in ((self.net_HeatMap, 0, 2 * J, bn_batch[0]), (self.net_RotHeatMap, 2 * J, 4 * J, bn_batch[1])):
                 if batch_stats:
+                    if getattr(net, "bottleneck", False):
+                        raise NotImplementedError(f"batch-statistics BatchNorm of a {net.model_name} estimator (the wrapper is in train mode: train.py:91) is not "
+                                                  "built; set opt.frozen_heatmap_bn_eval (--frozen_heatmap_bn_eval) or call model.eval()")
                     # batch statistics couple the frames of a batch: the whole batch goes through in one piece, per eye
                     from .hm_training import hm_train_forward_nograd
-                    cat[:, c0:c0 + 2 * J] = hm_train_forward_nograd(net, left, right)
+                    cat[:, c0:c0 + cn] = hm_train_forward_nograd(net, left, right)
                 else:
                     # eval-mode estimators treat frames independently: walk a large batch in chunks so that the U-Net scratch stays
                     # at the chunk's size (B = 1024 from RGB, BASELINE config 3); one scratch shared by both estimators
@@ -400,10 +404,8 @@ class HeatmapSharedModel(nn.Module):
         self.net_HeatMap.train()
         self.optimizer_HeatMap.zero_grad()
         self.forward()
-        self.backward_HeatMap()
-        from . import parallel
-        parallel.allreduce_gradients(list(self.net_HeatMap.parameters()))
-        self.optimizer_HeatMap.step()
+        self.backward_HeatMap()            # data parallel: the gradient all-reduce runs INSIDE the backward, bucket by bucket on the flat
+        self.optimizer_HeatMap.step()      # gradient arena (hm_training.HmTrainFn + parallel.GradReducer), as the lifting head's
 
     def evaluate(self, runnning_average_dict):
         from . import hm_ops as H

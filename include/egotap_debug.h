@@ -22,6 +22,11 @@ int egotap_debug_pu_drop_workgroups(egotap_handle h, int n);
  * 2+i = return after ViT layer i.  The state is then readable as intermediate "x". */
 int egotap_lift_debug_stop(egotap_handle h, int stage);
 
+/* ---- measurement / test switch (process wide, one definition in the library): which K-tile depth the bf16-storage NT GEMM with plain
+ * operands uses: 0 (default) = 64-deep kernel (csrc/gemm_bf16s64.h) where the shape allows, else the 32-deep one (csrc/gemm_bf16s.h);
+ * 32 / 64 = always that one (64 fails on shapes it does not take).  Both run the same MFMAs in the same k order: bit-identical results. */
+int egotap_debug_gemm_bk(int bk);
+
 /* ---- host-side planning, exposed for unit tests ---- */
 /* (test aid, host only: no device call) the number of partial slabs a weight-gradient launch splits its contraction into, and the slabs per split:
  * workgroups in a row on the busiest CU x slabs each + a fixed part per workgroup + the traffic of the slab reduction, within slab_bytes of

@@ -90,6 +90,47 @@ def test_gemm_nt_gelu_save_and_grad(M, N, K):
     _close_bf16(dz, ref, "dz", abs_=2e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (257, 512, 192), (1153, 1024, 1024), (2304, 1024, 4096), (5000, 3072, 1024), (70000, 1024, 256),
+                                   (66000, 4096, 1024)])
+def test_gemm_nt_64_deep_kernel_has_the_bits_of_the_32_deep_one(M, N, K):
+    """csrc/gemm_bf16s64.h (64-deep K-tiles, 128-byte DMA row segments, quadrant phases over two K-tiles of LDS) against csrc/gemm_bf16s.h
+    (32-deep ring): both run the same MFMAs in the same k order per output element, so EVERY epilogue's outputs must be bit-identical --
+    two K-tiles only (fewer than the pipeline's depth), ragged M (clamped rows), one tile, tiles < CUs, many tiles per workgroup (the
+    operand streams run on across tile boundaries, the store allowance after an exact epilogue), the column sums of the GELU-grad epilogue;
+    canary rows catch stores past M.  Run-to-run bits of the 64-deep kernel too (a DMA / fragment-read race shows as a flicker)."""
+    from egotap_amd import bf16s, lib
+    L = lib.load()
+    x, w, b = _rand((M, K), 41).bfloat16().cuda(), (_rand((N, K), 42, -2, 2) / math.sqrt(K)).bfloat16().cuda(), _rand((N,), 43).cuda()
+    r = _rand((M, N), 44, -3, 3).cuda()
+    zsave = (_rand((M, N), 45, -3, 3)).bfloat16().cuda()
+
+    def run_all():
+        o = {}
+        pad = torch.full((M + 2, N), 5.0, dtype=torch.bfloat16, device="cuda")
+        bf16s.gemm_nt(x, w, b, out=pad[:M])
+        o["bf16"], o["canary"] = pad[:M].clone(), pad[M:].clone()
+        o["res"] = bf16s.gemm_nt(x, w, b, epi="residual", aux=r, out=torch.empty_like(r))
+        o["z"], o["h"] = (t.clone() for t in bf16s.gemm_nt(x, w, b, epi="gelu_save"))
+        cs = torch.empty(N, device="cuda")
+        o["dz"] = bf16s.gemm_nt(x, w, None, epi="gelu_grad", aux=zsave, colsum_out=cs)
+        o["dz_colsum"] = cs
+        o["f32"] = bf16s.gemm_nt(x, w, b, epi="f32")
+        torch.cuda.synchronize()
+        return o
+    try:
+        lib.check(L.egotap_debug_gemm_bk(32))
+        old = run_all()
+        lib.check(L.egotap_debug_gemm_bk(64))
+        new = run_all()
+        again = run_all()
+    finally:
+        lib.check(L.egotap_debug_gemm_bk(0))
+    assert float((new["canary"].float() - 5.0).abs().max()) == 0.0
+    for k in old:
+        assert torch.equal(old[k], new[k]), (k, float((old[k].float() - new[k].float()).abs().max()))
+        assert torch.equal(new[k], again[k]), k
+
+
 def test_gemm_nt_f32_out():
     from egotap_amd import bf16s
     M, N, K = 930, 2048, 1024

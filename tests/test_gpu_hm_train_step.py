@@ -298,7 +298,7 @@ def test_wrappers_with_model_name_resnet34(tmp_path):
     assert mm.net_HeatMap.blocks == (3, 4, 6, 3) and mm.net_RotHeatMap.blocks == (3, 4, 6, 3)
     mm.net_HeatMap.load_state_dict(m.net_HeatMap.state_dict())
     mm.set_input({"input_rgb_left": data["input_rgb_left"], "input_rgb_right": data["input_rgb_right"]})
-    mm.set_eval_mode()
+    mm.eval()                                   # test.py: utils/evaluate.py:93
     poses = {}
     for mode in ("f32", "bf16"):
         mm.set_precision(mode)
@@ -347,7 +347,10 @@ def test_wrappers_with_model_name_resnet50(tmp_path):
     mm = models.create_model(opt2)
     mm.net_HeatMap.load_state_dict(m.net_HeatMap.state_dict())
     mm.set_input(data)
-    mm.set_eval_mode()
+    mm.train()
+    with pytest.raises(NotImplementedError, match="frozen_heatmap_bn_eval"):      # batch-statistics BatchNorm of a Bottleneck estimator is not built
+        mm.forward()
+    mm.eval()                                                                      # test.py's flow (utils/evaluate.py:93)
     mm.set_precision("bf16")
     assert getattr(mm.net_HeatMap, "precision", "f32") == "f32" and mm.net_AutoEncoder.precision == "bf16"
     with torch.no_grad():

@@ -36,6 +36,7 @@ def test_wrapper_evaluate_matches_oracle_chain():
             "input_rgb_right": torch.from_numpy(synth_input("w_rgb_r", (B, 3, 256, 256), -2.0, 2.0)),
             "gt_local_pose": torch.from_numpy(synth_input("w_gt", (B, 16, 3), -1.0, 1.0))}
     m.set_input(data)
+    m.eval()                                 # test.py -> utils/evaluate.py:93 (set_eval_mode() alone leaves net_RotHeatMap in its mode, as the reference's)
     avg = _Avg()
     pose, hm_cat, avg = m.evaluate(avg)
     torch.cuda.synchronize()
@@ -44,7 +45,8 @@ def test_wrapper_evaluate_matches_oracle_chain():
         rot = H.hm_forward(data["input_rgb_left"], data["input_rgb_right"], H.to_torch_sd(sds["RotHeatMap"]))
         cat = torch.cat([pos, rot], dim=1)
         ref = O.lift_forward(cat, O.to_torch_sd(sds["AutoEncoder"]), p)
-        aligned = O.procrustes_align(ref, data["gt_local_pose"])
+        # a batch of TWO frames: the reference's Procrustes step takes its no-transpose branch (utils/util.py:337), reproduced by default
+        aligned = O.procrustes_align_batch_axes(ref.double(), data["gt_local_pose"].double()).float()
     assert tuple(hm_cat.shape) == (B, 90, 64, 64)
     np.testing.assert_allclose(hm_cat.cpu().numpy(), cat.numpy(), atol=2e-4, rtol=1e-4)
     np.testing.assert_allclose(pose.cpu().numpy(), ref.numpy(), atol=1e-4, rtol=0)

@@ -264,7 +264,7 @@ def test_pose_metrics_reference_batch_axes_for_batches_of_two_and_three(B, J):
     _close(pa2, torch.linalg.norm(b.double() - O.procrustes_align(a.double(), b.double()), dim=-1).mean(-1), atol=1e-4)
     a4, b4 = torch.cat([a, a])[:4], torch.cat([b, b])[:4]                  # the same frames inside a batch of 4
     _, pa4 = lib.pose_metrics(a4.cuda(), b4.cuda(), reference_batch_axes=True)
-    _close(pa4[:B], pa2, atol=1e-6)
+    _close(pa4[:B], pa2.double().cpu(), atol=1e-6)
 
 
 def test_pose_metrics_reflection_and_identity():

@@ -104,7 +104,7 @@ def _reducer_worker(rank, world, port, out_dir):
     n = red.finish()
     assert n == 3 and red.last_buckets == 3 and red.last_bytes == 4 * 10_000 and red.steps == 1 and red.pending == []
     assert red.read_exposed_ms() == 0.0                         # CPU tensors: nothing to time
-    # the same gradients through the generic bucketed reducer (what the stage-1 wrapper uses)
+    # the same gradients through the generic packing reducer (parallel.allreduce_gradients: a utility; both wrappers use GradReducer)
     prm = torch.nn.Parameter(torch.zeros(10_000))
     prm.grad = base * (rank + 1)
     P.allreduce_gradients([prm], bucket_bytes=8_000)
@@ -134,3 +134,56 @@ def test_grad_reducer_is_a_noop_without_a_group():
     red.begin(arena)
     red.bucket_ready(0, 8)
     assert red.finish() == 0 and red.pending == [] and torch.equal(arena, torch.ones(8))
+
+
+def _stage1_worker(rank, world, port, out_dir):
+    """the stage-1 estimator's gradient arena exactly as hm_training.HmTrainFn.backward drives it: arena layout and bucket bounds from
+    the real module's parameter list (hm_training._grad_arena), bucket_ready in backward-completion order, finish()"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from egotap_amd import hm_training as HT, networks
+    from egotap_amd.options import preset_defaults
+    opt = preset_defaults("UnrealEgo")
+    opt.num_rot_heatmap = 0
+    net = networks.HeatMap_UnrealEgo_Shared(opt, "resnet18", 2)            # parameters only: no kernel runs on the CPU
+    Pm = dict(HT._param_items(net))
+    G = HT._grad_arena(net, Pm)
+    ga = net._hm_grad_arena
+    g = torch.Generator().manual_seed(5)
+    for k in Pm:                                                           # this rank's gradients: base * (rank + 1)
+        G[k].copy_(torch.rand(G[k].shape, generator=g) * (rank + 1))
+    red = HT._reducer(net)
+    red.begin(ga["flat"])
+    b = ga["bounds"]
+    for lo, hi in zip(b, b[1:]):
+        red.bucket_ready(lo, hi)
+    n = red.finish()
+    sums = {k: float(G[k].double().sum()) for k in Pm}
+    torch.save(dict(n=n, bounds=b, bytes=red.last_bytes, sums=sums, total=ga["flat"].numel(),
+                    first=list(Pm.keys())[0], order_head=[k for k, _ in sorted(ga["offs"].items(), key=lambda kv: kv[1])][:3]), os.path.join(out_dir, f"s{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_stage1_estimator_arena_buckets_two_ranks(tmp_path):
+    """the stage-1 wrapper averages its gradients with the in-backward arena reducer too (round 4; it packed with torch.cat before): the
+    estimator's arena is laid out in backward-completion order -- decoder, layer4, the rest of the backbone -- and its three buckets
+    leave every rank with the MEAN of the per-rank gradients, in place"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_stage1_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"s{r}.pt") for r in range(2))
+    assert r0["n"] == 3 and r0["bounds"][0] == 0 and r0["bounds"][-1] == r0["total"] and r0["bytes"] == 4 * r0["total"]
+    assert sorted(r0["bounds"]) == r0["bounds"] and len(set(r0["bounds"])) == 4
+    assert all(k.startswith("after_backbone.") for k in r0["order_head"])              # the decoder's gradients come first in the arena
+    assert r0["bounds"][1] > 0.6 * r0["total"]                                         # ... and are two thirds of it
+    from egotap_amd import hm_training as HT, networks
+    from egotap_amd.options import preset_defaults
+    opt = preset_defaults("UnrealEgo")
+    opt.num_rot_heatmap = 0
+    net = networks.HeatMap_UnrealEgo_Shared(opt, "resnet18", 2)
+    g = torch.Generator().manual_seed(5)
+    for k, prm in HT._param_items(net):
+        want = float((torch.rand(prm.shape, generator=g) * 1.5).double().sum())        # mean of base and 2 * base
+        for r in (r0, r1):
+            np.testing.assert_allclose(r["sums"][k], want, rtol=1e-5, err_msg=k)
