@@ -250,7 +250,8 @@ struct PackSeg {
     const float *w, *b;              // [Cout][Cin][taps] weights, bias (1x1 with bias) or null
     unsigned dst_w, dst_b;           // byte offsets into the region: packed bf16 weights, padded fp32 bias
     unsigned short Cout, Cin, Cp, Np;
-    int taps, first_block;
+    short taps, slab;                // slab: input channels per K slab of a 3x3 weight: 32 (gemm_bf16s.h's XConv3 / XConvE) or 64 (gemm_bf16s64.h's X64Conv3)
+    int first_block;
 };
 struct BnSeg {
     const float *g, *b, *m, *v;
@@ -282,7 +283,7 @@ static __global__ __launch_bounds__(256) void pack_all_bf16s_kernel(PackTable T,
             const int c8 = (int)(i % c8n), co = (int)(i / c8n);
             float v[72];
             const bool row = co < sg.Cout;
-            if (row && c8 * 8 + 8 <= sg.Cin) {
+            if (row && c8 * 8 + 8 <= sg.Cin && ((size_t)sg.w & 15) == 0) {                       // (a parameter bound from a 4-byte-aligned view takes the scalar branch)
                 const f32x4* src = (const f32x4*)(sg.w + ((long)co * sg.Cin + c8 * 8) * 9);      // 288-byte pieces: 16-byte aligned
 #pragma unroll
                 for (int q = 0; q < 18; ++q) {
@@ -301,7 +302,9 @@ static __global__ __launch_bounds__(256) void pack_all_bf16s_kernel(PackTable T,
                 bf16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j * 9 + tap];
-                *(bf16x8*)(wb + (long)co * 9 * sg.Cp + ((long)(c8 >> 2) * 9 + tap) * 32 + (c8 & 3) * 8) = o;
+                // k = (ci / slab, tap, ci % slab)
+                if (sg.slab == 64) *(bf16x8*)(wb + (long)co * 9 * sg.Cp + ((long)(c8 >> 3) * 9 + tap) * 64 + (c8 & 7) * 8) = o;
+                else *(bf16x8*)(wb + (long)co * 9 * sg.Cp + ((long)(c8 >> 2) * 9 + tap) * 32 + (c8 & 3) * 8) = o;
             }
         } else {
             const int c8n = sg.Cin / 8;

@@ -1081,15 +1081,19 @@ struct HmWs {
 // the bf16 forward uses them; p == nullptr: sizes only.  Returns the bytes of the region; fills T (segment table of pack_all_bf16s_kernel).
 // conv_heatmap's GEMM N: 30 / 34 / 60 / 68 heatmap channels padded to the 64- or 128-column tile (256 before: 4-8 x the MFMAs)
 static inline int hm_head_np(int n_out) { return n_out <= 64 ? 64 : n_out <= 128 ? 128 : 256; }
+static constexpr int HM_CAT3P = 1600;      // channels per pixel of the first decoder concat in the bf16 mode: 1024 + 516 = 1540, padded to a multiple of 64
 static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T) {
     size_t o = 0;
     int nw = 0, nb = 0, blk = 0;
     auto al = [&](size_t n) { size_t r = o; o = (o + n + 255) & ~(size_t)255; return r; };
-    auto wseg = [&](const float* w, const float* b, int Cout, int Cin, int Cp, int Np, int taps) {
+    bool in_range = true;            // the table narrows offsets to 32 bits and channel counts to 16: checked here, once
+    auto wseg = [&](const float* w, const float* b, int Cout, int Cin, int Cp, int Np, int taps, int slab = 32) {
         PackSeg sg{};
-        sg.w = w; sg.b = b; sg.Cout = Cout; sg.Cin = Cin; sg.Cp = Cp; sg.Np = Np; sg.taps = taps;
-        sg.dst_w = al((size_t)Np * taps * Cp * 2);
-        sg.dst_b = al((size_t)Np * 4);
+        sg.w = w; sg.b = b; sg.Cout = Cout; sg.Cin = Cin; sg.Cp = Cp; sg.Np = Np; sg.taps = (short)taps; sg.slab = (short)slab;
+        const size_t ow = al((size_t)Np * taps * Cp * 2), ob = al((size_t)Np * 4);
+        in_range = in_range && o < ((size_t)1 << 32) && Cout < 65536 && Cin < 65536 && Cp < 65536 && Np < 65536 && Cp % slab == 0;
+        sg.dst_w = (unsigned)ow;
+        sg.dst_b = (unsigned)ob;
         sg.first_block = blk;
         const long items = taps == 9 ? (long)Np * (Cp / 8) : (long)Np * (Cin / 8);       // 3x3: one thread per (co, 8 input channels), all taps
         blk += (int)((items + 255) / 256);
@@ -1115,11 +1119,13 @@ static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T) {
     auto cv = [&](int which, int k) -> HmParams::Cv { return p ? (which == 0 ? p->l1x1[k] : which == 1 ? p->up[k] : p->head) : HmParams::Cv{nullptr, nullptr}; };
     wseg(cv(0, 3).w, cv(0, 3).b, 1024, 1024, 1024, 1024, 1);
     wseg(cv(0, 2).w, cv(0, 2).b, 516, 512, 512, 768, 1);
-    wseg(cv(1, 2).w, nullptr, 1024, 1540, 1568, 1024, 9);
+    // the three 3x3 decoder convolutions run on the 64-deep GEMM (gemm_bf16s64.h, X64Conv3): concat widths padded to a multiple of 64
+    // (1540 -> HM_CAT3P = 1600), weights packed in 64-channel slabs
+    wseg(cv(1, 2).w, nullptr, 1024, 1540, HM_CAT3P, 1024, 9, 64);
     wseg(cv(0, 1).w, cv(0, 1).b, 256, 256, 256, 256, 1);
-    wseg(cv(1, 1).w, nullptr, 512, 1280, 1280, 512, 9);
+    wseg(cv(1, 1).w, nullptr, 512, 1280, 1280, 512, 9, 64);
     wseg(cv(0, 0).w, cv(0, 0).b, 128, 128, 128, 256, 1);
-    wseg(cv(1, 0).w, nullptr, 512, 640, 640, 512, 9);
+    wseg(cv(1, 0).w, nullptr, 512, 640, 640, 512, 9, 64);
     wseg(cv(2, 0).w, cv(2, 0).b, p ? p->n_out : 30, 512, 512, p ? hm_head_np(p->n_out) : 256, 1);      // (sizes-only: the largest padding)
     const int blocks_w = blk;
     for (int k = 0; k < nb && k < PackTable::MAXB; ++k) {
@@ -1133,7 +1139,7 @@ static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T) {
         if (T) T->bn[k] = bs;
     }
     if (T) { T->nw = nw; T->nb = nb; T->blocks_w = blocks_w; T->blocks = blk; }
-    return (nw <= PackTable::MAXW && nb <= PackTable::MAXB) ? o : 0;
+    return (nw <= PackTable::MAXW && nb <= PackTable::MAXB && in_range && o < ((size_t)1 << 32)) ? o : 0;
 }
 static HmWs hm_ws(const Handle* h, int B) {
     HmWs w;
@@ -1267,9 +1273,10 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
         auto conv3 = [&](const char* role, const __bf16* in, long M, int side, const HmParams::Cv& cv, int Cin, int Cp, int Cout, __bf16* o) {
             const PackSeg& sg = PT.w[li++];
             if (sg.w != cv.w || sg.Cp != Cp || sg.Np != Cout) return hipErrorInvalidValue;
-            GemmTimer t(h, s, role, "gemm_bf16s_kernel<XConv3>", 2.0 * M * Cout * 9.0 * Cin);
-            const XConv3 xl{in, ZP, Cp, ilog2(side)};
-            return gemm_bf16s_launch(xl, (const __bf16*)(reg + sg.dst_w), 9L * Cp, SEpiConvBf16<false>{cv.b, o, (long)Cout, Cout, 1}, (int)M, Cout, 9 * Cp, cus, s);
+            if (sg.slab != 64 || Cp % 64 != 0 || Cout % 256 != 0) return hipErrorInvalidValue;
+            GemmTimer t(h, s, role, "gemm_bf16s64_kernel<X64Conv3>", 2.0 * M * Cout * 9.0 * Cin);
+            const X64Conv3 xl{in, ZP, Cp, ilog2(side)};
+            return gemm_bf16s64_launch_x(xl, (const __bf16*)(reg + sg.dst_w), 9L * Cp, SEpiConvBf16<false>{cv.b, o, (long)Cout, Cout, 1}, (int)M, Cout, 9 * Cp, cus, s);
         };
         // E2: max-pool of the stem's bf16 [B * (2 s64)^2, 2 x 64] -> [B * s64^2, 2 x 64]; E3: the four stages on the same GEMM kernel (eye-interleaved rows, see conv_bf16s.h)
         __bf16* P0 = Hb(w.P0);
@@ -1330,11 +1337,11 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
                 cin = c;
             }
         }
-        EGO_HIP(zero_fill(C3, (size_t)B * p16 * 1568 * 2, s));                    // channels 1544..1567 of the first concat are padding
+        EGO_HIP(zero_fill(C3, (size_t)B * p16 * HM_CAT3P * 2, s));                // channels 1544..1599 of the first concat are padding
         EGO_HIP(conv1("hm.layer4_1x1", A4, B * p8, p.l1x1[3], 1024, 1024, T4, 1024));
-        EGO_HIP(up2(T4, C3, 1024, s8, 1568));
-        EGO_HIP(conv1("hm.layer3_1x1", A3, B * p16, p.l1x1[2], 512, 516, C3 + 1024, 1568));
-        EGO_HIP(conv3("hm.conv_up3", C3, B * p16, s16, p.up[2], 1540, 1568, 1024, Y3));
+        EGO_HIP(up2(T4, C3, 1024, s8, HM_CAT3P));
+        EGO_HIP(conv1("hm.layer3_1x1", A3, B * p16, p.l1x1[2], 512, 516, C3 + 1024, HM_CAT3P));
+        EGO_HIP(conv3("hm.conv_up3", C3, B * p16, s16, p.up[2], 1540, HM_CAT3P, 1024, Y3));
         EGO_HIP(up2(Y3, C2, 1024, s16, 1280));
         EGO_HIP(conv1("hm.layer2_1x1", A2, B * p32, p.l1x1[1], 256, 256, C2 + 1024, 1280));
         EGO_HIP(conv3("hm.conv_up2", C2, B * p32, s32, p.up[1], 1280, 1280, 512, Y2));

@@ -124,7 +124,13 @@ __device__ __forceinline__ void store_bf16x8(__bf16* p, const float* v) {
     for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
     // [r3] streaming store: a bf16 activation is 0.3-2.4 GB, written once and read by the NEXT kernel -- keeping its lines out of
     // the L2 leaves the operand panels this kernel re-reads there (+2-3 % on every bf16-output GEMM, profiles/r03_gemm_ablation.md)
+#if defined(EGOTAP_ABL) && (EGOTAP_ABL & 4)      // timing-only: the functor's arithmetic without the store
+    asm volatile("" ::"v"(o));
+#elif defined(EGOTAP_ABL) && (EGOTAP_ABL & 8)    // A/B: write-back instead of streaming stores
+    *(bf16x8*)p = o;
+#else
     __builtin_nontemporal_store(o, (bf16x8*)p);
+#endif
 }
 struct SBias8 { f32x4 b0, b1; };
 __device__ __forceinline__ void s_keep(const SBias8& b) { asm volatile("" ::"v"(b.b0), "v"(b.b1)); }

@@ -24,6 +24,8 @@
 //     base (scalar unit) + one 32-bit lane offset per row block (global_load_lds ..., s[base] form): no per-lane pointer arithmetic.
 //   * Epilogue, store allowance after an exact epilogue, staggered start: as gemm_bf16s_kernel.
 #pragma once
+#include <type_traits>
+
 #include "gemm_bf16s.h"
 
 struct S64Cfg {
@@ -37,8 +39,60 @@ struct S64Cfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <class Epi>
-__global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const __bf16* __restrict__ Xb, long ldx, const __bf16* __restrict__ Wb, long ldw, Epi epi,
+// ---------------------------------------------------------------------------------------------------- X-operand loaders
+// SBASE loaders: row m of the operand is A + m * lda (plain row-major): the DMA address is a wave-uniform base + a 32-bit lane offset.
+// Pointer loaders: row(m) -> per-lane state, ptr(row, kt, chunk) -> address of the 8 k of 16-byte chunk `chunk` (0..7) of the row's
+// 64-deep K-tile kt (kt wave-uniform: the index arithmetic on it stays on the scalar unit).
+struct X64Plain {
+    static constexpr bool SBASE = true;
+    const __bf16* A;
+    long lda;
+};
+// 3x3 convolution (pad 1, stride 1) on a channels-last bf16 map [Nimg * S * S, Cp], Cp a multiple of 64 (conv_bf16s.h's XConv3 for this
+// kernel): k = (ci / 64, tap, ci % 64), so a 64-deep K-tile is ONE tap of one 64-channel slab and row m of it is the 128 contiguous
+// bytes of input pixel (y + dy, x + dx), channels 64 s .. 64 s + 63 -- whole lines again; a page of zeros where the tap leaves the image.
+struct X64Conv3 {
+    static constexpr bool SBASE = false;
+    const __bf16* in;
+    const __bf16* zero;      // >= 128 bytes of zeros
+    int Cp, log2S;
+    struct Row { const __bf16* p; unsigned mask; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int S = 1 << log2S, x = m & (S - 1), y = (m >> log2S) & (S - 1);
+        unsigned mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            if (y + dy >= 0 && y + dy < S && x + dx >= 0 && x + dx < S) mask |= 1u << t;
+        }
+        return Row{in + (long)m * Cp, mask};
+    }
+    __device__ __forceinline__ const __bf16* ptr(const Row& r, int kt, int chunk) const {
+        const int slab = (kt * 7282) >> 16, tap = kt - 9 * slab;                     // kt / 9 exactly for kt < 7000
+        const int dy = ((tap * 11) >> 5) - 1, dx = tap - 3 * (dy + 1) - 1;
+        const int off = ((dy << log2S) + dx) * Cp + 64 * slab;
+        return ((r.mask >> tap) & 1u) ? r.p + off + chunk * 8 : zero + chunk * 8;
+    }
+};
+
+// Epilogues whose per-column constants are just the bias (Col = SBias8 or f32x4 read from `bias`): the kernel stages the wave's 64 bias
+// values in its (idle) epilogue patch by one 4-byte LDS DMA per tile, issued in the tile's first phase and counted like every other DMA.
+// The epilogue then starts with two LDS reads instead of a global load whose wait -- vmcnt is in order -- drained every DMA in flight
+// and exposed a full memory round trip per tile.
+template <class E, class C = typename E::Col> struct s64_lds_bias { static constexpr bool value = false; };
+template <class E> struct s64_lds_bias<E, SBias8> { static constexpr bool value = true; };
+template <class E> struct s64_lds_bias<E, f32x4> { static constexpr bool value = true; };
+template <class E> __device__ __forceinline__ const float* s64_bias_ptr(const E& e, std::true_type) { return e.bias; }
+template <class E> __device__ __forceinline__ const float* s64_bias_ptr(const E&, std::false_type) { return nullptr; }
+template <class C> struct s64_col_lds;
+template <> struct s64_col_lds<SBias8> { static __device__ __forceinline__ SBias8 get(const float* p) { return SBias8{*(const f32x4*)p, *(const f32x4*)(p + 4)}; } };
+template <> struct s64_col_lds<f32x4> { static __device__ __forceinline__ f32x4 get(const float* p) { return *(const f32x4*)p; } };
+
+template <class XL, bool SB = XL::SBASE> struct S64RowState { };                                   // SBASE loaders keep no per-lane row state
+template <class XL> struct S64RowState<XL, false> { typename XL::Row r[2][2]; };                    // [a][g]
+
+template <class XL, class Epi>
+__global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl, const __bf16* __restrict__ Wb, long ldw, Epi epi,
                                                                            int M, int N, int K, int tiles_m, int tiles_n) {
     using Cfg = S64Cfg;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, ROWB = Cfg::ROWB, PART = Cfg::PART, KBUF = Cfg::KBUF;
@@ -75,7 +129,8 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
     // X parts: local row r of XA_a -> tile row (r >> 6) * 128 + a * 64 + (r & 63): block wid is group 0's rows, block wid + 8 group 1's.
     // W parts: local row r of WB_b -> tile column (r >> 5) * 64 + b * 32 + (r & 31): block wid -> wave column wid >> 2, block wid + 8 -> 2 + (wid >> 2).
     // Lane offsets in bytes from the wave-uniform base of the part (rows past M re-read row M - 1: their results are never stored).
-    unsigned xo[2][2];                               // [a][g]
+    unsigned xo[2][2];                               // [a][g]  (SBASE loaders: lane offsets)
+    S64RowState<XL> xrow;                            //         (pointer loaders: per-lane row state)
     const unsigned wo = (unsigned)((8 * (wid & 3) + drow) * ldw * 2 + dchunk * 16);
     struct Stream { int tile, kt; };                 // position of an issue stream: (tile index of this workgroup, K-tile inside it)
     Stream s_xa[2] = {{0, 0}, {0, 0}}, s_wb[2] = {{0, 0}, {0, 0}};
@@ -88,9 +143,14 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
         int tm, tn;
         tile_of(i, tm, tn);
         const int r0 = tm * BM + a * 64 + 8 * wid + drow;      // group 0's row of this lane; group 1's is 128 further
-        xbase[a] = uniform64((unsigned long long)(size_t)Xb + (unsigned long long)tm * BM * ldx * 2);
+        if constexpr (XL::SBASE) {
+            xbase[a] = uniform64((unsigned long long)(size_t)xl.A + (unsigned long long)tm * BM * xl.lda * 2);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) xo[a][g] = (unsigned)((long)(min(r0 + g * 128, M - 1) - tm * BM) * ldx * 2 + dchunk * 16);
+            for (int g = 0; g < 2; ++g) xo[a][g] = (unsigned)((long)(min(r0 + g * 128, M - 1) - tm * BM) * xl.lda * 2 + dchunk * 16);
+        } else {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) xrow.r[a][g] = xl.row(min(r0 + g * 128, M - 1));
+        }
     };
     auto set_w = [&](int b, int i) __attribute__((always_inline)) {
         int tm, tn;
@@ -106,17 +166,25 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
         asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
     auto advance = [&](Stream& st, int which, bool is_x) __attribute__((always_inline)) {
-        if (st.tile < my_n && ++st.kt == KT) {
+        if (__builtin_expect(st.tile < my_n && ++st.kt == KT, 0)) {          // (rare: the common path falls through without a taken branch)
             st.kt = 0;
             if (++st.tile < my_n) { if (is_x) set_x(which, st.tile); else set_w(which, st.tile); }
             else st.kt = KT - 1;                     // stream exhausted: keep re-reading the last K-tile into a region nobody reads
         }
     };
+    auto dma1v = [&](const __bf16* g, unsigned lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+    };
     auto issue_x = [&](int a, int buf) __attribute__((always_inline)) {        // XA_a of the stream's next K-tile -> K-tile buffer buf
         const unsigned sa = lds0 + buf * KBUF + (a ? Cfg::O_XA1 : Cfg::O_XA0) + wid * 1024;
-        const unsigned long long kb = xbase[a] + (unsigned long long)s_xa[a].kt * (BK * 2);
-        dma1(xo[a][0], kb, sa);
-        dma1(xo[a][1], kb, sa + 8 * 1024);
+        if constexpr (XL::SBASE) {
+            const unsigned long long kb = xbase[a] + (unsigned long long)s_xa[a].kt * (BK * 2);
+            dma1(xo[a][0], kb, sa);
+            dma1(xo[a][1], kb, sa + 8 * 1024);
+        } else {
+            dma1v(xl.ptr(xrow.r[a][0], s_xa[a].kt, dchunk), sa);
+            dma1v(xl.ptr(xrow.r[a][1], s_xa[a].kt, dchunk), sa + 8 * 1024);
+        }
         advance(s_xa[a], a, true);
     };
     auto issue_w = [&](int b, int buf) __attribute__((always_inline)) {
@@ -140,7 +208,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
     const int xa_base = (grp * 64) * ROWB;            // + i * 16 * ROWB: m-tile i of the half
     const int wb_base = (wc * 32) * ROWB;             // + j * 16 * ROWB: n-tile j of the half
 
-    int c_tile = 0, c_kt = 0;
+    int c_tile = 0;
     // vmcnt is ONE in-order counter for DMA, loads and stores: for the first four phases after an exact epilogue the parts a wait
     // must retire were all issued before the epilogue's NST stores, so the allowance is 8 + NST and the stores stay in flight
     // (derivation in gemm_bf16s.h); after a ragged tile the plain allowance makes the first wait drain them.
@@ -148,8 +216,28 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
     static_assert(!CS || Epi::W == 8, "column sums ride on the bf16-output epilogues");
     constexpr int IT = Epi::W == 4 ? 4 : 2, NST = 8 * IT * Epi::STORES + (CS ? 2 : 0);
     constexpr int SLK = s_epi_exact<Epi>::value ? VMC + NST : VMC;
-    static_assert(SLK <= 63, "vmcnt is a 6-bit counter");
-    int slack_ph = 0;
+    static_assert(SLK + 1 <= 63, "vmcnt is a 6-bit counter");
+    bool slack_on = false;           // the next tile's first K-tile leaves the stores of the epilogue before it in flight
+    constexpr bool LB = s64_lds_bias<Epi>::value;
+    const float* bias_g = s64_bias_ptr(epi, std::integral_constant<bool, LB>{});
+    const bool has_bias = LB && bias_g != nullptr;    // the same for every wave of the launch: the DMA count per phase stays uniform
+    const unsigned patch_lds = lds0 + 2 * KBUF + wid * Cfg::EPATCH;
+    auto issue_bias = [&]() __attribute__((always_inline)) {      // the 64 bias values of this wave's columns of tile c_tile -> the head of its patch
+        int tm, tn;
+        tile_of(c_tile, tm, tn);
+        // (no bias: the DMA still runs, from any valid 256 bytes -- the count per phase is a compile-time constant -- and is never read)
+        const unsigned long long b = has_bias ? uniform64((unsigned long long)(size_t)bias_g + (unsigned long long)(tn * BN + wc * 64) * 4)
+                                              : uniform64((unsigned long long)(size_t)Wb);
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" ::"v"((unsigned)(lane * 4)), "s"(b), "s"(__builtin_amdgcn_readfirstlane(patch_lds)) : "memory");
+    };
+    // per-column constants of this lane: staged in the patch during the tile's first K-tile (LDS operations of a wave stay in order: the
+    // epilogue's patch writes cannot overtake these reads), or from global memory for the epilogues with other constants / no bias
+    auto epi_cols = [&](int en, int ecol) __attribute__((always_inline)) -> typename Epi::Col {
+        if constexpr (LB) {
+            if (has_bias) return s64_col_lds<typename Epi::Col>::get(Es + ecol);
+        }
+        return epi.col(en);
+    };
     auto epilogue = [&]() __attribute__((always_inline)) {
         int tm, tn;
         tile_of(c_tile, tm, tn);
@@ -157,7 +245,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
         const int q = lane >> 4;
         const int er = Epi::W == 4 ? q : (lane >> 3), ecol = Epi::W == 4 ? l15 * 4 : (lane & 7) * 8;
         const int en = n_wave + ecol;
-        const typename Epi::Col cc = epi.col(en);
+        typename Epi::Col cc = epi_cols(en, ecol);
         typename Epi::Aux ax[IT], an[IT];
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -183,13 +271,22 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
                 if constexpr (Epi::W == 4) {
                     const f32x4 v = *(const f32x4*)(Es + r * 64 + ((l15 ^ r) << 2));
                     float vv[4] = {v[0], v[1], v[2], v[3]};
+#if defined(EGOTAP_ABL) && (EGOTAP_ABL & 2)      // timing-only: the epilogue without its functor and global stores
+                    asm volatile("" ::"v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]));
+#else
                     if (m0 + r < M) epi.emit(vv, cc, ax[it], m0 + r, en);
+#endif
                 } else {
                     const int c2 = lane & 7;
                     const f32x4 v0 = *(const f32x4*)(Es + r * 64 + (((2 * c2) ^ r) << 2));
                     const f32x4 v1 = *(const f32x4*)(Es + r * 64 + (((2 * c2 + 1) ^ r) << 2));
                     float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#if defined(EGOTAP_ABL) && (EGOTAP_ABL & 2)
+                    asm volatile("" ::"v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]), "v"(vv[4]), "v"(vv[5]), "v"(vv[6]), "v"(vv[7]));
+                    if (false) {
+#else
                     if (m0 + r < M) {
+#endif
                         epi.emit(vv, cc, ax[it], m0 + r, en);              // (leaves the values it stored in vv)
                         if constexpr (CS) {
 #pragma unroll
@@ -214,7 +311,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
                 *(f32x4*)(cp + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
             }
         }
-        slack_ph = (s_epi_exact<Epi>::value && (tm + 1) * BM <= M && KT >= 2) ? 4 : 0;
+        slack_on = s_epi_exact<Epi>::value && (tm + 1) * BM <= M;       // (K >= 128: two K-tiles at least, so the allowance ends before the next epilogue)
     };
 
     if constexpr (s_epi_stagger<Epi>::value) {       // workgroups start a quarter tile apart (gemm_bf16s.h)
@@ -230,11 +327,6 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
 
     bf16x8 xf[4][2], wf0[2][2], wf1[2][2];
     int buf = 0;
-#define S64_WAIT()                                                                              \
-    do {                                                                                        \
-        if (slack_ph > 0) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLK) : "memory"); --slack_ph; } \
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMC) : "memory");                          \
-    } while (0)
 #define S64_PHASE_MFMA(A, WF, B)                                                                  \
     do {                                                                                        \
         __builtin_amdgcn_s_barrier();                                                           \
@@ -249,10 +341,17 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
         __builtin_amdgcn_s_barrier();                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     } while (0)
-    for (int T = 0; T < total; ++T) {
+    // One K-tile = four phases.  The vmcnt allowance WC of its four waits is a compile-time constant of the COPY of this body that runs:
+    // the steady-state copy (WC = 8, no branch anywhere between a phase's fragment reads and its barrier: per-phase wait selection by
+    // branches cost 0.1-0.25 us per K-tile, measured) and two copies for a tile's FIRST K-tile, whose waits also let the bias DMA
+    // (one more among the four newest phases) and, after an exact epilogue, that epilogue's stores stay in flight.
+    auto ktile = [&](auto waitc, auto first) __attribute__((always_inline)) {
+        constexpr int WC = decltype(waitc)::value;
+        constexpr bool FIRST = decltype(first)::value;
         const char* kb = smem_s64 + buf * KBUF;
         // ---------------- phase 0: a0 x b0
         issue_w(1, buf ^ 1);
+        if constexpr (FIRST && LB) issue_bias();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             wf0[j][0] = *(const bf16x8*)(kb + Cfg::O_WB0 + wb_base + j * 16 * ROWB + foff0);
@@ -264,7 +363,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
             xf[i][1] = *(const bf16x8*)(kb + Cfg::O_XA0 + xa_base + i * 16 * ROWB + foff1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        S64_WAIT();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WC) : "memory");
         S64_PHASE_MFMA(0, wf0, 0);
         // ---------------- phase 1: a0 x b1
         issue_x(1, buf ^ 1);
@@ -274,7 +373,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
             wf1[j][1] = *(const bf16x8*)(kb + Cfg::O_WB1 + wb_base + j * 16 * ROWB + foff1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        S64_WAIT();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WC) : "memory");
         S64_PHASE_MFMA(0, wf1, 1);
         // ---------------- phase 2: a1 x b1
         issue_x(0, buf);
@@ -284,25 +383,30 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
             xf[i][1] = *(const bf16x8*)(kb + Cfg::O_XA1 + xa_base + i * 16 * ROWB + foff1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        S64_WAIT();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WC) : "memory");
         S64_PHASE_MFMA(1, wf1, 1);
         // ---------------- phase 3: a1 x b0
         issue_w(0, buf);
         __builtin_amdgcn_sched_barrier(0);
-        S64_WAIT();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WC) : "memory");
         S64_PHASE_MFMA(1, wf0, 0);
         buf ^= 1;
-        if (++c_kt == KT) {
-            // one extra barrier per tile and group lets the two groups' epilogues run side by side (gemm_bf16s.h)
-            if (grp == 0) __builtin_amdgcn_s_barrier();
-            epilogue();
-            if (grp == 1) __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            c_kt = 0;
-            ++c_tile;
-        }
+    };
+    constexpr int XB = LB ? 1 : 0;                      // the bias DMA of a tile's first K-tile (issued whether or not there is a bias: a constant count)
+    for (c_tile = 0; c_tile < my_n; ++c_tile) {
+        if (slack_on) ktile(std::integral_constant<int, SLK + XB>{}, std::true_type{});
+        else ktile(std::integral_constant<int, VMC + XB>{}, std::true_type{});
+#if defined(EGOTAP_ABL) && (EGOTAP_ABL & 1)      // timing-only: the store allowance never ends (waits may pass before their data has landed: wrong results)
+        for (int kt = 1; kt < KT; ++kt) ktile(std::integral_constant<int, SLK>{}, std::false_type{});
+#else
+        for (int kt = 1; kt < KT; ++kt) ktile(std::integral_constant<int, VMC>{}, std::false_type{});
+#endif
+        // one extra barrier per tile and group lets the two groups' epilogues run side by side (gemm_bf16s.h)
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+        epilogue();
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
-#undef S64_WAIT
 #undef S64_PHASE_MFMA
     if (grp == 0) __builtin_amdgcn_s_barrier();          // matches group 1's extra barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing (dummy) DMAs must not outlive the workgroup's LDS
@@ -312,12 +416,12 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(const 
 static inline bool gemm_bf16s64_ok(int M, int N, int K, long ldx, long ldw) {
     return M > 0 && N % 256 == 0 && K % 64 == 0 && K >= 128 && ldx % 8 == 0 && ldw % 8 == 0 && (long)256 * (ldx > ldw ? ldx : ldw) * 2 < (1L << 31);
 }
-template <class Epi>
-static hipError_t gemm_bf16s64_launch(const __bf16* X, long ldx, const __bf16* Wb, long ldw, const Epi& epi, int M, int N, int K, int num_cu, hipStream_t stream) {
+template <class XL, class Epi>
+static hipError_t gemm_bf16s64_launch_x(const XL& xl, const __bf16* Wb, long ldw, const Epi& epi, int M, int N, int K, int num_cu, hipStream_t stream) {
     using Cfg = S64Cfg;
     if (M <= 0) return hipSuccess;
-    if (!gemm_bf16s64_ok(M, N, K, ldx, ldw)) return hipErrorInvalidValue;
-    auto kern = gemm_bf16s64_kernel<Epi>;
+    if (N % 256 != 0 || K % 64 != 0 || K < 128 || ldw % 8 != 0 || (long)256 * ldw * 2 >= (1L << 31)) return hipErrorInvalidValue;
+    auto kern = gemm_bf16s64_kernel<XL, Epi>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
@@ -327,8 +431,14 @@ static hipError_t gemm_bf16s64_launch(const __bf16* X, long ldx, const __bf16* W
     const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < num_cu ? ntiles : num_cu;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, X, ldx, Wb, ldw, epi, M, N, K, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xl, Wb, ldw, epi, M, N, K, tiles_m, tiles_n);
     return hipGetLastError();
+}
+template <class Epi>
+static hipError_t gemm_bf16s64_launch(const __bf16* X, long ldx, const __bf16* Wb, long ldw, const Epi& epi, int M, int N, int K, int num_cu, hipStream_t stream) {
+    if (M <= 0) return hipSuccess;
+    if (!gemm_bf16s64_ok(M, N, K, ldx, ldw)) return hipErrorInvalidValue;
+    return gemm_bf16s64_launch_x(X64Plain{X, ldx}, Wb, ldw, epi, M, N, K, num_cu, stream);
 }
 
 // Dispatch of a plain-operand NT product: the 64-deep kernel where its shape rules hold, the 32-deep one otherwise (ragged K, narrow

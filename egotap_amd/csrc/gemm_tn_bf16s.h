@@ -16,6 +16,8 @@
 //     partial fp32 slab, reduce_slabs_kernel adds the slabs in a fixed order (bitwise reproducible, no float atomics).  Rows past M
 //     are fetched from a caller-supplied page of zeros.
 #pragma once
+#include <type_traits>
+
 #include "gemm_bf16s.h"
 #include "gemm_tn_bf16.h"
 
@@ -55,7 +57,10 @@ struct TXRot {               // rows gathered as XRot (fc1 of the rotation encod
     }
 };
 
-template <class XL>
+// FAST (plain X operand, M a multiple of 32: every 32-row step of every split is whole): the DMA addresses are a wave-uniform 64-bit base
+// (scalar unit) + one 32-bit lane offset per row block, no per-lane pointer arithmetic, no zero-page selects (round 4: the issue path of
+// the general form costs 8 v_mul_lo, 4 v_mad_u64 and 4 exec-mask regions per phase; the NT kernel's counterpart change was worth 5-7 %).
+template <class XL, bool FAST = false>
 __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const __bf16* __restrict__ dY, long ldy, XL xl, const __bf16* __restrict__ zeros,
                                                                             float* __restrict__ slabs, int M, int N, int K, int tiles_n, int splits,
                                                                             int rows_per, int* __restrict__ sync) {
@@ -120,8 +125,32 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
         asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
     int ly = 0, lx = 0;            // next step of the dY / X issue streams; past the end they keep re-reading the zero page
+    // FAST: lane offsets (bytes) from the step's wave-uniform base; past the end the streams re-read the split's last step (valid memory,
+    // landing in a stage nobody reads)
+    unsigned oy0 = 0, oy1 = 0, ox0 = 0, ox1 = 0;
+    unsigned long long ybase = 0, xbase = 0;
+    auto uniform64 = [](unsigned long long v) __attribute__((always_inline)) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    auto dma_s = [&](unsigned voff, unsigned long long sbase, unsigned lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+    };
+    if constexpr (FAST) {
+        oy0 = (unsigned)(((long)r0 * ldy + c0 * 8) * 2); oy1 = (unsigned)(((long)r1 * ldy + c1 * 8) * 2);
+        ox0 = (unsigned)(((long)r0 * xl.lda + c0 * 8) * 2); ox1 = (unsigned)(((long)r1 * xl.lda + c1 * 8) * 2);
+        ybase = uniform64((unsigned long long)(size_t)dY + ((unsigned long long)m_lo * ldy + n0) * 2);
+        xbase = uniform64((unsigned long long)(size_t)xl.A + ((unsigned long long)m_lo * xl.lda + k0) * 2);
+    }
     auto issue_y = [&](int st) __attribute__((always_inline)) {
         const unsigned sa = lds0 + st * STAGE + wid * 1024;
+        if constexpr (FAST) {
+            const unsigned long long b = ybase + (unsigned long long)min(ly, total - 1) * (BKM * 2) * ldy;
+            dma_s(oy0, b, sa);
+            dma_s(oy1, b, sa + 8 * 1024);
+            ++ly;
+            return;
+        }
         const int mb = m_lo + ly * BKM;
         const bool in = ly < total;
         const int ma = mb + r0, mc = mb + r1;
@@ -131,6 +160,13 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
     };
     auto issue_x = [&](int st) __attribute__((always_inline)) {
         const unsigned sa = lds0 + st * STAGE + PART + wid * 1024;
+        if constexpr (FAST) {
+            const unsigned long long b = xbase + (unsigned long long)min(lx, total - 1) * (BKM * 2) * xl.lda;
+            dma_s(ox0, b, sa);
+            dma_s(ox1, b, sa + 8 * 1024);
+            ++lx;
+            return;
+        }
         const int mb = m_lo + lx * BKM;
         const bool in = lx < total;
         const int ma = mb + r0, mc = mb + r1;
@@ -266,12 +302,20 @@ static hipError_t gemm_tn_bf16s_launch(const __bf16* dY, long ldy, const XL& xl,
     const bool direct = splits == 1 && !accumulate;              // a single slab that is not added to anything IS the gradient
     if (!direct && (size_t)splits * N * K * 4 > slab_bytes) return hipErrorOutOfMemory;
     const int rows_per = ((M + splits - 1) / splits + Cfg::BKM - 1) / Cfg::BKM * Cfg::BKM;
+    // plain operand and whole 32-row steps everywhere: the scalar-base form of the DMA addresses
+    bool fast = false;
+#if !(defined(EGOTAP_ABL) && (EGOTAP_ABL & 16))      // A/B: the general addressing everywhere
+    if constexpr (std::is_same<XL, TXPlain>::value) fast = M % Cfg::BKM == 0 && (long)32 * (ldy > xl.lda ? ldy : xl.lda) * 2 < (1L << 31) && xl.lda % 8 == 0;
+#endif
     auto kern = gemm_tn_bf16s_kernel<XL>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    if constexpr (std::is_same<XL, TXPlain>::value) {
+        if (fast) kern = gemm_tn_bf16s_kernel<XL, true>;
+    }
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[fast]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[fast] = true;
     }
     // check-in counters of the L2-sharing groups (8 XCD chunks x splits) behind the slabs, cleared per launch
     int* sync = nullptr;

@@ -200,11 +200,14 @@ class EgoTAPAutoEncoderModel(nn.Module):
         if self.use_amp:           # --use_amp: reduced-precision training arithmetic (opt.amp_precision, default "bf16"); the reference's
             # autocast spans the frozen estimators' forward too (egotap_autoencoder_model.py:219).  The requested mode is set
             # explicitly: whatever a caller (or evaluate()) left on the networks, the step runs in opt.amp_precision.
+            # The mode is opt.amp_precision -- unless the caller chose a reduced mode for the whole model explicitly with
+            # model.set_precision("bf16x3" | "bf16"): that choice wins over the flag's default and is kept from step to step.
+            want = getattr(self, "_explicit_precision", None) or self.amp_precision
             for n in (self.net_AutoEncoder, self.net_HeatMap, self.net_RotHeatMap):
                 if getattr(n, "bottleneck", False):
                     continue                                     # resnet50 / resnet101 estimators run in fp32 only (frozen here anyway)
-                if getattr(n, "precision", "f32") != self.amp_precision:
-                    n.set_precision(self.amp_precision)
+                if getattr(n, "precision", "f32") != want:
+                    n.set_precision(want)
         for o in self.optimizers:
             o.zero_grad()
         self.forward()
@@ -215,7 +218,11 @@ class EgoTAPAutoEncoderModel(nn.Module):
             o.step()
 
     def set_precision(self, mode: str = "f32"):
-        """f32 (default) | bf16x3 | bf16 for the three networks (the reference's analogous switch is --use_amp)"""
+        """f32 (default) | bf16x3 | bf16 for the three networks (the reference's analogous switch is --use_amp).
+        Under --use_amp the training step runs in opt.amp_precision; an explicit set_precision("bf16x3" | "bf16") on the model overrides
+        that default for every following step, set_precision("f32") hands the choice back to the flag (a training step under --use_amp
+        is never fp32: the reference's is not either)."""
+        self._explicit_precision = mode if mode != "f32" else None
         for n in (self.net_HeatMap, self.net_RotHeatMap, self.net_AutoEncoder):
             if getattr(n, "bottleneck", False) and mode != "f32":
                 continue                                         # resnet50 / resnet101 estimators: fp32 only

@@ -189,7 +189,7 @@ def test_bottleneck_backbones_spec_and_module():
 
 def test_resnet34_backbone_spec_module_and_handle():
     """--model_name resnet34 (net_architecture.py:59-60, 104-105: torchvision resnet34, feature_scale 1): BasicBlocks (3, 4, 6, 3) per
-    stage under torchvision's key names, the same decoder; the Bottleneck ResNets (resnet50 / 101) are refused, not approximated."""
+    stage under torchvision's key names, the same decoder (the Bottleneck ResNets resnet50 / 101: test_bottleneck_backbones_spec_and_module -- fp32 evaluation only)."""
     import torch
     from egotap_amd import networks, spec
     from egotap_amd.options import preset_defaults
