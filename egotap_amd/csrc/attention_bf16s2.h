@@ -379,7 +379,9 @@ __global__ __launch_bounds__(64 * NW, 3) void attention_bf16s3_kernel(const __bf
             }
         }
     };
+    const int ntiles = N / 32;
     issue(0, 0);
+    if (ntiles > 1) issue(1, KVBUF);
     Frags<1> qf;
     attns::load_row_frags(qf, qkv + (long)(q0 + l31) * ld3, lh);
     const LaneAddr la = lane_addr(lane);
@@ -389,12 +391,19 @@ __global__ __launch_bounds__(64 * NW, 3) void attention_bf16s3_kernel(const __bf
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    const int ntiles = N / 32;
-    auto step = [&](int kt, unsigned boff) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // [r4] THREE K | V buffers: two 32-key tiles in flight.  With two buffers a tile was requested one step ahead, and a step of this
+    // workgroup (its waves share their SIMDs with two other workgroups' waves) is shorter than a loaded L2 round trip: every step ended
+    // in a DMA wait.  Step t: [own pieces of tile t landed: counted vmcnt, tile t + 1 may stay in flight] barrier [issue tile t + 2 into
+    // the buffer tile t - 1 was read from: every wave is past that step] compute tile t.  Every wave issues the same number of pieces
+    // (NW = 4: two K and two V pieces per tile), so the count is a constant.
+    constexpr int DPT = 2 * PPW;                               // DMA instructions per wave and tile
+    static_assert(NW == 4 || NW == 2, "every wave must issue the same number of pieces per tile (8 % NW == 0)");
+    auto step = [&](int kt, unsigned boff, unsigned bnext2) __attribute__((always_inline)) {
+        if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < ntiles) issue(kt + 1, boff ^ KVBUF);
+        if (kt + 2 < ntiles) issue(kt + 2, bnext2);
         if (!valid) return;
         f32x16 s = rows_x_frags(sm3 + boff, la, qf);
         float mx = s[0];
@@ -421,9 +430,10 @@ __global__ __launch_bounds__(64 * NW, 3) void attention_bf16s3_kernel(const __bf
         l_run += psum;
         imgT_x_p(o, sm3 + boff + TILEB, la, s);
     };
-    for (int kt = 0; kt < ntiles; kt += 2) {
-        step(kt, 0);
-        if (kt + 1 < ntiles) step(kt + 1, KVBUF);
+    for (int kt = 0; kt < ntiles; kt += 3) {                 // buffer of tile t: t mod 3
+        step(kt, 0, 2 * KVBUF);
+        if (kt + 1 < ntiles) step(kt + 1, KVBUF, 0);
+        if (kt + 2 < ntiles) step(kt + 2, 2 * KVBUF, KVBUF);
     }
     __syncthreads();
     if (valid) {
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attention_bf16s3_kernel(const __bf
 template <int NW>
 static hipError_t attention_bf16s3_fwd_launch_t(const __bf16* QKV, __bf16* CTX, float* LSE, int B, int N, int heads, hipStream_t stream) {
     using namespace att2;
-    constexpr size_t img = 2 * 2 * (size_t)TILEB, patch = (size_t)NW * 32 * 68 * 4;
+    constexpr size_t img = 3 * 2 * (size_t)TILEB, patch = (size_t)NW * 32 * 68 * 4;           // three K | V buffers
     constexpr size_t lds = img > patch ? img : patch;
     static_assert(NW == 2 || (12 / NW) * lds <= 160 * 1024, "twelve waves (three per SIMD) per CU (two-wave workgroups: five per CU, ten waves)");
     auto kern = attention_bf16s3_kernel<NW>;

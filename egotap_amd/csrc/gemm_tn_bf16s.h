@@ -16,6 +16,7 @@
 //     partial fp32 slab, reduce_slabs_kernel adds the slabs in a fixed order (bitwise reproducible, no float atomics).  Rows past M
 //     are fetched from a caller-supplied page of zeros.
 #pragma once
+#include <algorithm>
 #include <type_traits>
 
 #include "gemm_bf16s.h"
@@ -294,10 +295,19 @@ static hipError_t gemm_tn_bf16s_launch(const __bf16* dY, long ldy, const XL& xl,
     if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || ldy % 8 != 0 || M <= 0) return hipErrorInvalidValue;
     const int tiles_n = N / Cfg::BN, tiles_k = K / Cfg::BK;
     const int tiles = tiles_n * tiles_k;
-    int splits = (num_cu + tiles - 1) / tiles;                   // one 512-thread workgroup per CU (128 KB of LDS each)
+    // one 512-thread workgroup per CU (128 KB of LDS each): the launch runs ceil(tiles * splits / CUs) rounds of M / splits rows each --
+    // take the split count with the least rounds x rows (the smallest on ties: fewer slabs to reduce).  [r4: ceil(CUs / tiles) gave a
+    // 12 x 4 tile grid 6 splits = 288 workgroups, two rounds for 1.1 rounds of work; 5 splits = 240 workgroups run 40 % faster]
     const int max_by_rows = (M + 8 * Cfg::BKM - 1) / (8 * Cfg::BKM);
-    if (splits > max_by_rows) splits = max_by_rows;
-    if (splits < 1) splits = 1;
+    int splits = 1;
+    {
+        const int s_hi = std::min(max_by_rows, std::max(1, 2 * ((num_cu + tiles - 1) / tiles)));
+        double best = 1e30;
+        for (int sp = 1; sp <= s_hi; ++sp) {
+            const double cost = (double)(((long)tiles * sp + num_cu - 1) / num_cu) / sp;
+            if (cost < best * (1.0 - 1e-9)) { best = cost; splits = sp; }
+        }
+    }
     while ((size_t)splits * N * K * 4 > slab_bytes && splits > 1) --splits;
     const bool direct = splits == 1 && !accumulate;              // a single slab that is not added to anything IS the gradient
     if (!direct && (size_t)splits * N * K * 4 > slab_bytes) return hipErrorOutOfMemory;
