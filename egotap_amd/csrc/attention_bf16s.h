@@ -66,6 +66,16 @@ __device__ __forceinline__ void load_row_frags(Frags<1>& fr, const __bf16* rowp,
     for (int s = 0; s < 8; ++s) fr.f[0][s] = *(const bf16x8*)(rowp + 16 * s + 8 * lh);
 }
 
+// [r4] "Use" every fragment of a row right after its loads, OUTSIDE the tile loop.  The tile loops below prefetch with LDS DMAs issued from
+// inline asm and wait for them with hand-counted s_waitcnt: invisible to hipcc's waitcnt pass, which therefore still counted these plain
+// loads as possibly pending at the loop header and put s_waitcnt vmcnt(7) ... vmcnt(0) in front of the first MFMAs of EVERY step (the
+// first uses of the fragment registers).  vmcnt is one in-order counter: those waits drained the DMAs of the next tile, issued a few
+// instructions earlier -- the double buffering overlapped nothing (all three kernels: MFMA busy 0.37-0.44 in profiles/r04_config3_summary.md).
+__device__ __forceinline__ void settle_frags(const Frags<1>& fr) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" ::"v"(fr.f[0][s]));
+}
+
 // a wave's [4][32 d x 32 lane-rows] accumulators (times mul) as 32 rows of 128 bf16 (row stride ld) through an fp32 LDS patch.
 // [r3] colpart (optional): 128 floats that receive the column sums of the 32 STORED (bf16) rows -- the per-block share of the
 // q / k / v bias gradient, so that no kernel has to read the gradient tensor again just to sum its columns.

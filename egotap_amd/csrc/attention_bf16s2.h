@@ -163,6 +163,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_bf16s2_kernel(const _
 
     const int ntiles = N / 32;
     issue(0, 0);
+    attns::settle_frags(kf);                                    // (the waits for these loads belong here, not inside the tile loop: attention_bf16s.h)
     auto step = [&](int qt, unsigned boff) __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile qt (issued a whole tile ago) have landed ...
         __builtin_amdgcn_s_barrier();                           // ... and so have everyone's; everyone is done with the other buffer
@@ -279,6 +280,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_bf16s2_kernel(const __
     const float lse = LSE[(long)bh * N + q0 + l31];
     if (valid && lh == 0) DELTA[(long)bh * N + q0 + l31] = delta;
     const float c2 = scale * 1.4426950408889634f, lse2 = lse * 1.4426950408889634f;
+    attns::settle_frags(qf);
+    attns::settle_frags(dof);
+    asm volatile("" ::"v"(lse2), "v"(delta));
     const LaneAddr la = lane_addr(lane);
     f32x16 dq[4];
 #pragma unroll
@@ -384,6 +388,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attention_bf16s3_kernel(const __bf
     if (ntiles > 1) issue(1, KVBUF);
     Frags<1> qf;
     attns::load_row_frags(qf, qkv + (long)(q0 + l31) * ld3, lh);
+    attns::settle_frags(qf);
     const LaneAddr la = lane_addr(lane);
     f32x16 o[4];
 #pragma unroll
