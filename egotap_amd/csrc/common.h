@@ -68,6 +68,16 @@ struct SegVec {
     const float* p[3];
     int seg;  // floats per segment
     __device__ __forceinline__ float at(int n) const { return p[n / seg][n % seg]; }
+    // four consecutive values n0 .. n0 + 3 (n0 and seg multiples of 4: they lie in one segment).  The segment pointer is SELECTED, not
+    // indexed (a lane-dependent index into the kernel-argument struct is a gather from memory and a dependent wait), and the four values
+    // come as one 16-byte load where the pointer allows it -- [r4] the epilogues that built them from four at() calls kept 16 loads, the
+    // pointer loads in front of them and their waits in the half-block loop of gemm_f32_dma.h.
+    __device__ __forceinline__ f32x4 at4(int n0) const {
+        const int k = n0 >= 2 * seg ? 2 : (n0 >= seg ? 1 : 0);
+        const float* q = (k == 2 ? p[2] : (k == 1 ? p[1] : p[0])) + (n0 - k * seg);
+        if (((size_t)q & 15) == 0) return *(const f32x4*)q;
+        return f32x4{q[0], q[1], q[2], q[3]};
+    }
 };
 
 // [N,K] row-major weight (nn.Linear layout) split the same way along N.

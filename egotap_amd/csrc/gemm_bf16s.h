@@ -25,6 +25,8 @@
 //     functor on 4 (fp32 out) or 8 (bf16 out) consecutive n -> full-row-segment global stores.  No barrier inside, so the
 //     other group's MFMAs run under it.
 #pragma once
+#include <type_traits>
+
 #include "gemm_bf16.h"
 
 typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
@@ -452,7 +454,11 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
     constexpr int SLK = s_epi_exact<Epi>::value ? VMC + NST : VMC;      // vmcnt allowance of the first K-tiles after an (exact) epilogue
     static_assert(SLK <= 63, "vmcnt is a 6-bit counter");
     int slack_kt = 0;
-    auto epilogue = [&]() __attribute__((always_inline)) {
+    // [r4] FULL (every row of the tile exists): unconditional stores, so that hipcc counts them exactly and its waits for the aux rows of
+    // the next 16-row block leave this block's stores in flight (gemm_bf16s64.h has the derivation: under `if (m < M)` every block waited
+    // for the previous block's stores to complete)
+    auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
         int tm, tn;
         tile_of(c_tile, tm, tn);
         const int m_wave = tm * BM + grp * 128, n_wave = tn * BN + wc * 16 * NI;
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
                     const f32x4 v = *(const f32x4*)(Es + r * 64 + ((l15 ^ r) << 2));
                     float vv[4] = {v[0], v[1], v[2], v[3]};
 #if !(defined(EGOTAP_ABL) && (EGOTAP_ABL & 2))      // timing-only: the epilogue without its global stores / functor
-                    if (m0 + r < M && cact) epi.emit(vv, cc, ax[it], m0 + r, en);
+                    if ((FULL || m0 + r < M) && cact) epi.emit(vv, cc, ax[it], m0 + r, en);
 #else
                     asm volatile("" ::"v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]));
 #endif
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
                     const f32x4 v1 = *(const f32x4*)(Es + r * 64 + (((2 * c2 + 1) ^ r) << 2));
                     float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #if !(defined(EGOTAP_ABL) && (EGOTAP_ABL & 2))
-                    if (m0 + r < M && cact) {
+                    if ((FULL || m0 + r < M) && cact) {
                         epi.emit(vv, cc, ax[it], m0 + r, en);              // (leaves the values it stored in vv)
                         if constexpr (CS) {
 #pragma unroll
@@ -603,7 +609,14 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
             // last MFMA phase (256 cycles idle), then both store their tiles concurrently; without it each group sits at a barrier
             // through most of the other's epilogue (they are latency-bound: LDS round trips, residual loads, store issue).
             if (grp == 0) __builtin_amdgcn_s_barrier();
-            epilogue();
+            {
+                int tm_, tn_;
+                tile_of(c_tile, tm_, tn_);
+                // (fp32-output epilogues only: with the bf16-output GELU-grad epilogue the unconditional copy let hipcc hoist aux loads across
+            // blocks -- 254 VGPRs -- and ran 11 % slower)
+            if (Epi::W == 4 && (tm_ + 1) * BM <= M) epilogue(std::integral_constant<bool, Epi::W == 4>{});
+                else epilogue(std::false_type{});
+            }
             if (grp == 1) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             c_kt = 0;

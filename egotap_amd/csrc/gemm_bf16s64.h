@@ -238,7 +238,12 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
         }
         return epi.col(en);
     };
-    auto epilogue = [&]() __attribute__((always_inline)) {
+    // FULL (every row of the tile exists): the stores are unconditional, so hipcc counts them exactly and its waits for the aux rows of the
+    // NEXT 16-row block (requested before this block's stores) leave this block's stores in flight.  Under `if (m < M)` it had to assume the
+    // stores might not have been issued and waited as if only loads followed the ones it needs -- vmcnt is in order: every block then sat
+    // until the previous block's stores had completed (eight store round trips per tile in the residual / GELU-grad epilogues).
+    auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
         int tm, tn;
         tile_of(c_tile, tm, tn);
         const int m_wave = tm * BM + grp * 128, n_wave = tn * BN + wc * 64;
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
 #if defined(EGOTAP_ABL) && (EGOTAP_ABL & 2)      // timing-only: the epilogue without its functor and global stores
                     asm volatile("" ::"v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]));
 #else
-                    if (m0 + r < M) epi.emit(vv, cc, ax[it], m0 + r, en);
+                    if (FULL || m0 + r < M) epi.emit(vv, cc, ax[it], m0 + r, en);
 #endif
                 } else {
                     const int c2 = lane & 7;
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
                     asm volatile("" ::"v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]), "v"(vv[4]), "v"(vv[5]), "v"(vv[6]), "v"(vv[7]));
                     if (false) {
 #else
-                    if (m0 + r < M) {
+                    if (FULL || m0 + r < M) {
 #endif
                         epi.emit(vv, cc, ax[it], m0 + r, en);              // (leaves the values it stored in vv)
                         if constexpr (CS) {
@@ -403,7 +408,14 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
 #endif
         // one extra barrier per tile and group lets the two groups' epilogues run side by side (gemm_bf16s.h)
         if (grp == 0) __builtin_amdgcn_s_barrier();
-        epilogue();
+        {
+            int tm_, tn_;
+            tile_of(c_tile, tm_, tn_);
+            // (fp32-output epilogues only: with the bf16-output GELU-grad epilogue the unconditional copy let hipcc hoist aux loads across
+            // blocks -- 254 VGPRs -- and ran 11 % slower)
+            if (Epi::W == 4 && (tm_ + 1) * BM <= M) epilogue(std::integral_constant<bool, Epi::W == 4>{});
+            else epilogue(std::false_type{});
+        }
         if (grp == 1) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }

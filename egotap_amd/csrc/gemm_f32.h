@@ -147,7 +147,7 @@ struct EpiBias {          // C = acc + bias
     __device__ __forceinline__ Col col(int n) const { return Col{bias.at(n)}; }
     __device__ __forceinline__ float apply(float acc, const Col& c, int m, int n) const { return acc + c.b; }
     struct Col4 { f32x4 b; };
-    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{f32x4{bias.at(n0), bias.at(n0 + 1), bias.at(n0 + 2), bias.at(n0 + 3)}}; }
+    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{bias.at4(n0)}; }
     static constexpr bool HAS_RES = false;
     __device__ __forceinline__ f32x4 res4(int m, int n0) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
     __device__ __forceinline__ f32x4 apply4(f32x4 acc, const Col4& c, f32x4 res, int m, int n0) const { return acc + c.b; }
@@ -162,7 +162,7 @@ struct EpiBiasRes {       // C = acc + bias + R[m, n]   (R may alias C)
         return acc + c.b + R[(long)m * ldr + n];
     }
     struct Col4 { f32x4 b; };
-    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{f32x4{bias.at(n0), bias.at(n0 + 1), bias.at(n0 + 2), bias.at(n0 + 3)}}; }
+    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{bias.at4(n0)}; }
     static constexpr bool HAS_RES = true;
     __device__ __forceinline__ f32x4 res4(int m, int n0) const { return *(const f32x4*)(R + (long)m * ldr + n0); }
     __device__ __forceinline__ f32x4 apply4(f32x4 acc, const Col4& c, f32x4 res, int m, int n0) const { return acc + c.b + res; }
@@ -176,7 +176,7 @@ struct EpiBiasGelu {      // exact erf GELU (modeling_vit.py:320-327, hidden_act
         return gelu_erf(x);
     }
     struct Col4 { f32x4 b; };
-    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{f32x4{bias.at(n0), bias.at(n0 + 1), bias.at(n0 + 2), bias.at(n0 + 3)}}; }
+    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{bias.at4(n0)}; }
     static constexpr bool HAS_RES = false;
     __device__ __forceinline__ f32x4 res4(int m, int n0) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
     __device__ __forceinline__ f32x4 apply4(f32x4 acc, const Col4& c, f32x4 res, int m, int n0) const {
@@ -269,7 +269,7 @@ struct EpiBiasGeluSave {  // z = acc + bias is stored to Z (kept for the backwar
         return gelu_erf(x);
     }
     struct Col4 { f32x4 b; };
-    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{f32x4{bias.at(n0), bias.at(n0 + 1), bias.at(n0 + 2), bias.at(n0 + 3)}}; }
+    __device__ __forceinline__ Col4 col4(int n0) const { return Col4{bias.at4(n0)}; }
     static constexpr bool HAS_RES = false;
     __device__ __forceinline__ f32x4 res4(int m, int n0) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
     __device__ __forceinline__ f32x4 apply4(f32x4 acc, const Col4& c, f32x4 res, int m, int n0) const {

@@ -7,6 +7,7 @@
 // Any loader that is pure address math (HAS_PTR: plain rows, the per-heatmap token regroup, the cos/sin maps) can feed the DMA;
 // k order per output element is that of every other fp32 tile: bit-identical results.
 #pragma once
+#include <type_traits>
 #include "gemm_f32.h"
 
 struct DmaF32Cfg {
@@ -117,7 +118,12 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
     // as they stand (global_store_dword, two 128-byte row segments per instruction, no LDS patch): 135 TF against 140 at K = 1024,
     // and 86 with a residual read the same way.  Per tile the epilogue costs ~9 us (3.8 % at K = 1024, 1 % at K = 4096).
     int c_tile = 0, c_kt = 0;
-    auto epilogue = [&]() __attribute__((always_inline)) {
+    // FULL (every row of the tile exists: all tiles but a ragged last tile row): the stores are unconditional, so hipcc counts them exactly
+    // and its waits for the residual rows of the NEXT half block (requested before this one's stores) leave this one's stores in flight;
+    // with `if (m < M)` around them it had to assume they might not have been issued and waited as if they were the only thing in flight
+    // behind the loads -- in order, i.e. for the previous half block's stores to complete: a store round trip per half block.
+    auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
         int tm, tn;
         tile_of(c_tile, tm, tn);
         const int er = lane >> 3, ec = (lane & 7) * 4;
@@ -129,11 +135,16 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) rs[s2] = epi.res4(min(mb0 + s2 * 8, M - 1), nb0);
         }
+        // [r4] the per-column constants (bias ...) of half block q + 1 are requested while half block q is processed, like its residual
+        // rows: loaded and waited for inside one half block they cost a memory round trip each -- and more: vmcnt counts stores too, in
+        // order, so that wait also sat until the previous half block's stores had completed (sixteen serialised round trips per tile, the
+        // ~9 us per tile measured in round 3).
+        typename Epi::Col4 cc = epi.col4(nb0), cn = cc;
 #pragma unroll
         for (int q = 0; q < TN * TM * 2; ++q) {
             const int j = q / (TM * 2), i = (q / 2) % TM, hf = q & 1;
             const int n0 = nb0 + j * 32, mb = mb0 + i * 32;
-            const typename Epi::Col4 cc = epi.col4(n0);
+            if (q + 1 < TN * TM * 2 && (q + 1) / (TM * 2) != j) cn = epi.col4(nb0 + ((q + 1) / (TM * 2)) * 32);
             if (Epi::HAS_RES && q + 1 < TN * TM * 2) {
                 const int jn = (q + 1) / (TM * 2), in = ((q + 1) / 2) % TM, hn = (q + 1) & 1;
 #pragma unroll
@@ -146,12 +157,13 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int m = mb + hf * 16 + s2 * 8;
-                if (m < M) {
+                if (FULL || m < M) {
                     const f32x4 o = epi.apply4(*(const f32x4*)(Es + (s2 * 8 + er) * ELD + ec), cc, rs[s2], m, n0);
                     *(f32x4*)(C + (long)m * ldc + n0) = o;
                 }
             }
             if (Epi::HAS_RES) { rs[0] = rn[0]; rs[1] = rn[1]; }
+            cc = cn;
         }
     };
 
@@ -238,7 +250,16 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
         if (++c_kt == KT) {
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // slab gs+2 (only slab gs+3 may still be in flight)
             after_epi = true;
-            epilogue();
+            {
+                int tm_, tn_;
+                tile_of(c_tile, tm_, tn_);
+                // (epilogues with wide per-column constants -- patch embedding, BatchNorm -- keep the one predicated copy: two copies of
+                // their epilogue pushed the kernel past 256 registers)
+                // (... and the two training epilogues with a residual operand and no constants, EpiAccum / EpiGeluGrad, spilled with two)
+                constexpr bool DUAL = sizeof(typename Epi::Col4) <= 16 && !(Epi::HAS_RES && sizeof(typename Epi::Col4) < 16);
+                if (DUAL && (tm_ + 1) * BM <= M) epilogue(std::integral_constant<bool, DUAL>{});
+                else epilogue(std::false_type{});
+            }
             c_kt = 0;
             ++c_tile;
         }
