@@ -19,6 +19,7 @@
 //   decoder's concat buffers and of the lifting head's input tensor (no torch.cat, no chunk).
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 template <int TAPS_, int STRIDE_, int LOG2W_, int CO_T_, int WCO_, int WPX_, int CI_S_>
 struct ConvCfg {
@@ -61,6 +62,7 @@ struct ConvArgs {
     long in_istride, out_istride, res_istride;
     int Nimg, Cin, Cout, relu;
     int tiles_co, tiles_px;
+    int vec_ok;             // set by the launcher: every per-channel vector is 16-byte aligned (float4 loads of 4 channels)
 };
 
 template <class Cfg>
@@ -197,32 +199,120 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_f32_kernel(ConvArgs a) {
     }
 
     // epilogue: accumulator register r of lane l = D[co = 32x32 row (r&3) + 8*(r>>2) + 4*(l>>5)][pixel l&31]
+    // One group = the 4 consecutive output channels (r&3) of one r>>2, all TPX pixel tiles: 4*TPX stores.  The
+    // per-channel constants of group g+1 and the residuals of group g+1 are loaded BEFORE the stores of group g
+    // are issued: vmcnt retires in order, so a load issued after a store cannot be waited for without waiting for
+    // the store's write acknowledge as well (the first version waited vmcnt(0) in front of every single store).
+    // Tiles with every channel and image in range run an unpredicated copy (the waitcnt pass counts it exactly).
     const long ch_out = (long)W * W;
+    auto epilogue = [&](auto full_tag, auto bn_tag, auto res_tag) {
+        constexpr bool FULL = decltype(full_tag)::value, BN = decltype(bn_tag)::value, RES = decltype(res_tag)::value;
+        constexpr int NG = TCO * 4;
+        long ooff[TPX], roff[TPX];
+        bool pok[TPX];
 #pragma unroll
-    for (int i = 0; i < TCO; ++i) {
+        for (int j = 0; j < TPX; ++j) {
+            const int p = (wpx * TPX + j) * 32 + l31;
+            const int g = p / (RSEG * W), rem = p - g * (RSEG * W);
+            const int n = n0 + g;
+            pok[j] = FULL || n < a.Nimg;
+            const long pix = (long)y0 * W + rem;       // (y0 + yy) * W + x
+            ooff[j] = (long)n * a.out_istride + pix;
+            roff[j] = (long)n * a.res_istride + pix;
+        }
+        struct Raw {
+            f32x4 g, v, b, m;      // bias rides in b when there is no BatchNorm
+        };
+        auto group_co = [&](int idx) { return co0 + (wco * TCO + (idx >> 2)) * 32 + 8 * (idx & 3) + 4 * lh; };
+        auto ld4 = [&](const float* ptr, int co) -> f32x4 {
+            if (FULL) return *(const f32x4*)(ptr + co);
+            f32x4 o;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (co >= a.Cout) continue;
-            float sc = 1.f, sh;
-            if (a.gamma) {
-                sc = a.gamma[co] / sqrtf(a.var[co] + 1e-5f);
-                sh = a.beta[co] - a.mean[co] * sc;
+            for (int e = 0; e < 4; ++e) o[e] = co + e < a.Cout ? ptr[co + e] : 0.f;
+            return o;
+        };
+        auto load_raw = [&](int idx) -> Raw {
+            const int co = group_co(idx);
+            Raw o;
+            if (BN) {
+                o.g = ld4(a.gamma, co);
+                o.v = ld4(a.var, co);
+                o.b = ld4(a.beta, co);
+                o.m = ld4(a.mean, co);
             } else {
-                sh = a.bias[co];
+                o.b = ld4(a.bias, co);
+                o.g = o.v = o.m = o.b;
             }
+            return o;
+        };
+        struct Res {
+            float v[4][TPX];
+        };
+        auto load_res = [&](int idx) -> Res {
+            const int co = group_co(idx);
+            Res o;
 #pragma unroll
-            for (int j = 0; j < TPX; ++j) {
-                const int p = (wpx * TPX + j) * 32 + l31;
-                const int g = p / (RSEG * W), rem = p - g * (RSEG * W);
-                const int n = n0 + g;
-                if (n >= a.Nimg) continue;
-                const long pix = (long)y0 * W + rem;       // (y0 + yy) * W + x
-                float v = acc[i][j][r] * sc + sh;
-                if (a.res) v += a.res[(long)n * a.res_istride + co * ch_out + pix];
-                if (a.relu) v = fmaxf(v, 0.f);
-                a.out[(long)n * a.out_istride + co * ch_out + pix] = v;
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < TPX; ++j)
+                    o.v[e][j] = (RES && (FULL || (co + e < a.Cout && pok[j]))) ? a.res[roff[j] + (co + e) * ch_out] : 0.f;
+            return o;
+        };
+        Raw cur = load_raw(0);
+        Res rcur = load_res(0);
+#pragma unroll
+        for (int idx = 0; idx < NG; ++idx) {
+            Raw nxt = cur;
+            Res rnxt = rcur;
+            if (idx + 1 < NG) {
+                nxt = load_raw(idx + 1);
+                rnxt = load_res(idx + 1);
             }
+            // the scheduler must not pull group idx+1's arithmetic (which waits for the loads just issued, i.e. for
+            // everything older: group idx-1's stores) in front of group idx's stores
+            __builtin_amdgcn_sched_barrier(0);
+            const int i = idx >> 2, q = idx & 3;
+            const int co = group_co(idx);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sc = 1.f, sh;
+                if (BN) {
+                    sc = cur.g[e] / sqrtf(cur.v[e] + 1e-5f);
+                    sh = cur.b[e] - cur.m[e] * sc;
+                } else {
+                    sh = cur.b[e];
+                }
+#pragma unroll
+                for (int j = 0; j < TPX; ++j) {
+                    float v = acc[i][j][4 * q + e] * sc + sh;
+                    if (RES) v += rcur.v[e][j];
+                    v = a.relu ? fmaxf(v, 0.f) : v;
+                    if (FULL || (co + e < a.Cout && pok[j])) a.out[ooff[j] + (co + e) * ch_out] = v;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+            rcur = rnxt;
+        }
+    };
+    const bool full = a.vec_ok && co0 + CO_T <= a.Cout && n0 + G <= a.Nimg;
+    using T = std::true_type;
+    using F = std::false_type;
+    if (__builtin_expect(full, 1)) {
+        if (a.gamma) {
+            if (a.res) epilogue(T{}, T{}, T{});
+            else epilogue(T{}, T{}, F{});
+        } else {
+            if (a.res) epilogue(T{}, F{}, T{});
+            else epilogue(T{}, F{}, F{});
+        }
+    } else {
+        if (a.gamma) {
+            if (a.res) epilogue(F{}, T{}, T{});
+            else epilogue(F{}, T{}, F{});
+        } else {
+            if (a.res) epilogue(F{}, F{}, T{});
+            else epilogue(F{}, F{}, F{});
         }
     }
 }
@@ -239,6 +329,7 @@ static hipError_t conv_f32_launch(ConvArgs a, hipStream_t stream) {
         attr_done = true;
     }
     a.tiles_co = (a.Cout + Cfg::CO_T - 1) / Cfg::CO_T;
+    a.vec_ok = (((size_t)a.gamma | (size_t)a.beta | (size_t)a.mean | (size_t)a.var | (size_t)a.bias) & 15) == 0;
     const long px = (long)a.Nimg * Cfg::W * Cfg::W;
     a.tiles_px = Cfg::G == 1 ? (int)(px / Cfg::PX_T) : (a.Nimg + Cfg::G - 1) / Cfg::G;
     hipLaunchKernelGGL(kern, dim3(a.tiles_co * a.tiles_px), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a);
