@@ -1082,7 +1082,10 @@ struct HmWs {
 // conv_heatmap's GEMM N: 30 / 34 / 60 / 68 heatmap channels padded to the 64- or 128-column tile (256 before: 4-8 x the MFMAs)
 static inline int hm_head_np(int n_out) { return n_out <= 64 ? 64 : n_out <= 128 ? 128 : 256; }
 static constexpr int HM_CAT3P = 1600;      // channels per pixel of the first decoder concat in the bf16 mode: 1024 + 516 = 1540, padded to a multiple of 64
-static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T) {
+// n2 / sides / cus / split_floats (forward only; the size query leaves them 0): image count, map side per stage and the split-K budget, from
+// which the plan decides per BasicBlock convolution whether it runs on the 64-deep GEMM (64-channel weight slabs) -- stride 1, Cin = Cout a
+// multiple of 256 (layer3 / layer4), and enough pixels that the 32-deep kernel's split-K path is not taken.  Same bytes either way.
+static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T, long n2 = 0, const int* sides = nullptr, int cus = 0, size_t split_floats = 0) {
     size_t o = 0;
     int nw = 0, nb = 0, blk = 0;
     auto al = [&](size_t n) { size_t r = o; o = (o + n + 255) & ~(size_t)255; return r; };
@@ -1110,9 +1113,11 @@ static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T) {
         for (int bk = 0; bk < nblk[i]; ++bk) {
             const int bc = bk == 0 ? cin : c;
             const bool down = p ? p->blk[i][bk].wd != nullptr : (bk == 0 && i > 0);
-            wseg(p ? p->blk[i][bk].w1 : nullptr, nullptr, c, bc, bc, npad(c), 9); bseg(p ? p->blk[i][bk].bn1 : nobn, c, npad(c));
+            const bool deep = sides && n2 > 0 && c % 256 == 0 && gemm_bf16s_ksplit((int)(n2 * sides[i] * sides[i]), c, 9 * c, cus, split_floats) == 1;
+            const bool s1 = !(bk == 0 && i > 0);                                   // conv1 of a stage's first block is the stride-2 one
+            wseg(p ? p->blk[i][bk].w1 : nullptr, nullptr, c, bc, bc, npad(c), 9, deep && s1 && bc == c ? 64 : 32); bseg(p ? p->blk[i][bk].bn1 : nobn, c, npad(c));
             if (down) { wseg(p ? p->blk[i][bk].wd : nullptr, nullptr, c, bc, bc, npad(c), 1); bseg(p ? p->blk[i][bk].bnd : nobn, c, npad(c)); }
-            wseg(p ? p->blk[i][bk].w2 : nullptr, nullptr, c, c, c, npad(c), 9); bseg(p ? p->blk[i][bk].bn2 : nobn, c, npad(c));
+            wseg(p ? p->blk[i][bk].w2 : nullptr, nullptr, c, c, c, npad(c), 9, deep ? 64 : 32); bseg(p ? p->blk[i][bk].bn2 : nobn, c, npad(c));
         }
         cin = c;
     }
@@ -1246,13 +1251,14 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
         // [r3] all 27 weight repacks and 19 BatchNorm folds of this forward in ONE launch (conv_bf16s.h, pack_all_bf16s_kernel): the
         // parameters stay the caller's live fp32 tensors, nothing is kept between calls
         PackTable PT;
-        EGO_CHECK(hm_pack_plan(&p, p.nblk, &PT) != 0, "egotap_hm_forward: the estimator has more layers than the pack table holds");
+        const size_t split_floats = (size_t)N2 * 64 * (S0 / 2) * (S0 / 2);
+        const int stage_sides[4] = {s64, s32, s16, s8};
+        EGO_CHECK(hm_pack_plan(&p, p.nblk, &PT, N2, stage_sides, cus, split_floats) != 0, "egotap_hm_forward: the estimator has more layers than the pack table holds");
         char* reg = base + w.WALL;
         hipLaunchKernelGGL(pack_all_bf16s_kernel, dim3(PT.blocks), dim3(256), 0, s, PT, reg);
         EGO_HIP(hipGetLastError());
         int li = 0, bi = 0;
         float* split_slab = F(w.L0);                                               // the fp32 stem map's slot: unused (fused stem) or dead after the max-pool
-        const size_t split_floats = (size_t)N2 * 64 * (S0 / 2) * (S0 / 2);
         auto up2 = [&](const __bf16* in, __bf16* o, int C, int hin, long ld) {
             const long total = (long)B * 4 * hin * hin * (C / 8);
             hipLaunchKernelGGL(upsample2x_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, o, C, hin, ld, total);
@@ -1296,8 +1302,12 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
                         2.0 * M * c * taps * (double)cin);
             if (direct)
                 return conv64_direct_bf16s_launch(in, ZP, WPl, SC, SH, res, o, ilog2(side), N2, relu, cus, s);
-            const XConvE xl{in, ZP, cin, ilog2(side), stride, taps};
             const SEpiBnBf16<false> ep{SC, SH, res, o, c, ilog2(side), relu};
+            if (sg.slab == 64) {      // [r4] layer3 / layer4's stride-1 convolutions on the 64-deep GEMM (the plan checked the shape rules)
+                if (taps != 9 || stride != 1 || cin != c || Np != c) return hipErrorInvalidValue;
+                return gemm_bf16s64_launch_x(X64ConvE{in, ZP, cin, ilog2(side)}, WPl, 9L * cin, ep, (int)M, Np, 9 * cin, cus, s);
+            }
+            const XConvE xl{in, ZP, cin, ilog2(side), stride, taps};
             if (Np == 64 && c == 64) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 1>(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
             if (Np == 128 && c == 128) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 2>(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
             if (Np == c) {

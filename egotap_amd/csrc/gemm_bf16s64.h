@@ -75,6 +75,32 @@ struct X64Conv3 {
     }
 };
 
+// BasicBlock 3x3 convolution (pad 1, stride 1) on the backbone's eye-interleaved maps [B * S * S, 2 C] (conv_bf16s.h's XConvE for this kernel:
+// image n = 2 b + eye reads the C-channel slice eye * C of rows b * S * S + pixel), C a multiple of 64, k = (ci / 64, tap, ci % 64)
+struct X64ConvE {
+    static constexpr bool SBASE = false;
+    const __bf16* in;
+    const __bf16* zero;      // >= 128 bytes of zeros
+    int C, log2S;
+    struct Row { const __bf16* p; unsigned mask; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int S = 1 << log2S, x = m & (S - 1), y = (m >> log2S) & (S - 1), n = m >> (2 * log2S);
+        unsigned mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            if (y + dy >= 0 && y + dy < S && x + dx >= 0 && x + dx < S) mask |= 1u << t;
+        }
+        return Row{in + ((((long)(n >> 1) << (2 * log2S)) + (y << log2S) + x) * 2 + (n & 1)) * C, mask};
+    }
+    __device__ __forceinline__ const __bf16* ptr(const Row& r, int kt, int chunk) const {
+        const int slab = (kt * 7282) >> 16, tap = kt - 9 * slab;                     // kt / 9 exactly for kt < 7000
+        const int dy = ((tap * 11) >> 5) - 1, dx = tap - 3 * (dy + 1) - 1;
+        const int off = ((dy << log2S) + dx) * (2 * C) + 64 * slab;
+        return ((r.mask >> tap) & 1u) ? r.p + off + chunk * 8 : zero + chunk * 8;
+    }
+};
+
 // Epilogues whose per-column constants are just the bias (Col = SBias8 or f32x4 read from `bias`): the kernel stages the wave's 64 bias
 // values in its (idle) epilogue patch by one 4-byte LDS DMA per tile, issued in the tile's first phase and counted like every other DMA.
 // The epilogue then starts with two LDS reads instead of a global load whose wait -- vmcnt is in order -- drained every DMA in flight
