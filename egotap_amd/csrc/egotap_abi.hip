@@ -1083,8 +1083,8 @@ struct HmWs {
 static inline int hm_head_np(int n_out) { return n_out <= 64 ? 64 : n_out <= 128 ? 128 : 256; }
 static constexpr int HM_CAT3P = 1600;      // channels per pixel of the first decoder concat in the bf16 mode: 1024 + 516 = 1540, padded to a multiple of 64
 // n2 / sides / cus / split_floats (forward only; the size query leaves them 0): image count, map side per stage and the split-K budget, from
-// which the plan decides per BasicBlock convolution whether it runs on the 64-deep GEMM (64-channel weight slabs) -- stride 1, Cin = Cout a
-// multiple of 256 (layer3 / layer4), and enough pixels that the 32-deep kernel's split-K path is not taken.  Same bytes either way.
+// which the plan decides per BasicBlock 3x3 convolution whether it runs on the 64-deep GEMM (64-channel weight slabs) -- Cin a multiple of 64, Cout = 128
+// (layer2, on the 256 x 128 tile) or a multiple of 256 (layer3 / layer4), and enough pixels that the 32-deep kernel's split-K path is not taken.  Same bytes either way.
 static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T, long n2 = 0, const int* sides = nullptr, int cus = 0, size_t split_floats = 0) {
     size_t o = 0;
     int nw = 0, nb = 0, blk = 0;
@@ -1113,11 +1113,11 @@ static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T, lon
         for (int bk = 0; bk < nblk[i]; ++bk) {
             const int bc = bk == 0 ? cin : c;
             const bool down = p ? p->blk[i][bk].wd != nullptr : (bk == 0 && i > 0);
-            const bool deep = sides && n2 > 0 && c % 256 == 0 && gemm_bf16s_ksplit((int)(n2 * sides[i] * sides[i]), c, 9 * c, cus, split_floats) == 1;
-            const bool s1 = !(bk == 0 && i > 0);                                   // conv1 of a stage's first block is the stride-2 one
-            wseg(p ? p->blk[i][bk].w1 : nullptr, nullptr, c, bc, bc, npad(c), 9, deep && s1 && bc == c ? 64 : 32); bseg(p ? p->blk[i][bk].bn1 : nobn, c, npad(c));
+            auto deep = [&](int K) { return sides && n2 > 0 && (c % 256 == 0 || c == 128) && gemm_bf16s_ksplit((int)(n2 * sides[i] * sides[i]), c, K, cus, split_floats) == 1; };
+            // (conv1 of a stage's first block is the stride-2 one with Cin = Cout / 2: a multiple of 64 from layer2 on, 9 Cin >= 128)
+            wseg(p ? p->blk[i][bk].w1 : nullptr, nullptr, c, bc, bc, npad(c), 9, bc % 64 == 0 && deep(9 * bc) ? 64 : 32); bseg(p ? p->blk[i][bk].bn1 : nobn, c, npad(c));
             if (down) { wseg(p ? p->blk[i][bk].wd : nullptr, nullptr, c, bc, bc, npad(c), 1); bseg(p ? p->blk[i][bk].bnd : nobn, c, npad(c)); }
-            wseg(p ? p->blk[i][bk].w2 : nullptr, nullptr, c, c, c, npad(c), 9, deep ? 64 : 32); bseg(p ? p->blk[i][bk].bn2 : nobn, c, npad(c));
+            wseg(p ? p->blk[i][bk].w2 : nullptr, nullptr, c, c, c, npad(c), 9, deep(9 * c) ? 64 : 32); bseg(p ? p->blk[i][bk].bn2 : nobn, c, npad(c));
         }
         cin = c;
     }
@@ -1304,8 +1304,10 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
                 return conv64_direct_bf16s_launch(in, ZP, WPl, SC, SH, res, o, ilog2(side), N2, relu, cus, s);
             const SEpiBnBf16<false> ep{SC, SH, res, o, c, ilog2(side), relu};
             if (sg.slab == 64) {      // [r4] layer3 / layer4's stride-1 convolutions on the 64-deep GEMM (the plan checked the shape rules)
-                if (taps != 9 || stride != 1 || cin != c || Np != c) return hipErrorInvalidValue;
-                return gemm_bf16s64_launch_x(X64ConvE{in, ZP, cin, ilog2(side)}, WPl, 9L * cin, ep, (int)M, Np, 9 * cin, cus, s);
+                if (taps != 9 || cin % 64 != 0 || Np != c) return hipErrorInvalidValue;
+                const X64ConvE xl{in, ZP, cin, ilog2(side), stride};
+                if (c == 128) return gemm_bf16s64_launch_x<X64ConvE, SEpiBnBf16<false>, 1>(xl, WPl, 9L * cin, ep, (int)M, Np, 9 * cin, cus, s);   // layer2: 256 x 128 tile
+                return gemm_bf16s64_launch_x(xl, WPl, 9L * cin, ep, (int)M, Np, 9 * cin, cus, s);
             }
             const XConvE xl{in, ZP, cin, ilog2(side), stride, taps};
             if (Np == 64 && c == 64) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 1>(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);

@@ -75,28 +75,30 @@ struct X64Conv3 {
     }
 };
 
-// BasicBlock 3x3 convolution (pad 1, stride 1) on the backbone's eye-interleaved maps [B * S * S, 2 C] (conv_bf16s.h's XConvE for this kernel:
-// image n = 2 b + eye reads the C-channel slice eye * C of rows b * S * S + pixel), C a multiple of 64, k = (ci / 64, tap, ci % 64)
+// BasicBlock 3x3 convolution (pad 1, stride 1 or 2) on the backbone's eye-interleaved maps [B * Si * Si, 2 C], Si = So * stride (conv_bf16s.h's
+// XConvE for this kernel: image n = 2 b + eye reads the C-channel slice eye * C of rows b * Si * Si + pixel), C a multiple of 64,
+// k = (ci / 64, tap, ci % 64)
 struct X64ConvE {
     static constexpr bool SBASE = false;
     const __bf16* in;
     const __bf16* zero;      // >= 128 bytes of zeros
-    int C, log2S;
+    int C, log2So, stride;
     struct Row { const __bf16* p; unsigned mask; };
     __device__ __forceinline__ Row row(int m) const {
-        const int S = 1 << log2S, x = m & (S - 1), y = (m >> log2S) & (S - 1), n = m >> (2 * log2S);
+        const int So = 1 << log2So, xo = m & (So - 1), yo = (m >> log2So) & (So - 1), n = m >> (2 * log2So);
+        const int Si = So * stride, yi = yo * stride, xi = xo * stride;
         unsigned mask = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dy = t / 3 - 1, dx = t % 3 - 1;
-            if (y + dy >= 0 && y + dy < S && x + dx >= 0 && x + dx < S) mask |= 1u << t;
+            if (yi + dy >= 0 && yi + dy < Si && xi + dx >= 0 && xi + dx < Si) mask |= 1u << t;
         }
-        return Row{in + ((((long)(n >> 1) << (2 * log2S)) + (y << log2S) + x) * 2 + (n & 1)) * C, mask};
+        return Row{in + (((long)(n >> 1) * Si * Si + (long)yi * Si + xi) * 2 + (n & 1)) * C, mask};
     }
     __device__ __forceinline__ const __bf16* ptr(const Row& r, int kt, int chunk) const {
         const int slab = (kt * 7282) >> 16, tap = kt - 9 * slab;                     // kt / 9 exactly for kt < 7000
         const int dy = ((tap * 11) >> 5) - 1, dx = tap - 3 * (dy + 1) - 1;
-        const int off = ((dy << log2S) + dx) * (2 * C) + 64 * slab;
+        const int off = (dy * (stride << log2So) + dx) * (2 * C) + 64 * slab;
         return ((r.mask >> tap) & 1u) ? r.p + off + chunk * 8 : zero + chunk * 8;
     }
 };
@@ -117,12 +119,19 @@ template <> struct s64_col_lds<f32x4> { static __device__ __forceinline__ f32x4 
 template <class XL, bool SB = XL::SBASE> struct S64RowState { };                                   // SBASE loaders keep no per-lane row state
 template <class XL> struct S64RowState<XL, false> { typename XL::Row r[2][2]; };                    // [a][g]
 
-template <class XL, class Epi>
+// NJ = 16-column MFMA tiles per wave and half: 2 -> the 256 x 256 output tile (default); [r4] 1 -> 256 x 128 for N = 128 (layer2 of the bf16
+// estimators ran on the 32-deep kernel's 128-column tile at MFMA busy 0.165: a K-tile there costs what it costs at 256 columns).  The W
+// parts shrink to 64 rows (ONE DMA instruction per wave: row block wid), a phase to 8 MFMAs per wave; the X parts, the part offsets in
+// LDS, the phase order and the barriers are unchanged.  Any four consecutive issues of the cycle WB1, XA1, XA0, WB0 hold two X and two W
+// parts, so the allowance for "the four newest parts" is the constant 4 + 2 NJ.
+template <class XL, class Epi, int NJ = 2>
 __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl, const __bf16* __restrict__ Wb, long ldw, Epi epi,
                                                                            int M, int N, int K, int tiles_m, int tiles_n) {
     using Cfg = S64Cfg;
-    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, ROWB = Cfg::ROWB, PART = Cfg::PART, KBUF = Cfg::KBUF;
-    constexpr int VMC = 8;                           // vmcnt allowance: the four newest parts (two DMA instructions per wave each) may stay in flight
+    static_assert(NJ == 2 || NJ == 1, "n-tiles per wave and half");
+    constexpr int BM = Cfg::BM, BN = 128 * NJ, BK = Cfg::BK, ROWB = Cfg::ROWB, PART = Cfg::PART, KBUF = Cfg::KBUF;
+    constexpr int WCOLS = 32 * NJ;                   // output columns per wave
+    constexpr int VMC = 4 + 2 * NJ;                  // vmcnt allowance: the four newest parts (X: two DMA instructions per wave, W: NJ) may stay in flight
     extern __shared__ __attribute__((aligned(16))) char smem_s64[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wid >> 2, wc = wid & 3;
@@ -157,7 +166,8 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
     // Lane offsets in bytes from the wave-uniform base of the part (rows past M re-read row M - 1: their results are never stored).
     unsigned xo[2][2];                               // [a][g]  (SBASE loaders: lane offsets)
     S64RowState<XL> xrow;                            //         (pointer loaders: per-lane row state)
-    const unsigned wo = (unsigned)((8 * (wid & 3) + drow) * ldw * 2 + dchunk * 16);
+    // (NJ = 1: local row r of WB_b -> tile column (r >> 4) * 32 + b * 16 + (r & 15): block wid -> wave column wid >> 1, rows 8 (wid & 1) ..)
+    const unsigned wo = (unsigned)((8 * (NJ == 2 ? (wid & 3) : (wid & 1)) + drow) * ldw * 2 + dchunk * 16);
     struct Stream { int tile, kt; };                 // position of an issue stream: (tile index of this workgroup, K-tile inside it)
     Stream s_xa[2] = {{0, 0}, {0, 0}}, s_wb[2] = {{0, 0}, {0, 0}};
     unsigned long long xbase[2], wbase[2];           // wave-uniform bases of the streams' current tiles (bytes)
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
     auto set_w = [&](int b, int i) __attribute__((always_inline)) {
         int tm, tn;
         tile_of(i, tm, tn);
-        wbase[b] = uniform64((unsigned long long)(size_t)Wb + ((unsigned long long)(tn * BN + (wid >> 2) * 64 + b * 32) * ldw) * 2);
+        wbase[b] = uniform64((unsigned long long)(size_t)Wb + ((unsigned long long)(tn * BN + (NJ == 2 ? (wid >> 2) * 64 + b * 32 : (wid >> 1) * 32 + b * 16)) * ldw) * 2);
     };
     set_x(0, 0); set_x(1, 0);
     set_w(0, 0); set_w(1, 0);
@@ -217,22 +227,22 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
         const unsigned sa = lds0 + buf * KBUF + (b ? Cfg::O_WB1 : Cfg::O_WB0) + wid * 1024;
         const unsigned long long kb = wbase[b] + (unsigned long long)s_wb[b].kt * (BK * 2);
         dma1(wo, kb, sa);
-        dma1(wo, kb + (unsigned long long)128 * ldw * 2, sa + 8 * 1024);
+        if constexpr (NJ == 2) dma1(wo, kb + (unsigned long long)128 * ldw * 2, sa + 8 * 1024);
         advance(s_wb[b], b, false);
     };
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][2 * NJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2 * NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment byte offset of this lane inside a 16-row block: row lane & 15, logical chunk 4 s + (lane >> 4) of k-step s
     const int l15 = lane & 15;
     const int foff0 = l15 * ROWB + (((lane >> 4) ^ (l15 >> 1)) << 4);           // k-step 0; k-step 1 is the chunk position xor 4: offset xor 64
     const int foff1 = foff0 ^ 64;
     const int xa_base = (grp * 64) * ROWB;            // + i * 16 * ROWB: m-tile i of the half
-    const int wb_base = (wc * 32) * ROWB;             // + j * 16 * ROWB: n-tile j of the half
+    const int wb_base = (wc * 16 * NJ) * ROWB;        // + j * 16 * ROWB: n-tile j of the half
 
     int c_tile = 0;
     // vmcnt is ONE in-order counter for DMA, loads and stores: for the first four phases after an exact epilogue the parts a wait
@@ -240,11 +250,14 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
     // (derivation in gemm_bf16s.h); after a ragged tile the plain allowance makes the first wait drain them.
     constexpr bool CS = s_epi_colsum<Epi>::value;
     static_assert(!CS || Epi::W == 8, "column sums ride on the bf16-output epilogues");
-    constexpr int IT = Epi::W == 4 ? 4 : 2, NST = 8 * IT * Epi::STORES + (CS ? 2 : 0);
+    static_assert(NJ == 2 || !CS, "column sums: 256-column tiles only");
+    constexpr int LPR = (Epi::W == 4 ? 8 : 4) * NJ;  // epilogue: lanes per patch row (W columns each)
+    constexpr int IT = LPR / 4, NST = 8 * IT * Epi::STORES + (CS ? 2 : 0);
     constexpr int SLK = s_epi_exact<Epi>::value ? VMC + NST : VMC;
     static_assert(SLK + 1 <= 63, "vmcnt is a 6-bit counter");
     bool slack_on = false;           // the next tile's first K-tile leaves the stores of the epilogue before it in flight
     constexpr bool LB = s64_lds_bias<Epi>::value;
+    static_assert(NJ == 2 || !LB, "the bias staging covers 64 columns per wave");
     const float* bias_g = s64_bias_ptr(epi, std::integral_constant<bool, LB>{});
     const bool has_bias = LB && bias_g != nullptr;    // the same for every wave of the launch: the DMA count per phase stays uniform
     const unsigned patch_lds = lds0 + 2 * KBUF + wid * Cfg::EPATCH;
@@ -272,9 +285,9 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
         constexpr bool FULL = decltype(full_tag)::value;
         int tm, tn;
         tile_of(c_tile, tm, tn);
-        const int m_wave = tm * BM + grp * 128, n_wave = tn * BN + wc * 64;
+        const int m_wave = tm * BM + grp * 128, n_wave = tn * BN + wc * WCOLS;
         const int q = lane >> 4;
-        const int er = Epi::W == 4 ? q : (lane >> 3), ecol = Epi::W == 4 ? l15 * 4 : (lane & 7) * 8;
+        const int er = lane / LPR, ec = lane % LPR, ecol = ec * Epi::W;
         const int en = n_wave + ecol;
         typename Epi::Col cc = epi_cols(en, ecol);
         typename Epi::Aux ax[IT], an[IT];
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
             }
             // accumulators -> patch[16 m][64 n] (fp32), 16-byte chunk ch of row r at position ch ^ r
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
+            for (int ni = 0; ni < 2 * NJ; ++ni) {
                 *(f32x4*)(Es + l15 * 64 + (((4 * ni + q) ^ l15) << 2)) = acc[mi][ni];
                 acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
                 const int r = (16 / IT) * it + er;
                 s_keep(ax[it]);
                 if constexpr (Epi::W == 4) {
-                    const f32x4 v = *(const f32x4*)(Es + r * 64 + ((l15 ^ r) << 2));
+                    const f32x4 v = *(const f32x4*)(Es + r * 64 + ((ec ^ r) << 2));
                     float vv[4] = {v[0], v[1], v[2], v[3]};
 #if defined(EGOTAP_ABL) && (EGOTAP_ABL & 2)      // timing-only: the epilogue without its functor and global stores
                     asm volatile("" ::"v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]));
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
                     if (FULL || m0 + r < M) epi.emit(vv, cc, ax[it], m0 + r, en);
 #endif
                 } else {
-                    const int c2 = lane & 7;
+                    const int c2 = ec;
                     const f32x4 v0 = *(const f32x4*)(Es + r * 64 + (((2 * c2) ^ r) << 2));
                     const f32x4 v1 = *(const f32x4*)(Es + r * 64 + (((2 * c2 + 1) ^ r) << 2));
                     float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -351,12 +364,12 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
     // ---- prologue: K-tile 0 complete, then XA0 and WB0 of K-tile 1 -- what the steady-state schedule would have issued by now
     issue_x(0, 0); issue_w(0, 0); issue_w(1, 0); issue_x(1, 0);
     issue_x(0, 1); issue_w(0, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         // K-tile 0 has landed (the two parts of K-tile 1 may be in flight) ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NJ) : "memory");   // K-tile 0 has landed (the two parts of K-tile 1 may be in flight) ...
     __builtin_amdgcn_s_barrier();                          // ... for every wave: phase 0 may read it
     __builtin_amdgcn_sched_barrier(0);
     if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
 
-    bf16x8 xf[4][2], wf0[2][2], wf1[2][2];
+    bf16x8 xf[4][2], wf0[NJ][2], wf1[NJ][2];
     int buf = 0;
 #define S64_PHASE_MFMA(A, WF, B)                                                                  \
     do {                                                                                        \
@@ -364,9 +377,9 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
         __builtin_amdgcn_sched_barrier(0);                                                      \
         __builtin_amdgcn_s_setprio(1);                                                          \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                      \
                 _Pragma("unroll") for (int s = 0; s < 2; ++s)                                   \
-                    acc[4 * (A) + i][2 * (B) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j][s], xf[i][s], acc[4 * (A) + i][2 * (B) + j], 0, 0, 0); \
+                    acc[4 * (A) + i][NJ * (B) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j][s], xf[i][s], acc[4 * (A) + i][NJ * (B) + j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                      \
         __builtin_amdgcn_s_barrier();                                                           \
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
         issue_w(1, buf ^ 1);
         if constexpr (FIRST && LB) issue_bias();
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             wf0[j][0] = *(const bf16x8*)(kb + Cfg::O_WB0 + wb_base + j * 16 * ROWB + foff0);
             wf0[j][1] = *(const bf16x8*)(kb + Cfg::O_WB0 + wb_base + j * 16 * ROWB + foff1);
         }
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
         // ---------------- phase 1: a0 x b1
         issue_x(1, buf ^ 1);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             wf1[j][0] = *(const bf16x8*)(kb + Cfg::O_WB1 + wb_base + j * 16 * ROWB + foff0);
             wf1[j][1] = *(const bf16x8*)(kb + Cfg::O_WB1 + wb_base + j * 16 * ROWB + foff1);
         }
@@ -454,19 +467,19 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
 static inline bool gemm_bf16s64_ok(int M, int N, int K, long ldx, long ldw) {
     return M > 0 && N % 256 == 0 && K % 64 == 0 && K >= 128 && ldx % 8 == 0 && ldw % 8 == 0 && (long)256 * (ldx > ldw ? ldx : ldw) * 2 < (1L << 31);
 }
-template <class XL, class Epi>
+template <class XL, class Epi, int NJ = 2>
 static hipError_t gemm_bf16s64_launch_x(const XL& xl, const __bf16* Wb, long ldw, const Epi& epi, int M, int N, int K, int num_cu, hipStream_t stream) {
     using Cfg = S64Cfg;
     if (M <= 0) return hipSuccess;
-    if (N % 256 != 0 || K % 64 != 0 || K < 128 || ldw % 8 != 0 || (long)256 * ldw * 2 >= (1L << 31)) return hipErrorInvalidValue;
-    auto kern = gemm_bf16s64_kernel<XL, Epi>;
+    if (N % (128 * NJ) != 0 || K % 64 != 0 || K < 128 || ldw % 8 != 0 || (long)256 * ldw * 2 >= (1L << 31)) return hipErrorInvalidValue;
+    auto kern = gemm_bf16s64_kernel<XL, Epi, NJ>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
+    const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / (128 * NJ);
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < num_cu ? ntiles : num_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xl, Wb, ldw, epi, M, N, K, tiles_m, tiles_n);
