@@ -1113,7 +1113,7 @@ static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T, lon
         for (int bk = 0; bk < nblk[i]; ++bk) {
             const int bc = bk == 0 ? cin : c;
             const bool down = p ? p->blk[i][bk].wd != nullptr : (bk == 0 && i > 0);
-            auto deep = [&](int K) { return sides && n2 > 0 && (c % 256 == 0 || c == 128) && gemm_bf16s_ksplit((int)(n2 * sides[i] * sides[i]), c, K, cus, split_floats) == 1; };
+            auto deep = [&](int K) { return sides && n2 > 0 && g_gemm_bf16s_bk != 32 && (c % 256 == 0 || c == 128) && gemm_bf16s_ksplit((int)(n2 * sides[i] * sides[i]), c, K, cus, split_floats) == 1; };
             // (conv1 of a stage's first block is the stride-2 one with Cin = Cout / 2: a multiple of 64 from layer2 on, 9 Cin >= 128)
             wseg(p ? p->blk[i][bk].w1 : nullptr, nullptr, c, bc, bc, npad(c), 9, bc % 64 == 0 && deep(9 * bc) ? 64 : 32); bseg(p ? p->blk[i][bk].bn1 : nobn, c, npad(c));
             if (down) { wseg(p ? p->blk[i][bk].wd : nullptr, nullptr, c, bc, bc, npad(c), 1); bseg(p ? p->blk[i][bk].bnd : nobn, c, npad(c)); }

@@ -146,6 +146,44 @@ def test_hm_forward_bf16_channels_last_decoder_against_float64_oracle(which, pre
         assert 1e-5 < rel < (2e-2 if model_name == "resnet18" else 3e-2), (b, rel)         # resnet34: twice the backbone depth
 
 
+def test_hm_forward_bf16_large_batch_routes_layers_2_to_4_through_the_64_deep_gemm():
+    """[r4] At serving / training batches the BasicBlock 3x3 convolutions of layer2 (256 x 128 tile), layer3 and layer4 run on the 64-deep
+    GEMM with the X64ConvE loader (stride 1 and 2, 64-channel weight slabs); below ~130 frames layer4 still takes the 32-deep kernel's
+    split-K path, so the small-batch tests never reach it.  B = 136: against the same forward pinned to the 32-deep kernels
+    (egotap_debug_gemm_bk(32): another summation order, so bf16 roundings flip -- relative L2 of a few 1e-3, a wrong tap / slab / eye
+    would be O(1)), run-to-run bits, and the last frame against the float64 oracle."""
+    from gpu_util import hm_net
+    from oracle import hm_ref as H
+    from egotap_amd import lib
+    L = lib.load()
+    net, sd_np = hm_net("rot")
+    B = 136
+    left = torch.from_numpy(synth_input("rgbL_big", (8, 3, 256, 256), -2.0, 2.0)).repeat(B // 8, 1, 1, 1)
+    right = torch.from_numpy(synth_input("rgbR_big", (8, 3, 256, 256), -2.0, 2.0)).repeat(B // 8, 1, 1, 1)
+    left[B - 1] = torch.from_numpy(synth_input("rgbL_big_last", (3, 256, 256), -2.0, 2.0))
+    with torch.no_grad():
+        ref = H.hm_forward(left[B - 1:].double(), right[B - 1:].double(), H.to_torch_sd(sd_np, torch.float64))[0]
+    lc, rc = left.cuda(), right.cuda()
+    try:
+        net.set_precision("bf16")
+        lib.check(L.egotap_debug_gemm_bk(32))
+        old = net(lc, rc)
+        lib.check(L.egotap_debug_gemm_bk(0))
+        new = net(lc, rc)
+        again = net(lc, rc)
+    finally:
+        lib.check(L.egotap_debug_gemm_bk(0))
+        net.set_precision("f32")
+    assert torch.equal(new, again)
+    assert not torch.equal(new, old)                        # the two routings are different kernels
+    new, old = new.double().cpu(), old.double().cpu()
+    rel_route = float((new - old).norm() / old.norm())
+    rel_last = float((new[B - 1] - ref).norm() / ref.norm())
+    rel_first = float((new[0] - new[8]).norm())             # frames 0 and 8 are the same image pair: the same bits wherever they sit in the batch
+    print(f"64-deep vs 32-deep routing: relative L2 {rel_route:.2e}; last frame against float64: {rel_last:.2e}")
+    assert rel_route < 1e-2 and 1e-5 < rel_last < 2e-2 and rel_first == 0.0, (rel_route, rel_last, rel_first)
+
+
 def test_hm_forward_bf16_mode_against_float64_oracle():
     """plain bf16 operands (2^-9 per rounding) in the 3x3 convolutions of the estimator, checked against the FLOAT64 ORACLE: the
     heatmaps stay within 3 % relative L2 of it (fp32 mode: 1e-6), and are not the fp32 result"""
