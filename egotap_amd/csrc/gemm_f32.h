@@ -914,14 +914,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // P: scratch of at least splits * M * N floats; returns hipErrorInvalidValue for shapes the tile does not cover
 template <class Cfg, class ALoad, class Epi>
 static hipError_t gemm_f32_splitk_launch(const ALoad& al, const SegMat& W, const Epi& epi, float* C, long ldc, float* P, size_t p_floats, int M,
-                                         int N, int K, hipStream_t stream) {
+                                         int N, int K, hipStream_t stream, int num_cu = 256) {
     if (M <= 0) return hipSuccess;
     if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0) return hipErrorInvalidValue;
     const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
-    int splits = 1;      // enough K ranges to put ~2 workgroups on every CU, each range at least 4 slabs, partials within the scratch
-    while (splits < 32 && tiles_m * tiles_n * splits < 512 && (size_t)(2 * splits) * M * N <= p_floats && K / (2 * splits) >= 4 * Cfg::BK) splits <<= 1;
+    // [r4] The split count with the least estimated time: a CU runs its ceil(tiles * splits / CUs) workgroups' K-slabs one after the other
+    // on its four matrix pipes (1.7 us per 128 x 128 x 32 fp32 slab) + ~2.5 us per workgroup (first slab's round trip, partial store), and
+    // the partials cost their bytes twice.  The doubling rule it replaces overshot (qkv at B = 1: 120 tiles x 8 = 960 workgroups of 4
+    // slabs each, 56 MB of partials, 44.8 us; 2 splits: one workgroup per CU) or left half-empty rounds (N = 4096: 160 x 4 = 2.5 per CU).
+    const int KT = K / Cfg::BK, tiles = tiles_m * tiles_n;
+    int splits = 1;
+    double best = 1e30;
+    for (int sp = 1; sp <= 32; ++sp) {
+        const int kp = (KT + sp - 1) / sp;
+        if ((sp > 1 && kp < 4) || (long)kp * (sp - 1) >= KT) continue;      // at least 4 slabs per range; no empty last range
+        if ((size_t)sp * M * N > p_floats) break;
+        const int per_cu = (tiles * sp + num_cu - 1) / num_cu;
+        // (a workgroup alone on its CU has one wave per SIMD and nothing to run under its loads: ~2.0 us per slab, measured on fc1 at B = 32)
+        const double t = per_cu * (kp * (per_cu == 1 ? 2.0 : 1.7) + 2.5) + (sp > 1 ? 2.0 * sp * (double)M * N * 4 / 4.0e6 : 0.0);
+        if (t < best - 1e-9) { best = t; splits = sp; }
+    }
     if ((size_t)splits * M * N > p_floats) return hipErrorInvalidValue;
-    const int kper = ((K / Cfg::BK + splits - 1) / splits) * Cfg::BK;
+    const int kper = ((KT + splits - 1) / splits) * Cfg::BK;
     auto kern = gemm_f32_splitk_kernel<Cfg, ALoad>;
     static bool attr_done = false;
     if (!attr_done) {
