@@ -470,7 +470,7 @@ def bench_latency(net, p, dev):
     out = {"unit": "ms per forward (median of 20, synchronised)"}
     for B in (1, 8):
         hm = torch.from_numpy(synth_input("hm_lat", (B, p.in_channels, p.hm_size, p.hm_size))).to(dev)
-        for mode in ("f32", "bf16x3"):
+        for mode in ("f32", "bf16x3", "bf16"):
             net.set_precision(mode)
             for _ in range(3):
                 net.predict_pose(hm)

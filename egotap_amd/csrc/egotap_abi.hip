@@ -788,7 +788,11 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     // EGOTAP_PREC_BF16 at a batch that fills the chip: bf16 ACTIVATION STORAGE (the same workspace slices hold bf16): LayerNorm, the
     // GEMM epilogues and attention write bf16, every GEMM reads bf16 operands through the LDS DMA (gemm_bf16s.h); weights are rounded
     // into the caller's weight scratch right before each launch (nothing cached: the fp32 parameters stay the source of truth)
-    const bool bf16s = h->precision == EGOTAP_PREC_BF16 && D == 1024 && M >= 4096 && h->wscratch != nullptr &&
+#ifndef EGOTAP_BF16S_MIN_ROWS
+#define EGOTAP_BF16S_MIN_ROWS 512       // [r4] 4096 before: a B = 4 forward (2304 rows) took 2.1 ms on the fp32-tensor path, 1.5 ms on this one (B = 1: 1.46 -> 1.38)
+#endif
+    constexpr int g_bf16s_min_rows = EGOTAP_BF16S_MIN_ROWS;
+    const bool bf16s = h->precision == EGOTAP_PREC_BF16 && D == 1024 && M >= g_bf16s_min_rows && h->wscratch != nullptr &&
                        h->wscratch_bytes >= (size_t)2 * 2048 * (size_t)(h->ppd * h->ppd * D);
     // H1+H2: tile -> patch embed -> mask token -> + position embeddings
     if (bf16s) {

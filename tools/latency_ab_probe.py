@@ -14,7 +14,7 @@ net, sd, p = lift_net(sys.argv[1] if len(sys.argv) > 1 else "UnrealEgo")
 out = {}
 for B in (1, 2, 4, 8, 16, 32):
     hm = torch.from_numpy(synth_input("hm_lat", (B, p.in_channels, p.hm_size, p.hm_size))).cuda()
-    for mode in ("f32", "bf16x3"):
+    for mode in ("f32", "bf16x3", "bf16"):
         net.set_precision(mode)
         for _ in range(3):
             net.predict_pose(hm)
