@@ -919,13 +919,15 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     }
     }       // fp32 tensors in HBM
     // H13-H14: propagation units.  State-independent projections of all J steps as GEMMs (rows time-major t*B+b) ...
+    // ([r4] through fc_gemm: below 1024 rows -- serving batches: J rows per frame -- a 128-row tiling has one row tile and 4-16 column tiles,
+    // 24-41 us per launch at B = 1 for work the chip does in 2; K is split like the encoders' fc layers)
     const int x = 2 * hid, NF0 = H + x;
     ALoadStereo xs{POSZ, B, J, hid};
-    EGO_HIP((gemm<Tile>(h, "pu0_x2f", xs, segmat1(p.x2f0_w, NF0, x), EpiBias{segvec1(p.x2f0_b, NF0)}, F0, NF0, JB, NF0, x, s)));
-    EGO_HIP((gemm<Tile>(h, "pu0_x2h", xs, segmat1(p.x2h0_w, 4 * H, x), EpiBias{segvec1(p.x2h0_b, 4 * H)}, G0, 4L * H, JB, 4 * H, x, s)));
+    EGO_HIP((fc_gemm(h, "pu0_x2f", xs, segmat1(p.x2f0_w, NF0, x), EpiBias{segvec1(p.x2f0_b, NF0)}, F0, NF0, JB, NF0, x, SPK, s)));
+    EGO_HIP((fc_gemm(h, "pu0_x2h", xs, segmat1(p.x2h0_w, 4 * H, x), EpiBias{segvec1(p.x2h0_b, 4 * H)}, G0, 4L * H, JB, 4 * H, x, SPK, s)));
     {
         ALoadStereoGated bs{ALoadStereo{ROTZ, B, J, hid}, F0, NF0, H};
-        EGO_HIP((gemm<Tile>(h, "pu0_b2h", bs, segmat1(p.b2h0_w, 4 * H, x), EpiBiasRes{segvec1(p.b2h0_b, 4 * H), G0, 4L * H}, G0, 4L * H, JB, 4 * H, x, s)));
+        EGO_HIP((fc_gemm(h, "pu0_b2h", bs, segmat1(p.b2h0_w, 4 * H, x), EpiBiasRes{segvec1(p.b2h0_b, 4 * H), G0, 4L * H}, G0, 4L * H, JB, 4 * H, x, SPK, s)));
     }
     // ... then the two J-step recurrences (layer 0 never reads layer-1 state, so the layers run one after the other)
     EGO_HIP(zero_fill(C0, (size_t)(w.ZERO - w.C0) + al256((size_t)B * H * 4), s));   // C0, C1, ZERO are contiguous (256-byte aligned slices)
@@ -940,8 +942,8 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
                        t + 1 < J ? F0 + (size_t)(t + 1) * B * NF0 : nullptr, NF0, (t & 1) ? HPB : HPA, nullptr);
     }
     EGO_HIP(hipGetLastError());
-    EGO_HIP((gemm<Tile>(h, "pu1_x2f", ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, s)));
-    EGO_HIP((gemm<Tile>(h, "pu1_x2h", ALoadPlain{HS0, H}, segmat1(p.x2h1_w, 4 * H, H), EpiBias{segvec1(p.x2h1_b, 4 * H)}, G1, 4L * H, JB, 4 * H, H, s)));
+    EGO_HIP((fc_gemm(h, "pu1_x2f", ALoadPlain{HS0, H}, segmat1(p.x2f1_w, H, H), EpiBias{segvec1(p.x2f1_b, H)}, F1, H, JB, H, H, SPK, s)));
+    EGO_HIP((fc_gemm(h, "pu1_x2h", ALoadPlain{HS0, H}, segmat1(p.x2h1_w, 4 * H, H), EpiBias{segvec1(p.x2h1_b, 4 * H)}, G1, 4L * H, JB, 4 * H, H, SPK, s)));
     const PuChain ch1{F1, (long)B * H, H, G1, (long)B * 4 * H, nullptr, p.h2h1_w, p.h2h1_b, nullptr, 0, HS1, (long)B * H, HPA, (long)B * H, B, H, J,
                       FAULT, h->pu_fault_dev};
     if (!pu_chain_launch(s, h->pu_resident[0], h->pu_resident[1], ch1, B, h->pu_debug_drop))
