@@ -594,10 +594,23 @@ static hipError_t gemm_small(Handle* h, const char* role, const AL& al, const Se
                              int M, int N, int K, float* P, hipStream_t s) {
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const long fill = (h && h->precision != EGOTAP_PREC_F32) ? 64 : 160;
-    if (tiles256 >= fill || N % 128 != 0 || K % 32 != 0 || W.seg % 128 != 0) return gemm_big(h, role, al, W, epi, C, ldc, M, N, K, s);
+    if (N % 128 != 0 || K % 32 != 0 || W.seg % 128 != 0) return gemm_big(h, role, al, W, epi, C, ldc, M, N, K, s);
+    if (tiles256 >= fill) {
+        // [r4] fp32, plain operands, fewer than four rounds of 256 x 256 tiles: the 256 x 256 kernel runs WHOLE rounds at 0.92 of the matrix
+        // pipe (B = 8, N = 4096: 288 tiles = two rounds for 1.1 rounds of work, 484 us) -- the 128 x 128 kernel with its epilogue inside takes
+        // 415 us there.  Both estimates are fitted to tools/gemm_small_vs_big_probe.py and name the faster kernel at 46 of its 48 points.
+        if constexpr (std::is_same<AL, ALoadPlain>::value) {
+            const int cus = device_cu_count();
+            if (h && h->precision == EGOTAP_PREC_F32 && tiles256 < 4L * cus) {
+                const double t_big = (double)((tiles256 + cus - 1) / cus) * (K * 0.2319 + 5.0);  // us: 2 * 256 * 256 * K flop per tile at 0.92 x 157.3 TF / 256 CUs
+                if (gemm_f32_direct_estimate_us<TileA>(M, N, K, cus) < t_big) return gemm<TileA>(h, role, al, W, epi, C, ldc, M, N, K, s);
+            }
+        }
+        return gemm_big(h, role, al, W, epi, C, ldc, M, N, K, s);
+    }
     static const std::string kname = std::string("gemm_f32_splitk_kernel<128x128x32,") + AlName<AL>::v + ">+splitk_reduce_kernel<" + EpiName<Epi>::v + ">";
     GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
-    return gemm_f32_splitk_launch<TileA>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s);
+    return gemm_f32_splitk_launch<TileA>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s, device_cu_count());
 }
 
 // fc2 / fc3 of the two encoders: one or two 128-row tiles at small batch -> split K as fc1 does (same row threshold)

@@ -911,6 +911,38 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     C[(long)m * ldc + n] = epi.apply(s, epi.col(n), m, n);
 }
 
+// [r4] The split count with the least estimated time: a CU runs its ceil(tiles * splits / CUs) workgroups' K-slabs one after the other
+// on its four matrix pipes (1.7 us per 128 x 128 x 32 fp32 slab at the MFMA rate, ~1.9 measured; ~2.1 when the workgroup is alone on its CU:
+// one wave per SIMD and nothing to run under its loads) + ~2.5 us per workgroup (first slab's round trip, partial store), and the partials
+// cost their bytes twice.  The doubling rule it replaces overshot (qkv at B = 1: 120 tiles x 8 = 960 workgroups of 4 slabs each, 56 MB of
+// partials, 44.8 us; 2 splits: one workgroup per CU) or left half-empty rounds (N = 4096: 160 x 4 = 2.5 per CU).
+struct SplitPlan { int splits; double us; };
+template <class Cfg>
+static inline SplitPlan gemm_f32_splitk_plan(int M, int N, int K, size_t p_floats, int num_cu) {
+    const int KT = K / Cfg::BK, tiles = ((M + Cfg::BM - 1) / Cfg::BM) * (N / Cfg::BN);
+    SplitPlan best{1, 1e30};
+    for (int sp = 1; sp <= 32; ++sp) {
+        const int kp = (KT + sp - 1) / sp;
+        if ((sp > 1 && kp < 4) || (long)kp * (sp - 1) >= KT) continue;      // at least 4 slabs per range; no empty last range
+        if ((size_t)sp * M * N > p_floats) break;
+        const int per_cu = (tiles * sp + num_cu - 1) / num_cu;
+        const double t = per_cu * (kp * (per_cu == 1 ? 2.1 : 1.9) + 2.5) + (sp > 1 ? 2.0 * sp * (double)M * N * 4 / 4.0e6 : 0.0);
+        if (t < best.us - 1e-9) best = SplitPlan{sp, t};
+    }
+    return best;
+}
+// Estimated time (us) of the same 128 x 128 kernel WITHOUT a split, its epilogue inside (gemm_f32_launch), for shapes with many slabs per
+// tile -- fitted to tools/gemm_small_vs_big_probe.py (48 shapes, M = 3456 ... 55296, K = 1024 / 4096): p = tiles / CUs workgroups per CU.
+// p <= 1: every workgroup is alone on its CU: 2.3 us per slab + 15.  p > 1: two workgroups share a CU (1.95 us per slab each + 10) and the
+// dispatcher hands a CU whose pair has finished the next PAIR, so rounds come in twos: ceil(p / 2) x 2 x that -- p = 2.25 costs what p = 3.4
+// costs (1016 / 1028 us at K = 4096).  Within 3 % of every K = 4096 point, 10 % of every K = 1024 one.
+template <class Cfg>
+static inline double gemm_f32_direct_estimate_us(int M, int N, int K, int num_cu) {
+    const int KT = K / Cfg::BK, tiles = ((M + Cfg::BM - 1) / Cfg::BM) * (N / Cfg::BN);
+    const double p = (double)tiles / num_cu;
+    return p <= 1.0 ? 2.3 * KT + 15.0 : ceil(p / 2.0) * 2.0 * (1.95 * KT + 10.0);
+}
+
 // P: scratch of at least splits * M * N floats; returns hipErrorInvalidValue for shapes the tile does not cover
 template <class Cfg, class ALoad, class Epi>
 static hipError_t gemm_f32_splitk_launch(const ALoad& al, const SegMat& W, const Epi& epi, float* C, long ldc, float* P, size_t p_floats, int M,
@@ -918,22 +950,8 @@ static hipError_t gemm_f32_splitk_launch(const ALoad& al, const SegMat& W, const
     if (M <= 0) return hipSuccess;
     if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0) return hipErrorInvalidValue;
     const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
-    // [r4] The split count with the least estimated time: a CU runs its ceil(tiles * splits / CUs) workgroups' K-slabs one after the other
-    // on its four matrix pipes (1.7 us per 128 x 128 x 32 fp32 slab) + ~2.5 us per workgroup (first slab's round trip, partial store), and
-    // the partials cost their bytes twice.  The doubling rule it replaces overshot (qkv at B = 1: 120 tiles x 8 = 960 workgroups of 4
-    // slabs each, 56 MB of partials, 44.8 us; 2 splits: one workgroup per CU) or left half-empty rounds (N = 4096: 160 x 4 = 2.5 per CU).
-    const int KT = K / Cfg::BK, tiles = tiles_m * tiles_n;
-    int splits = 1;
-    double best = 1e30;
-    for (int sp = 1; sp <= 32; ++sp) {
-        const int kp = (KT + sp - 1) / sp;
-        if ((sp > 1 && kp < 4) || (long)kp * (sp - 1) >= KT) continue;      // at least 4 slabs per range; no empty last range
-        if ((size_t)sp * M * N > p_floats) break;
-        const int per_cu = (tiles * sp + num_cu - 1) / num_cu;
-        // (a workgroup alone on its CU has one wave per SIMD and nothing to run under its loads: ~2.0 us per slab, measured on fc1 at B = 32)
-        const double t = per_cu * (kp * (per_cu == 1 ? 2.0 : 1.7) + 2.5) + (sp > 1 ? 2.0 * sp * (double)M * N * 4 / 4.0e6 : 0.0);
-        if (t < best - 1e-9) { best = t; splits = sp; }
-    }
+    const int KT = K / Cfg::BK;
+    const int splits = gemm_f32_splitk_plan<Cfg>(M, N, K, p_floats, num_cu).splits;
     if ((size_t)splits * M * N > p_floats) return hipErrorInvalidValue;
     const int kper = ((KT + splits - 1) / splits) * Cfg::BK;
     auto kern = gemm_f32_splitk_kernel<Cfg, ALoad>;
