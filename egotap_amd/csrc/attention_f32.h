@@ -28,7 +28,10 @@ struct AttnCfg {
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* __restrict__ QKV,
                                                                  float* __restrict__ CTX, int N, int heads,
-                                                                 int qgroups, float scale_log2e, float* __restrict__ LSE) {
+                                                                 int qgroups, float scale_log2e, float* __restrict__ LSE, int ksplit) {
+    // [r4] ksplit > 1 (serving batches: B x heads x query groups is a fraction of the chip): workgroup (pair, query group, split) attends to
+    // key tiles [split * ntiles / ksplit, ...) only and writes its own normalised output and log-sum-exp -- CTX / LSE are then the PARTIAL
+    // buffers [ksplit][B * N][D] / [ksplit][B * heads * N], merged by attention_f32_merge_kernel.
     using Cfg = AttnCfg<NW>;
     constexpr int DH = Cfg::DH, KT = Cfg::KT, KLD = Cfg::KLD, THREADS = Cfg::THREADS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -39,7 +42,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int q8 = nblk >> 3, r8 = nblk & 7, x8 = bid & 7;
     const int lin = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (bid >> 3);
-    const int bh = lin / qgroups, qg = lin - bh * qgroups;
+    const int split = ksplit > 1 ? lin % ksplit : 0;
+    const int lq = ksplit > 1 ? lin / ksplit : lin;
+    const int bh = lq / qgroups, qg = lq - bh * qgroups;
     const int b = bh / heads, h = bh - b * heads;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -90,19 +95,21 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
             else *(f32x4*)(Ks + row * KLD + c4 * 4) = stg[i];
         }
     };
-    const int ntiles = N / KT;
-    // prologue: K(0) and V(0) into LDS, K(1) into the staging registers
-    tile_req(0, 0);
+    const int tiles_all = N / KT;
+    const int kt0 = ksplit > 1 ? (int)((long)split * tiles_all / ksplit) : 0;
+    const int ntiles = ksplit > 1 ? (int)((long)(split + 1) * tiles_all / ksplit) : tiles_all;      // one past this workgroup's last key tile
+    // prologue: K(kt0) and V(kt0) into LDS, K(kt0 + 1) into the staging registers
+    tile_req(kt0, 0);
     tile_put(0);
-    tile_req(0, 1);
+    tile_req(kt0, 1);
     tile_put(1);
-    if (ntiles > 1) tile_req(1, 0);
+    if (kt0 + 1 < ntiles) tile_req(kt0 + 1, 0);
     __syncthreads();
     // The running maximum is raised (and the output rescaled) only when a query's scores exceed it by more than 2^RESC in the
     // softmax's base-2 units (T13): probabilities stay below 2^RESC -- harmless in fp32 -- and the 64 multiplies per tile vanish
     // from almost every tile.
     constexpr float RESC = 8.0f;
-    for (int kt = 0; kt < ntiles; ++kt) {
+    for (int kt = kt0; kt < ntiles; ++kt) {
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -164,7 +171,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
         // training: log-sum-exp of the scaled scores (natural log) per query row, for the flash-style backward
-        if (LSE != nullptr && lh == 0) LSE[((long)b * heads + h) * N + qb * 32 + l31] = m_run * 0.6931471805599453f + logf(l_tot);      // m_run is in base-2 units
+        const long part = ksplit > 1 ? (long)split * (gridDim.x / (ksplit * qgroups)) : 0;      // split * (B * heads): offset of this split's partial buffers, in pairs
+        if (LSE != nullptr && lh == 0) LSE[(part + (long)b * heads + h) * N + qb * 32 + l31] = m_run * 0.6931471805599453f + logf(l_tot);      // m_run is in base-2 units
         float* Os = smem + wid * 32 * KLD;     // [32 q][132]
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
                 *(f32x4*)(Os + l31 * KLD + dt * 32 + 8 * g + 4 * lh) = v;
             }
         // same wave reads back what it wrote: no barrier needed, only LDS completion (compiler waits)
-        float* out = CTX + ((long)b * N + qb * 32) * D + h * DH;
+        float* out = CTX + (part / heads * N + (long)b * N + qb * 32) * D + h * DH;       // (part / heads = split * B images)
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int row = it * 2 + lh;
@@ -186,8 +194,43 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
     }
 }
 
+// ctx[b, n, h, :] = sum_s w_s part_s[b, n, h, :],  w_s = exp(lse_s - lse) / sum_s' exp(lse_s' - lse): the exact merge of softmax attention over
+// disjoint key ranges (each part is normalised by its own sum).  One thread = 4 channels of one (token, head).
+static __global__ __launch_bounds__(256) void attention_f32_merge_kernel(const float* __restrict__ part, const float* __restrict__ lse_part, float* __restrict__ ctx,
+                                                                         int B, int N, int heads, int ksplit) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;         // over B * N * heads * 32 float4
+    const long total = (long)B * N * heads * 32;
+    if (i >= total) return;
+    const int c4 = (int)(i & 31);
+    const long t = i >> 5;                                              // (b * N + n) * heads + h
+    const int h = (int)(t % heads);
+    const long bn = t / heads;
+    const int b = (int)(bn / N), n = (int)(bn - (long)b * N);
+    float l[8], m = -INFINITY;
+    for (int sp = 0; sp < ksplit; ++sp) {
+        l[sp] = lse_part[(((long)sp * B + b) * heads + h) * N + n];
+        m = fmaxf(m, l[sp]);
+    }
+    float wsum = 0.f;
+    for (int sp = 0; sp < ksplit; ++sp) {
+        l[sp] = expf(l[sp] - m);
+        wsum += l[sp];
+    }
+    const float inv = 1.0f / wsum;
+    f32x4 acc{0.f, 0.f, 0.f, 0.f};
+    const long D = (long)heads * 128, off = bn * D + h * 128 + c4 * 4;
+    for (int sp = 0; sp < ksplit; ++sp) {
+        const f32x4 v = *(const f32x4*)(part + (long)sp * B * N * D + off);
+        const float w = l[sp] * inv;
+        acc[0] += w * v[0]; acc[1] += w * v[1]; acc[2] += w * v[2]; acc[3] += w * v[3];
+    }
+    *(f32x4*)(ctx + off) = acc;
+}
+
+// scratch / scratch_floats (inference at serving batches only; LSE must be null): room for the key-split partials.  The split count
+// fills ~1.5 workgroups per CU: B = 1 (72 workgroups) -> 6 splits of 3 key tiles, B = 2 -> 3, B >= 4 -> none.
 static hipError_t attention_f32_launch(const float* QKV, float* CTX, int B, int N, int heads, hipStream_t stream,
-                                       float* LSE = nullptr) {
+                                       float* LSE = nullptr, float* scratch = nullptr, size_t scratch_floats = 0, int num_cu = 256) {
     constexpr int NW = 2;
     using Cfg = AttnCfg<NW>;
     if (B <= 0) return hipSuccess;
@@ -195,8 +238,26 @@ static hipError_t attention_f32_launch(const float* QKV, float* CTX, int B, int 
     auto kern = attention_f32_kernel<NW>;
     const int qgroups = (N / 32 + NW - 1) / NW;
     const float scale_log2e = 1.4426950408889634f / sqrtf(128.0f);
+    const long wgs = (long)B * heads * qgroups;
+    int ksplit = 1;
+    if (scratch != nullptr && LSE == nullptr) {
+        const int ntiles = N / 32;
+        for (int k = 8; k >= 2; --k)
+            if (ntiles % k == 0 && wgs * k <= 3L * num_cu / 2 + wgs && (size_t)k * ((size_t)B * N * heads * 128 + (size_t)B * heads * N) <= scratch_floats) { ksplit = k; break; }
+        if (wgs * 2 > 3L * num_cu / 2) ksplit = 1;
+    }
+    if (ksplit > 1) {
+        float* part = scratch;
+        float* lse_part = scratch + (size_t)ksplit * B * N * heads * 128;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(wgs * ksplit)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, QKV, part, N, heads, qgroups, scale_log2e, lse_part, ksplit);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const long total = (long)B * N * heads * 32;
+        hipLaunchKernelGGL(attention_f32_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const float*)part, (const float*)lse_part, CTX, B, N, heads, ksplit);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(kern, dim3(B * heads * qgroups), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, QKV, CTX, N, heads,
-                       qgroups, scale_log2e, LSE);
+                       qgroups, scale_log2e, LSE, 1);
     return hipGetLastError();
 }
 #endif

@@ -896,7 +896,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
         }
         if (h->precision == EGOTAP_PREC_BF16X3) EGO_HIP(attention_bf16_launch<3>(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
         else if (h->precision == EGOTAP_PREC_BF16) EGO_HIP(attention_bf16_launch<1>(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
-        else EGO_HIP(attention_f32_launch(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
+        else EGO_HIP(attention_f32_launch(QKV, CTX, B, h->seq, h->cfg.vit_heads, s, nullptr, SPK, SPLITK_FLOATS, device_cu_count()));   // (SPK: free between the GEMMs; key-split partials at B <= 2)
         EGO_HIP((gemm_small(h, "attn_out", ALoadPlain{CTX, D}, segmat1(L.o_w, D, D), EpiBiasRes{segvec1(L.o_b, D), X, D}, X, D, M, D, D, SPK, s)));
         EGO_HIP(launch_ln(X, Y, L.ln2_g, L.ln2_b, M, 1e-12f, s));
         EGO_HIP((gemm_small(h, "mlp_up", ALoadPlain{Y, D}, segmat1(L.up_w, 4 * D, D), EpiBiasGelu{segvec1(L.up_b, 4 * D)}, HID, 4L * D, M, 4 * D, D, SPK, s)));

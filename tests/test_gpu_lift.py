@@ -60,7 +60,7 @@ def test_vit_hidden_states_match_golden():
         lib.check(L.egotap_lift_debug_stop(net._ensure_handle(), 0))
 
 
-@pytest.mark.parametrize("preset,B", [("UnrealEgo", 3), ("EgoCap", 1), ("UnrealEgo", 5)])
+@pytest.mark.parametrize("preset,B", [("UnrealEgo", 3), ("EgoCap", 1), ("UnrealEgo", 5), ("UnrealEgo", 1), ("UnrealEgo", 2)])      # (B = 1 / 2: key-split attention, 6 / 3 ranges)
 def test_lift_forward_matches_oracle(preset, B):
     from gpu_util import lift_net
     from oracle import lift_ref as O
