@@ -417,18 +417,45 @@ static __global__ __launch_bounds__(256) void pose_head_kernel(const float* __re
     // grid (B, J + 1): block (b, j) = joint j of sample b, block (b, J) = the head joint (UnrealEgo).  Wave c < 3 owns coordinate c:
     // it computes the global output it needs itself (offset c for a joint, head coordinate c for the head block -- a 7680-long dot,
     // recomputed per joint: 16 x redundant and free) and then its joint's dot, so no wave waits for another and a B = 1 forward
-    // spreads over 17 workgroups instead of running 54 dots on 4 waves (119 us).  Per-lane order and the wave reduction are the
-    // one-block-per-sample kernel's: same bits.
+    // spreads over 17 workgroups instead of running 54 dots on 4 waves (119 us).
     const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63, c = tid >> 6;
     if (c >= 3 || (j == J && !estimate_head)) return;
     float other = 0.f;
     if (estimate_head) {
         const int o = j == J ? 3 + c : c;
         float s = 0.f;
-        for (int jj = 0; jj < J; ++jj) {
-            const float* hrow = hseq + ((long)jj * B + b) * H;
-            const float* wrow = Wg + (long)o * J * H + (long)jj * H;
-            for (int u = lane; u < H; u += 64) s += hrow[u] * wrow[u];
+        if (H == 512) {
+            // [r4] The 7680-long dot streams 61 KB per wave that nobody has touched yet: every (load, load, fma) round of the scalar loop below
+            // was a full miss (48 us of a 1.4 ms B = 1 forward).  Five rows of h and of W are requested at once (20 x 16 bytes per lane),
+            // three round trips in all.  Every batch size runs this same order, so rows stay bit-identical across batch sizes.
+            f32x4 acc{0.f, 0.f, 0.f, 0.f};
+            for (int j0 = 0; j0 < J; j0 += 5) {
+                f32x4 a[5][2], w[5][2];
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const int jj = min(j0 + r, J - 1);
+                    const float* hrow = hseq + ((long)jj * B + b) * H + 4 * lane;
+                    const float* wrow = Wg + (long)o * J * H + (long)jj * H + 4 * lane;
+                    a[r][0] = *(const f32x4*)hrow; a[r][1] = *(const f32x4*)(hrow + 256);
+                    w[r][0] = *(const f32x4*)wrow; w[r][1] = *(const f32x4*)(wrow + 256);
+                }
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    if (j0 + r < J) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[e] += a[r][q][e] * w[r][q][e];
+                    }
+                }
+            }
+            s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        } else {
+            for (int jj = 0; jj < J; ++jj) {
+                const float* hrow = hseq + ((long)jj * B + b) * H;
+                const float* wrow = Wg + (long)o * J * H + (long)jj * H;
+                for (int u = lane; u < H; u += 64) s += hrow[u] * wrow[u];
+            }
         }
         s = wave_sum(s);
         other = s + bg[o];
