@@ -67,6 +67,8 @@ using TileD = GemmCfg<256, 256, 16, 4, 2, 2>;   // 8 waves, 64x128 per wave, 1 b
 using TileE = GemmCfg<256, 128, 16, 2, 2, 2>;   // 4 waves, 128x64 per wave, 2 blocks/CU
 using TileF = GemmCfg<64, 64, 32, 2, 2, 2>;     // 4 waves, 32x32 per wave (small problems)
 using TileG = GemmCfg<256, 128, 32, 2, 2, 1>;   // 4 waves, 128x64 per wave, 1 block/CU
+using TileS = GemmCfg<64, 128, 32, 2, 2, 2>;    // [r4] 4 waves, 32x64 per wave: GEMMs of at most 64 rows (the encoders' fc layers and the PU projections at B <= 2-4) --
+                                                // on the 128-row tile a 30-row product is paced by its MFMAs on 98 rows of zeros (fc1 at B = 1: 1.7 TB/s of weights)
 using PipeA = PipeCfg<128, 128, 16, 2, 2, 2>;   // pipelined: 3 x 20 KiB slabs, 2 blocks/CU
 using PipeB = PipeCfg<128, 128, 32, 2, 2, 1>;   // pipelined: 3 x 36 KiB slabs, 1 block/CU
 using PipeC = PipeCfg<256, 128, 16, 4, 2, 2>;   // pipelined, 8 waves: 3 x 30 KiB slabs, 1 block/CU
@@ -608,6 +610,18 @@ static hipError_t gemm_small(Handle* h, const char* role, const AL& al, const Se
         }
         return gemm_big(h, role, al, W, epi, C, ldc, M, N, K, s);
     }
+    if (M <= 640) {   // [r4] one frame (576 rows = 4.5 tiles of 128 rows): the 64-row tile when its plan is estimated faster -- nine row tiles exactly, up
+        // to one workgroup per CU without a split (qkv: 216 tiles, epilogue in the kernel: no partials, no reduce launch).  Measured: B = 1 forward
+        // -33 us; from two frames on the 64-row tile loses what it gains (its slab is shorter than a load's round trip), so the rule stops here.
+        const int cus = device_cu_count();
+        const SplitPlan pa = gemm_f32_splitk_plan<TileA>(M, N, K, SPLITK_FLOATS, cus), ps = gemm_f32_splitk_plan<TileS>(M, N, K, SPLITK_FLOATS, cus);
+        if (ps.us < pa.us) {
+            if (ps.splits == 1) return gemm<TileS>(h, role, al, W, epi, C, ldc, M, N, K, s);
+            static const std::string kname64 = std::string("gemm_f32_splitk_kernel<64x128x32,") + AlName<AL>::v + ">+splitk_reduce_kernel<" + EpiName<Epi>::v + ">";
+            GemmTimer t(h, s, role, kname64.c_str(), 2.0 * M * N * K);
+            return gemm_f32_splitk_launch<TileS>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s, cus);
+        }
+    }
     static const std::string kname = std::string("gemm_f32_splitk_kernel<128x128x32,") + AlName<AL>::v + ">+splitk_reduce_kernel<" + EpiName<Epi>::v + ">";
     GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
     return gemm_f32_splitk_launch<TileA>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s, device_cu_count());
@@ -623,6 +637,11 @@ static hipError_t fc_gemm(Handle* h, const char* role, const AL& al, const SegMa
     const bool few_tiles = h && h->precision == EGOTAP_PREC_BF16 && 2L * ((M + 127) / 128) * (N / 128) <= device_cu_count() &&
                            (size_t)M * N * 8 <= SPLITK_FLOATS;
     if ((M >= SKINNY_ROWS && !few_tiles) || N % 128 != 0 || K % 32 != 0) return gemm<TileA>(h, role, al, W, epi, C, ldc, M, N, K, s);
+    if (M <= 64) {
+        static const std::string kname64 = std::string("gemm_f32_splitk_kernel<64x128x32,") + AlName<AL>::v + ">+splitk_reduce_kernel<" + EpiName<Epi>::v + ">";
+        GemmTimer t(h, s, role, kname64.c_str(), 2.0 * M * N * K);
+        return gemm_f32_splitk_launch<TileS>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s, device_cu_count());
+    }
     static const std::string kname = std::string("gemm_f32_splitk_kernel<128x128x32,") + AlName<AL>::v + ">+splitk_reduce_kernel<" + EpiName<Epi>::v + ">";
     GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
     return gemm_f32_splitk_launch<TileA>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s);
@@ -913,7 +932,9 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     {
         const int K1 = h->ppd * h->ppd * D;
         ALoadTokens al{Y, h->T, D, h->seq, h->side, h->ppd, h->grid};
-        if (skinny_fc1)            // few row tiles: split K over the CUs
+        if (skinny_fc1 && BT <= 64)     // [r4] at most 64 rows: the 64-row tile (TileS)
+            EGO_HIP((gemm_f32_splitk_launch<TileS>(al, segmat1(p.pos_fc[0].w, 2048, K1), bn(p.pos_fc[0]), Z1, 2048, SPK, SPLITK_FLOATS, BT, 2048, K1, s, device_cu_count())));
+        else if (skinny_fc1)       // few row tiles: split K over the CUs
             EGO_HIP((gemm_f32_splitk_launch<TileA>(al, segmat1(p.pos_fc[0].w, 2048, K1), bn(p.pos_fc[0]), Z1, 2048, SPK, SPLITK_FLOATS, BT, 2048, K1, s)));
         else
             EGO_HIP((gemm_big(h, "pos_fc1", al, segmat1(p.pos_fc[0].w, 2048, K1), bn(p.pos_fc[0]), Z1, 2048, BT, 2048, K1, s)));
@@ -923,7 +944,9 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
     // H11-H12: rotation (cos/sin) heatmaps straight from the input tensor
     {
         ALoadRot al{hm, h->C, J, HW};
-        if (skinny_fc1)
+        if (skinny_fc1 && BT <= 64)
+            EGO_HIP((gemm_f32_splitk_launch<TileS>(al, segmat1(p.rot_fc[0].w, 2048, 2L * HW), bn(p.rot_fc[0]), Z1, 2048, SPK, SPLITK_FLOATS, BT, 2048, 2 * HW, s, device_cu_count())));
+        else if (skinny_fc1)
             EGO_HIP((gemm_f32_splitk_launch<TileA>(al, segmat1(p.rot_fc[0].w, 2048, 2L * HW), bn(p.rot_fc[0]), Z1, 2048, SPK, SPLITK_FLOATS, BT, 2048, 2 * HW, s)));
         else
             EGO_HIP((gemm_big(h, "rot_fc1", al, segmat1(p.rot_fc[0].w, 2048, 2L * HW), bn(p.rot_fc[0]), Z1, 2048, BT, 2048, 2 * HW, s)));

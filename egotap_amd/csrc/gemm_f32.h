@@ -926,7 +926,8 @@ static inline SplitPlan gemm_f32_splitk_plan(int M, int N, int K, size_t p_float
         if ((sp > 1 && kp < 4) || (long)kp * (sp - 1) >= KT) continue;      // at least 4 slabs per range; no empty last range
         if ((size_t)sp * M * N > p_floats) break;
         const int per_cu = (tiles * sp + num_cu - 1) / num_cu;
-        const double t = per_cu * (kp * (per_cu == 1 ? 2.1 : 1.9) + 2.5) + (sp > 1 ? 2.0 * sp * (double)M * N * 4 / 4.0e6 : 0.0);
+        constexpr double AREA = (double)Cfg::BM * Cfg::BN / (128.0 * 128.0);      // slab time scales with the tile's MFMA count (the constants are the 128 x 128 tile's)
+        const double t = per_cu * (kp * (per_cu == 1 ? 2.1 : 1.9) * AREA + 2.5) + (sp > 1 ? 2.0 * sp * (double)M * N * 4 / 4.0e6 : 0.0);
         if (t < best.us - 1e-9) best = SplitPlan{sp, t};
     }
     return best;
