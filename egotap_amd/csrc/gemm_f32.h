@@ -343,14 +343,17 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_kernel(
 #pragma unroll
     for (int i = 0; i < B_V4; ++i) brow[i] = W.row(bn + r0 + i * RPP);
 
-    f32x4 pa[A_V4], pb[B_V4];
-    auto gload = [&](int k0) {
+    // [r4] global loads run TWO slabs ahead in two register sets (slab j: set j & 1 from its request to its LDS write): with one set a slab's
+    // loads had the length of one slab's MFMAs to arrive, which a workgroup alone on its CU (serving batches: one wave per SIMD, 1.7 us per
+    // 128 x 128 slab, 0.85 for 64 x 128) does not cover -- a 64-row tile ran at 1.5 us per slab
+    f32x4 pa0[A_V4], pb0[B_V4], pa1[A_V4], pb1[B_V4];
+    auto gload = [&](f32x4 (&pa)[A_V4], f32x4 (&pb)[B_V4], int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) pa[i] = al.load(arow[i], k0 + c4 * 4);
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) pb[i] = *(const f32x4*)(brow[i] + k0 + c4 * 4);
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const f32x4 (&pa)[A_V4], const f32x4 (&pb)[B_V4], int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) *(f32x4*)(As + (buf * BM + r0 + i * RPP) * LDK + c4 * 4) = pa[i];
 #pragma unroll
@@ -365,13 +368,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int KT = K / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) gload((kt + 1) * BK);
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const float* Ab = As + (buf * BM + wm * (TM * 32) + l31) * LDK + 4 * lh;
         const float* Bb = Bs + (buf * BN + wn * (TN * 32) + l31) * LDK + 4 * lh;
 #pragma unroll
@@ -389,8 +386,36 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_kernel(
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[j][u], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) lstore(buf ^ 1);
+    };
+    const int KT = K / BK;
+    constexpr bool DEEP = TM * TN <= 4 && A_V4 + B_V4 <= 8;     // (the wide tiles of the sweep tool have no registers for a second set: one slab ahead)
+    if constexpr (DEEP) {
+        gload(pa0, pb0, 0);
+        lstore(pa0, pb0, 0);
+        if (KT > 1) gload(pa1, pb1, BK);
         __syncthreads();
+        for (int kt = 0; kt < KT; kt += 2) {
+            if (kt + 2 < KT) gload(pa0, pb0, (kt + 2) * BK);
+            compute(0);
+            if (kt + 1 < KT) lstore(pa1, pb1, 1);
+            __syncthreads();
+            if (kt + 1 >= KT) break;
+            if (kt + 3 < KT) gload(pa1, pb1, (kt + 3) * BK);
+            compute(1);
+            if (kt + 2 < KT) lstore(pa0, pb0, 0);
+            __syncthreads();
+        }
+    } else {
+        gload(pa0, pb0, 0);
+        lstore(pa0, pb0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < KT) gload(pa0, pb0, (kt + 1) * BK);
+            compute(buf);
+            if (kt + 1 < KT) lstore(pa0, pb0, buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // epilogue: acc reg r of lane l is C[32x32 tile row (r&3) + 8*(r>>2) + 4*(l>>5)][col l&31]
@@ -834,14 +859,14 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_splitk_kerne
     for (int i = 0; i < A_V4; ++i) arow[i] = al.row(min(bm + r0 + i * RPP, M - 1));
 #pragma unroll
     for (int i = 0; i < B_V4; ++i) brow[i] = W.row(bn + r0 + i * RPP);
-    f32x4 pa[A_V4], pb[B_V4];
-    auto gload = [&](int k0) {
+    f32x4 pa0[A_V4], pb0[B_V4], pa1[A_V4], pb1[B_V4];      // two register sets: loads run two slabs ahead (gemm_f32_kernel)
+    auto gload = [&](f32x4 (&pa)[A_V4], f32x4 (&pb)[B_V4], int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) pa[i] = al.load(arow[i], k0 + c4 * 4);
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) pb[i] = *(const f32x4*)(brow[i] + k0 + c4 * 4);
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const f32x4 (&pa)[A_V4], const f32x4 (&pb)[B_V4], int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) *(f32x4*)(As + (buf * BM + r0 + i * RPP) * LDK + c4 * 4) = pa[i];
 #pragma unroll
@@ -854,16 +879,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_splitk_kerne
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int k_lo = split * kper, k_hi = min(K, k_lo + kper);
-    const int KT = (k_hi - k_lo) / BK;
-    if (KT > 0) {
-        gload(k_lo);
-        lstore(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) gload(k_lo + (kt + 1) * BK);
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const float* Ab = As + (buf * BM + wm * (TM * 32) + l31) * LDK + 4 * lh;
         const float* Bb = Bs + (buf * BN + wn * (TN * 32) + l31) * LDK + 4 * lh;
 #pragma unroll
@@ -881,7 +897,24 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MINW) void gemm_f32_splitk_kerne
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u], b[j][u], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) lstore(buf ^ 1);
+    };
+    const int k_lo = split * kper, k_hi = min(K, k_lo + kper);
+    const int KT = (k_hi - k_lo) / BK;
+    if (KT > 0) {
+        gload(pa0, pb0, k_lo);
+        lstore(pa0, pb0, 0);
+        if (KT > 1) gload(pa1, pb1, k_lo + BK);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt += 2) {
+        if (kt + 2 < KT) gload(pa0, pb0, k_lo + (kt + 2) * BK);
+        compute(0);
+        if (kt + 1 < KT) lstore(pa1, pb1, 1);
+        __syncthreads();
+        if (kt + 1 >= KT) break;
+        if (kt + 3 < KT) gload(pa1, pb1, k_lo + (kt + 3) * BK);
+        compute(1);
+        if (kt + 2 < KT) lstore(pa0, pb0, 0);
         __syncthreads();
     }
     float* out = P + (long)split * M * N;
