@@ -67,7 +67,7 @@ using TileD = GemmCfg<256, 256, 16, 4, 2, 2>;   // 8 waves, 64x128 per wave, 1 b
 using TileE = GemmCfg<256, 128, 16, 2, 2, 2>;   // 4 waves, 128x64 per wave, 2 blocks/CU
 using TileF = GemmCfg<64, 64, 32, 2, 2, 2>;     // 4 waves, 32x32 per wave (small problems)
 using TileG = GemmCfg<256, 128, 32, 2, 2, 1>;   // 4 waves, 128x64 per wave, 1 block/CU
-using TileS = GemmCfg<64, 128, 32, 2, 2, 2>;    // [r4] 4 waves, 32x64 per wave: GEMMs of at most 64 rows (the encoders' fc layers and the PU projections at B <= 2-4) --
+using TileS = GemmCfg<64, 128, 32, 2, 4, 1>;    // [r4] 8 waves, 32x32 per wave (two waves per SIMD when the workgroup is alone on its CU: -1.8 % on a B = 1 forward against 4 waves): GEMMs of at most 64 rows (the encoders' fc layers and the PU projections at B <= 2-4) --
                                                 // on the 128-row tile a 30-row product is paced by its MFMAs on 98 rows of zeros (fc1 at B = 1: 1.7 TB/s of weights)
 using PipeA = PipeCfg<128, 128, 16, 2, 2, 2>;   // pipelined: 3 x 20 KiB slabs, 2 blocks/CU
 using PipeB = PipeCfg<128, 128, 32, 2, 2, 1>;   // pipelined: 3 x 36 KiB slabs, 1 block/CU
