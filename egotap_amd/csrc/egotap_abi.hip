@@ -791,6 +791,33 @@ static hipError_t launch_ln(const float* x, float* y, const float* g, const floa
 }
 
 #if EGOTAP_IN(0)
+// [r4] x = x + ctx W^T + bias, y = LayerNorm(x): at serving batches (the product is split over K) the reduce of the partials and the LayerNorm
+// that follows are ONE launch (splitk_reduce_res_ln_kernel: same bits as the two); otherwise gemm_small + launch_ln as before.
+static hipError_t gemm_res_ln(Handle* h, const char* role, const float* A, long lda, const float* Wp, const float* bias, float* X, int M, int D, int K,
+                              const float* ln_g, const float* ln_b, float* Y, float* P, hipStream_t s) {
+    const long tiles256 = (long)((M + 255) / 256) * (D / 256);
+    const long fill = (h && h->precision != EGOTAP_PREC_F32) ? 64 : 160;
+    if (D == 1024 && K % 32 == 0 && tiles256 < fill) {
+        const int cus = device_cu_count();
+        const SplitPlan pa = gemm_f32_splitk_plan<TileA>(M, D, K, SPLITK_FLOATS, cus), ps = gemm_f32_splitk_plan<TileS>(M, D, K, SPLITK_FLOATS, cus);
+        const bool s64 = M <= 640 && ps.us < pa.us;          // (gemm_small's rule)
+        if ((s64 ? ps.splits : pa.splits) > 1) {
+            static const std::string kname = "gemm_f32_splitk_kernel<ALoadPlain>+splitk_reduce_res_ln_kernel";
+            GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * D * K);
+            int splits = 1;
+            hipError_t e = s64 ? gemm_f32_splitk_partials<TileS>(ALoadPlain{A, lda}, segmat1(Wp, D, K), P, SPLITK_FLOATS, M, D, K, s, cus, &splits)
+                               : gemm_f32_splitk_partials<TileA>(ALoadPlain{A, lda}, segmat1(Wp, D, K), P, SPLITK_FLOATS, M, D, K, s, cus, &splits);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(splitk_reduce_res_ln_kernel<1024>, dim3(min((M + 3) / 4, 256 * 8)), dim3(256), 0, s, (const float*)P, bias, (const float*)X, X, ln_g,
+                               ln_b, Y, M, splits, 1e-12f);
+            return hipGetLastError();
+        }
+    }
+    hipError_t e = gemm_small(h, role, ALoadPlain{A, lda}, segmat1(Wp, D, K), EpiBiasRes{segvec1(bias, D), X, D}, X, D, M, D, K, P, s);
+    if (e != hipSuccess) return e;
+    return launch_ln(X, Y, ln_g, ln_b, M, 1e-12f, s);
+}
+
 extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, float* pose, void* ws, size_t ws_bytes,
                                    void* stream) {
     EGO_CHECK(h, "null handle");
@@ -904,10 +931,12 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
             EGO_HIP((fc_gemm(h, "rot_fc3", ALoadPlain{Z2, 512}, segmat1(p.rot_fc[2].w, hid, 512), bn(p.rot_fc[2]), ROTZ, hid, BT, hid, 512, SPK, s)));
         }
     } else {
-    // H3-H8: pre-LN transformer layers
-    for (int i = 0; i < h->cfg.vit_layers; ++i) {
+    // H3-H8: pre-LN transformer layers.  [r4] Every LayerNorm but the first follows a residual projection: gemm_res_ln runs the two as one launch
+    // where the projection is split over K (serving batches); ln1 of layer i + 1 (or the final LayerNorm) therefore rides with layer i's MLP.
+    const int NL = h->cfg.vit_layers;
+    EGO_HIP(launch_ln(X, Y, NL > 0 ? p.layer[0].ln1_g : p.lnf_g, NL > 0 ? p.layer[0].ln1_b : p.lnf_b, M, 1e-12f, s));
+    for (int i = 0; i < NL; ++i) {
         const auto& L = p.layer[i];
-        EGO_HIP(launch_ln(X, Y, L.ln1_g, L.ln1_b, M, 1e-12f, s));
         {
             SegMat Wqkv; Wqkv.p[0] = L.q_w; Wqkv.p[1] = L.k_w; Wqkv.p[2] = L.v_w; Wqkv.seg = D; Wqkv.ld = D;
             SegVec bqkv; bqkv.p[0] = L.q_b; bqkv.p[1] = L.k_b; bqkv.p[2] = L.v_b; bqkv.seg = D;
@@ -916,13 +945,13 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
         if (h->precision == EGOTAP_PREC_BF16X3) EGO_HIP(attention_bf16_launch<3>(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
         else if (h->precision == EGOTAP_PREC_BF16) EGO_HIP(attention_bf16_launch<1>(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
         else EGO_HIP(attention_f32_launch(QKV, CTX, B, h->seq, h->cfg.vit_heads, s, nullptr, SPK, SPLITK_FLOATS, device_cu_count()));   // (SPK: free between the GEMMs; key-split partials at B <= 2)
-        EGO_HIP((gemm_small(h, "attn_out", ALoadPlain{CTX, D}, segmat1(L.o_w, D, D), EpiBiasRes{segvec1(L.o_b, D), X, D}, X, D, M, D, D, SPK, s)));
-        EGO_HIP(launch_ln(X, Y, L.ln2_g, L.ln2_b, M, 1e-12f, s));
+        EGO_HIP(gemm_res_ln(h, "attn_out", CTX, D, L.o_w, L.o_b, X, M, D, D, L.ln2_g, L.ln2_b, Y, SPK, s));
         EGO_HIP((gemm_small(h, "mlp_up", ALoadPlain{Y, D}, segmat1(L.up_w, 4 * D, D), EpiBiasGelu{segvec1(L.up_b, 4 * D)}, HID, 4L * D, M, 4 * D, D, SPK, s)));
-        EGO_HIP((gemm_small(h, "mlp_down", ALoadPlain{HID, 4L * D}, segmat1(L.dn_w, D, 4L * D), EpiBiasRes{segvec1(L.dn_b, D), X, D}, X, D, M, D, 4 * D, SPK, s)));
+        const bool last = i + 1 == NL;
+        EGO_HIP(gemm_res_ln(h, "mlp_down", HID, 4L * D, L.dn_w, L.dn_b, X, M, D, 4 * D, last ? p.lnf_g : p.layer[i + 1].ln1_g, last ? p.lnf_b : p.layer[i + 1].ln1_b, Y,
+                            SPK, s));
         if (h->debug_stop == 2 + i) return EGOTAP_OK;
     }
-    EGO_HIP(launch_ln(X, Y, p.lnf_g, p.lnf_b, M, 1e-12f, s));
     // H9-H10: per-heatmap regroup folded into fc1's A loader; fc blocks with folded BatchNorm + LeakyReLU
     auto bn = [](const LiftParams::Fc& f) { return EpiBnLrelu{f.b, f.g, f.beta, f.mean, f.var, 1e-5f, 0.2f}; };
     // fc1 of the two encoders has few rows (30 / 34 per frame) and a huge K (16384 ... 65536): below 100 tiles of 256 x 256 (UnrealEgo:

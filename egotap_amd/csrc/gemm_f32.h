@@ -978,10 +978,10 @@ static inline double gemm_f32_direct_estimate_us(int M, int N, int K, int num_cu
 }
 
 // P: scratch of at least splits * M * N floats; returns hipErrorInvalidValue for shapes the tile does not cover
-template <class Cfg, class ALoad, class Epi>
-static hipError_t gemm_f32_splitk_launch(const ALoad& al, const SegMat& W, const Epi& epi, float* C, long ldc, float* P, size_t p_floats, int M,
-                                         int N, int K, hipStream_t stream, int num_cu = 256) {
-    if (M <= 0) return hipSuccess;
+// the partial-sum launch alone: *splits_out ranges of K into P[split][M][N] (the caller reduces)
+template <class Cfg, class ALoad>
+static hipError_t gemm_f32_splitk_partials(const ALoad& al, const SegMat& W, float* P, size_t p_floats, int M, int N, int K, hipStream_t stream, int num_cu,
+                                           int* splits_out) {
     if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0) return hipErrorInvalidValue;
     const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
     const int KT = K / Cfg::BK;
@@ -996,7 +996,15 @@ static hipError_t gemm_f32_splitk_launch(const ALoad& al, const SegMat& W, const
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, al, W, P, M, N, K, tiles_m, tiles_n, kper);
-    hipError_t e = hipGetLastError();
+    *splits_out = splits;
+    return hipGetLastError();
+}
+template <class Cfg, class ALoad, class Epi>
+static hipError_t gemm_f32_splitk_launch(const ALoad& al, const SegMat& W, const Epi& epi, float* C, long ldc, float* P, size_t p_floats, int M,
+                                         int N, int K, hipStream_t stream, int num_cu = 256) {
+    if (M <= 0) return hipSuccess;
+    int splits = 1;
+    hipError_t e = gemm_f32_splitk_partials<Cfg>(al, W, P, p_floats, M, N, K, stream, num_cu, &splits);
     if (e != hipSuccess) return e;
     const long total = (long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel<Epi>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const float*)P, epi, C, ldc, M, N, splits);
