@@ -64,11 +64,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
             qreg[4 * t + 0] = v[0]; qreg[4 * t + 1] = v[1]; qreg[4 * t + 2] = v[2]; qreg[4 * t + 3] = v[3];
         }
     }
-    f32x16 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
     // K / V tiles go global -> registers -> LDS in two steps (cdna_hip_programming.md T14), and [r3] the two operands take turns in
@@ -98,12 +93,30 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
     const int tiles_all = N / KT;
     const int kt0 = ksplit > 1 ? (int)((long)split * tiles_all / ksplit) : 0;
     const int ntiles = ksplit > 1 ? (int)((long)(split + 1) * tiles_all / ksplit) : tiles_all;      // one past this workgroup's last key tile
-    // prologue: K(kt0) and V(kt0) into LDS, K(kt0 + 1) into the staging registers
-    tile_req(kt0, 0);
-    tile_put(0);
-    tile_req(kt0, 1);
-    tile_put(1);
+    // prologue: K(kt0) and V(kt0) into LDS, K(kt0 + 1) into the staging registers.  [r4] K(kt0) and V(kt0) are requested TOGETHER (the output
+    // accumulators are not live yet: a second staging set costs nothing) -- they were two dependent round trips in front of every block's first MFMA
+    {
+        f32x4 stg2[PER];
+        const float* vp = base + (long)(kt0 * KT) * ld + 2 * D;
+        tile_req(kt0, 0);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
+            stg2[i] = *(const f32x4*)(vp + (size_t)(unsigned)(row * (int)ld + c4 * 4));
+        }
+        tile_put(0);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
+            *(f32x4*)(Vs + row * DH + c4 * 4) = stg2[i];
+        }
+    }
     if (kt0 + 1 < ntiles) tile_req(kt0 + 1, 0);
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     __syncthreads();
     // The running maximum is raised (and the output rescaled) only when a query's scores exceed it by more than 2^RESC in the
     // softmax's base-2 units (T13): probabilities stay below 2^RESC -- harmless in fp32 -- and the 64 multiplies per tile vanish
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
             float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = exp2f(fmaf(s[r], scale_log2e, -m_run));
+                s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_run));      // (v_exp_f32: arguments <= 2^RESC; what exp2f adds is the denormal range, 1e-38 of a probability)
                 psum += s[r];
             }
             l_run += psum;                   // per lane-half partial sum; halves are added at the end
