@@ -1,7 +1,8 @@
 """Race screen at the bench's sizes (development probe, GPU): everything below must be bit-identical from run to run.
   * the bf16-storage training step at B = 1024 (config 3): two fresh models, one step each -> losses and every gradient;
     then three more steps on the first model against the same three on the second
-  * bf16 inference at B = 256 and the bf16 estimators at B = 136 / 256 (layer2-4 on the 64-deep GEMM): five forwards each
+  * bf16 inference at B = 256, fp32 inference at B = 1 / 2 / 8 / 20 (the serving-batch routing of round 4) and the bf16 estimators at
+    B = 136 / 256 (layer2-4 on the 64-deep GEMM): five or six forwards each
 The hand-counted vmcnt waits of the DMA-staged kernels are the reason this exists: a wait that is one too generous shows up as a rare
 run-to-run difference at full occupancy, not in the small parity cases."""
 import sys
@@ -52,6 +53,12 @@ nd = sum(0 if torch.equal(outs[0], o) else 1 for o in outs[1:])
 print(f"bf16 inference B = 256: {nd} of 4 repeats differ")
 bad += nd
 net.set_precision("f32")
+for Bs in (1, 2, 8, 20):        # serving batches in fp32: split-K GEMMs, the 64-row tile, key-split attention, the fused reduce + LayerNorm
+    hs = torch.from_numpy(synth_input("hm_det_small", (Bs, p.in_channels, 64, 64))).cuda()
+    outs = [net.predict_pose(hs).clone() for _ in range(6)]
+    nd = sum(0 if torch.equal(outs[0], o) else 1 for o in outs[1:])
+    print(f"fp32 inference B = {Bs}: {nd} of 5 repeats differ")
+    bad += nd
 for Bh in (136, 256):
     est, _ = hm_net("rot")
     l = torch.from_numpy(synth_input("det_l", (8, 3, 256, 256), -2.0, 2.0)).cuda().repeat(Bh // 8, 1, 1, 1).contiguous()
