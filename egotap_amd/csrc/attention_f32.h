@@ -241,7 +241,7 @@ static __global__ __launch_bounds__(256) void attention_f32_merge_kernel(const f
 }
 
 // scratch / scratch_floats (inference at serving batches only; LSE must be null): room for the key-split partials.  The split count
-// fills ~1.5 workgroups per CU: B = 1 (72 workgroups) -> 6 splits of 3 key tiles, B = 2 -> 3, B >= 4 -> none.
+// fills ~4.5 two-wave workgroups per CU: B = 1 / 2 (72 / 144 workgroups) -> 6 ranges of 3 key tiles, B = 4 -> 3, B = 8 -> 2, B >= 16 -> none.
 static hipError_t attention_f32_launch(const float* QKV, float* CTX, int B, int N, int heads, hipStream_t stream,
                                        float* LSE = nullptr, float* scratch = nullptr, size_t scratch_floats = 0, int num_cu = 256) {
     constexpr int NW = 2;
@@ -255,9 +255,9 @@ static hipError_t attention_f32_launch(const float* QKV, float* CTX, int B, int 
     int ksplit = 1;
     if (scratch != nullptr && LSE == nullptr) {
         const int ntiles = N / 32;
+        // as many ranges as keep the chip at ~2 waves per SIMD (a workgroup is two waves: 4.5 workgroups per CU), each a whole number of key tiles
         for (int k = 8; k >= 2; --k)
-            if (ntiles % k == 0 && wgs * k <= 3L * num_cu / 2 + wgs && (size_t)k * ((size_t)B * N * heads * 128 + (size_t)B * heads * N) <= scratch_floats) { ksplit = k; break; }
-        if (wgs * 2 > 3L * num_cu / 2) ksplit = 1;
+            if (ntiles % k == 0 && wgs * k <= 9L * num_cu / 2 && (size_t)k * ((size_t)B * N * heads * 128 + (size_t)B * heads * N) <= scratch_floats) { ksplit = k; break; }
     }
     if (ksplit > 1) {
         float* part = scratch;
