@@ -63,6 +63,11 @@ struct ConvArgs {
     int Nimg, Cin, Cout, relu;
     int tiles_co, tiles_px;
     int vec_ok;             // set by the launcher: every per-channel vector is 16-byte aligned (float4 loads of 4 channels)
+    // [r4] serving batches: the input channels are split over blockIdx.y (splits ranges of slabs), raw partial sums go to part[split][Nimg][Cout][H*W]
+    // and conv_f32_reduce_kernel applies BatchNorm / bias, residual and ReLU.  The caller sets part / part_floats (scratch it owns), the launcher the rest.
+    float* part;
+    size_t part_floats;
+    int splits;
 };
 
 template <class Cfg>
@@ -162,14 +167,21 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_f32_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nslab = (a.Cin + CI_S - 1) / CI_S;
-    gload(0);
+    const int nslab_all = (a.Cin + CI_S - 1) / CI_S;
+    int s_lo = 0, s_hi = nslab_all;
+    if (a.splits > 1) {
+        const int per = (nslab_all + a.splits - 1) / a.splits;
+        s_lo = min((int)blockIdx.y * per, nslab_all);
+        s_hi = min(nslab_all, s_lo + per);
+    }
+    const int nslab = s_hi - s_lo;       // (0 for a trailing range: the workgroup stores zeros)
+    if (nslab > 0) gload(s_lo);
     __syncthreads();          // zero fill done before the first staged rows land
-    lstore(0);
+    if (nslab > 0) lstore(0);
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nslab) gload(s + 1);
+        if (s + 1 < nslab) gload(s_lo + s + 1);
         const float* As = smem + buf * STAGE + a_off;
         const float* Bs = smem + buf * STAGE + A_FLOATS;
 #pragma unroll
@@ -295,6 +307,23 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_f32_kernel(ConvArgs a) {
             rcur = rnxt;
         }
     };
+    if (a.splits > 1) {       // raw partial sums of this range of input channels
+        float* P = a.part + (size_t)blockIdx.y * a.Nimg * a.Cout * ch_out;
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+                for (int j = 0; j < TPX; ++j) {
+                    const int p = (wpx * TPX + j) * 32 + l31;
+                    const int g = p / (RSEG * W), rem = p - g * (RSEG * W);
+                    const int n = n0 + g;
+                    if (co < a.Cout && n < a.Nimg) P[((size_t)n * a.Cout + co) * ch_out + (long)y0 * W + rem] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     const bool full = a.vec_ok && co0 + CO_T <= a.Cout && n0 + G <= a.Nimg;
     using T = std::true_type;
     using F = std::false_type;
@@ -317,8 +346,39 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_f32_kernel(ConvArgs a) {
     }
 }
 
+// sum of the channel-range partials + the convolution's epilogue (same expressions as conv_f32_kernel's); one thread = 4 pixels of one (image, channel)
+static __global__ __launch_bounds__(256) void conv_f32_reduce_kernel(ConvArgs a, int HW) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total4 = (long)a.Nimg * a.Cout * HW / 4;
+    if (i >= total4) return;
+    const int hw4 = HW / 4;
+    const int px = (int)(i % hw4) * 4;
+    const long nc = i / hw4;
+    const int co = (int)(nc % a.Cout), n = (int)(nc / a.Cout);
+    f32x4 acc{0.f, 0.f, 0.f, 0.f};
+    const size_t stride = (size_t)a.Nimg * a.Cout * HW;
+    const float* P = a.part + (size_t)nc * HW + px;
+    for (int k = 0; k < a.splits; ++k) acc += *(const f32x4*)(P + (size_t)k * stride);
+    float sc = 1.f, sh;
+    if (a.gamma) {
+        sc = a.gamma[co] / sqrtf(a.var[co] + 1e-5f);
+        sh = a.beta[co] - a.mean[co] * sc;
+    } else {
+        sh = a.bias[co];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = acc[e] * sc + sh;
+    if (a.res) o += *(const f32x4*)(a.res + (long)n * a.res_istride + (long)co * HW + px);
+    if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+    }
+    *(f32x4*)(a.out + (long)n * a.out_istride + (long)co * HW + px) = o;
+}
+
 template <class Cfg>
-static hipError_t conv_f32_launch(ConvArgs a, hipStream_t stream) {
+static hipError_t conv_f32_launch(ConvArgs a, hipStream_t stream, int num_cu = 256) {
     if (a.Nimg <= 0) return hipSuccess;
     if ((a.Cin * Cfg::TAPS) % 4 != 0) return hipErrorInvalidValue;
     auto kern = conv_f32_kernel<Cfg>;
@@ -332,7 +392,27 @@ static hipError_t conv_f32_launch(ConvArgs a, hipStream_t stream) {
     a.vec_ok = (((size_t)a.gamma | (size_t)a.beta | (size_t)a.mean | (size_t)a.var | (size_t)a.bias) & 15) == 0;
     const long px = (long)a.Nimg * Cfg::W * Cfg::W;
     a.tiles_px = Cfg::G == 1 ? (int)(px / Cfg::PX_T) : (a.Nimg + Cfg::G - 1) / Cfg::G;
-    hipLaunchKernelGGL(kern, dim3(a.tiles_co * a.tiles_px), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a);
+    // [r4] a few frames: 8 ... 64 workgroups each walking the whole Cin (layer4 at B = 1: 8 workgroups x 64 slabs = 315 us; conv_up2: 32 x 160 slabs =
+    // 600 us, on 256 CUs) -> input-channel ranges over blockIdx.y until ~2 workgroups per CU, at least two slabs per range, partials within the scratch
+    a.splits = 1;
+    const long wgs = (long)a.tiles_co * a.tiles_px;
+    const int nslab = (a.Cin + Cfg::CI_S - 1) / Cfg::CI_S;
+    const size_t out_floats = (size_t)a.Nimg * a.Cout * Cfg::W * Cfg::W;
+    if (a.part != nullptr && 2 * wgs <= num_cu && nslab >= 4 && ((size_t)a.out_istride % 4 == 0) && (a.res == nullptr || a.res_istride % 4 == 0)) {
+        long sp = (2L * num_cu) / wgs;
+        if (sp > nslab / 2) sp = nslab / 2;
+        if (sp > 32) sp = 32;
+        while (sp > 1 && (size_t)sp * out_floats > a.part_floats) --sp;
+        if (sp > 1) {
+            const int per = (nslab + (int)sp - 1) / (int)sp;
+            a.splits = (nslab + per - 1) / per;             // no empty trailing range
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_co * a.tiles_px, a.splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || a.splits == 1) return e;
+    const long total4 = (long)out_floats / 4;
+    hipLaunchKernelGGL(conv_f32_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, a, Cfg::W * Cfg::W);
     return hipGetLastError();
 }
 

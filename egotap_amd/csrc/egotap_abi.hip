@@ -154,6 +154,8 @@ struct egotap_handle_s {
     __bf16* ascratch = nullptr;        // scratch for the bf16 copy of a GEMM's activation operand (plain-bf16 mode, gemm_bf16_dma_kernel), caller-owned
     size_t ascratch_bytes = 0;
     __bf16* conv_pack = nullptr;       // scratch for repacked conv weights (set per egotap_hm_forward call from the workspace)
+    float* conv_part = nullptr;        // [r4] fp32 egotap_hm_forward only (null outside it): scratch for the input-channel-split partials of conv_f32.h
+    size_t conv_part_floats = 0;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;   // start/stop pairs
@@ -1093,7 +1095,10 @@ static hipError_t conv(Handle* h, const char* role, const ConvArgs& a, hipStream
                                      std::to_string(Cfg::STRIDE) + ",W" + std::to_string(Cfg::W) + ",co" +
                                      std::to_string(Cfg::CO_T) + ">";
     GemmTimer t(h, s, role, kname.c_str(), 2.0 * a.Cout * a.Cin * Cfg::TAPS * (double)a.Nimg * Cfg::W * Cfg::W);
-    return conv_f32_launch<Cfg>(a, s);
+    ConvArgs b = a;
+    b.part = h->conv_part;
+    b.part_floats = h->conv_part_floats;
+    return conv_f32_launch<Cfg>(b, s, device_cu_count());
 }
 
 template <class Cfg>
@@ -1295,6 +1300,12 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
     const HmParams& p = h->hp[net];
     EGO_CHECK(out_image_stride >= (int64_t)p.n_out * s64 * s64, "out_image_stride smaller than the output image");
     h->conv_pack = (__bf16*)((char*)ws + w.WPACK);
+    // [r4] exact-fp32 mode: the two weight-pack regions at the end of the workspace are unused -> scratch of the serving-batch channel split (conv_f32.h)
+    struct PartGuard { Handle* h; ~PartGuard() { h->conv_part = nullptr; h->conv_part_floats = 0; } } part_guard{h};
+    if (h->precision == EGOTAP_PREC_F32) {
+        h->conv_part = (float*)((char*)ws + w.WPACK);
+        h->conv_part_floats = (w.total - w.WPACK) / 4;
+    }
     hipStream_t s = (hipStream_t)stream;
     char* base = (char*)ws;
     auto F = [&](size_t off) { return (float*)(base + off); };
