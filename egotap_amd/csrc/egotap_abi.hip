@@ -1157,11 +1157,19 @@ struct HmWs {
 // the bf16 forward uses them; p == nullptr: sizes only.  Returns the bytes of the region; fills T (segment table of pack_all_bf16s_kernel).
 // conv_heatmap's GEMM N: 30 / 34 / 60 / 68 heatmap channels padded to the 64- or 128-column tile (256 before: 4-8 x the MFMAs)
 static inline int hm_head_np(int n_out) { return n_out <= 64 ? 64 : n_out <= 128 ? 128 : 256; }
+// split count of a decoder convolution at serving batches: gemm_bf16s_ksplit's, capped at 8 so that every small batch lands on the SAME count
+// (a frame's heatmaps then do not depend on the batch it arrives in, bit for bit -- the cap, not the batch, decides below ~8 frames)
+static inline int hm_dec_ksplit(int M, int N, int K, int cus, size_t floats) {
+    int sp = gemm_bf16s_ksplit(M, N, K, cus, floats);
+    if (sp > 8) { sp = 8; while (sp > 1 && K % (sp * 32) != 0) --sp; }
+    return sp;
+}
 static constexpr int HM_CAT3P = 1600;      // channels per pixel of the first decoder concat in the bf16 mode: 1024 + 516 = 1540, padded to a multiple of 64
 // n2 / sides / cus / split_floats (forward only; the size query leaves them 0): image count, map side per stage and the split-K budget, from
 // which the plan decides per BasicBlock 3x3 convolution whether it runs on the 64-deep GEMM (64-channel weight slabs) -- Cin a multiple of 64, Cout = 128
 // (layer2, on the 256 x 128 tile) or a multiple of 256 (layer3 / layer4), and enough pixels that the 32-deep kernel's split-K path is not taken.  Same bytes either way.
-static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T, long n2 = 0, const int* sides = nullptr, int cus = 0, size_t split_floats = 0) {
+static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T, long n2 = 0, const int* sides = nullptr, int cus = 0, size_t split_floats = 0,
+                           size_t dec_split_floats = 0) {
     size_t o = 0;
     int nw = 0, nb = 0, blk = 0;
     auto al = [&](size_t n) { size_t r = o; o = (o + n + 255) & ~(size_t)255; return r; };
@@ -1202,11 +1210,18 @@ static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T, lon
     wseg(cv(0, 2).w, cv(0, 2).b, 516, 512, 512, 768, 1);
     // the three 3x3 decoder convolutions run on the 64-deep GEMM (gemm_bf16s64.h, X64Conv3): concat widths padded to a multiple of 64
     // (1540 -> HM_CAT3P = 1600), weights packed in 64-channel slabs
-    wseg(cv(1, 2).w, nullptr, 1024, 1540, HM_CAT3P, 1024, 9, 64);
+    // [r4] ... unless the map has so few pixels (serving batches: conv_up3 at B = 1 is one row tile x four column tiles walking K = 14400) that the
+    // product is split over K: that path is the 32-deep kernel's (XConv3, 32-channel slabs), partial sums in the free head of the WPACK region
+    auto dec_slab = [&](int k, int Cout, int Cp) {      // k: 2 = conv_up3 (side s16), 1 = conv_up2 (s32), 0 = conv_up1 (s64); sides[] = {s64, s32, s16, s8}
+        if (!sides || n2 <= 0) return 64;
+        if (g_gemm_bf16s_bk == 32) return 32;
+        return hm_dec_ksplit((int)(n2 / 2 * sides[k] * sides[k]), Cout, 9 * Cp, cus, dec_split_floats) > 1 ? 32 : 64;
+    };
+    wseg(cv(1, 2).w, nullptr, 1024, 1540, HM_CAT3P, 1024, 9, dec_slab(2, 1024, HM_CAT3P));
     wseg(cv(0, 1).w, cv(0, 1).b, 256, 256, 256, 256, 1);
-    wseg(cv(1, 1).w, nullptr, 512, 1280, 1280, 512, 9, 64);
+    wseg(cv(1, 1).w, nullptr, 512, 1280, 1280, 512, 9, dec_slab(1, 512, 1280));
     wseg(cv(0, 0).w, cv(0, 0).b, 128, 128, 128, 256, 1);
-    wseg(cv(1, 0).w, nullptr, 512, 640, 640, 512, 9, 64);
+    wseg(cv(1, 0).w, nullptr, 512, 640, 640, 512, 9, dec_slab(0, 512, 640));
     wseg(cv(2, 0).w, cv(2, 0).b, p ? p->n_out : 30, 512, 512, p ? hm_head_np(p->n_out) : 256, 1);      // (sizes-only: the largest padding)
     const int blocks_w = blk;
     for (int k = 0; k < nb && k < PackTable::MAXB; ++k) {
@@ -1335,7 +1350,9 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
         PackTable PT;
         const size_t split_floats = (size_t)N2 * 64 * (S0 / 2) * (S0 / 2);
         const int stage_sides[4] = {s64, s32, s16, s8};
-        EGO_CHECK(hm_pack_plan(&p, p.nblk, &PT, N2, stage_sides, cus, split_floats) != 0, "egotap_hm_forward: the estimator has more layers than the pack table holds");
+        float* dec_slab = (float*)(base + w.WPACK);                               // [r4] the first 40 MB of the WPACK region (the zero page sits behind them): split-K partials of the decoder
+        const size_t dec_split_floats = ((size_t)40 << 20) / 4;
+        EGO_CHECK(hm_pack_plan(&p, p.nblk, &PT, N2, stage_sides, cus, split_floats, dec_split_floats) != 0, "egotap_hm_forward: the estimator has more layers than the pack table holds");
         char* reg = base + w.WALL;
         hipLaunchKernelGGL(pack_all_bf16s_kernel, dim3(PT.blocks), dim3(256), 0, s, PT, reg);
         EGO_HIP(hipGetLastError());
@@ -1361,6 +1378,15 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
         auto conv3 = [&](const char* role, const __bf16* in, long M, int side, const HmParams::Cv& cv, int Cin, int Cp, int Cout, __bf16* o) {
             const PackSeg& sg = PT.w[li++];
             if (sg.w != cv.w || sg.Cp != Cp || sg.Np != Cout) return hipErrorInvalidValue;
+            if (sg.slab == 32) {      // [r4] few pixels: the 32-deep kernel, split over K when the plan's rule says so (serving batches)
+                if (Cp % 32 != 0 || Cout % 256 != 0) return hipErrorInvalidValue;
+                GemmTimer t(h, s, role, "gemm_bf16s_kernel<XConv3>", 2.0 * M * Cout * 9.0 * Cin);
+                const XConv3 xl{in, ZP, Cp, ilog2(side)};
+                const SEpiConvBf16<false> ep{cv.b, o, (long)Cout, Cout, 1};
+                const int sp = hm_dec_ksplit((int)M, Cout, 9 * Cp, cus, dec_split_floats);
+                if (sp > 1) return gemm_bf16s_splitk_launch(xl, (const __bf16*)(reg + sg.dst_w), 9L * Cp, ep, dec_slab, sp, (int)M, Cout, 9 * Cp, cus, s);
+                return gemm_bf16s_launch(xl, (const __bf16*)(reg + sg.dst_w), 9L * Cp, ep, (int)M, Cout, 9 * Cp, cus, s);
+            }
             if (sg.slab != 64 || Cp % 64 != 0 || Cout % 256 != 0) return hipErrorInvalidValue;
             GemmTimer t(h, s, role, "gemm_bf16s64_kernel<X64Conv3>", 2.0 * M * Cout * 9.0 * Cin);
             const X64Conv3 xl{in, ZP, Cp, ilog2(side)};

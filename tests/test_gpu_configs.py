@@ -150,10 +150,11 @@ def test_create_model_with_the_reference_training_flags(tmp_path):
     m.set_precision("f32")
     m.forward(evaluate=True)
     assert torch.equal(hm_eval, m.pred_heatmap_cat)
-    # the estimators' chunked forward (opt.hm_chunk) equals the unchunked one: frames are independent in eval mode
+    # the estimators' chunked forward (opt.hm_chunk) equals the unchunked one: frames are independent in eval mode ([r4] to rounding: below 65
+    # frames the small-map convolutions split their input channels by the batch they see, conv_f32.h)
     m.opt.hm_chunk = 1
     m.forward(evaluate=True)
-    assert torch.equal(hm_eval, m.pred_heatmap_cat)
+    assert float((hm_eval - m.pred_heatmap_cat).abs().max()) < 1e-5 * float(hm_eval.abs().max())
 
     opt2 = options.parse_train(shlex.split(UNREALEGO_TRAIN_FLAGS.replace("--path_to_trained_heatmap ./log/unrealego_heatmap_shared/best_net_HeatMap.pth", "")))
     with pytest.raises(ValueError):

@@ -130,8 +130,8 @@ def test_hm_forward_bf16_channels_last_decoder_against_float64_oracle(which, pre
     """EGOTAP_PREC_BF16: the decoder runs on bf16 channels-last activations, every convolution as an implicit GEMM on the bf16-storage
     GEMM kernel (conv_bf16s.h: 3x3 taps through a loader with a zero page for the padding, 1x1 lateral convs with padded N, the
     concat buffers' channel slices written in place, conv_heatmap back to fp32 NCHW).  Against the FLOAT64 ORACLE: relative L2 below
-    2 % (about ten bf16 roundings deep), every frame of the batch (ragged last tile at the 8x8 level), bit-reproducible, and a frame's
-    result does not depend on the batch it is in."""
+    2 % (about ten bf16 roundings deep), every frame of the batch (ragged last tile at the 8x8 level), bit-reproducible run to run; a frame's
+    result moves with the batch size only by flipped bf16 roundings."""
     from gpu_util import hm_net
     from oracle import hm_ref as H
     net, sd_np = hm_net(which, preset=preset, hm=hm, model_name=model_name)
@@ -147,7 +147,12 @@ def test_hm_forward_bf16_channels_last_decoder_against_float64_oracle(which, pre
         last = net(left[B - 1:].cuda(), right[B - 1:].cuda())
     finally:
         net.set_precision("f32")
-    assert torch.equal(low, again) and torch.equal(low[B - 1:], last)
+    assert torch.equal(low, again)
+    # [r4] which kernel a convolution runs on follows its pixel count (few pixels: 32-deep K-tiles split over the chip; many: 64-deep), so a frame's
+    # bf16 heatmaps move with the batch size by flipped bf16 roundings (the fp32 mode is the one that is batch-independent to 1e-5): a wrong
+    # routing would be O(1)
+    rel_batch = float((low[B - 1:].double() - last.double()).norm() / last.double().norm())
+    assert rel_batch < 1e-2, rel_batch
     low = low.double().cpu()
     assert tuple(low.shape) == tuple(ref.shape)
     rels = [float((low[b] - ref[b]).norm() / ref[b].norm()) for b in range(B)]
