@@ -463,6 +463,45 @@ def bench_stage1(args, p, dev, rank, world, barrier, mode="f32"):
             "peak_hbm_gib": round(peak_gb, 1)}
 
 
+def bench_latency_rgb(args, p, dev):
+    """Serving-shaped leg: latency of the WHOLE path from RGB (two estimators + head, evaluate-style forward of the wrapper) at B = 1 and 8."""
+    import torch
+    from egotap_amd import models, spec
+    from egotap_amd.options import preset_defaults
+    from egotap_amd.synthetic import synth_hm_state_dict, synth_input, synth_state_dict
+    opt = preset_defaults(args.preset)
+    opt.gpu_ids = [dev.index]
+    m = models.create_model(opt)
+    J = p.n_joints_hm
+    for name, sd in (("AutoEncoder", synth_state_dict(spec.lift_state_spec(p))), ("HeatMap", synth_hm_state_dict(J, "hm_pos.")),
+                     ("RotHeatMap", synth_hm_state_dict(2 * J, "hm_rot."))):
+        getattr(m, "net_" + name).load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.eval()
+    S = 4 * p.hm_size
+    out = {"unit": "ms per forward from RGB (both estimators + head; median of 12, synchronised)"}
+    for B in (1, 8):
+        l = torch.from_numpy(synth_input("rgb_l_lat", (B, 3, S, S), -2.0, 2.0)).to(dev)
+        r = torch.from_numpy(synth_input("rgb_r_lat", (B, 3, S, S), -2.0, 2.0)).to(dev)
+        m.set_input({"input_rgb_left": l, "input_rgb_right": r})
+        for mode in ("f32", "bf16"):
+            m.set_precision(mode)
+            with torch.no_grad():
+                for _ in range(3):
+                    m.forward(evaluate=True)
+                ts = []
+                for _ in range(12):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    m.forward(evaluate=True)
+                    torch.cuda.synchronize(dev)
+                    ts.append(time.perf_counter() - t0)
+            ts.sort()
+            out[f"b{B}_{mode}"] = round(1e3 * ts[len(ts) // 2], 3)
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def bench_latency(net, p, dev):
     """Serving-shaped leg: latency of the lifting head at B = 1 and 8 (split-K small-batch GEMM path), per precision mode."""
     import torch
@@ -713,6 +752,8 @@ def main():
     latency = None
     if rank == 0 and world == 1 and not args.lift_only:
         latency = leg(bench_latency, net, p, dev)
+        if isinstance(latency, dict) and "error" not in latency:
+            latency["from_rgb"] = leg(bench_latency_rgb, args, p, dev)
 
     cpu = None
     gpu_vs_oracle = None
