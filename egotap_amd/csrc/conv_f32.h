@@ -398,7 +398,10 @@ static hipError_t conv_f32_launch(ConvArgs a, hipStream_t stream, int num_cu = 2
     const long wgs = (long)a.tiles_co * a.tiles_px;
     const int nslab = (a.Cin + Cfg::CI_S - 1) / Cfg::CI_S;
     const size_t out_floats = (size_t)a.Nimg * a.Cout * Cfg::W * Cfg::W;
-    if (a.part != nullptr && 2 * wgs <= num_cu && nslab >= 4 && ((size_t)a.out_istride % 4 == 0) && (a.res == nullptr || a.res_istride % 4 == 0)) {
+    // (the reduce kernel moves f32x4: image strides AND base pointers must be 16-byte multiples -- a caller's channel-offset view of `out` may be
+    // only 4-byte aligned, and then the scalar epilogue of the unsplit kernel is the one that works)
+    if (a.part != nullptr && 2 * wgs <= num_cu && nslab >= 4 && ((size_t)a.out_istride % 4 == 0) && (a.res == nullptr || a.res_istride % 4 == 0) &&
+        (((size_t)a.out | (size_t)a.res | (size_t)a.part) & 15) == 0) {
         long sp = (2L * num_cu) / wgs;
         if (sp > nslab / 2) sp = nslab / 2;
         if (sp > 32) sp = 32;

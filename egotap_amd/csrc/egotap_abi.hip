@@ -33,6 +33,7 @@
 #include "conv_bf16s.h"
 #include "stem_bf16s.h"
 #include "conv64_bf16s.h"
+#include "bn_bf16s.h"
 
 // The library is ONE source compiled as four translation units in parallel (egotap_amd/build.py: -DEGOTAP_PART=0 core and
 // inference, 1 lifting-head training operators, 2 heatmap-estimator training operators, 3 bf16-storage operators); every exported function belongs to one
@@ -593,40 +594,56 @@ static hipError_t gemm_big(Handle* h, const char* role, const AL& al, const SegM
 // tile row for fc1).  Below `fill` tiles the GEMM runs as exact-fp32 128x128 tiles with K split over blockIdx.y
 // (gemm_f32_splitk_launch) in every precision mode; at and above it gemm_big as before, so large-batch results do not change.
 static constexpr size_t SPLITK_FLOATS = (size_t)1 << 24;
-template <class AL, class Epi>
-static hipError_t gemm_small(Handle* h, const char* role, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc,
-                             int M, int N, int K, float* P, hipStream_t s) {
+// ONE routing decision for an fp32-tensor NT product, used by gemm_small (which launches it) and by gemm_res_ln (which fuses the reduce of a split
+// product with the LayerNorm behind it and therefore must see exactly the split layout gemm_small would produce).
+// The fitted constants below (0.2319 us per 16-deep K step of a 256 x 256 tile = 0.92 x 157.3 TF over 256 CUs, 5 us per round; the per-slab times inside
+// gemm_f32_splitk_plan / gemm_f32_direct_estimate_us) were measured on the 256-CU MI355X; `cus` only scales the round counts.  On another part they
+// would still pick a CORRECT kernel, not necessarily the faster one.
+enum { GS_BIG = 0, GS_DIRECT_A, GS_DIRECT_S, GS_SPLIT_S, GS_SPLIT_A };
+struct SmallRoute { int kind, splits; };
+static SmallRoute gemm_small_route(const Handle* h, bool plain_loader, int M, int N, int K, int wseg, int cus) {
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const long fill = (h && h->precision != EGOTAP_PREC_F32) ? 64 : 160;
-    if (N % 128 != 0 || K % 32 != 0 || W.seg % 128 != 0) return gemm_big(h, role, al, W, epi, C, ldc, M, N, K, s);
+    if (N % 128 != 0 || K % 32 != 0 || wseg % 128 != 0) return SmallRoute{GS_BIG, 1};
     if (tiles256 >= fill) {
         // [r4] fp32, plain operands, fewer than four rounds of 256 x 256 tiles: the 256 x 256 kernel runs WHOLE rounds at 0.92 of the matrix
         // pipe (B = 8, N = 4096: 288 tiles = two rounds for 1.1 rounds of work, 484 us) -- the 128 x 128 kernel with its epilogue inside takes
         // 415 us there.  Both estimates are fitted to tools/gemm_small_vs_big_probe.py and name the faster kernel at 46 of its 48 points.
-        if constexpr (std::is_same<AL, ALoadPlain>::value) {
-            const int cus = device_cu_count();
-            if (h && h->precision == EGOTAP_PREC_F32 && tiles256 < 4L * cus) {
-                const double t_big = (double)((tiles256 + cus - 1) / cus) * (K * 0.2319 + 5.0);  // us: 2 * 256 * 256 * K flop per tile at 0.92 x 157.3 TF / 256 CUs
-                if (gemm_f32_direct_estimate_us<TileA>(M, N, K, cus) < t_big) return gemm<TileA>(h, role, al, W, epi, C, ldc, M, N, K, s);
-            }
+        if (plain_loader && h && h->precision == EGOTAP_PREC_F32 && tiles256 < 4L * cus) {
+            const double t_big = (double)((tiles256 + cus - 1) / cus) * (K * 0.2319 + 5.0);
+            if (gemm_f32_direct_estimate_us<TileA>(M, N, K, cus) < t_big) return SmallRoute{GS_DIRECT_A, 1};
         }
-        return gemm_big(h, role, al, W, epi, C, ldc, M, N, K, s);
+        return SmallRoute{GS_BIG, 1};
     }
+    const SplitPlan pa = gemm_f32_splitk_plan<TileA>(M, N, K, SPLITK_FLOATS, cus);
     if (M <= 640) {   // [r4] one frame (576 rows = 4.5 tiles of 128 rows): the 64-row tile when its plan is estimated faster -- nine row tiles exactly, up
         // to one workgroup per CU without a split (qkv: 216 tiles, epilogue in the kernel: no partials, no reduce launch).  Measured: B = 1 forward
         // -33 us; from two frames on the 64-row tile loses what it gains (its slab is shorter than a load's round trip), so the rule stops here.
-        const int cus = device_cu_count();
-        const SplitPlan pa = gemm_f32_splitk_plan<TileA>(M, N, K, SPLITK_FLOATS, cus), ps = gemm_f32_splitk_plan<TileS>(M, N, K, SPLITK_FLOATS, cus);
-        if (ps.us < pa.us) {
-            if (ps.splits == 1) return gemm<TileS>(h, role, al, W, epi, C, ldc, M, N, K, s);
+        const SplitPlan ps = gemm_f32_splitk_plan<TileS>(M, N, K, SPLITK_FLOATS, cus);
+        if (ps.us < pa.us) return SmallRoute{ps.splits == 1 ? GS_DIRECT_S : GS_SPLIT_S, ps.splits};
+    }
+    return SmallRoute{GS_SPLIT_A, pa.splits};
+}
+template <class AL, class Epi>
+static hipError_t gemm_small(Handle* h, const char* role, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc,
+                             int M, int N, int K, float* P, hipStream_t s) {
+    const int cus = device_cu_count();
+    const SmallRoute r = gemm_small_route(h, std::is_same<AL, ALoadPlain>::value, M, N, K, W.seg, cus);
+    switch (r.kind) {
+        case GS_BIG: return gemm_big(h, role, al, W, epi, C, ldc, M, N, K, s);
+        case GS_DIRECT_A: return gemm<TileA>(h, role, al, W, epi, C, ldc, M, N, K, s);
+        case GS_DIRECT_S: return gemm<TileS>(h, role, al, W, epi, C, ldc, M, N, K, s);
+        case GS_SPLIT_S: {
             static const std::string kname64 = std::string("gemm_f32_splitk_kernel<64x128x32,") + AlName<AL>::v + ">+splitk_reduce_kernel<" + EpiName<Epi>::v + ">";
             GemmTimer t(h, s, role, kname64.c_str(), 2.0 * M * N * K);
-            return gemm_f32_splitk_launch<TileS>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s, cus);
+            return gemm_f32_splitk_launch<TileS>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s, cus, r.splits);
+        }
+        default: {
+            static const std::string kname = std::string("gemm_f32_splitk_kernel<128x128x32,") + AlName<AL>::v + ">+splitk_reduce_kernel<" + EpiName<Epi>::v + ">";
+            GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
+            return gemm_f32_splitk_launch<TileA>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s, cus, r.splits);
         }
     }
-    static const std::string kname = std::string("gemm_f32_splitk_kernel<128x128x32,") + AlName<AL>::v + ">+splitk_reduce_kernel<" + EpiName<Epi>::v + ">";
-    GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * N * K);
-    return gemm_f32_splitk_launch<TileA>(al, W, epi, C, ldc, P, SPLITK_FLOATS, M, N, K, s, device_cu_count());
 }
 
 // fc2 / fc3 of the two encoders: one or two 128-row tiles at small batch -> split K as fc1 does (same row threshold)
@@ -797,21 +814,16 @@ static hipError_t launch_ln(const float* x, float* y, const float* g, const floa
 // that follows are ONE launch (splitk_reduce_res_ln_kernel: same bits as the two); otherwise gemm_small + launch_ln as before.
 static hipError_t gemm_res_ln(Handle* h, const char* role, const float* A, long lda, const float* Wp, const float* bias, float* X, int M, int D, int K,
                               const float* ln_g, const float* ln_b, float* Y, float* P, hipStream_t s) {
-    const long tiles256 = (long)((M + 255) / 256) * (D / 256);
-    const long fill = (h && h->precision != EGOTAP_PREC_F32) ? 64 : 160;
-    if (D == 1024 && K % 32 == 0 && tiles256 < fill) {
-        const int cus = device_cu_count();
-        const SplitPlan pa = gemm_f32_splitk_plan<TileA>(M, D, K, SPLITK_FLOATS, cus), ps = gemm_f32_splitk_plan<TileS>(M, D, K, SPLITK_FLOATS, cus);
-        const bool s64 = M <= 640 && ps.us < pa.us;          // (gemm_small's rule)
-        if ((s64 ? ps.splits : pa.splits) > 1) {
+    if (D == 1024) {
+        const SmallRoute r = gemm_small_route(h, true, M, D, K, D, device_cu_count());      // gemm_small's own decision, not a copy of its rule
+        if ((r.kind == GS_SPLIT_S || r.kind == GS_SPLIT_A) && r.splits > 1) {
             static const std::string kname = "gemm_f32_splitk_kernel<ALoadPlain>+splitk_reduce_res_ln_kernel";
             GemmTimer t(h, s, role, kname.c_str(), 2.0 * M * D * K);
-            int splits = 1;
-            hipError_t e = s64 ? gemm_f32_splitk_partials<TileS>(ALoadPlain{A, lda}, segmat1(Wp, D, K), P, SPLITK_FLOATS, M, D, K, s, cus, &splits)
-                               : gemm_f32_splitk_partials<TileA>(ALoadPlain{A, lda}, segmat1(Wp, D, K), P, SPLITK_FLOATS, M, D, K, s, cus, &splits);
+            hipError_t e = r.kind == GS_SPLIT_S ? gemm_f32_splitk_partials<TileS>(ALoadPlain{A, lda}, segmat1(Wp, D, K), P, SPLITK_FLOATS, M, D, K, s, r.splits)
+                                                : gemm_f32_splitk_partials<TileA>(ALoadPlain{A, lda}, segmat1(Wp, D, K), P, SPLITK_FLOATS, M, D, K, s, r.splits);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(splitk_reduce_res_ln_kernel<1024>, dim3(min((M + 3) / 4, 256 * 8)), dim3(256), 0, s, (const float*)P, bias, (const float*)X, X, ln_g,
-                               ln_b, Y, M, splits, 1e-12f);
+                               ln_b, Y, M, r.splits, 1e-12f);
             return hipGetLastError();
         }
     }
@@ -1169,7 +1181,8 @@ static constexpr int HM_CAT3P = 1600;      // channels per pixel of the first de
 // which the plan decides per BasicBlock 3x3 convolution whether it runs on the 64-deep GEMM (64-channel weight slabs) -- Cin a multiple of 64, Cout = 128
 // (layer2, on the 256 x 128 tile) or a multiple of 256 (layer3 / layer4), and enough pixels that the 32-deep kernel's split-K path is not taken.  Same bytes either way.
 static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T, long n2 = 0, const int* sides = nullptr, int cus = 0, size_t split_floats = 0,
-                           size_t dec_split_floats = 0) {
+                           size_t dec_split_floats = 0, long n2_dec = -1) {
+    if (n2_dec < 0) n2_dec = n2;            // [r5] the batch-statistics forward runs the backbone over the whole batch and the decoder in chunks
     size_t o = 0;
     int nw = 0, nb = 0, blk = 0;
     auto al = [&](size_t n) { size_t r = o; o = (o + n + 255) & ~(size_t)255; return r; };
@@ -1213,9 +1226,9 @@ static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T, lon
     // [r4] ... unless the map has so few pixels (serving batches: conv_up3 at B = 1 is one row tile x four column tiles walking K = 14400) that the
     // product is split over K: that path is the 32-deep kernel's (XConv3, 32-channel slabs), partial sums in the free head of the WPACK region
     auto dec_slab = [&](int k, int Cout, int Cp) {      // k: 2 = conv_up3 (side s16), 1 = conv_up2 (s32), 0 = conv_up1 (s64); sides[] = {s64, s32, s16, s8}
-        if (!sides || n2 <= 0) return 64;
+        if (!sides || n2_dec <= 0) return 64;
         if (g_gemm_bf16s_bk == 32) return 32;
-        return hm_dec_ksplit((int)(n2 / 2 * sides[k] * sides[k]), Cout, 9 * Cp, cus, dec_split_floats) > 1 ? 32 : 64;
+        return hm_dec_ksplit((int)(n2_dec / 2 * sides[k] * sides[k]), Cout, 9 * Cp, cus, dec_split_floats) > 1 ? 32 : 64;
     };
     wseg(cv(1, 2).w, nullptr, 1024, 1540, HM_CAT3P, 1024, 9, dec_slab(2, 1024, HM_CAT3P));
     wseg(cv(0, 1).w, cv(0, 1).b, 256, 256, 256, 256, 1);
@@ -1258,6 +1271,208 @@ static HmWs hm_ws(const Handle* h, int B) {
     w.WALL = take(hm_pack_plan(nullptr, nblk_, nullptr) / 4 + 64);    // [r3] bf16 mode: every layer's packed weights at once (one pack launch per forward)
     w.total = o;
     return w;
+}
+
+// ---- [r5] the bf16 channels-last forward as two pieces -- backbone (stem + four stages) and decoder -- so that the batch-statistics forward of the FROZEN
+// estimators (egotap_hm_forward_bnbatch: train.py:91) can run the backbone over the whole batch (its BatchNorm couples the frames of a batch) and the
+// decoder, which has no BatchNorm, in chunks.  The eval-mode egotap_hm_forward calls both with one set of buffers: same launches, same bits as before.
+struct HmBf16Bufs {
+    __bf16 *P0, *A[4], *Ta[4], *Tb[4], *Td[4];      // backbone: pooled stem, per stage the level (= pyramid level = decoder operand) and three temporaries
+    __bf16 *T4, *C3, *Y3, *C2, *Y2, *C1, *Y1;        // decoder
+    __bf16* ZP;                                     // 256 bytes of zeros
+    char* reg;                                      // packed weights / folded BatchNorms (pack_all_bf16s_kernel)
+    float* split_slab; size_t split_floats;         // split-K partials of the backbone's few-pixel layers
+    float* dec_slab; size_t dec_split_floats;       // ... of the decoder's 3x3 convolutions at serving batches
+    const float *ones, *zeros;                      // batch-statistics mode: unit scale / zero shift (1024 floats each) for the raw-output epilogue
+};
+struct HmBnBatch {                                  // batch-statistics mode: where the finish kernel finds each BatchNorm's buffers
+    BnBatchScratch scr;
+    Handle* h; int net;
+};
+static inline int hm_ilog2(long v) { int l = 0; while ((1L << l) < v) ++l; return l; }
+// running_mean / running_var (mutable) and num_batches_tracked of the BatchNorm whose weight tensor is `g`: looked up by pointer in the bound set
+static bool hm_bn_buffers(Handle* h, int net, const float* g, float** rm, float** rv, long long** nbt) {
+    for (auto& kv : h->bound[net]) {
+        if (kv.second.ptr != (const void*)g) continue;
+        const std::string& k = kv.first;
+        if (k.size() < 7 || k.compare(k.size() - 7, 7, ".weight") != 0) continue;
+        const std::string base = k.substr(0, k.size() - 7);
+        auto m = h->bound[net].find(base + ".running_mean"), v = h->bound[net].find(base + ".running_var"), n = h->bound[net].find(base + ".num_batches_tracked");
+        if (m == h->bound[net].end() || v == h->bound[net].end()) continue;
+        *rm = (float*)m->second.ptr; *rv = (float*)v->second.ptr;
+        *nbt = (n != h->bound[net].end() && n->second.dtype == EGOTAP_I64 && n->second.numel == 1) ? (long long*)n->second.ptr : nullptr;
+        return true;
+    }
+    return false;
+}
+
+static hipError_t hm_bf16_backbone(Handle* h, const HmParams& p, const PackTable& PT, int& li, int& bi, const HmBf16Bufs& q, const float* left, const float* right, int B,
+                                   int S0, const HmBnBatch* bnb, hipStream_t s) {
+    const int N2 = 2 * B, cus = device_cu_count();
+    const int s64 = S0 / 4, s32 = S0 / 8, s16 = S0 / 16, s8 = S0 / 32;
+    char* reg = q.reg;
+    __bf16* ZP = q.ZP;
+    // E1 + E2: stem conv7x7/2 + BN + ReLU + max-pool in one kernel (stem_bf16s.h): bf16 [B * s64^2, 2 x 64], image n = 2b + eye in the eye's column half
+    if (!bnb) {
+        hipError_t e = stem_pool_bf16s_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, q.P0, S0, N2, cus, s);
+        if (e != hipSuccess) return e;
+    } else {
+        // batch statistics: the convolution twice -- a statistics-only pass (the 128 x 128 x 64 map still never reaches HBM), then the fused pass with per-eye tables
+        int grid = 0;
+        hipError_t e = stem_pool_bf16s_launch_mode<1>(left, right, p.stem_w, nullptr, nullptr, nullptr, nullptr, (__bf16*)bnb->scr.part, S0, N2, cus, s, &grid);
+        if (e != hipSuccess) return e;
+        float *rm, *rv; long long* nbt;
+        if (!hm_bn_buffers(bnb->h, bnb->net, p.stem_bn.g, &rm, &rv, &nbt)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(bn_finish_bf16s_kernel, dim3(1), dim3(256), 0, s, (const float*)bnb->scr.part, grid, 64, (double)B * (S0 / 2) * (S0 / 2), p.stem_bn.g, p.stem_bn.b, rm, rv,
+                           nbt, bnb->scr.sc, bnb->scr.sh);
+        e = stem_pool_bf16s_launch_mode<2>(left, right, p.stem_w, bnb->scr.sc, bnb->scr.sh, nullptr, nullptr, q.P0, S0, N2, cus, s);
+        if (e != hipSuccess) return e;
+    }
+    // E3: the four stages on the same GEMM kernel (eye-interleaved rows, see conv_bf16s.h)
+    auto bconv = [&](const char* role, const __bf16* in, int cin, int c, int taps, int stride, int side, const float* wgt,
+                     const HmParams::Bn& bn, const __bf16* res_, int relu_, __bf16* o) -> hipError_t {
+        // [r3] Cout = 64 / 128 run on the 64- / 128-column tile (256 x 64 NI, gemm_bf16s.h) instead of N = 256 with a column guard
+        const int Np = c <= 64 ? 64 : c <= 128 ? 128 : (c + 255) / 256 * 256;
+        const PackSeg& sg = PT.w[li++];
+        const BnSeg& bs = PT.bn[bi++];
+        if (sg.w != wgt || sg.Np != Np || sg.taps != taps || bs.g != bn.g) return hipErrorInvalidValue;
+        const __bf16* WPl = (const __bf16*)(reg + sg.dst_w);
+        // batch statistics: the convolution stores its raw bf16 output (unit scale, zero shift, no residual, no ReLU); bn_batch below does the rest in place
+        const float *SC = bnb ? q.ones : (const float*)(reg + bs.dst_sc), *SH = bnb ? q.zeros : (const float*)(reg + bs.dst_sh);
+        const __bf16* res = bnb ? nullptr : res_;
+        const int relu = bnb ? 0 : relu_;
+        const long M = (long)N2 * side * side;
+        auto run = [&]() -> hipError_t {
+            const bool direct = taps == 9 && stride == 1 && cin == 64 && c == 64;      // [r3] layer1: the direct kernel (conv64_bf16s.h)
+            GemmTimer t(h, s, role, direct ? "conv64_direct_bf16s_kernel" : taps == 9 ? "gemm_bf16s_kernel<XConvE,3x3>" : "gemm_bf16s_kernel<XConvE,1x1>",
+                        2.0 * M * c * taps * (double)cin);
+            if (direct)
+                return conv64_direct_bf16s_launch(in, ZP, WPl, SC, SH, res, o, hm_ilog2(side), N2, relu, cus, s);
+            const SEpiBnBf16<false> ep{SC, SH, res, o, c, hm_ilog2(side), relu};
+            if (sg.slab == 64) {      // [r4] layer3 / layer4's stride-1 convolutions on the 64-deep GEMM (the plan checked the shape rules)
+                if (taps != 9 || cin % 64 != 0 || Np != c) return hipErrorInvalidValue;
+                const X64ConvE xl{in, ZP, cin, hm_ilog2(side), stride};
+                if (c == 128) return gemm_bf16s64_launch_x<X64ConvE, SEpiBnBf16<false>, 1>(xl, WPl, 9L * cin, ep, (int)M, Np, 9 * cin, cus, s);   // layer2: 256 x 128 tile
+                return gemm_bf16s64_launch_x(xl, WPl, 9L * cin, ep, (int)M, Np, 9 * cin, cus, s);
+            }
+            const XConvE xl{in, ZP, cin, hm_ilog2(side), stride, taps};
+            if (Np == 64 && c == 64) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 1>(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
+            if (Np == 128 && c == 128) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 2>(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
+            if (Np == c) {
+                // [r3] few pixels (layer3 / layer4 at small batches: 512 x 512 RGB at B = 32 leaves layer4 128 tiles for 256 CUs): split K,
+                // partial sums in the (by now free) slot of the stem's map, BatchNorm / residual / ReLU in the fixed-order reduce
+                const int sp = gemm_bf16s_ksplit((int)M, Np, taps * cin, cus, q.split_floats);
+                if (sp > 1) return gemm_bf16s_splitk_launch(xl, WPl, (long)taps * cin, ep, q.split_slab, sp, (int)M, Np, taps * cin, cus, s);
+                return gemm_bf16s_launch(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
+            }
+            return gemm_bf16s_launch(xl, WPl, (long)taps * cin, SEpiBnBf16<true>{SC, SH, res, o, c, hm_ilog2(side), relu}, (int)M, Np, taps * cin, cus, s);
+        };
+        hipError_t e = run();
+        if (e != hipSuccess || !bnb) return e;
+        float *rm, *rv; long long* nbt;
+        if (!hm_bn_buffers(bnb->h, bnb->net, bn.g, &rm, &rv, &nbt)) return hipErrorInvalidValue;
+        return bn_batch_bf16s_launch(o, res_, (long)B * side * side, c, bn.g, bn.b, rm, rv, nbt, relu_, bnb->scr, s);
+    };
+    const int sides[4] = {s64, s32, s16, s8};
+    const __bf16* x = q.P0;
+    int cin = 64;
+    for (int i = 0; i < 4; ++i) {
+        const int c = HM_CH[i], side = sides[i], nb = p.nblk[i];
+        __bf16 *Ta = q.Ta[i], *Tb = q.Tb[i], *Td = q.Td[i];                       // q.A[i] is the level itself
+        const __bf16* xin = x;
+        for (int bk = 0; bk < nb; ++bk) {
+            const auto& K = p.blk[i][bk];
+            const int stride = (bk == 0 && i > 0) ? 2 : 1, bc = bk == 0 ? cin : c;
+            // block outputs alternate between Tb and the level so that the last block writes the level (a block never writes
+            // the buffer it reads its identity from)
+            __bf16* y = ((nb - 1 - bk) & 1) ? Tb : q.A[i];
+            hipError_t e = bconv(HM_R1[i][bk], xin, bc, c, 9, stride, side, K.w1, K.bn1, nullptr, 1, Ta);
+            if (e != hipSuccess) return e;
+            const __bf16* idt = xin;
+            if (K.wd) {
+                e = bconv(HM_RD[i], xin, bc, c, 1, 2, side, K.wd, K.bnd, nullptr, 0, Td);
+                if (e != hipSuccess) return e;
+                idt = Td;
+            }
+            e = bconv(HM_R2[i][bk], Ta, c, c, 9, 1, side, K.w2, K.bn2, idt, 1, y);
+            if (e != hipSuccess) return e;
+            xin = y;
+        }
+        x = q.A[i];
+        cin = c;
+    }
+    return hipSuccess;
+}
+
+// E4-E9 on Bc frames whose pyramid levels start at lv[0..3] (layer1 .. layer4 outputs, bf16 [Bc * s^2, 2 C]); li = first decoder entry of the pack table
+static hipError_t hm_bf16_decoder(Handle* h, const HmParams& p, const PackTable& PT, int li, const HmBf16Bufs& q, const __bf16* const* lv, int B, int S0, float* out,
+                                  int64_t out_image_stride, hipStream_t s) {
+    const int cus = device_cu_count();
+    const int s64 = S0 / 4, s32 = S0 / 8, s16 = S0 / 16, s8 = S0 / 32;
+    const long p8 = (long)s8 * s8, p16 = (long)s16 * s16, p32 = (long)s32 * s32, p64 = (long)s64 * s64;
+    char* reg = q.reg;
+    __bf16* ZP = q.ZP;
+    __bf16 *T4 = q.T4, *C3 = q.C3, *Y3 = q.Y3, *C2 = q.C2, *Y2 = q.Y2, *C1 = q.C1, *Y1 = q.Y1;
+    auto up2 = [&](const __bf16* in, __bf16* o, int C, int hin, long ld) {
+        const long total = (long)B * 4 * hin * hin * (C / 8);
+        hipLaunchKernelGGL(upsample2x_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, o, C, hin, ld, total);
+        return hipGetLastError();
+    };
+    // 1x1 convrelu: rows = pixels; the output goes to columns [0, Cout) of o (row stride ld)
+    auto conv1 = [&](const char* role, const __bf16* in, long M, const HmParams::Cv& cv, int Cin, int Cout, __bf16* o, long ld) {
+        const int Np = (Cout + 255) / 256 * 256;
+        const PackSeg& sg = PT.w[li++];
+        if (sg.w != cv.w || sg.Np != Np || sg.Cin != Cin) return hipErrorInvalidValue;      // the plan and the forward walk the layers in one order
+        const __bf16* WPl = (const __bf16*)(reg + sg.dst_w);
+        const float* BPl = (const float*)(reg + sg.dst_b);
+        GemmTimer t(h, s, role, "gemm_bf16s_kernel<XPlain,conv1x1>", 2.0 * M * Cout * Cin);
+        if (Np == Cout) return gemm_bf16s_launch(XPlain{in, Cin}, WPl, (long)Cin, SEpiConvBf16<false>{BPl, o, ld, Np, 1}, (int)M, Np, Cin, cus, s);
+        return gemm_bf16s_launch(XPlain{in, Cin}, WPl, (long)Cin, SEpiConvBf16<true>{BPl, o, ld, (Cout + 7) / 8 * 8, 1}, (int)M, Np, Cin, cus, s);
+    };
+    // 3x3 convrelu on a concat buffer of Cp channels per pixel (Cp a multiple of 32; channels past Cin are zero)
+    auto conv3 = [&](const char* role, const __bf16* in, long M, int side, const HmParams::Cv& cv, int Cin, int Cp, int Cout, __bf16* o) {
+        const PackSeg& sg = PT.w[li++];
+        if (sg.w != cv.w || sg.Cp != Cp || sg.Np != Cout) return hipErrorInvalidValue;
+        if (sg.slab == 32) {      // [r4] few pixels: the 32-deep kernel, split over K when the plan's rule says so (serving batches)
+            if (Cp % 32 != 0 || Cout % 256 != 0) return hipErrorInvalidValue;
+            GemmTimer t(h, s, role, "gemm_bf16s_kernel<XConv3>", 2.0 * M * Cout * 9.0 * Cin);
+            const XConv3 xl{in, ZP, Cp, hm_ilog2(side)};
+            const SEpiConvBf16<false> ep{cv.b, o, (long)Cout, Cout, 1};
+            const int sp = hm_dec_ksplit((int)M, Cout, 9 * Cp, cus, q.dec_split_floats);
+            if (sp > 1) return gemm_bf16s_splitk_launch(xl, (const __bf16*)(reg + sg.dst_w), 9L * Cp, ep, q.dec_slab, sp, (int)M, Cout, 9 * Cp, cus, s);
+            return gemm_bf16s_launch(xl, (const __bf16*)(reg + sg.dst_w), 9L * Cp, ep, (int)M, Cout, 9 * Cp, cus, s);
+        }
+        if (sg.slab != 64 || Cp % 64 != 0 || Cout % 256 != 0) return hipErrorInvalidValue;
+        GemmTimer t(h, s, role, "gemm_bf16s64_kernel<X64Conv3>", 2.0 * M * Cout * 9.0 * Cin);
+        const X64Conv3 xl{in, ZP, Cp, hm_ilog2(side)};
+        return gemm_bf16s64_launch_x(xl, (const __bf16*)(reg + sg.dst_w), 9L * Cp, SEpiConvBf16<false>{cv.b, o, (long)Cout, Cout, 1}, (int)M, Cout, 9 * Cp, cus, s);
+    };
+    const __bf16 *A1 = lv[0], *A2 = lv[1], *A3 = lv[2], *A4 = lv[3];
+#define HMD(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
+    HMD(zero_fill(C3, (size_t)B * p16 * HM_CAT3P * 2, s));                    // channels 1544..1599 of the first concat are padding
+    HMD(conv1("hm.layer4_1x1", A4, B * p8, p.l1x1[3], 1024, 1024, T4, 1024));
+    HMD(up2(T4, C3, 1024, s8, HM_CAT3P));
+    HMD(conv1("hm.layer3_1x1", A3, B * p16, p.l1x1[2], 512, 516, C3 + 1024, HM_CAT3P));
+    HMD(conv3("hm.conv_up3", C3, B * p16, s16, p.up[2], 1540, HM_CAT3P, 1024, Y3));
+    HMD(up2(Y3, C2, 1024, s16, 1280));
+    HMD(conv1("hm.layer2_1x1", A2, B * p32, p.l1x1[1], 256, 256, C2 + 1024, 1280));
+    HMD(conv3("hm.conv_up2", C2, B * p32, s32, p.up[1], 1280, 1280, 512, Y2));
+    HMD(up2(Y2, C1, 512, s32, 640));
+    HMD(conv1("hm.layer1_1x1", A1, B * p64, p.l1x1[0], 128, 128, C1 + 512, 640));
+    HMD(conv3("hm.conv_up1", C1, B * p64, s64, p.up[0], 640, 640, 512, Y1));
+    {   // conv_heatmap: fp32 NCHW into the caller's channel slice
+        const PackSeg& sg = PT.w[li++];
+        if (sg.w != p.head.w || li != PT.nw) return hipErrorInvalidValue;      // the pack plan is out of step with the forward
+        GemmTimer t(h, s, "hm.conv_heatmap", "gemm_bf16s_kernel<XPlain,heatmap>", 2.0 * B * p64 * p.n_out * 512);
+        const SEpiHeatNCHW he{(const float*)(reg + sg.dst_b), out, (long)out_image_stride, p.n_out, hm_ilog2(p64)};
+        const __bf16* hw = (const __bf16*)(reg + sg.dst_w);
+        const int hn = hm_head_np(p.n_out);
+        if (hn == 64) HMD((gemm_bf16s_launch<XPlain, SEpiHeatNCHW, 1>(XPlain{Y1, 512}, hw, 512L, he, (int)(B * p64), 64, 512, cus, s)));
+        else if (hn == 128) HMD((gemm_bf16s_launch<XPlain, SEpiHeatNCHW, 2>(XPlain{Y1, 512}, hw, 512L, he, (int)(B * p64), 128, 512, cus, s)));
+        else HMD(gemm_bf16s_launch(XPlain{Y1, 512}, hw, 512L, he, (int)(B * p64), 256, 512, cus, s));
+    }
+#undef HMD
+    return hipSuccess;
 }
 
 #if EGOTAP_IN(0)
@@ -1338,147 +1553,30 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
         // bf16 mode: everything after the stem on bf16 channels-last activations, every convolution on the bf16-storage GEMM
         // (conv_bf16s.h).  Buffers live in the fp32 path's slots (each at most half as large).
         auto Hb = [&](size_t off) { return (__bf16*)(base + off); };
-        __bf16 *A1 = Hb(w.S[0][0]), *A2 = Hb(w.S[1][0]), *A3 = Hb(w.S[2][0]), *A4 = Hb(w.S[3][0]);
-        __bf16 *T4 = Hb(w.U4), *C3 = Hb(w.CAT3), *Y3 = Hb(w.X3), *C2 = Hb(w.CAT2), *Y2 = Hb(w.X2), *C1 = Hb(w.CAT1), *Y1 = Hb(w.X1);
-        __bf16* ZP = (__bf16*)(base + w.WPACK + ((size_t)40 << 20) + 32768);        // 256 bytes of zeros (taps outside the image)
+        HmBf16Bufs q{};
+        q.P0 = Hb(w.P0);
+        for (int i = 0; i < 4; ++i) { q.A[i] = Hb(w.S[i][0]); q.Ta[i] = Hb(w.S[i][1]); q.Tb[i] = Hb(w.S[i][2]); q.Td[i] = Hb(w.S[i][3]); }
+        q.T4 = Hb(w.U4); q.C3 = Hb(w.CAT3); q.Y3 = Hb(w.X3); q.C2 = Hb(w.CAT2); q.Y2 = Hb(w.X2); q.C1 = Hb(w.CAT1); q.Y1 = Hb(w.X1);
+        q.ZP = (__bf16*)(base + w.WPACK + ((size_t)40 << 20) + 32768);              // 256 bytes of zeros (taps outside the image)
+        q.reg = base + w.WALL;
+        q.split_slab = F(w.L0);                                                    // the fp32 stem map's slot: unused (fused stem)
+        q.split_floats = (size_t)N2 * 64 * (S0 / 2) * (S0 / 2);
+        q.dec_slab = (float*)(base + w.WPACK);                                     // [r4] the first 40 MB of the WPACK region (the zero page sits behind them): split-K partials of the decoder
+        q.dec_split_floats = ((size_t)40 << 20) / 4;
         const int cus = device_cu_count();
-        const long p8 = (long)s8 * s8, p16 = (long)s16 * s16, p32 = (long)s32 * s32, p64 = (long)s64 * s64;
-        auto ilog2 = [](long v) { int l = 0; while ((1L << l) < v) ++l; return l; };
-        EGO_HIP(zero_fill(ZP, 256, s));
+        EGO_HIP(zero_fill(q.ZP, 256, s));
         // [r3] all 27 weight repacks and 19 BatchNorm folds of this forward in ONE launch (conv_bf16s.h, pack_all_bf16s_kernel): the
         // parameters stay the caller's live fp32 tensors, nothing is kept between calls
         PackTable PT;
-        const size_t split_floats = (size_t)N2 * 64 * (S0 / 2) * (S0 / 2);
         const int stage_sides[4] = {s64, s32, s16, s8};
-        float* dec_slab = (float*)(base + w.WPACK);                               // [r4] the first 40 MB of the WPACK region (the zero page sits behind them): split-K partials of the decoder
-        const size_t dec_split_floats = ((size_t)40 << 20) / 4;
-        EGO_CHECK(hm_pack_plan(&p, p.nblk, &PT, N2, stage_sides, cus, split_floats, dec_split_floats) != 0, "egotap_hm_forward: the estimator has more layers than the pack table holds");
-        char* reg = base + w.WALL;
-        hipLaunchKernelGGL(pack_all_bf16s_kernel, dim3(PT.blocks), dim3(256), 0, s, PT, reg);
+        EGO_CHECK(hm_pack_plan(&p, p.nblk, &PT, N2, stage_sides, cus, q.split_floats, q.dec_split_floats) != 0, "egotap_hm_forward: the estimator has more layers than the pack table holds");
+        hipLaunchKernelGGL(pack_all_bf16s_kernel, dim3(PT.blocks), dim3(256), 0, s, PT, q.reg);
         EGO_HIP(hipGetLastError());
         int li = 0, bi = 0;
-        float* split_slab = F(w.L0);                                               // the fp32 stem map's slot: unused (fused stem) or dead after the max-pool
-        auto up2 = [&](const __bf16* in, __bf16* o, int C, int hin, long ld) {
-            const long total = (long)B * 4 * hin * hin * (C / 8);
-            hipLaunchKernelGGL(upsample2x_nhwc_bf16s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, o, C, hin, ld, total);
-            return hipGetLastError();
-        };
-        // 1x1 convrelu: rows = pixels; the output goes to columns [0, Cout) of o (row stride ld)
-        auto conv1 = [&](const char* role, const __bf16* in, long M, const HmParams::Cv& cv, int Cin, int Cout, __bf16* o, long ld) {
-            const int Np = (Cout + 255) / 256 * 256;
-            const PackSeg& sg = PT.w[li++];
-            if (sg.w != cv.w || sg.Np != Np || sg.Cin != Cin) return hipErrorInvalidValue;      // the plan and the forward walk the layers in one order
-            const __bf16* WPl = (const __bf16*)(reg + sg.dst_w);
-            const float* BPl = (const float*)(reg + sg.dst_b);
-            GemmTimer t(h, s, role, "gemm_bf16s_kernel<XPlain,conv1x1>", 2.0 * M * Cout * Cin);
-            if (Np == Cout) return gemm_bf16s_launch(XPlain{in, Cin}, WPl, (long)Cin, SEpiConvBf16<false>{BPl, o, ld, Np, 1}, (int)M, Np, Cin, cus, s);
-            return gemm_bf16s_launch(XPlain{in, Cin}, WPl, (long)Cin, SEpiConvBf16<true>{BPl, o, ld, (Cout + 7) / 8 * 8, 1}, (int)M, Np, Cin, cus, s);
-        };
-        // 3x3 convrelu on a concat buffer of Cp channels per pixel (Cp a multiple of 32; channels past Cin are zero)
-        auto conv3 = [&](const char* role, const __bf16* in, long M, int side, const HmParams::Cv& cv, int Cin, int Cp, int Cout, __bf16* o) {
-            const PackSeg& sg = PT.w[li++];
-            if (sg.w != cv.w || sg.Cp != Cp || sg.Np != Cout) return hipErrorInvalidValue;
-            if (sg.slab == 32) {      // [r4] few pixels: the 32-deep kernel, split over K when the plan's rule says so (serving batches)
-                if (Cp % 32 != 0 || Cout % 256 != 0) return hipErrorInvalidValue;
-                GemmTimer t(h, s, role, "gemm_bf16s_kernel<XConv3>", 2.0 * M * Cout * 9.0 * Cin);
-                const XConv3 xl{in, ZP, Cp, ilog2(side)};
-                const SEpiConvBf16<false> ep{cv.b, o, (long)Cout, Cout, 1};
-                const int sp = hm_dec_ksplit((int)M, Cout, 9 * Cp, cus, dec_split_floats);
-                if (sp > 1) return gemm_bf16s_splitk_launch(xl, (const __bf16*)(reg + sg.dst_w), 9L * Cp, ep, dec_slab, sp, (int)M, Cout, 9 * Cp, cus, s);
-                return gemm_bf16s_launch(xl, (const __bf16*)(reg + sg.dst_w), 9L * Cp, ep, (int)M, Cout, 9 * Cp, cus, s);
-            }
-            if (sg.slab != 64 || Cp % 64 != 0 || Cout % 256 != 0) return hipErrorInvalidValue;
-            GemmTimer t(h, s, role, "gemm_bf16s64_kernel<X64Conv3>", 2.0 * M * Cout * 9.0 * Cin);
-            const X64Conv3 xl{in, ZP, Cp, ilog2(side)};
-            return gemm_bf16s64_launch_x(xl, (const __bf16*)(reg + sg.dst_w), 9L * Cp, SEpiConvBf16<false>{cv.b, o, (long)Cout, Cout, 1}, (int)M, Cout, 9 * Cp, cus, s);
-        };
-        // E2: max-pool of the stem's bf16 [B * (2 s64)^2, 2 x 64] -> [B * s64^2, 2 x 64]; E3: the four stages on the same GEMM kernel (eye-interleaved rows, see conv_bf16s.h)
-        __bf16* P0 = Hb(w.P0);
-        EGO_HIP(stem_pool_bf16s_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, P0, S0, N2, cus, s));
-        auto bconv = [&](const char* role, const __bf16* in, int cin, int c, int taps, int stride, int side, const float* wgt,
-                         const HmParams::Bn& bn, const __bf16* res, int relu, __bf16* o) {
-            // [r3] Cout = 64 / 128 run on the 64- / 128-column tile (256 x 64 NI, gemm_bf16s.h) instead of N = 256 with a column guard
-            const int Np = c <= 64 ? 64 : c <= 128 ? 128 : (c + 255) / 256 * 256;
-            const PackSeg& sg = PT.w[li++];
-            const BnSeg& bs = PT.bn[bi++];
-            if (sg.w != wgt || sg.Np != Np || sg.taps != taps || bs.g != bn.g) return hipErrorInvalidValue;
-            const __bf16* WPl = (const __bf16*)(reg + sg.dst_w);
-            const float *SC = (const float*)(reg + bs.dst_sc), *SH = (const float*)(reg + bs.dst_sh);
-            const long M = (long)N2 * side * side;
-            const bool direct = taps == 9 && stride == 1 && cin == 64 && c == 64;      // [r3] layer1: the direct kernel (conv64_bf16s.h)
-            GemmTimer t(h, s, role, direct ? "conv64_direct_bf16s_kernel" : taps == 9 ? "gemm_bf16s_kernel<XConvE,3x3>" : "gemm_bf16s_kernel<XConvE,1x1>",
-                        2.0 * M * c * taps * (double)cin);
-            if (direct)
-                return conv64_direct_bf16s_launch(in, ZP, WPl, SC, SH, res, o, ilog2(side), N2, relu, cus, s);
-            const SEpiBnBf16<false> ep{SC, SH, res, o, c, ilog2(side), relu};
-            if (sg.slab == 64) {      // [r4] layer3 / layer4's stride-1 convolutions on the 64-deep GEMM (the plan checked the shape rules)
-                if (taps != 9 || cin % 64 != 0 || Np != c) return hipErrorInvalidValue;
-                const X64ConvE xl{in, ZP, cin, ilog2(side), stride};
-                if (c == 128) return gemm_bf16s64_launch_x<X64ConvE, SEpiBnBf16<false>, 1>(xl, WPl, 9L * cin, ep, (int)M, Np, 9 * cin, cus, s);   // layer2: 256 x 128 tile
-                return gemm_bf16s64_launch_x(xl, WPl, 9L * cin, ep, (int)M, Np, 9 * cin, cus, s);
-            }
-            const XConvE xl{in, ZP, cin, ilog2(side), stride, taps};
-            if (Np == 64 && c == 64) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 1>(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
-            if (Np == 128 && c == 128) return gemm_bf16s_launch<XConvE, SEpiBnBf16<false>, 2>(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
-            if (Np == c) {
-                // [r3] few pixels (layer3 / layer4 at small batches: 512 x 512 RGB at B = 32 leaves layer4 128 tiles for 256 CUs): split K,
-                // partial sums in the (by now free) slot of the stem's map, BatchNorm / residual / ReLU in the fixed-order reduce
-                const int sp = gemm_bf16s_ksplit((int)M, Np, taps * cin, cus, split_floats);
-                if (sp > 1) return gemm_bf16s_splitk_launch(xl, WPl, (long)taps * cin, ep, split_slab, sp, (int)M, Np, taps * cin, cus, s);
-                return gemm_bf16s_launch(xl, WPl, (long)taps * cin, ep, (int)M, Np, taps * cin, cus, s);
-            }
-            return gemm_bf16s_launch(xl, WPl, (long)taps * cin, SEpiBnBf16<true>{SC, SH, res, o, c, ilog2(side), relu}, (int)M, Np, taps * cin, cus, s);
-        };
-        {
-            const int sides[4] = {s64, s32, s16, s8};
-            __bf16* Ls[4] = {A1, A2, A3, A4};                                       // stage outputs = pyramid levels = the decoder's operands
-            const __bf16* x = P0;
-            int cin = 64;
-            for (int i = 0; i < 4; ++i) {
-                const int c = HM_CH[i], side = sides[i], nb = p.nblk[i];
-                __bf16 *Ta = Hb(w.S[i][1]), *Tb = Hb(w.S[i][2]), *Td = Hb(w.S[i][3]);   // S[i][0] is the level itself (A1..A4)
-                const __bf16* xin = x;
-                for (int bk = 0; bk < nb; ++bk) {
-                    const auto& K = p.blk[i][bk];
-                    const int stride = (bk == 0 && i > 0) ? 2 : 1, bc = bk == 0 ? cin : c;
-                    // block outputs alternate between Tb and the level so that the last block writes the level (a block never writes
-                    // the buffer it reads its identity from)
-                    __bf16* y = ((nb - 1 - bk) & 1) ? Tb : Ls[i];
-                    EGO_HIP(bconv(HM_R1[i][bk], xin, bc, c, 9, stride, side, K.w1, K.bn1, nullptr, 1, Ta));
-                    const __bf16* idt = xin;
-                    if (K.wd) {
-                        EGO_HIP(bconv(HM_RD[i], xin, bc, c, 1, 2, side, K.wd, K.bnd, nullptr, 0, Td));
-                        idt = Td;
-                    }
-                    EGO_HIP(bconv(HM_R2[i][bk], Ta, c, c, 9, 1, side, K.w2, K.bn2, idt, 1, y));
-                    xin = y;
-                }
-                x = Ls[i];
-                cin = c;
-            }
-        }
-        EGO_HIP(zero_fill(C3, (size_t)B * p16 * HM_CAT3P * 2, s));                // channels 1544..1599 of the first concat are padding
-        EGO_HIP(conv1("hm.layer4_1x1", A4, B * p8, p.l1x1[3], 1024, 1024, T4, 1024));
-        EGO_HIP(up2(T4, C3, 1024, s8, HM_CAT3P));
-        EGO_HIP(conv1("hm.layer3_1x1", A3, B * p16, p.l1x1[2], 512, 516, C3 + 1024, HM_CAT3P));
-        EGO_HIP(conv3("hm.conv_up3", C3, B * p16, s16, p.up[2], 1540, HM_CAT3P, 1024, Y3));
-        EGO_HIP(up2(Y3, C2, 1024, s16, 1280));
-        EGO_HIP(conv1("hm.layer2_1x1", A2, B * p32, p.l1x1[1], 256, 256, C2 + 1024, 1280));
-        EGO_HIP(conv3("hm.conv_up2", C2, B * p32, s32, p.up[1], 1280, 1280, 512, Y2));
-        EGO_HIP(up2(Y2, C1, 512, s32, 640));
-        EGO_HIP(conv1("hm.layer1_1x1", A1, B * p64, p.l1x1[0], 128, 128, C1 + 512, 640));
-        EGO_HIP(conv3("hm.conv_up1", C1, B * p64, s64, p.up[0], 640, 640, 512, Y1));
-        {   // conv_heatmap: fp32 NCHW into the caller's channel slice
-            const PackSeg& sg = PT.w[li++];
-            EGO_CHECK(sg.w == p.head.w && li == PT.nw && bi == PT.nb, "egotap_hm_forward: pack plan out of step with the forward");
-            GemmTimer t(h, s, "hm.conv_heatmap", "gemm_bf16s_kernel<XPlain,heatmap>", 2.0 * B * p64 * p.n_out * 512);
-            const SEpiHeatNCHW he{(const float*)(reg + sg.dst_b), out, (long)out_image_stride, p.n_out, ilog2(p64)};
-            const __bf16* hw = (const __bf16*)(reg + sg.dst_w);
-            const int hn = hm_head_np(p.n_out);
-            if (hn == 64) EGO_HIP((gemm_bf16s_launch<XPlain, SEpiHeatNCHW, 1>(XPlain{Y1, 512}, hw, 512L, he, (int)(B * p64), 64, 512, cus, s)));
-            else if (hn == 128) EGO_HIP((gemm_bf16s_launch<XPlain, SEpiHeatNCHW, 2>(XPlain{Y1, 512}, hw, 512L, he, (int)(B * p64), 128, 512, cus, s)));
-            else EGO_HIP(gemm_bf16s_launch(XPlain{Y1, 512}, hw, 512L, he, (int)(B * p64), 256, 512, cus, s));
-        }
+        EGO_HIP(hm_bf16_backbone(h, p, PT, li, bi, q, left, right, B, S0, nullptr, s));
+        const __bf16* lv[4] = {q.A[0], q.A[1], q.A[2], q.A[3]};
+        EGO_HIP(hm_bf16_decoder(h, p, PT, li, q, lv, B, S0, out, out_image_stride, s));
+        EGO_CHECK(bi == PT.nb, "egotap_hm_forward: pack plan out of step with the forward");
         return EGOTAP_OK;
     }
     // E2: maxpool 3x3/2
@@ -1543,6 +1641,130 @@ extern "C" int egotap_hm_forward(egotap_handle h, int net, const float* left, co
     EGO_HIP(biasconv("hm.layer1_1x1", 1, s64, L1, 128 * p64, p.l1x1[0], 128, 128, CAT1 + 512 * p64, 640 * p64, 1));
     EGO_HIP(biasconv("hm.conv_up1", 9, s64, CAT1, 640 * p64, p.up[0], 640, 512, X1, 512 * p64, 1));
     EGO_HIP(biasconv("hm.conv_heatmap", 1, s64, X1, 512 * p64, p.head, 512, p.n_out, out, out_image_stride, 0));
+    return EGOTAP_OK;
+}
+#endif
+
+// ---- [r5] batch-statistics forward of a frozen estimator on the bf16 channels-last kernels (train.py:91; egotap_autoencoder_model.py:127-129, 177-216)
+struct HmBnWs {
+    size_t P0, S[4][4], T4, C3, Y3, C2, Y2, C1, Y1, WALL, DEC, ZP, SPLIT, PART, SC, SH, ONES, ZEROS, total;
+};
+static constexpr size_t HM_BN_SPLIT_FLOATS = (size_t)1 << 24;      // split-K partials of the backbone: tiles x splits <= CUs x 65536 floats
+static HmBnWs hm_bn_ws(const Handle* h, int B, int chunk) {
+    HmBnWs w;
+    const size_t S0 = (size_t)h->cfg.hm_size * 4, s64 = S0 / 4, s32 = S0 / 8, s16 = S0 / 16, s8 = S0 / 32;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = al256(o + bytes); return r; };
+    w.P0 = take((size_t)B * s64 * s64 * 128 * 2);
+    for (int i = 0; i < 4; ++i) {
+        const size_t side = S0 / (4u << i), bytes = (size_t)B * side * side * 2 * HM_CH[i] * 2;
+        for (int k = 0; k < 4; ++k) w.S[i][k] = take(bytes);
+    }
+    const size_t c = (size_t)chunk;
+    w.T4 = take(c * s8 * s8 * 1024 * 2);
+    w.C3 = take(c * s16 * s16 * HM_CAT3P * 2); w.Y3 = take(c * s16 * s16 * 1024 * 2);
+    w.C2 = take(c * s32 * s32 * 1280 * 2);     w.Y2 = take(c * s32 * s32 * 512 * 2);
+    w.C1 = take(c * s64 * s64 * 640 * 2);      w.Y1 = take(c * s64 * s64 * 512 * 2);
+    const int nblk_[4] = {hm_nblk(h, 0), hm_nblk(h, 1), hm_nblk(h, 2), hm_nblk(h, 3)};
+    w.WALL = take(hm_pack_plan(nullptr, nblk_, nullptr) + 256);
+    w.DEC = take((size_t)40 << 20);
+    w.ZP = take(256);
+    w.SPLIT = take(HM_BN_SPLIT_FLOATS * 4);
+    w.PART = take(BnBatchScratch::part_floats() * 4);
+    w.SC = take(4096); w.SH = take(4096); w.ONES = take(4096); w.ZEROS = take(4096);
+    w.total = o;
+    return w;
+}
+static __global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ p, float v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+#if EGOTAP_IN(0)
+extern "C" int egotap_hm_forward_bnbatch_workspace_bytes(egotap_handle h, int B, int chunk, size_t* bytes) {
+    EGO_CHECK(h && bytes, "null argument");
+    EGO_CHECK(B >= 0 && chunk >= 0, "negative batch or chunk");
+    const int b = B > 0 ? B : 1;
+    *bytes = hm_bn_ws(h, b, chunk > 0 && chunk < b ? chunk : b).total;
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(0)
+extern "C" int egotap_hm_forward_bnbatch_intermediate(egotap_handle h, int B, int chunk, const char* name, size_t* offset, int64_t* numel) {
+    EGO_CHECK(h && name && offset && numel, "null argument");
+    EGO_CHECK(B >= 1, "batch");
+    const HmBnWs w = hm_bn_ws(h, B, chunk > 0 && chunk < B ? chunk : B);
+    const int64_t S0 = h->cfg.hm_size * 4;
+    auto px = [&](int i) { const int64_t side = S0 / (4 << i); return (int64_t)B * side * side; };
+    if (!strcmp(name, "pool0")) { *offset = w.P0; *numel = px(0) * 128; }
+    else if (!strcmp(name, "layer1")) { *offset = w.S[0][0]; *numel = px(0) * 2 * HM_CH[0]; }
+    else if (!strcmp(name, "layer2")) { *offset = w.S[1][0]; *numel = px(1) * 2 * HM_CH[1]; }
+    else if (!strcmp(name, "layer3")) { *offset = w.S[2][0]; *numel = px(2) * 2 * HM_CH[2]; }
+    else if (!strcmp(name, "layer4")) { *offset = w.S[3][0]; *numel = px(3) * 2 * HM_CH[3]; }
+    else { egotap_set_error("unknown intermediate '%s'", name); return EGOTAP_ERR_INVALID; }
+    return EGOTAP_OK;
+}
+#endif
+
+#if EGOTAP_IN(0)
+extern "C" int egotap_hm_forward_bnbatch(egotap_handle h, int net, const float* left, const float* right, int B, float* out, int64_t out_image_stride, int chunk,
+                                         void* ws, size_t ws_bytes, void* stream) {
+    EGO_CHECK(h, "null handle");
+    EGO_CHECK(net == EGOTAP_NET_HM_POS || net == EGOTAP_NET_HM_ROT, "egotap_hm_forward_bnbatch: net must be EGOTAP_NET_HM_POS or _ROT");
+    EGO_CHECK(h->precision == EGOTAP_PREC_BF16, "egotap_hm_forward_bnbatch runs on the bf16 channels-last kernels: egotap_set_precision(EGOTAP_PREC_BF16) first "
+              "(fp32 / bf16x3: compose the train-mode forward from egotap_hmtrain_conv_fwd + egotap_hmtrain_bn2d_fwd)");
+    if (B == 0) return EGOTAP_OK;
+    EGO_CHECK(B >= 2, "batch-statistics BatchNorm needs more than one value per channel and every map has them only from two frames on at the deepest level "
+              "(torch raises for one 1 x 1 map; keep B >= 2)");
+    EGO_CHECK(left && right && out && ws, "egotap_hm_forward_bnbatch: null argument");
+    EGO_CHECK((((uintptr_t)left | (uintptr_t)right | (uintptr_t)out) & 15) == 0 && ((uintptr_t)ws & 255) == 0, "pointers must be 16-byte (ws: 256-byte) aligned");
+    const int S0 = h->cfg.hm_size * 4, s64 = S0 / 4, s32 = S0 / 8, s16 = S0 / 16, s8 = S0 / 32;
+    EGO_CHECK(s64 == 64 || s64 == 128, "this build instantiates the conv kernels for 256x256 and 512x512 RGB (64x64 / 128x128 heatmaps)");
+    if (chunk <= 0 || chunk > B) chunk = B;
+    int rc = hm_resolve(h, net);
+    if (rc != EGOTAP_OK) return rc;
+    const HmBnWs w = hm_bn_ws(h, B, chunk);
+    if (ws_bytes < w.total) {
+        egotap_set_error("workspace too small: %zu bytes given, %zu needed for B=%d, chunk=%d", ws_bytes, w.total, B, chunk);
+        return EGOTAP_ERR_WORKSPACE;
+    }
+    const HmParams& p = h->hp[net];
+    EGO_CHECK(out_image_stride >= (int64_t)p.n_out * s64 * s64, "out_image_stride smaller than the output image");
+    hipStream_t s = (hipStream_t)stream;
+    char* base = (char*)ws;
+    auto Hb = [&](size_t off) { return (__bf16*)(base + off); };
+    HmBf16Bufs q{};
+    q.P0 = Hb(w.P0);
+    for (int i = 0; i < 4; ++i) { q.A[i] = Hb(w.S[i][0]); q.Ta[i] = Hb(w.S[i][1]); q.Tb[i] = Hb(w.S[i][2]); q.Td[i] = Hb(w.S[i][3]); }
+    q.T4 = Hb(w.T4); q.C3 = Hb(w.C3); q.Y3 = Hb(w.Y3); q.C2 = Hb(w.C2); q.Y2 = Hb(w.Y2); q.C1 = Hb(w.C1); q.Y1 = Hb(w.Y1);
+    q.ZP = Hb(w.ZP);
+    q.reg = base + w.WALL;
+    q.split_slab = (float*)(base + w.SPLIT); q.split_floats = HM_BN_SPLIT_FLOATS;
+    q.dec_slab = (float*)(base + w.DEC);     q.dec_split_floats = ((size_t)40 << 20) / 4;
+    q.ones = (const float*)(base + w.ONES);  q.zeros = (const float*)(base + w.ZEROS);
+    HmBnBatch bnb{BnBatchScratch{(float*)(base + w.PART), (float*)(base + w.SC), (float*)(base + w.SH)}, h, net};
+    const int cus = device_cu_count();
+    EGO_HIP(zero_fill(q.ZP, 256, s));
+    EGO_HIP(zero_fill((void*)q.zeros, 4096, s));
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(4), dim3(256), 0, s, (float*)q.ones, 1.f, 1024);
+    EGO_HIP(hipGetLastError());
+    PackTable PT;
+    const int stage_sides[4] = {s64, s32, s16, s8};
+    EGO_CHECK(hm_pack_plan(&p, p.nblk, &PT, 2L * B, stage_sides, cus, q.split_floats, q.dec_split_floats, 2L * chunk) != 0,
+              "egotap_hm_forward_bnbatch: the estimator has more layers than the pack table holds");
+    hipLaunchKernelGGL(pack_all_bf16s_kernel, dim3(PT.blocks), dim3(256), 0, s, PT, q.reg);      // (its eval-mode BatchNorm folds are written and not read here)
+    EGO_HIP(hipGetLastError());
+    int li = 0, bi = 0;
+    EGO_HIP(hm_bf16_backbone(h, p, PT, li, bi, q, left, right, B, S0, &bnb, s));      // whole batch: the statistics couple its frames
+    EGO_CHECK(bi == PT.nb, "egotap_hm_forward_bnbatch: pack plan out of step with the forward");
+    const long px[4] = {(long)s64 * s64, (long)s32 * s32, (long)s16 * s16, (long)s8 * s8};
+    for (int lo = 0; lo < B; lo += chunk) {                                             // the decoder has no BatchNorm: chunks keep its scratch small
+        const int bc = B - lo < chunk ? B - lo : chunk;
+        const __bf16* lv[4];
+        for (int i = 0; i < 4; ++i) lv[i] = q.A[i] + (size_t)lo * px[i] * 2 * HM_CH[i];
+        EGO_HIP(hm_bf16_decoder(h, p, PT, li, q, lv, bc, S0, out + (size_t)lo * out_image_stride, out_image_stride, s));
+    }
     return EGOTAP_OK;
 }
 #endif

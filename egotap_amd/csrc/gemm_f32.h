@@ -979,13 +979,13 @@ static inline double gemm_f32_direct_estimate_us(int M, int N, int K, int num_cu
 
 // P: scratch of at least splits * M * N floats; returns hipErrorInvalidValue for shapes the tile does not cover
 // the partial-sum launch alone: *splits_out ranges of K into P[split][M][N] (the caller reduces)
+// `splits` comes from the caller's plan (gemm_f32_splitk_plan: ONE decision, shared by whoever reduces the partials afterwards)
 template <class Cfg, class ALoad>
-static hipError_t gemm_f32_splitk_partials(const ALoad& al, const SegMat& W, float* P, size_t p_floats, int M, int N, int K, hipStream_t stream, int num_cu,
-                                           int* splits_out) {
+static hipError_t gemm_f32_splitk_partials(const ALoad& al, const SegMat& W, float* P, size_t p_floats, int M, int N, int K, hipStream_t stream, int splits) {
     if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0) return hipErrorInvalidValue;
     const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = N / Cfg::BN;
     const int KT = K / Cfg::BK;
-    const int splits = gemm_f32_splitk_plan<Cfg>(M, N, K, p_floats, num_cu).splits;
+    if (splits < 1 || (splits > 1 && (long)((KT + splits - 1) / splits) * (splits - 1) >= KT)) return hipErrorInvalidValue;      // no empty last range
     if ((size_t)splits * M * N > p_floats) return hipErrorInvalidValue;
     const int kper = ((KT + splits - 1) / splits) * Cfg::BK;
     auto kern = gemm_f32_splitk_kernel<Cfg, ALoad>;
@@ -996,15 +996,15 @@ static hipError_t gemm_f32_splitk_partials(const ALoad& al, const SegMat& W, flo
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, al, W, P, M, N, K, tiles_m, tiles_n, kper);
-    *splits_out = splits;
     return hipGetLastError();
 }
+// splits = 0: the plan's count for this shape
 template <class Cfg, class ALoad, class Epi>
 static hipError_t gemm_f32_splitk_launch(const ALoad& al, const SegMat& W, const Epi& epi, float* C, long ldc, float* P, size_t p_floats, int M,
-                                         int N, int K, hipStream_t stream, int num_cu = 256) {
+                                         int N, int K, hipStream_t stream, int num_cu = 256, int splits = 0) {
     if (M <= 0) return hipSuccess;
-    int splits = 1;
-    hipError_t e = gemm_f32_splitk_partials<Cfg>(al, W, P, p_floats, M, N, K, stream, num_cu, &splits);
+    if (splits == 0) splits = gemm_f32_splitk_plan<Cfg>(M, N, K, p_floats, num_cu).splits;
+    hipError_t e = gemm_f32_splitk_partials<Cfg>(al, W, P, p_floats, M, N, K, stream, splits);
     if (e != hipSuccess) return e;
     const long total = (long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel<Epi>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const float*)P, epi, C, ldc, M, N, splits);

@@ -424,7 +424,7 @@ static __global__ __launch_bounds__(256) void pose_head_kernel(const float* __re
     if (estimate_head) {
         const int o = j == J ? 3 + c : c;
         float s = 0.f;
-        if (H == 512) {
+        if (H == 512 && (((size_t)Wg | (size_t)hseq) & 15) == 0) {      // (wave-uniform; a 4-byte-aligned view of either takes the scalar loop)
             // [r4] The 7680-long dot streams 61 KB per wave that nobody has touched yet: every (load, load, fma) round of the scalar loop below
             // was a full miss (48 us of a 1.4 ms B = 1 forward).  Five rows of h and of W are requested at once (20 x 16 bytes per lane),
             // three round trips in all.  Every batch size runs this same order, so rows stay bit-identical across batch sizes.

@@ -28,7 +28,7 @@ struct StemPoolCfg {
     static constexpr int RING_ROW = (XS + 1) * 128, RING_BYTES = 4 * RING_ROW;      // [slot][1 + 64 columns][64 channels] bf16
     static constexpr int CARRY_BYTES = 2 * SR * 128;
     static constexpr int OFF_RING = PATCH_BYTES, OFF_CARRY = OFF_RING + RING_BYTES, OFF_BN = OFF_CARRY + CARRY_BYTES;
-    static constexpr int LDS_BYTES = OFF_BN + 2 * 64 * 4;
+    static constexpr int LDS_BYTES = OFF_BN + 2 * 128 * 4;            // scale | shift, 64 channels x 2 eyes (MODE 2: per-eye batch statistics)
     static constexpr int THREADS = 256;
     static constexpr int NPRE = (3 * PR * (PCOLS / 2) + THREADS - 1) / THREADS;      // column pairs per thread: 32
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
@@ -37,6 +37,14 @@ struct StemPoolCfg {
 typedef unsigned short u16x8s __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 
+// [r5] MODE 0: BatchNorm folded from the running statistics (gamma, beta, mean, var: eval mode).
+// MODE 1: STATISTICS ONLY -- the same staging and MFMAs, no BatchNorm / pool / store: every lane sums its 32 (channel, pixel-column) accumulators and
+//         their squares over the stem rows its workgroup OWNS (ys >= 1: row ys = 0 of a run is the row group above's last row, computed again only as
+//         pooling halo), and the workgroup writes one partial row part[block][eye * 64 + c][2] (`out`, as floats; the other eye's 64 columns zero).
+//         The launcher makes the grid a multiple of 2 x (row groups per image), so every run of a workgroup belongs to the same eye.
+// MODE 2: BatchNorm with per-eye scale / shift tables (gamma = scale[2][64], beta = shift[2][64], from bn_finish_bf16s_kernel over MODE 1's partials):
+//         batch-statistics BatchNorm of the frozen estimators under train.py:91 (bn_bf16s.h).
+template <int MODE>
 static __global__ __launch_bounds__(StemPoolCfg::THREADS, 2) void stem_pool_bf16s_kernel(
     const float* __restrict__ left, const float* __restrict__ right, const float* __restrict__ w, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, __bf16* __restrict__ out, int HIN, int nimg) {
@@ -47,7 +55,7 @@ static __global__ __launch_bounds__(StemPoolCfg::THREADS, 2) void stem_pool_bf16
     char* ring = sp_sm + Cfg::OFF_RING;
     char* carry = sp_sm + Cfg::OFF_CARRY;
     float* bn_sc = (float*)(sp_sm + Cfg::OFF_BN);
-    float* bn_sh = bn_sc + 64;
+    float* bn_sh = bn_sc + 128;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, xl = lane & 31, h = lane >> 5;
     const int HO = HIN / 2, HP = HIN / 4, xsegs = HO / XS, groups = HP / R;
     // a workgroup takes whole (image, row group) runs -- run blockIdx.x + k gridDim.x -- and walks a run's segments left to right, so a
@@ -62,11 +70,15 @@ static __global__ __launch_bounds__(StemPoolCfg::THREADS, 2) void stem_pool_bf16
         n = (int)(run / groups);
     };
 
-    if (tid < 64) {
+    if (MODE == 0 && tid < 64) {
         const float sc = gamma[tid] / sqrtf(var[tid] + 1e-5f);
         bn_sc[tid] = sc;
         bn_sh[tid] = beta[tid] - mean[tid] * sc;
     }
+    if (MODE == 2 && tid < 128) { bn_sc[tid] = gamma[tid]; bn_sh[tid] = beta[tid]; }
+    f32x16 ssum[2], ssq[2];                                  // MODE 1 only (dead otherwise)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ssum[0][r] = 0.f; ssum[1][r] = 0.f; ssq[0][r] = 0.f; ssq[1][r] = 0.f; }
     // ---- A fragments: channel mt * 32 + xl, k row rr = 2 step + h (c = rr / 7, ky = rr % 7), element j = kx (7 -> zero)
     bf16x8 af[2][11];
 #pragma unroll
@@ -151,6 +163,16 @@ static __global__ __launch_bounds__(StemPoolCfg::THREADS, 2) void stem_pool_bf16
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][st], bfrag, acc[1], 0, 0, 0);
                 }
             }
+            if constexpr (MODE == 1) {
+                if (ys >= 1) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { ssum[mt][r] += acc[mt][r]; ssq[mt][r] += acc[mt][r] * acc[mt][r]; }
+                }
+                continue;
+            }
+            const int eo = MODE == 2 ? (n & 1) * 64 : 0;      // this run's eye selects the scale / shift table
             __syncthreads();                                 // A: the previous pair's pooling has read its three ring rows
             if (rowact) {
                 char* rrow = ring + (ys & 3) * Cfg::RING_ROW;
@@ -160,7 +182,7 @@ static __global__ __launch_bounds__(StemPoolCfg::THREADS, 2) void stem_pool_bf16
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         const int co0 = mt * 32 + 8 * gq + 4 * h;
-                        const f32x4 sc = *(const f32x4*)(bn_sc + co0), sh = *(const f32x4*)(bn_sh + co0);
+                        const f32x4 sc = *(const f32x4*)(bn_sc + eo + co0), sh = *(const f32x4*)(bn_sh + eo + co0);
                         bf16x4s o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -197,21 +219,61 @@ static __global__ __launch_bounds__(StemPoolCfg::THREADS, 2) void stem_pool_bf16
         }
         cbuf ^= 1;                                           // the column this segment saved is the next segment's neighbour
     }
+    if constexpr (MODE == 1) {
+        // lanes of equal h hold the same 32 channels for 32 pixel columns: fold the 32 columns (fixed order), then the four waves through LDS
+        __syncthreads();
+        float* red = (float*)sp_sm;                          // [wave][64 channels][2]
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = ssum[mt][r], b = ssq[mt][r];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (xl == 0) {
+                    const int co = mt * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                    red[(wid * 64 + co) * 2] = a;
+                    red[(wid * 64 + co) * 2 + 1] = b;
+                }
+            }
+        __syncthreads();
+        if (tid < 128) {
+            const int co = tid >> 1, qq = tid & 1;
+            const float a = (nq > 0) ? red[(0 * 64 + co) * 2 + qq] + red[(1 * 64 + co) * 2 + qq] + red[(2 * 64 + co) * 2 + qq] + red[(3 * 64 + co) * 2 + qq] : 0.f;
+            const int groups_ = HP / R;
+            const int eye = (int)((blockIdx.x / groups_) & 1);
+            float* part = (float*)out + (long)blockIdx.x * 256;
+            part[(eye * 64 + co) * 2 + qq] = a;
+            part[((eye ^ 1) * 64 + co) * 2 + qq] = 0.f;
+        }
+    }
 }
 
-static inline hipError_t stem_pool_bf16s_launch(const float* left, const float* right, const float* w, const float* gamma, const float* beta,
-                                                const float* mean, const float* var, __bf16* out, int HIN, int nimg, int num_cu, hipStream_t s) {
+template <int MODE>
+static inline hipError_t stem_pool_bf16s_launch_mode(const float* left, const float* right, const float* w, const float* gamma, const float* beta,
+                                                     const float* mean, const float* var, __bf16* out, int HIN, int nimg, int num_cu, hipStream_t s, int* grid_out = nullptr) {
     using Cfg = StemPoolCfg;
     const int HO = HIN / 2, HP = HIN / 4;
     if (HO % Cfg::XS != 0 || HP % Cfg::R != 0 || nimg <= 0) return hipErrorInvalidValue;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)stem_pool_bf16s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)stem_pool_bf16s_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    const long runs = (long)nimg * (HP / Cfg::R);
-    const long grid = runs < 2L * num_cu ? runs : 2L * num_cu;
-    hipLaunchKernelGGL(stem_pool_bf16s_kernel, dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, left, right, w, gamma, beta, mean, var, out, HIN, nimg);
+    const int groups = HP / Cfg::R;
+    const long runs = (long)nimg * groups;
+    long grid = runs < 2L * num_cu ? runs : 2L * num_cu;
+    if (MODE == 1) {           // every run of a workgroup in ONE eye: run = block + k * grid, image = run / groups -> the grid a multiple of 2 * groups
+        if (nimg % 2 != 0) return hipErrorInvalidValue;
+        grid = grid / (2 * groups) * (2 * groups);
+        if (grid <= 0) return hipErrorInvalidValue;
+    }
+    if (grid_out) *grid_out = (int)grid;
+    hipLaunchKernelGGL(stem_pool_bf16s_kernel<MODE>, dim3((unsigned)grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, left, right, w, gamma, beta, mean, var, out, HIN, nimg);
     return hipGetLastError();
+}
+static inline hipError_t stem_pool_bf16s_launch(const float* left, const float* right, const float* w, const float* gamma, const float* beta,
+                                                const float* mean, const float* var, __bf16* out, int HIN, int nimg, int num_cu, hipStream_t s) {
+    return stem_pool_bf16s_launch_mode<0>(left, right, w, gamma, beta, mean, var, out, HIN, nimg, num_cu, s);
 }

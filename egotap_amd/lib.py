@@ -47,6 +47,10 @@ _PROTOS = {
     "egotap_hm_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),
     "egotap_hm_intermediate": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
+    "egotap_hm_forward_bnbatch_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "egotap_hm_forward_bnbatch_intermediate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
+    "egotap_hm_forward_bnbatch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                            C.c_size_t, C.c_void_p]),
     "egotap_linear_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
     "egotap_gemm_tile_name": (C.c_char_p, [C.c_int]),
     "egotap_linear_bf16_dma": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),

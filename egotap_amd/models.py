@@ -144,11 +144,25 @@ class EgoTAPAutoEncoderModel(nn.Module):
             bn_batch = self._estimator_bn_modes()
             # position net: channels [0, 2J) (left | right), limb net: [2J, 6J) (left cos, sin | right cos, sin)
             for net, c0, cn, batch_stats in ((self.net_HeatMap, 0, 2 * J, bn_batch[0]), (self.net_RotHeatMap, 2 * J, 4 * J, bn_batch[1])):
-                if batch_stats:
-                    if getattr(net, "bottleneck", False):
-                        raise NotImplementedError(f"batch-statistics BatchNorm of a {net.model_name} estimator (the wrapper is in train mode: train.py:91) is not "
-                                                  "built; set opt.frozen_heatmap_bn_eval (--frozen_heatmap_bn_eval) or call model.eval()")
-                    # batch statistics couple the frames of a batch: the whole batch goes through in one piece, per eye
+                if batch_stats and getattr(net, "bottleneck", False):
+                    # resnet50 / resnet101 estimators have no batch-statistics forward: keep the reference command line running on the
+                    # eval-mode (folded running statistics) forward below and say so once -- the deviation is exactly what
+                    # --frozen_heatmap_bn_eval selects explicitly
+                    if not getattr(self, "_warned_bottleneck_bn", False):
+                        import warnings
+                        warnings.warn(f"frozen {net.model_name} estimators run with running-statistics BatchNorm although the wrapper is in train mode "
+                                      "(train.py:91 would use batch statistics; only resnet18 / resnet34 have that forward here): same as "
+                                      "--frozen_heatmap_bn_eval; running statistics are not updated", RuntimeWarning, stacklevel=3)
+                        self._warned_bottleneck_bn = True
+                    batch_stats = False
+                if batch_stats and getattr(net, "precision", "f32") == "bf16" and B >= 2:
+                    # [r5] --use_amp: batch-statistics BatchNorm on the bf16 channels-last kernels (egotap_hm_forward_bnbatch) -- the backbone over
+                    # the whole batch (the statistics couple its frames), the BatchNorm-free decoder in hm_chunk pieces, straight into the
+                    # head's input slice; one scratch shared by both estimators
+                    chunk = min(B, int(getattr(self.opt, "hm_chunk", 256)))
+                    net.forward_bnbatch_into(left, right, cat, c0, chunk=chunk, workspace=self.net_HeatMap.bnbatch_workspace(B, chunk, left.device))
+                elif batch_stats:
+                    # fp32 / bf16x3: the stage-1 train-mode forward without a graph (conv_f32 / conv_bf16 kernels + bn2d_fwd), whole batch
                     from .hm_training import hm_train_forward_nograd
                     cat[:, c0:c0 + cn] = hm_train_forward_nograd(net, left, right)
                 else:

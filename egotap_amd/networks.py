@@ -354,10 +354,26 @@ class HeatMap_UnrealEgo_Shared(nn.Module):
                 mod.register_parameter(parts[-1], src_mod._parameters[src_leaf])
             else:
                 mod.register_buffer(parts[-1], src_mod._buffers[src_leaf])
+        self._aliases = [(k, a) for k, s, a in entries if a is not None]
         _kaiming_init_(self)
         self._handle = None
         self._bound_sig = None
         self._ws = None
+
+    def _apply(self, fn, *args, **kwargs):
+        """Module._apply (.to / .cuda / .float ...) replaces every registered BUFFER by fn(buffer) -- once per registration, so the
+        ``backbone.backbone.layerK.*`` aliases of the BatchNorm statistics would stop being the tensors the forward updates (parameters keep
+        their identity: torch swaps .data).  In the reference the aliases are the same nn.BatchNorm2d MODULES (net_architecture.py:68-73), so they
+        can never drift apart, and its load_state_dict reads the alias keys LAST: a checkpoint written with stale aliases would load stale
+        statistics there.  Re-tie them after every _apply."""
+        super()._apply(fn, *args, **kwargs)
+        for k, a in getattr(self, "_aliases", ()):
+            src_mod, src_leaf = self._locate(a)
+            mod, leaf = self._locate(k)
+            if src_leaf in src_mod._buffers:
+                mod._buffers[leaf] = src_mod._buffers[src_leaf]
+        self._bound_sig = None
+        return self
 
     def set_precision(self, mode: str = "f32"):
         """Arithmetic of the 3x3 stride-1 convolutions with >= 128 output channels (88 % of the FLOPs): "f32" exact (default),
@@ -459,6 +475,67 @@ class HeatMap_UnrealEgo_Shared(nn.Module):
                 C.c_void_p(out.data_ptr() + 4 * channel_offset * hw), out.shape[1] * hw, C.c_void_p(ws.data_ptr()),
                 ws.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return out
+
+    @torch.no_grad()
+    def forward_bnbatch_into(self, left, right, out, channel_offset: int = 0, chunk: int = 256, workspace=None):
+        """forward_into with BATCH-statistics BatchNorm2d and no graph (egotap.h egotap_hm_forward_bnbatch): what a FROZEN estimator computes
+        while the lifting head trains under train.py:91 model.train() -- per-eye statistics, running_mean / running_var /
+        num_batches_tracked of every BatchNorm updated twice (left, right).  bf16 precision only (the bf16 channels-last kernels); the
+        backbone runs over the whole batch, the decoder in pieces of `chunk` frames.  The module's own .training flag is not consulted."""
+        if self.bottleneck:
+            raise NotImplementedError(f"backbone {self.model_name!r}: no batch-statistics forward (resnet18 / resnet34 have one)")
+        if getattr(self, "precision", "f32") != "bf16":
+            raise _lib.EgotapError("forward_bnbatch_into runs on the bf16 channels-last kernels: set_precision('bf16') first "
+                                   "(fp32 / bf16x3: hm_training.hm_train_forward_nograd)")
+        for t in (left, right, out):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise _lib.EgotapError("heatmap estimator needs contiguous float32 CUDA tensors (no CPU fallback)")
+        B, S = left.shape[0], 4 * self.hm_size
+        if tuple(left.shape) != (B, 3, S, S) or tuple(right.shape) != (B, 3, S, S):
+            raise ValueError(f"expected left/right [B, 3, {S}, {S}], got {tuple(left.shape)} / {tuple(right.shape)}")
+        n_out = 2 * self.num_heatmap
+        if out.dim() != 4 or out.shape[0] != B or out.shape[2] != self.hm_size or out.shape[3] != self.hm_size \
+                or channel_offset + n_out > out.shape[1]:
+            raise ValueError("output tensor does not hold the requested channel slice")
+        if B < 2:
+            raise ValueError("batch-statistics BatchNorm needs at least two frames")
+        dev = left.device
+        chunk = B if chunk is None or chunk <= 0 else min(int(chunk), B)
+        with torch.cuda.device(dev):
+            self._bind(dev)
+            lib, h = _lib.load(), self._ensure_handle()
+            need = C.c_size_t()
+            _lib.check(lib.egotap_hm_forward_bnbatch_workspace_bytes(h, B, chunk, C.byref(need)))
+            ws = workspace
+            if ws is None or ws.numel() < need.value or ws.device != dev:
+                cur = getattr(self, "_ws_bn", None)
+                if cur is None or cur.numel() < need.value or cur.device != dev:
+                    self._ws_bn = None
+                    self._ws_bn = torch.empty(need.value, dtype=torch.uint8, device=dev)
+                ws = self._ws_bn
+            hw = self.hm_size * self.hm_size
+            _lib.check(lib.egotap_hm_forward_bnbatch(
+                h, self._net, C.c_void_p(left.data_ptr()), C.c_void_p(right.data_ptr()), B,
+                C.c_void_p(out.data_ptr() + 4 * channel_offset * hw), out.shape[1] * hw, chunk, C.c_void_p(ws.data_ptr()), ws.numel(),
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return out
+
+    def bnbatch_intermediate(self, name: str, B: int, chunk: int, ws=None):
+        """bf16 view [B * s * s, 2 C] of a backbone map of the LAST forward_bnbatch_into inside its workspace (parity tests)"""
+        off, n = C.c_size_t(), C.c_int64()
+        _lib.check(_lib.load().egotap_hm_forward_bnbatch_intermediate(self._ensure_handle(), B, min(chunk, B) if chunk else B, name.encode(), C.byref(off), C.byref(n)))
+        ws = ws if ws is not None else self._ws_bn
+        return ws[off.value: off.value + 2 * n.value].view(torch.bfloat16)
+
+    def bnbatch_workspace(self, B, chunk, device):
+        """scratch of forward_bnbatch_into for (B, chunk), kept on the module (both estimators of a wrapper can share one)"""
+        need = C.c_size_t()
+        _lib.check(_lib.load().egotap_hm_forward_bnbatch_workspace_bytes(self._ensure_handle(), B, min(chunk, B) if chunk else B, C.byref(need)))
+        cur = getattr(self, "_ws_bn", None)
+        if cur is None or cur.numel() < need.value or cur.device != device:
+            self._ws_bn = None
+            self._ws_bn = torch.empty(need.value, dtype=torch.uint8, device=device)
+        return self._ws_bn
 
     @torch.no_grad()
     def _forward_bottleneck(self, left, right, out, channel_offset):

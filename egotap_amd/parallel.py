@@ -78,40 +78,6 @@ def gather_poses(pose: torch.Tensor, counts=None) -> torch.Tensor:
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
 
 
-def allreduce_gradients(params, bucket_bytes: int = 64 << 20):
-    """Data-parallel gradient averaging: sum every parameter's .grad over the ranks and divide by the
-    world size, bucketed so a few large collectives run instead of one per tensor (RCCL over xGMI is per-link bound:
-    large messages), issued asynchronously so bucket k+1 is packed while bucket k is on the wire.  Parameters whose
-    .grad is None (cls_token, pooler: never used, so never differentiated) are skipped identically on every rank.
-    No-op for one rank."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return 0
-    world = dist.get_world_size()
-    grads = [p.grad for p in params if p.grad is not None]
-    buckets, cur, size = [], [], 0
-    for g in grads:
-        cur.append(g)
-        size += g.numel() * g.element_size()
-        if size >= bucket_bytes:
-            buckets.append(cur)
-            cur, size = [], 0
-    if cur:
-        buckets.append(cur)
-    pending = []
-    for b in buckets:
-        flat = torch.cat([g.reshape(-1) for g in b])
-        pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, b))
-    for work, flat, b in pending:
-        work.wait()
-        flat.div_(world)
-        off = 0
-        for g in b:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
-    return len(buckets)
-
-
 class GradReducer:
     """Gradient averaging OVERLAPPED with the backward: the head's gradients live in one flat fp32 arena laid out
     in the order the backward finishes them (head + encoders first, then ViT layers last to first, patch embedding last); as soon as

@@ -96,6 +96,21 @@ int egotap_hm_forward(egotap_handle h, int net, const float* left, const float* 
                       int64_t out_image_stride, void* ws, size_t ws_bytes, void* stream);
 /* name in {"layer0".."layer4" (backbone pyramid, images interleaved n = 2b + eye), "conv_up3","conv_up2","conv_up1"} */
 int egotap_hm_intermediate(egotap_handle h, int B, const char* name, size_t* offset, int64_t* numel);
+/* [r5] The same forward with BATCH-statistics BatchNorm2d and no graph: what the reference's FROZEN estimators compute while the lifting
+ * head trains -- train.py:91 model.train() leaves their BatchNorm2d in training mode (model/egotap_autoencoder_model.py:127-129 freezes
+ * parameters only, :177-216 calls them under autocast); the shared backbone runs once per eye (model/net_architecture.py:45-50), so each
+ * BatchNorm normalises every eye's batch with that eye's statistics and updates its bound buffers twice per call, left then right:
+ * running_mean / running_var (momentum 0.1, unbiased variance) and, where bound as EGOTAP_I64, num_batches_tracked += 2.
+ * EGOTAP_PREC_BF16 only (bf16 channels-last kernels; the fp32 form is composed from egotap_hmtrain_conv_fwd / egotap_hmtrain_bn2d_fwd).
+ * The backbone runs over the whole batch (its statistics couple the frames); the decoder, which has no BatchNorm, runs in pieces of
+ * `chunk` frames (0 = the whole batch) so that its scratch stays at the chunk's size.  B >= 2.  Arguments as egotap_hm_forward;
+ * ws at least egotap_hm_forward_bnbatch_workspace_bytes(B, chunk). */
+int egotap_hm_forward_bnbatch_workspace_bytes(egotap_handle h, int B, int chunk, size_t* bytes);
+int egotap_hm_forward_bnbatch(egotap_handle h, int net, const float* left, const float* right, int B, float* out, int64_t out_image_stride,
+                              int chunk, void* ws, size_t ws_bytes, void* stream);
+/* where a backbone map lives inside ws after egotap_hm_forward_bnbatch (parity tests): name in {"pool0" (stem + max-pool), "layer1" ..
+ * "layer4"}; bf16 [B * s * s, 2 C], pixel (b, y, x) = [left C | right C]; offset in bytes, numel in bf16 elements */
+int egotap_hm_forward_bnbatch_intermediate(egotap_handle h, int B, int chunk, const char* name, size_t* offset, int64_t* numel);
 
 /* Arithmetic of the large GEMMs of the lifting head (nn.Linear layers of the ViT and fc1; everything else is always fp32).
  *   EGOTAP_PREC_F32     v_mfma_f32_32x32x2_f32: exact fp32 products (default; what the headline benchmark measures)

@@ -118,6 +118,30 @@ def test_module_mirror_has_reference_state_dict():
         net(torch.zeros(1, 90, 64, 64))          # training mode: same rule, no CPU path
 
 
+def test_estimator_alias_buffers_stay_tied_through_module_apply():
+    """The reference registers the ResNet's children twice (backbone.backbone.backbone.* and backbone.backbone.layerK.*: the same
+    nn.BatchNorm2d modules, net_architecture.py:68-73), so both key families are ONE tensor there and its load_state_dict reads the
+    layerK.* keys last.  Module._apply (.to / .cuda / .double) replaces buffers per registration: the mirror re-ties them, so a
+    train-mode forward that updates running statistics can never save stale aliases."""
+    import types
+    import torch
+    from egotap_amd import networks
+    opt = types.SimpleNamespace(joint_preset="UnrealEgo", num_heatmap=15, num_rot_heatmap=0, heatmap_type="none", ae_hidden_size=128,
+                                load_size_heatmap=[64, 64])
+    net = networks.HeatMap_UnrealEgo_Shared(opt, "resnet18", 2).double().float()
+    sd = net.state_dict(keep_vars=True)
+    pairs = [("backbone.backbone.backbone.bn1", "backbone.backbone.layer0.1"),
+             ("backbone.backbone.backbone.layer3.1.bn2", "backbone.backbone.layer3.1.bn2"),
+             ("backbone.backbone.backbone.layer2.0.downsample.1", "backbone.backbone.layer2.0.downsample.1")]
+    for a, b in pairs:
+        for leaf in ("running_mean", "running_var", "num_batches_tracked", "weight"):
+            assert sd[f"{a}.{leaf}"] is sd[f"{b}.{leaf}"], (a, b, leaf)
+    assert len(sd) == 258 and len(list(net.named_buffers())) == 60 and len(list(net.named_buffers(remove_duplicate=False))) == 120
+    with torch.no_grad():
+        sd["backbone.backbone.backbone.bn1.running_mean"].add_(1.0)
+    assert torch.equal(net.state_dict()["backbone.backbone.layer0.1.running_mean"], net.state_dict()["backbone.backbone.backbone.bn1.running_mean"])
+
+
 def test_host_side_argument_checks_of_the_newer_entry_points():
     """no GPU here: everything below must be rejected (or accepted) by host-side checks before any launch"""
     import torch

@@ -348,8 +348,20 @@ def test_wrappers_with_model_name_resnet50(tmp_path):
     mm.net_HeatMap.load_state_dict(m.net_HeatMap.state_dict())
     mm.set_input(data)
     mm.train()
-    with pytest.raises(NotImplementedError, match="frozen_heatmap_bn_eval"):      # batch-statistics BatchNorm of a Bottleneck estimator is not built
-        mm.forward()
+    # batch-statistics BatchNorm of a Bottleneck estimator is not built: the reference command line (train mode) keeps running on the
+    # folded running-statistics forward, with ONE warning that names the flag which selects exactly that
+    stats_before = {k: v.clone() for k, v in mm.net_HeatMap.named_buffers()}
+    with pytest.warns(RuntimeWarning, match="frozen_heatmap_bn_eval"):
+        with torch.no_grad():
+            mm.forward_heatmap()
+    import warnings as _w
+    with _w.catch_warnings():
+        _w.simplefilter("error")                                                   # ... once per model, not per step
+        with torch.no_grad():
+            mm.forward_heatmap()
+    assert torch.equal(mm.pred_heatmap_cat[:, :30], alone)
+    for k, v in mm.net_HeatMap.named_buffers():
+        assert torch.equal(v, stats_before[k]), k
     mm.eval()                                                                      # test.py's flow (utils/evaluate.py:93)
     mm.set_precision("bf16")
     assert getattr(mm.net_HeatMap, "precision", "f32") == "f32" and mm.net_AutoEncoder.precision == "bf16"

@@ -55,6 +55,41 @@ def test_two_rank_gloo(tmp_path):
         np.testing.assert_array_equal(got[1:], ref)             # same gathered batch on every rank, rank order
 
 
+def _packing_allreduce(params, bucket_bytes: int = 64 << 20):
+    """Test-side reference for GradReducer (it lived in egotap_amd.parallel until both wrappers moved to the arena reducer): sum every parameter's .grad over the ranks and divide by the
+    world size, bucketed so a few large collectives run instead of one per tensor (RCCL over xGMI is per-link bound:
+    large messages), issued asynchronously so bucket k+1 is packed while bucket k is on the wire.  Parameters whose
+    .grad is None (cls_token, pooler: never used, so never differentiated) are skipped identically on every rank.
+    No-op for one rank."""
+    dist = torch.distributed
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    grads = [p.grad for p in params if p.grad is not None]
+    buckets, cur, size = [], [], 0
+    for g in grads:
+        cur.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+    if cur:
+        buckets.append(cur)
+    pending = []
+    for b in buckets:
+        flat = torch.cat([g.reshape(-1) for g in b])
+        pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, b))
+    for work, flat, b in pending:
+        work.wait()
+        flat.div_(world)
+        off = 0
+        for g in b:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+    return len(buckets)
+
+
 def _grad_worker(rank, world, port, out_dir):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
@@ -65,7 +100,7 @@ def _grad_worker(rank, world, port, out_dir):
     for i, prm in enumerate(params):
         base = torch.rand(prm.shape, generator=g)
         prm.grad = None if i == 3 else base * (rank + 1)      # parameter 3 never gets a gradient (like cls_token / pooler)
-    n = P.allreduce_gradients(params, bucket_bytes=100_000)   # small buckets: several collectives in flight
+    n = _packing_allreduce(params, bucket_bytes=100_000)   # small buckets: several collectives in flight
     assert n >= 2 and params[3].grad is None
     np.save(os.path.join(out_dir, f"g{rank}.npy"), torch.cat([q.grad.reshape(-1) for q in params if q.grad is not None]).numpy())
     torch.distributed.destroy_process_group()
@@ -104,17 +139,17 @@ def _reducer_worker(rank, world, port, out_dir):
     n = red.finish()
     assert n == 3 and red.last_buckets == 3 and red.last_bytes == 4 * 10_000 and red.steps == 1 and red.pending == []
     assert red.read_exposed_ms() == 0.0                         # CPU tensors: nothing to time
-    # the same gradients through the generic packing reducer (parallel.allreduce_gradients: a utility; both wrappers use GradReducer)
+    # the same gradients through the generic packing reducer (the test-side packing reducer above)
     prm = torch.nn.Parameter(torch.zeros(10_000))
     prm.grad = base * (rank + 1)
-    P.allreduce_gradients([prm], bucket_bytes=8_000)
+    _packing_allreduce([prm], bucket_bytes=8_000)
     np.save(os.path.join(out_dir, f"a{rank}.npy"), np.stack([arena.numpy(), prm.grad.numpy()]))
     torch.distributed.destroy_process_group()
 
 
 def test_grad_reducer_two_ranks(tmp_path):
     """parallel.GradReducer (the in-backward bucketed all-reduce on the flat gradient arena): after finish() every rank holds the
-    MEAN of the per-rank arenas, bucket by bucket in place, identical to allreduce_gradients"""
+    MEAN of the per-rank arenas, bucket by bucket in place, identical to the packing reference reducer"""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
