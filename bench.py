@@ -327,7 +327,7 @@ def bench_full(args, p, dev, rank, world, barrier, lib, L, mode="f32"):
     }
 
 
-def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from_rgb=False):
+def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from_rgb=False, reference_default_bn=False, preset=None, hm_size=None):
     """Secondary measurement: one optimisation step of the lifting head (train-mode forward from resident heatmaps,
     loss, backward, gradient all-reduce when world > 1, AdamW).  mode = arithmetic of the GEMMs (egotap_set_precision):
     f32 exact, bf16x3 split (fp32-grade gradients), bf16 (BASELINE config 3: bf16 MFMA, fp32 accumulate and master weights).
@@ -340,7 +340,9 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
     from egotap_amd.synthetic import synth_hm_state_dict, synth_input, synth_state_dict
     torch.cuda.empty_cache()
     held = torch.cuda.memory_allocated(dev)      # what the earlier legs of this process still hold (the headline net and its workspace)
-    opt = preset_defaults(args.preset)
+    if preset is not None:                       # another preset / heatmap side than the headline's (config 5: EgoCap, 128 x 128 heatmaps)
+        p = spec.lift_preset(preset, hm_size or 64)
+    opt = preset_defaults(preset or args.preset, hm_size) if hm_size else preset_defaults(preset or args.preset)
     opt.gpu_ids, opt.isTrain, opt.use_gt_heatmap = [dev.index], True, not from_rgb
     opt.lr, opt.opt_eps, opt.weight_decay = 1e-3, 1e-4, 0.0
     tmp = None
@@ -353,10 +355,12 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
         opt.log_dir = tmp.name
         opt.path_to_trained_heatmap = os.path.join(tmp.name, "hm", "best_net_HeatMap.pth")
         opt.use_amp, opt.amp_precision = mode != "f32", (mode if mode != "f32" else "bf16")
-        # the benchmark's frozen estimators use folded running-statistics BatchNorm (frames independent, the
-        # bf16 channels-last kernels, chunks of 256 frames).  The wrapper's DEFAULT is the reference's batch-statistics BatchNorm under
-        # model.train() (train.py:91); this leg opts out explicitly and says so in its "input" field.
-        opt.frozen_heatmap_bn_eval = True
+        # the opt-out leg's frozen estimators use folded running-statistics BatchNorm (frames independent, the
+        # bf16 channels-last kernels, chunks of 256 frames) and says so in its "input" field.  reference_default_bn: the wrapper's DEFAULT,
+        # which is the reference's -- batch-statistics BatchNorm in the frozen estimators under model.train() (train.py:91), per eye, running
+        # statistics drifting; under --use_amp on the bf16 channels-last kernels (egotap_hm_forward_bnbatch: backbone over the whole batch,
+        # decoder in chunks of 256 frames).  [r5] measured BESIDE the opt-out leg.
+        opt.frozen_heatmap_bn_eval = not reference_default_bn
     m = models.create_model(opt)
     m.net_AutoEncoder.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(p)).items()})
     m.net_AutoEncoder.set_precision(mode)
@@ -374,6 +378,8 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
             blk = torch.from_numpy(synth_input(f"rgb_{side}_train_rank{rank}", (8, 3, S, S), -2.0, 2.0)).to(dev)
             data["input_rgb_" + side] = blk.repeat((B + 7) // 8, 1, 1, 1)[:B].contiguous()
     m.set_input(data)
+    if from_rgb and reference_default_bn:
+        m.train()                                # train.py:91: the wrapper -- frozen estimators included -- in training mode
     for _ in range(2):
         m.optimize_parameters()                  # warm-up (allocator, BN buffers, optimizer state)
     barrier()
@@ -412,9 +418,14 @@ def bench_train(args, p, dev, rank, world, barrier, mode="f32", batch=None, from
             "allreduce_op": ("avg (RCCL ReduceOp.AVG, in place on the gradient arena)" if world > 1 and dist_backend() == "nccl" else
                              "sum + 1/world scaling pass (gloo)" if world > 1 else None),
             "per_rank_ms_per_step": per_rank, "device_allocations_in_timed_region": int(dev_allocs),
-            "input": "RGB frames through the two frozen heatmap estimators (opt.frozen_heatmap_bn_eval: running-statistics BatchNorm, "
-                     "SURVEY Appendix D.5; --use_amp arithmetic), then the head" if from_rgb
-                     else "resident heatmaps (--use_gt_heatmap): the frozen estimators are not run",
+            "input": ("RGB frames through the two frozen heatmap estimators in TRAIN mode as train.py:91 leaves them (the reference's and the wrapper's "
+                      "default: batch-statistics BatchNorm per eye, running statistics updated; --use_amp arithmetic on bf16 channels-last tensors), then the head"
+                      if from_rgb and reference_default_bn else
+                      "RGB frames through the two frozen heatmap estimators (opt.frozen_heatmap_bn_eval: running-statistics BatchNorm, "
+                      "SURVEY Appendix D.5; --use_amp arithmetic), then the head" if from_rgb
+                      else "resident heatmaps (--use_gt_heatmap): the frozen estimators are not run"),
+            "frozen_estimators_bn": ("batch statistics (reference default)" if reference_default_bn else "running statistics (opt-out)") if from_rgb else None,
+            "preset": preset or args.preset, "hm_size": p.hm_size,
             "note": "gradient all-reduce (N > 1) overlapped with the backward, bucket by bucket, in place on a flat arena; the attention "
                     "backward recomputes the scores (two kernels, 7 MFMA products), not counted in flops_per_frame"}
 
@@ -554,6 +565,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=2, help="timed optimisation steps of the secondary training measurement (0 = skip)")
     ap.add_argument("--train-batch", type=int, default=256)
     ap.add_argument("--config5-batch", type=int, default=64, help="per-GPU batch of the EgoCap / 128x128-heatmap measurement (0 = skip)")
+    ap.add_argument("--config5-train-batch", type=int, default=256, help="per-GPU batch of the EgoCap / 128x128-heatmap TRAINING step (BASELINE config 5)")
     ap.add_argument("--stage1-batch", type=int, default=32, help="per-GPU batch of the stage-1 heatmap-estimator training measurement")
     ap.add_argument("--train-batch-bf16", type=int, default=1024, help="per-GPU batch of the bf16 training measurement (BASELINE config 3)")
     ap.add_argument("--all-legs", action="store_true", help="N > 1: also run the single-GPU secondary legs on every rank (default at N > 1: "
@@ -743,6 +755,24 @@ def main():
             # the same step as train.py runs it without --use_gt_heatmap: RGB frames -> two frozen heatmap estimators -> head ("RGB for full")
             train["config3_bf16_b1024_from_rgb"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16", batch=args.train_batch_bf16,
                                                        from_rgb=True)
+            # [r5] ... and as train.py REALLY runs it: the frozen estimators in train mode (batch-statistics BatchNorm), at config 3's batch and at the
+            # reference's own batch (scripts/train/PoseEstimator/unrealego.sh: --batch_size 32), each beside its opt-out twin
+            train["config3_bf16_b1024_from_rgb_reference_default"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16", batch=args.train_batch_bf16,
+                                                                         from_rgb=True, reference_default_bn=True)
+            a, b = train["config3_bf16_b1024_from_rgb_reference_default"], train["config3_bf16_b1024_from_rgb"]
+            if "ms_per_step" in a and "ms_per_step" in b:
+                a["ms_per_step_vs_opt_out"] = round(a["ms_per_step"] / b["ms_per_step"], 3)
+            train["reference_batch_b32_bf16_from_rgb_reference_default"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16", batch=32, from_rgb=True,
+                                                                               reference_default_bn=True)
+            train["reference_batch_b32_bf16_from_rgb"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16", batch=32, from_rgb=True)
+            # BASELINE config 5 "fwd (+ train step)": EgoCap, 128 x 128 heatmaps (512 x 512 RGB), bf16: the head's training step at the largest batch
+            # one GPU holds comfortably (activations ~4 x config 3's per frame), and the same step from RGB with the estimators as train.py runs them
+            if not args.no_fast_mode and args.config5_batch > 0:
+                train["config5_egocap_hm128_bf16"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16", batch=args.config5_train_batch,
+                                                          preset="EgoCap", hm_size=128)
+                train["config5_egocap_hm128_bf16_from_rgb_reference_default"] = leg(bench_train, args, p, dev, rank, world, barrier, mode="bf16",
+                                                                                    batch=min(64, args.config5_train_batch), from_rgb=True, reference_default_bn=True,
+                                                                                    preset="EgoCap", hm_size=128)
             train["stage1_heatmap_estimator"] = leg(bench_stage1, args, p, dev, rank, world, barrier)
             if not args.no_fast_mode:
                 train["stage1_heatmap_estimator"]["bf16x3"] = leg(bench_stage1, args, p, dev, rank, world, barrier, mode="bf16x3")

@@ -53,26 +53,38 @@ static __global__ __launch_bounds__(256) void bn_colstats_bf16s_kernel(const __b
     }
 }
 
-// one thread per channel: both eyes' statistics from the partials (float64, fixed order), scale / shift per column, and the module's buffers
-// updated as nn.BatchNorm2d does in training mode -- left batch first, then right (net_architecture.py:45-50): running = (1 - m) running + m batch,
-// unbiased variance, in fp32 with hm_train.h's bn2d_finish_kernel's expressions; num_batches_tracked += 2
-static __global__ __launch_bounds__(256) void bn_finish_bf16s_kernel(const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ gamma,
+// one workgroup per channel (128 threads = 2 eyes x 64): both eyes' statistics from the partials -- float64, every thread a strided share of the
+// partial rows, folded through LDS in a fixed order -- then scale / shift per column and the module's buffers updated as nn.BatchNorm2d does in
+// training mode, left batch first, then right (net_architecture.py:45-50): running = (1 - m) running + m batch, unbiased variance, in fp32 with
+// hm_train.h's bn2d_finish_kernel's expressions; num_batches_tracked += 2.  (One THREAD per channel walking up to 2048 partial rows took 0.25-1.1 ms
+// per BatchNorm: 26 ms of a B = 1024 step.)
+static __global__ __launch_bounds__(128) void bn_finish_bf16s_kernel(const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta, float* __restrict__ run_mean, float* __restrict__ run_var,
                                                                      long long* __restrict__ nbt, float* __restrict__ sc, float* __restrict__ sh) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[2][128];
+    const int c = blockIdx.x, tid = threadIdx.x, eye = tid >> 6, sub = tid & 63;
+    const int col = eye * C + c;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = sub; k < nparts; k += 64) {
+        const float2 v = *(const float2*)(part + ((long)k * 2 * C + col) * 2);
+        s0 += (double)v.x; s1 += (double)v.y;
+    }
+    red[0][tid] = s0; red[1][tid] = s1;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+        if (sub < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+        __syncthreads();
+    }
+    if (tid != 0) return;
     const float momentum = 0.1f, eps = 1e-5f;
-    for (int eye = 0; eye < 2; ++eye) {
-        const int col = eye * C + c;
-        double s0 = 0.0, s1 = 0.0;
-        for (int k = 0; k < nparts; ++k) { s0 += (double)part[((long)k * 2 * C + col) * 2]; s1 += (double)part[((long)k * 2 * C + col) * 2 + 1]; }
-        const double mu = s0 / count;
-        double var = s1 / count - mu * mu;
+    for (int e = 0; e < 2; ++e) {
+        const double mu = red[0][e * 64] / count;
+        double var = red[1][e * 64] / count - mu * mu;
         if (var < 0.0) var = 0.0;
         const float mean = (float)mu, rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float scale = rstd * gamma[c];
-        sc[col] = scale;
-        sh[col] = beta[c] - mean * scale;
+        sc[e * C + c] = scale;
+        sh[e * C + c] = beta[c] - mean * scale;
         if (run_mean) {
             run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
             run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * count / (count - 1.0));
@@ -125,7 +137,7 @@ static inline hipError_t bn_batch_bf16s_launch(__bf16* z, const __bf16* res, lon
     long nblk = (R + per - 1) / per;
     if (nblk > BnBatchScratch::MAX_PARTS) { per = ((R + BnBatchScratch::MAX_PARTS - 1) / BnBatchScratch::MAX_PARTS + rstep - 1) / rstep * rstep; nblk = (R + per - 1) / per; }
     hipLaunchKernelGGL(bn_colstats_bf16s_kernel, dim3((unsigned)nblk), dim3(256), 0, s, (const __bf16*)z, R, NC, per, ws.part);
-    hipLaunchKernelGGL(bn_finish_bf16s_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws.part, (int)nblk, C, (double)R, gamma, beta, run_mean, run_var, nbt,
+    hipLaunchKernelGGL(bn_finish_bf16s_kernel, dim3(C), dim3(128), 0, s, (const float*)ws.part, (int)nblk, C, (double)R, gamma, beta, run_mean, run_var, nbt,
                        ws.sc, ws.sh);
     const long total8 = R * (NC >> 3);
     hipLaunchKernelGGL(bn_apply_bf16s_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, (const __bf16*)z, res, z, (const float*)ws.sc, (const float*)ws.sh,

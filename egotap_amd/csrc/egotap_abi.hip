@@ -1323,7 +1323,7 @@ static hipError_t hm_bf16_backbone(Handle* h, const HmParams& p, const PackTable
         if (e != hipSuccess) return e;
         float *rm, *rv; long long* nbt;
         if (!hm_bn_buffers(bnb->h, bnb->net, p.stem_bn.g, &rm, &rv, &nbt)) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(bn_finish_bf16s_kernel, dim3(1), dim3(256), 0, s, (const float*)bnb->scr.part, grid, 64, (double)B * (S0 / 2) * (S0 / 2), p.stem_bn.g, p.stem_bn.b, rm, rv,
+        hipLaunchKernelGGL(bn_finish_bf16s_kernel, dim3(64), dim3(128), 0, s, (const float*)bnb->scr.part, grid, 64, (double)B * (S0 / 2) * (S0 / 2), p.stem_bn.g, p.stem_bn.b, rm, rv,
                            nbt, bnb->scr.sc, bnb->scr.sh);
         e = stem_pool_bf16s_launch_mode<2>(left, right, p.stem_w, bnb->scr.sc, bnb->scr.sh, nullptr, nullptr, q.P0, S0, N2, cus, s);
         if (e != hipSuccess) return e;
