@@ -349,6 +349,26 @@ __device__ __forceinline__ void store_rows_bf16_2pass(const f32x16 (&o)[4], floa
 }
 }  // namespace att2
 
+namespace att2 {
+// o^T += V^T P for bf16 P fragments that already exist (the deferred form keeps a tile's P across a step)
+__device__ __forceinline__ void imgT_x_ph(f32x16 (&o)[4], const char* img, const LaneAddr& la, const bf16x8 (&ph)[2]) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + la.tr0 + 4096 * ss + 512 * dt));
+            const bf16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + la.tr1 + 4096 * ss + 512 * dt));
+            bf16x8 f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[e] = a[e];
+                f[4 + e] = c[e];
+            }
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, ph[ss], o[dt], 0, 0, 0);
+        }
+}
+}  // namespace att2
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 3) void attention_bf16s3_kernel(const __bf16* __restrict__ QKV, __bf16* __restrict__ CTX, int N, int heads,
                                                                      int qgroups, float scale_log2e, float* __restrict__ LSE) {
@@ -385,7 +405,6 @@ __global__ __launch_bounds__(64 * NW, 3) void attention_bf16s3_kernel(const __bf
     };
     const int ntiles = N / 32;
     issue(0, 0);
-    if (ntiles > 1) issue(1, KVBUF);
     Frags<1> qf;
     attns::load_row_frags(qf, qkv + (long)(q0 + l31) * ld3, lh);
     attns::settle_frags(qf);
@@ -396,50 +415,126 @@ __global__ __launch_bounds__(64 * NW, 3) void attention_bf16s3_kernel(const __bf
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    // [r4] THREE K | V buffers: two 32-key tiles in flight.  With two buffers a tile was requested one step ahead, and a step of this
-    // workgroup (its waves share their SIMDs with two other workgroups' waves) is shorter than a loaded L2 round trip: every step ended
-    // in a DMA wait.  Step t: [own pieces of tile t landed: counted vmcnt, tile t + 1 may stay in flight] barrier [issue tile t + 2 into
-    // the buffer tile t - 1 was read from: every wave is past that step] compute tile t.  Every wave issues the same number of pieces
-    // (NW = 4: two K and two V pieces per tile), so the count is a constant.
-    constexpr int DPT = 2 * PPW;                               // DMA instructions per wave and tile
-    static_assert(NW == 4 || NW == 2, "every wave must issue the same number of pieces per tile (8 % NW == 0)");
-    auto step = [&](int kt, unsigned boff, unsigned bnext2) __attribute__((always_inline)) {
-        if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < ntiles) issue(kt + 2, bnext2);
-        if (!valid) return;
-        f32x16 s = rows_x_frags(sm3 + boff, la, qf);
+    // [r5] P V of tile t - 1 runs DURING the softmax of tile t.  Through round 4 a wave's step was the dependent chain  S (8 MFMAs) -> row maximum ->
+    // 16 exp2 -> bf16 P -> transposed V reads -> P V (8 MFMAs): its VALU part had no matrix work of its own beside it (round-4 verdict: "the waves
+    // run the same chain in phase").  Here the 8 MFMAs and 16 transposed reads of the PREVIOUS tile's P V are interleaved with the exponentials of this
+    // tile, group by group (sched_group_barrier): chain per step  S -> {softmax(t) || P V(t - 1)}.  The V image of tile t - 1 lives one step longer:
+    // the three K | V buffers hold tiles t - 1, t and (in flight) t + 1 -- ONE tile ahead (round 4 ran two ahead and measured that the DMA was never
+    // late), requested right after the barrier that ends every wave's use of tile t - 2.
+    // Measured (same-call A/Bs against the round-4 kernel, profiles/r05_attention_ab.log and DESIGN 3.13): 1.704 -> 1.685 ms per layer at B = 1024,
+    // N = 576 and 5.36 -> 5.30 ms at N = 2304 in one call, 1.710 / 1.714 and 5.382 / 5.381 in another: at most one per cent, inside the run-to-run
+    // spread; bit-identical context and log-sum-exp.  So the chain was NOT what holds the kernel at half the matrix pipe -- with three waves per SIMD
+    // the partners already ran under each other's softmax.  What the SIMD runs out of is issue time: per 32 x 32 wave-step 16 MFMAs x 8 cycles of
+    // issue, ~60 VALU, 16 transcendentals, 24 LDS reads and 4 LDS-DMA pieces at ~60 cycles each, times three waves, against 1536 matrix cycles.
+    // (Also measured: the same deferral left to hipcc's scheduler at two waves per SIMD: 236 VGPRs, 1.98 ms; the next tile's DMA issued from
+    // inside the softmax instead of behind the barrier: -0.8 % / -1.9 %.)
+    // ONE code path writes O (two paths -- a plain P V before a rescale, an interleaved one otherwise -- made hipcc copy the accumulator tuples
+    // between them: 210 spilled registers): the exponentials of tile t are taken against the NEW maximum while P V(t - 1) accumulates at the old
+    // scale; O and l are rescaled after it, before P V(t) in the next step.
+    bf16x8 ph[2];
+    auto softmax_head = [&](const f32x16& s, float& alpha, bool& any) __attribute__((always_inline)) {
         float mx = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
         const bool raise = mx > m_run + RESC;
-        if (__builtin_amdgcn_ballot_w64(raise) != 0) {
-            const float m_new = raise ? mx : m_run;
-            const float alpha = exp2f(m_run - m_new);
-            l_run *= alpha;
-            m_run = m_new;
+        any = __builtin_amdgcn_ballot_w64(raise) != 0;
+        const float m_new = raise ? mx : m_run;
+        alpha = any ? exp2f(m_run - m_new) : 1.f;
+        m_run = m_new;
+    };
+    auto open = [&](int kt, unsigned bnext) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < ntiles) issue(kt + 1, bnext);
+    };
+    auto to_ph = [&](const f32x16& s) __attribute__((always_inline)) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+        for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-        }
+            for (int e = 0; e < 8; ++e) ph[ss][e] = (__bf16)s[8 * ss + e];
+    };
+    // tile 0: nothing pending (m_run = -inf: alpha = 0 on an O and l of zeros)
+    open(0, KVBUF);
+    if (valid) {
+        f32x16 s = rows_x_frags(sm3, la, qf);
+        float alpha;
+        bool any;
+        softmax_head(s, alpha, any);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_run));
             psum += s[r];
         }
-        l_run += psum;
-        imgT_x_p(o, sm3 + boff + TILEB, la, s);
-    };
-    for (int kt = 0; kt < ntiles; kt += 3) {                 // buffer of tile t: t mod 3
-        step(kt, 0, 2 * KVBUF);
-        if (kt + 1 < ntiles) step(kt + 1, KVBUF, 0);
-        if (kt + 2 < ntiles) step(kt + 2, 2 * KVBUF, KVBUF);
+        l_run = psum;
+        to_ph(s);
     }
+    auto step = [&](int kt, unsigned boff, unsigned bnext, unsigned bprev) __attribute__((always_inline)) {
+        open(kt, bnext);
+        if (!valid) return;
+        f32x16 s = rows_x_frags(sm3 + boff, la, qf);
+        float alpha;
+        bool any;
+        softmax_head(s, alpha, any);
+        float psum = 0.f;
+        // 8 groups of { 1 MFMA of P V(t - 1) on fragments read one group ahead, the next group's 2 transposed reads, 2 exponentials of tile t }
+        // (left to itself hipcc hoists all 16 reads and all the exponentials: 236 VGPRs, two waves per SIMD, 1.98 ms)
+        const char* img = sm3 + bprev + TILEB;
+        auto frag = [&](int g) __attribute__((always_inline)) {
+            const int dt = g >> 1, ss = g & 1;
+            const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + la.tr0 + 4096 * ss + 512 * dt));
+            const bf16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + la.tr1 + 4096 * ss + 512 * dt));
+            bf16x8 f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[e] = a[e];
+                f[4 + e] = c[e];
+            }
+            return f;
+        };
+        bf16x8 fc = frag(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            bf16x8 fn = fc;
+            if (g < 7) fn = frag(g + 1);
+            o[g >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc, ph[g & 1], o[g >> 1], 0, 0, 0);
+#pragma unroll
+            for (int r = 2 * g; r < 2 * g + 2; ++r) {
+                s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_run));
+                psum += s[r];
+            }
+            fc = fn;
+        }
+        // the order above, spelled out for the machine scheduler (the IR optimiser sinks the exponentials below the last MFMA otherwise, and
+        // scheduling fences between the groups cannot bring them back): per group 1 MFMA, the next group's 2 reads, 2 fma + 2 exp + 2 add
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (g < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+        l_run = l_run * alpha + psum;
+        to_ph(s);                                                // (before the branch below: hipcc's IR passes sink the exponentials to their first use otherwise, out of the scheduled region)
+        asm volatile("" : "+v"(ph[0]), "+v"(ph[1]), "+v"(l_run));
+        __builtin_amdgcn_sched_barrier(0);
+        if (any) {                                               // (wave-uniform, rare: the maximum grew by more than 2^RESC)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+    };
+    for (int kt = 1; kt < ntiles; kt += 3) {                 // buffer of tile t: t mod 3; tile t + 1 goes where tile t - 2 was
+        step(kt, KVBUF, 2 * KVBUF, 0);
+        if (kt + 1 < ntiles) step(kt + 1, 2 * KVBUF, 0, KVBUF);
+        if (kt + 2 < ntiles) step(kt + 2, 0, KVBUF, 2 * KVBUF);
+    }
+    if (valid) imgT_x_ph(o, sm3 + ((ntiles - 1) % 3) * KVBUF + TILEB, la, ph);
     __syncthreads();
     if (valid) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

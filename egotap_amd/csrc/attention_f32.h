@@ -54,10 +54,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
     const float* base = QKV + (long)b * N * ld + h * DH;     // q of token 0 of this (b, h)
     const int qb = qg * NW + wid;                              // 32-row query block of this wave
     const bool valid = qb * 32 < N;                            // wave-uniform
+    // [r5] N need not be a multiple of 32 (the reference allows any heatmap side that is a multiple of 16, net_architecture.py:327: N = 144 at
+    // 32 x 32 heatmaps, 1296 at 96 x 96): the LAST query block and the LAST key tile start at N - 32 and overlap their predecessors; the
+    // overlapping keys -- already counted by the tile before -- are masked to -inf, the overlapping queries are simply computed twice (same bits)
+    const int q0 = min(qb * 32, N - 32);
 
     float qreg[64];
     {
-        const float* qp = base + (long)(min(qb * 32, N - 32) + l31) * ld + 4 * lh;
+        const float* qp = base + (long)(q0 + l31) * ld + 4 * lh;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const f32x4 v = *(const f32x4*)(qp + 8 * t);
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
     constexpr int PER = KT * (DH / 4) / THREADS;
     f32x4 stg[PER];
     auto tile_req = [&](int kt, int vpart) __attribute__((always_inline)) {      // vpart: 0 = K rows, 1 = V rows of key tile kt
-        const float* kp = base + (long)(kt * KT) * ld + D + vpart * D;
+        const float* kp = base + (long)min(kt * KT, N - KT) * ld + D + vpart * D;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = tid + i * THREADS, row = idx >> 5, c4 = idx & 31;
@@ -90,14 +94,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
             else *(f32x4*)(Ks + row * KLD + c4 * 4) = stg[i];
         }
     };
-    const int tiles_all = N / KT;
+    const int tiles_all = (N + KT - 1) / KT;
+    const int overlap = tiles_all * KT - N;                     // keys of the last tile that the tile before it already covered (0: N is a multiple of 32)
     const int kt0 = ksplit > 1 ? (int)((long)split * tiles_all / ksplit) : 0;
     const int ntiles = ksplit > 1 ? (int)((long)(split + 1) * tiles_all / ksplit) : tiles_all;      // one past this workgroup's last key tile
     // prologue: K(kt0) and V(kt0) into LDS, K(kt0 + 1) into the staging registers.  [r4] K(kt0) and V(kt0) are requested TOGETHER (the output
     // accumulators are not live yet: a second staging set costs nothing) -- they were two dependent round trips in front of every block's first MFMA
     {
         f32x4 stg2[PER];
-        const float* vp = base + (long)(kt0 * KT) * ld + 2 * D;
+        const float* vp = base + (long)min(kt0 * KT, N - KT) * ld + 2 * D;
         tile_req(kt0, 0);
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -141,6 +146,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
             tile_req(kt + 1, 1);              // V(kt + 1) flies under the softmax and the P V MFMAs
         }
         if (valid) {
+            if (overlap > 0 && kt == tiles_all - 1) {          // (wave-uniform) register r of lane half lh holds key (r & 3) + 8 (r >> 2) + 4 lh of the tile
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((r & 3) + 8 * (r >> 2) + 4 * lh < overlap) s[r] = -INFINITY;
+            }
             // online softmax; the 32 keys of this tile sit in 16 registers x 2 lane halves
             float mx = s[0];
 #pragma unroll
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
         const float inv = 1.0f / l_tot;
         // training: log-sum-exp of the scaled scores (natural log) per query row, for the flash-style backward
         const long part = ksplit > 1 ? (long)split * (gridDim.x / (ksplit * qgroups)) : 0;      // split * (B * heads): offset of this split's partial buffers, in pairs
-        if (LSE != nullptr && lh == 0) LSE[(part + (long)b * heads + h) * N + qb * 32 + l31] = m_run * 0.6931471805599453f + logf(l_tot);      // m_run is in base-2 units
+        if (LSE != nullptr && lh == 0) LSE[(part + (long)b * heads + h) * N + q0 + l31] = m_run * 0.6931471805599453f + logf(l_tot);      // m_run is in base-2 units
         float* Os = smem + wid * 32 * KLD;     // [32 q][132]
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
                 *(f32x4*)(Os + l31 * KLD + dt * 32 + 8 * g + 4 * lh) = v;
             }
         // same wave reads back what it wrote: no barrier needed, only LDS completion (compiler waits)
-        float* out = CTX + (part / heads * N + (long)b * N + qb * 32) * D + h * DH;       // (part / heads = split * B images)
+        float* out = CTX + (part / heads * N + (long)b * N + q0) * D + h * DH;       // (part / heads = split * B images)
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int row = it * 2 + lh;
@@ -247,14 +257,14 @@ static hipError_t attention_f32_launch(const float* QKV, float* CTX, int B, int 
     constexpr int NW = 2;
     using Cfg = AttnCfg<NW>;
     if (B <= 0) return hipSuccess;
-    if (N % 32 != 0) return hipErrorInvalidValue;
+    if (N < 32 || N % 4 != 0) return hipErrorInvalidValue;
     auto kern = attention_f32_kernel<NW>;
-    const int qgroups = (N / 32 + NW - 1) / NW;
+    const int qgroups = ((N + 31) / 32 + NW - 1) / NW;
     const float scale_log2e = 1.4426950408889634f / sqrtf(128.0f);
     const long wgs = (long)B * heads * qgroups;
     int ksplit = 1;
     if (scratch != nullptr && LSE == nullptr) {
-        const int ntiles = N / 32;
+        const int ntiles = (N + 31) / 32;
         // as many ranges as keep the chip at ~2 waves per SIMD (a workgroup is two waves: 4.5 workgroups per CU), each a whole number of key tiles
         for (int k = 8; k >= 2; --k)
             if (ntiles % k == 0 && wgs * k <= 9L * num_cu / 2 && (size_t)k * ((size_t)B * N * heads * 128 + (size_t)B * heads * N) <= scratch_floats) { ksplit = k; break; }

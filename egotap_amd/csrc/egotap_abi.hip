@@ -865,7 +865,9 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
 #define EGOTAP_BF16S_MIN_ROWS 512       // [r4] 4096 before: a B = 4 forward (2304 rows) took 2.1 ms on the fp32-tensor path, 1.5 ms on this one (B = 1: 1.46 -> 1.38)
 #endif
     constexpr int g_bf16s_min_rows = EGOTAP_BF16S_MIN_ROWS;
-    const bool bf16s = h->precision == EGOTAP_PREC_BF16 && D == 1024 && M >= g_bf16s_min_rows && h->wscratch != nullptr &&
+    // (sequence lengths that are not a multiple of 32 -- heatmap sides 32, 48, 96 ...: the bf16-storage attention tiles whole 32-key blocks -- stay on
+    // fp32 tensors with bf16 products in the GEMMs and the exact-fp32 attention kernel, which masks a ragged last key tile)
+    const bool bf16s = h->precision == EGOTAP_PREC_BF16 && D == 1024 && M >= g_bf16s_min_rows && h->wscratch != nullptr && h->seq % 32 == 0 &&
                        h->wscratch_bytes >= (size_t)2 * 2048 * (size_t)(h->ppd * h->ppd * D);
     // H1+H2: tile -> patch embed -> mask token -> + position embeddings
     if (bf16s) {
@@ -956,8 +958,8 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
             SegVec bqkv; bqkv.p[0] = L.q_b; bqkv.p[1] = L.k_b; bqkv.p[2] = L.v_b; bqkv.seg = D;
             EGO_HIP((gemm_small(h, "qkv", ALoadPlain{Y, D}, Wqkv, EpiBias{bqkv}, QKV, 3L * D, M, 3 * D, D, SPK, s)));
         }
-        if (h->precision == EGOTAP_PREC_BF16X3) EGO_HIP(attention_bf16_launch<3>(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
-        else if (h->precision == EGOTAP_PREC_BF16) EGO_HIP(attention_bf16_launch<1>(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
+        if (h->precision == EGOTAP_PREC_BF16X3 && h->seq % 32 == 0) EGO_HIP(attention_bf16_launch<3>(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
+        else if (h->precision == EGOTAP_PREC_BF16 && h->seq % 32 == 0) EGO_HIP(attention_bf16_launch<1>(QKV, CTX, B, h->seq, h->cfg.vit_heads, s));
         else EGO_HIP(attention_f32_launch(QKV, CTX, B, h->seq, h->cfg.vit_heads, s, nullptr, SPK, SPLITK_FLOATS, device_cu_count()));   // (SPK: free between the GEMMs; key-split partials at B <= 2)
         EGO_HIP(gemm_res_ln(h, "attn_out", CTX, D, L.o_w, L.o_b, X, M, D, D, L.ln2_g, L.ln2_b, Y, SPK, s));
         EGO_HIP((gemm_small(h, "mlp_up", ALoadPlain{Y, D}, segmat1(L.up_w, 4 * D, D), EpiBiasGelu{segvec1(L.up_b, 4 * D)}, HID, 4L * D, M, 4 * D, D, SPK, s)));
@@ -1856,7 +1858,7 @@ extern "C" int egotap_layernorm_f32(const float* x, float* y, const float* gamma
 #if EGOTAP_IN(0)
 extern "C" int egotap_attention_f32(const float* qkv, float* ctx, int B, int N, int heads, void* stream) {
     EGO_CHECK(qkv && ctx, "egotap_attention_f32: null argument");
-    EGO_CHECK(N > 0 && N % 32 == 0, "egotap_attention_f32: sequence length must be a multiple of 32");
+    EGO_CHECK(N >= 32 && N % 4 == 0, "egotap_attention_f32: sequence length must be at least 32 and a multiple of 4 (any heatmap side that is a multiple of 16)");
     EGO_CHECK(heads > 0, "egotap_attention_f32: heads must be positive");
     EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, (hipStream_t)stream));
     return EGOTAP_OK;
@@ -1917,9 +1919,11 @@ extern "C" int egotap_synth_heatmaps(const float* pts2d_left, const float* pts2d
 #if EGOTAP_IN(0)
 extern "C" int egotap_attention(const float* qkv, float* ctx, int B, int N, int heads, int precision, void* stream) {
     EGO_CHECK(qkv && ctx, "egotap_attention: null argument");
-    EGO_CHECK(N > 0 && N % 32 == 0, "egotap_attention: sequence length must be a multiple of 32");
+    EGO_CHECK(N >= 32 && N % 4 == 0, "egotap_attention: sequence length must be at least 32 and a multiple of 4");
     EGO_CHECK(heads > 0, "egotap_attention: heads must be positive");
-    if (precision == EGOTAP_PREC_F32) EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, (hipStream_t)stream));
+    // [r5] the bf16 / bf16x3 kernels tile the sequence in whole 32-key blocks; sequence lengths that are not (heatmap sides 32, 48, 96 ...: the
+    // reference allows every multiple of 16) run on the exact-fp32 kernel, which masks the last key tile -- a FALLBACK BY NAME, documented in egotap.h
+    if (precision == EGOTAP_PREC_F32 || N % 32 != 0) EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, (hipStream_t)stream));
     else if (precision == EGOTAP_PREC_BF16X3) EGO_HIP(attention_bf16_launch<3>(qkv, ctx, B, N, heads, (hipStream_t)stream));
     else if (precision == EGOTAP_PREC_BF16) EGO_HIP(attention_bf16_launch<1>(qkv, ctx, B, N, heads, (hipStream_t)stream));
     else { egotap_set_error("egotap_attention: unknown precision %d", precision); return EGOTAP_ERR_INVALID; }
@@ -2214,9 +2218,10 @@ extern "C" int egotap_train_bn_lrelu_bwd(const float* z, const float* y, const f
 #if EGOTAP_IN(1)
 extern "C" int egotap_train_attention_fwd(const float* qkv, float* ctx, float* lse, int B, int N, int heads, int precision, void* stream) {
     EGO_CHECK(qkv && ctx && lse, "egotap_train_attention_fwd: null argument");
-    EGO_CHECK(N > 0 && N % 32 == 0 && heads > 0, "egotap_train_attention_fwd: bad shape");
+    EGO_CHECK(N >= 32 && N % 4 == 0 && heads > 0, "egotap_train_attention_fwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
-    if (precision == EGOTAP_PREC_BF16X3) EGO_HIP(attention_bf16_launch<3>(qkv, ctx, B, N, heads, s, lse));
+    if (N % 32 != 0) EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, s, lse));      // (the exact-fp32 kernel masks a ragged last key tile; see egotap_attention)
+    else if (precision == EGOTAP_PREC_BF16X3) EGO_HIP(attention_bf16_launch<3>(qkv, ctx, B, N, heads, s, lse));
     else if (precision == EGOTAP_PREC_BF16) EGO_HIP(attention_bf16_launch<1>(qkv, ctx, B, N, heads, s, lse));
     else EGO_HIP(attention_f32_launch(qkv, ctx, B, N, heads, s, lse));
     return EGOTAP_OK;
@@ -2227,7 +2232,9 @@ extern "C" int egotap_train_attention_fwd(const float* qkv, float* ctx, float* l
 extern "C" int egotap_train_attention_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* delta,
                                           float* dqkv, int B, int N, int heads, int precision, void* stream) {
     EGO_CHECK(qkv && ctx && dctx && lse && delta && dqkv, "egotap_train_attention_bwd: null argument");
-    EGO_CHECK(N > 0 && N % 32 == 0 && heads > 0, "egotap_train_attention_bwd: bad shape");
+    EGO_CHECK(N > 0 && heads > 0, "egotap_train_attention_bwd: bad shape");
+    EGO_CHECK(N % 32 == 0, "egotap_train_attention_bwd: the attention BACKWARD kernels need a sequence length that is a multiple of 32 (heatmap sides 64, 128, ...: "
+              "every shipped configuration); N = %d (evaluation runs at any heatmap side that is a multiple of 16)", N);
     hipStream_t s = (hipStream_t)stream;
     if (precision == EGOTAP_PREC_BF16X3) EGO_HIP(attention_bwd_bf16_launch<3>(qkv, ctx, dctx, lse, delta, dqkv, B, N, heads, s));
     else if (precision == EGOTAP_PREC_BF16) EGO_HIP(attention_bwd_bf16_launch<1>(qkv, ctx, dctx, lse, delta, dqkv, B, N, heads, s));

@@ -164,9 +164,14 @@ int egotap_linear_bf16_dma(const void* x_bf16, const void* w_bf16, const float* 
 /* nn.LayerNorm over the last dim (1024), modeling_vit.py:357-358 */
 int egotap_layernorm_f32(const float* x, float* y, const float* gamma, const float* beta, int rows, int dim, float eps,
                          void* stream);
-/* ViTSelfAttention core (modeling_vit.py:233-252) on a fused [B*N, 3*heads*128] q|k|v buffer -> ctx [B*N, heads*128] */
+/* ViTSelfAttention core (modeling_vit.py:233-252) on a fused [B*N, 3*heads*128] q|k|v buffer -> ctx [B*N, heads*128].
+ * N >= 32, a multiple of 4: every heatmap side the reference allows (a multiple of 16, net_architecture.py:327: N = 36 (side / 16)^2 for
+ * UnrealEgo) -- a ragged last 32-key tile is masked, the last 32-query block overlaps its predecessor. */
 int egotap_attention_f32(const float* qkv, float* ctx, int B, int N, int heads, void* stream);
-/* the same operator with the arithmetic of egotap_set_precision (EGOTAP_PREC_F32 / _BF16X3 / _BF16) */
+/* the same operator with the arithmetic of egotap_set_precision (EGOTAP_PREC_F32 / _BF16X3 / _BF16).  The bf16 / bf16x3 kernels need
+ * N % 32 == 0 (heatmap sides 64, 128: every shipped configuration); for other N the call -- and egotap_lift_forward in those modes -- runs the
+ * exact-fp32 kernel above instead (a fallback by name: the result is MORE exact than asked for).  The attention BACKWARD
+ * (egotap_train_attention_bwd, egotap_lift_backward) needs N % 32 == 0 and says so. */
 int egotap_attention(const float* qkv, float* ctx, int B, int N, int heads, int precision, void* stream);
 
 /* Evaluation metrics of EgoTAPAutoEncoderModel.evaluate (model/egotap_autoencoder_model.py:329-350): per-sample MPJPE and

@@ -238,6 +238,48 @@ def test_attention_fwd_bwd_bf16(B, N):
     assert torch.equal(dqkv, again)
 
 
+@pytest.mark.parametrize("B,N", [(2, 576), (1, 96)])
+def test_attention_forward_running_maximum_rescale_with_a_pending_tile(B, N):
+    """The forward defers P V of a key tile by one step and runs it under the next tile's exponentials (attention_bf16s2.h); the running
+    maximum is raised only when a tile exceeds it by 2^6.  On bounded random scores that branch fires at the first tile only, so a passing
+    random test says nothing about it (cdna_hip_programming.md T13: nothing pending may be left at the old scale).  Here the scores of a row
+    GROW along the keys by `slope` per key in log2 units -- a rescale at every tile with the previous tile's P V still pending (slope 0.5, 2),
+    at every few tiles (0.05), never after the first (negative slopes), all mixed over the 32 rows of one wave's query block, heads with
+    noise on top; context and log-sum-exp against float64 softmax on the same bf16 operands."""
+    from egotap_amd import bf16s
+    heads, dh = 8, 128
+    D = heads * dh
+    g = torch.Generator().manual_seed(91)
+    u = torch.randn(dh, generator=g)
+    u = u / u.norm()
+    slopes = torch.tensor([0.5, -0.5, 2.0, 0.05, -0.05, 0.0, 1.0, -2.0])[torch.arange(B * N) % 8] * (1.0 + (torch.arange(B * N) % 5).float() / 4.0)
+    ln2 = math.log(2.0)
+    qkv = torch.randn(B * N, 3 * D, generator=g) * 0.05
+    key_pos = (torch.arange(B * N) % N).float()
+    for h in range(heads):
+        qkv[:, h * dh:(h + 1) * dh] += (slopes * ln2 * math.sqrt(dh))[:, None] * u[None, :] * (1.0 if h % 2 == 0 else 0.5)      # q_i = slope_i sqrt(dh) ln2 u
+        qkv[:, D + h * dh:D + (h + 1) * dh] += key_pos[:, None] * u[None, :]                                                    # k_j = j u  ->  q.k / sqrt(dh) = slope_i j ln2
+    qkv[:, 2 * D:] = torch.randn(B * N, D, generator=g)
+    qkv[:, 2 * D:2 * D + 4] = (key_pos / 64.0)[:, None]
+    qkv = qkv.bfloat16()
+    ctx, lse = bf16s.attention_fwd(qkv.cuda(), B, N, heads)
+    again, lse2 = bf16s.attention_fwd(qkv.cuda(), B, N, heads)
+    assert torch.equal(ctx, again) and torch.equal(lse, lse2)
+    t = qkv.double()
+    q, k, v = (t[:, i * D:(i + 1) * D].view(B, N, heads, dh).transpose(1, 2) for i in range(3))
+    sc = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    growth = float((sc[0, 0, 2, 1:] - sc[0, 0, 2, :-1]).mean() / ln2)               # row 2: slope 2 x gain: the maximum rises by > 2^6 every tile
+    assert growth * 32 > 6.0, growth
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * N, D)
+    err = (ctx.double().cpu() - ref).abs()
+    # one bf16 rounding of the stored context (|v| up to ~4; up to 9 in the key-index columns) + bf16 P and V in a peaked sum; a tile left at the
+    # wrong scale is an O(0.1 ... 1) error on every row whose maximum moved
+    excess = float((err - (2.0 ** -7 * ref.abs() + 1.5e-2)).max())
+    assert excess <= 0.0 and float(err.mean()) < 2e-3, (excess, float(err.max()), float(err.mean()))
+    ref_lse = torch.logsumexp(sc, -1).reshape(-1)
+    assert float((lse.double().cpu() - ref_lse).abs().max()) < 2e-3 * max(1.0, float(ref_lse.abs().max()) / 64.0)
+
+
 @pytest.mark.parametrize("B,N", [(3, 576), (2, 96)])
 def test_attention_backward_bias_sums_equal_the_column_sums_of_dqkv(B, N):
     """egotap_bf16_attention_bwd_bias: the q | k | v bias gradients.  N % 64 == 0: per-block partial sums written by the dQ / dK+dV

@@ -74,6 +74,42 @@ def test_lift_forward_matches_oracle(preset, B):
     np.testing.assert_allclose(pose.cpu().numpy(), ref.numpy(), atol=TOL, rtol=0)
 
 
+@pytest.mark.parametrize("preset,hm,B", [("UnrealEgo", 32, 3), ("UnrealEgo", 96, 2), ("EgoCap", 48, 2), ("UnrealEgo", 16, 4), ("UnrealEgo", 96, 40)])
+def test_lift_forward_at_heatmap_sides_whose_sequence_is_not_a_multiple_of_32(preset, hm, B):
+    """The reference accepts every heatmap side that is a multiple of 16 (net_architecture.py:327); the ViT sequence is then 36 (hm / 16)^2 tokens:
+    36, 144, 324, 1296 at 16 / 32 / 48 / 96 -- no multiple of 32.  The exact-fp32 attention kernel masks the ragged last key tile and overlaps
+    the last query block (attention_f32.h); everything else of the head is size-generic.  fp32 against the float64 oracle at the north-star
+    tolerance; the bf16 modes take the fp32 attention kernel BY NAME for such sequences (egotap.h egotap_attention) and are bf16-grade.
+    B = 40 at 96 x 96: batches past the serving split paths (51840 token rows)."""
+    from gpu_util import lift_net
+    from oracle import lift_ref as O
+    net, sd_np, p = lift_net(preset, hm)
+    assert p.seq % 32 != 0
+    nb = min(B, 4)
+    hmap = torch.from_numpy(synth_input(f"hm_side_{preset}_{hm}", (nb, p.in_channels, hm, hm)))
+    if B > nb:
+        hmap = (hmap[torch.arange(B) % nb] * (1.0 + 0.05 * (torch.arange(B) // nb).float()).view(B, 1, 1, 1)).contiguous()
+    sd = O.to_torch_sd(sd_np, torch.float64)
+    check = list(range(min(B, 3))) + ([B - 1] if B > 3 else [])
+    with torch.no_grad():
+        ref = O.lift_forward(hmap[check].double(), sd, p)
+    pose = net.predict_pose(hmap.cuda())
+    again = net.predict_pose(hmap.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(pose, again)
+    np.testing.assert_allclose(pose[check].cpu().numpy(), ref.numpy(), atol=TOL, rtol=0)
+    if B <= 4:
+        scale = float(ref.abs().max())
+        for mode, tol in (("bf16x3", 1e-4), ("bf16", 3e-2 * scale)):
+            try:
+                net.set_precision(mode)
+                low = net.predict_pose(hmap.cuda())
+            finally:
+                net.set_precision("f32")
+            err = float((low[check].double().cpu() - ref).abs().max())
+            assert err < tol, (mode, err, tol)
+
+
 def test_batch_rows_are_independent_and_deterministic():
     """Size-independent property at the benchmark batch: sample i of a B=256 batch equals the same
     sample run in a batch of 128, bit for bit (per-row k order does not depend on the tile the row is in),

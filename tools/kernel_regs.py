@@ -5,17 +5,19 @@ import glob, os, re, subprocess, sys, tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 pats = sys.argv[1:]
-for obj in sorted(glob.glob(os.path.join(REPO, "egotap_amd", "build", "*.o"))):
+for obj in sorted(glob.glob(os.path.join(os.environ.get("KREGS_DIR", os.path.join(REPO, "egotap_amd", "build")), "*.o"))):
     with tempfile.TemporaryDirectory() as td:
-        co = os.path.join(td, "dev.co")
-        subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={obj}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"],
-                       check=True, capture_output=True)
+        import shutil
+        tmp_obj = os.path.join(td, "o.o")
+        shutil.copy(obj, tmp_obj)
+        subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", tmp_obj], check=True, capture_output=True)      # writes <obj>.0.<target> next to it
+        co = glob.glob(tmp_obj + ".*gfx950")[0]
         notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
     for blk in notes.split("- .agpr_count")[1:]:
         name = re.search(r"\.name:\s+(\S+)", blk)
         if not name:
             continue
-        dem = subprocess.run([f"{LLVM}/llvm-cxxfilt", name.group(1)], capture_output=True, text=True).stdout.strip()
+        dem = subprocess.run(["c++filt", name.group(1)], capture_output=True, text=True).stdout.strip()
         vg, sp = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)), int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
         ag = int(re.match(r":\s+(\d+)", blk).group(1)) if re.match(r":\s+(\d+)", blk) else 0
         lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1))
