@@ -52,6 +52,24 @@ def _strided(t):
     return t.detach().reshape(-1)[:: max(1, t.numel() // 257)].cpu().numpy()
 
 
+SPREAD = np.load(os.path.join(GOLD, "wrapper_step_spread.npz"))
+
+
+def _spread(key):
+    """how far the REFERENCE moves from itself on this quantity when only its CPU thread count (summation order) changes: max over 1 and 3
+    threads against the fixtures' 8 (tools/make_golden.py gen_wrapper_spread)"""
+    return max(float(SPREAD[f"{key[0]}_t{t}_{key[1]}"].max()) for t in (1, 3))
+
+
+def _close(label, got, want, atol, spread_key=None):
+    """assert_allclose(atol) that also PRINTS the observed distance next to the gate and, where recorded, the reference's own spread"""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    err = float(np.abs(got - want).max())
+    ref = f", reference's own thread-count spread {_spread(spread_key):.1e}" if spread_key else ""
+    print(f"{label}: max |gpu - reference| = {err:.2e} (gate {atol:.0e}{ref})")
+    assert err <= atol, (label, err, atol)
+
+
 def test_three_wrapper_steps_match_the_reference_wrapper(tmp_path):
     from egotap_amd import models
     g = np.load(os.path.join(GOLD, "wrapper_step_ue_b2.npz"))
@@ -136,7 +154,7 @@ def test_three_wrapper_steps_match_the_reference_wrapper(tmp_path):
     torch.cuda.synchronize()
     errs2 = m.get_current_errors()
     np.testing.assert_allclose([errs2[k] for k in errs2], g["errors_step2"], rtol=2e-4, atol=1e-7)
-    np.testing.assert_allclose(m.pred_pose.detach().cpu().numpy(), g["pred_pose_step2"], atol=1e-4)
+    _close("gt step 2 pose", m.pred_pose.detach().cpu().numpy(), g["pred_pose_step2"], 1e-4, ("gt", "pose_step2"))
     for k, want in zip(g["grad_keys"], g["param_sums_step2"]):
         np.testing.assert_allclose(_strided(params[k]), g["p2:" + k], atol=3e-5, err_msg=k)
         np.testing.assert_allclose(float(params[k].detach().double().sum()), want, rtol=1e-4, atol=3e-5 * np.sqrt(params[k].numel()) + 1e-4, err_msg=k)
@@ -148,7 +166,10 @@ def test_three_wrapper_steps_match_the_reference_wrapper(tmp_path):
     torch.cuda.synchronize()
     errs3 = m.get_current_errors()
     np.testing.assert_allclose([errs3[k] for k in errs3], g["errors_step3"], rtol=2e-3, atol=2e-5)
-    np.testing.assert_allclose(m.pred_pose.detach().cpu().numpy(), g["pred_pose_step3"], atol=2e-3)
+    # [r5] gates of the multi-step quantities are set from data: the reference moves 6e-6 from ITSELF here when only its CPU thread count changes
+    # (wrapper_step_spread.npz); this build sits 1.1e-4 from the 8-thread run -- a third summation order plus exact-erf / BatchNorm expression
+    # differences, two AdamW(eps 1e-4) updates deep -- and is gated at 5e-4 (2e-3 through round 4)
+    _close("gt step 3 pose", m.pred_pose.detach().cpu().numpy(), g["pred_pose_step3"], 5e-4, ("gt", "pose_step3"))
     sd = m.net_AutoEncoder.state_dict()                          # BatchNorm1d running statistics after the three train-mode forwards
     for k in g.files:
         if k.startswith("buf:"):
@@ -276,13 +297,13 @@ def test_egocap_wrapper_step_and_evaluate_match_the_reference_wrapper(tmp_path):
     torch.cuda.synchronize()
     e3 = m.get_current_errors()
     np.testing.assert_allclose([e3[k] for k in e3], g["errors_step3"], rtol=2e-3, atol=2e-5)
-    np.testing.assert_allclose(m.pred_pose.detach().cpu().numpy(), g["pred_pose_step3"], atol=2e-3)
+    _close("EgoCap step 3 pose", m.pred_pose.detach().cpu().numpy(), g["pred_pose_step3"], 1e-3)
     m.eval()
     m.set_input(data(4, "ec_eval"))
     acc = _Acc()
     pose, _, _ = m.evaluate(acc)
     torch.cuda.synchronize()
-    np.testing.assert_allclose(pose.cpu().numpy(), g["eval_pred_pose"], atol=2e-3)          # three AdamW steps away from the initial weights
+    _close("EgoCap eval pose after three steps", pose.cpu().numpy(), g["eval_pred_pose"], 2e-3)          # three AdamW steps away from the initial weights
     np.testing.assert_allclose([r["mpjpe"] for r in acc.rows], g["eval_mpjpe"], rtol=1e-3)
     np.testing.assert_allclose([r["pa_mpjpe"] for r in acc.rows], g["eval_pa_mpjpe"], rtol=2e-3)
 
@@ -316,9 +337,9 @@ def test_wrapper_steps_from_rgb_match_the_reference_wrapper(tmp_path):
         # heatmaps: 2 x 21 convolutions with batch-statistics BatchNorm (B = 2: 128 values per channel in layer4) in fp32
         np.testing.assert_allclose(cat.reshape(-1)[::997].cpu().numpy(), g[f"cat_sample_step{step}"], atol=5e-4, err_msg=f"step {step}")
         np.testing.assert_allclose([float(cat.double().sum()), float(cat.double().abs().sum())], g[f"cat_stats_step{step}"], rtol=2e-4)
-        tol = 5e-4 if step < 3 else 2e-3                         # step 3 runs on parameters two AdamW updates away
+        tol = 5e-4                                               # [r5] step 3 too (2e-3 before): observed 3e-5, the reference's own thread-count spread is 1e-5
         np.testing.assert_allclose([errs[k] for k in errs], g[f"errors_step{step}"], rtol=max(tol, 1e-3), atol=2e-5)
-        np.testing.assert_allclose(m.pred_pose.detach().cpu().numpy(), g[f"pred_pose_step{step}"], atol=tol)
+        _close(f"rgb step {step} pose", m.pred_pose.detach().cpu().numpy(), g[f"pred_pose_step{step}"], tol, ("rgb", f"pose_step{step}"))
         if step == 1:
             assert not cat.requires_grad and int(g["cat_requires_grad"][0]) == 0
             params = dict(m.net_AutoEncoder.named_parameters())
@@ -358,7 +379,9 @@ def test_wrapper_steps_from_rgb_match_the_reference_wrapper(tmp_path):
     pose, cat, _ = m.evaluate(acc)
     torch.cuda.synchronize()
     np.testing.assert_allclose(cat.reshape(-1)[::997].cpu().numpy(), g["eval_cat_sample"], atol=1e-3)
-    np.testing.assert_allclose(pose.cpu().numpy(), g["eval_pred_pose"], atol=3e-3)
+    # (3e-3 stays: the reference ITSELF moves 4.2e-3 on this quantity between 8 threads and 1 -- evaluation normalises with BatchNorm1d running
+    # statistics gathered over three batches of two frames; observed here: 2.5e-5)
+    _close("rgb eval pose after three steps", pose.cpu().numpy(), g["eval_pred_pose"], 3e-3, ("rgb", "eval_pose"))
     np.testing.assert_allclose([r["mpjpe"] for r in acc.rows], g["eval_mpjpe"], rtol=1e-3)
     np.testing.assert_allclose([r["pa_mpjpe"] for r in acc.rows], g["eval_pa_mpjpe"], rtol=2e-3)
     m.train()
@@ -370,7 +393,7 @@ def test_wrapper_steps_from_rgb_match_the_reference_wrapper(tmp_path):
     k = "backbone.backbone.backbone.bn1.num_batches_tracked"
     assert [int(m.net_HeatMap.state_dict()[k]), int(m.net_RotHeatMap.state_dict()[k])] == list(g["quirk_num_batches_tracked"])
     np.testing.assert_allclose(cat.reshape(-1)[::997].cpu().numpy(), g["quirk_cat_sample"], atol=1e-3)
-    np.testing.assert_allclose(pose.cpu().numpy(), g["quirk_pred_pose"], atol=3e-3)
+    _close("rgb evaluate() straight from train mode, pose", pose.cpu().numpy(), g["quirk_pred_pose"], 1e-3)
 
 
 def test_wrapper_evaluate_batch_of_two_prints_the_reference_pa_mpjpe(tmp_path):

@@ -533,6 +533,70 @@ def gen_wrapper_rgb():
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+def gen_wrapper_spread():
+    """[r5] How far does the REFERENCE move from itself when only the summation order of its CPU kernels changes?  The reference wrapper's
+    three optimize_parameters() + evaluate() (exactly gen_wrapper's / gen_wrapper_rgb's runs: same flags, weights, data) repeated with
+    torch.set_num_threads(1) and (3) against the fixtures' 8 threads: MKL / oneDNN split their reductions by thread count, nothing else
+    differs.  wrapper_step_spread.npz holds, per step, max |pose_T - pose_8|, the loss differences and max |heatmap_T - heatmap_8| -- the
+    yardstick the multi-step gates of tests/test_gpu_wrapper_golden.py are set from (a GPU summation order is one more such order)."""
+    import tempfile
+    from model.egotap_autoencoder_model import EgoTAPAutoEncoderModel
+    from egotap_amd import spec
+    from egotap_amd.synthetic import synth_hm_state_dict, synth_state_dict
+
+    tmp = tempfile.mkdtemp(prefix="egotap_gold_spread_")
+    sd_lift = {k: torch.from_numpy(v) for k, v in synth_state_dict(spec.lift_state_spec(spec.lift_preset("UnrealEgo"))).items()}
+    for sub, nh, salt in (("hm_pos", 15, "hm_pos."), ("hm_sin", 30, "hm_rot.")):
+        os.makedirs(os.path.join(tmp, sub))
+        torch.save({k: torch.from_numpy(v) for k, v in synth_hm_state_dict(nh, salt).items()}, os.path.join(tmp, sub, "best_net_HeatMap.pth"))
+
+    class Acc:
+        def __init__(self):
+            self.rows = []
+
+        def update(self, d):
+            self.rows.append({k: float(v.detach()) for k, v in d.items()})
+
+    def run(threads, use_gt):
+        torch.set_num_threads(threads)
+        m = EgoTAPAutoEncoderModel()
+        m.initialize(_wrapper_opt(tmp, True, use_gt))
+        m.net_AutoEncoder.load_state_dict(sd_lift, strict=True)
+        m.train()
+        m.set_input(_wrapper_data(2, "step" if use_gt else "rgbstep"))
+        rec = {}
+        for step in (1, 2, 3):
+            m.optimize_parameters()
+            errs = m.get_current_errors()
+            rec[f"pose{step}"] = m.pred_pose.detach().numpy().copy()
+            rec[f"errs{step}"] = np.array([errs[k] for k in errs], dtype=np.float64)
+            rec[f"cat{step}"] = m.pred_heatmap_cat.detach().numpy().copy()
+            m.update_learning_rate()
+        m.eval()
+        m.set_input(_wrapper_data(4, "eval" if use_gt else "rgbeval"))
+        pose, cat, _ = m.evaluate(Acc())
+        rec["eval_pose"] = pose.detach().numpy().copy()
+        return rec
+
+    out = {}
+    for tag, use_gt in (("gt", True), ("rgb", False)):
+        base = run(8, use_gt)
+        for threads in (1, 3):
+            other = run(threads, use_gt)
+            for step in (1, 2, 3):
+                out[f"{tag}_t{threads}_pose_step{step}"] = np.array([np.abs(other[f"pose{step}"] - base[f"pose{step}"]).max()])
+                out[f"{tag}_t{threads}_errs_step{step}"] = np.abs(other[f"errs{step}"] - base[f"errs{step}"])
+                out[f"{tag}_t{threads}_cat_step{step}"] = np.array([np.abs(other[f"cat{step}"] - base[f"cat{step}"]).max()])
+            out[f"{tag}_t{threads}_eval_pose"] = np.array([np.abs(other["eval_pose"] - base["eval_pose"]).max()])
+        out[f"{tag}_pose_scale"] = np.array([np.abs(base["pose3"]).max()])
+    torch.set_num_threads(8)
+    np.savez_compressed(os.path.join(GOLD, "wrapper_step_spread.npz"), **out)
+    for k in sorted(out):
+        print(k, out[k])
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 def gen_procrustes():
     import utils.util as U
 
@@ -819,6 +883,8 @@ def main():
         gen_wrapper()
     if "wrapper_rgb" in which:
         gen_wrapper_rgb()
+    if "wrapper_spread" in which:      # (not in the default set: six reference wrapper runs, ~10 min)
+        gen_wrapper_spread()
 
 
 if __name__ == "__main__":
