@@ -153,6 +153,11 @@ def test_hm_forward_bf16_channels_last_decoder_against_float64_oracle(which, pre
     # routing would be O(1)
     rel_batch = float((low[B - 1:].double() - last.double()).norm() / last.double().norm())
     assert rel_batch < 1e-2, rel_batch
+    # ... and EVERY routing is gated against the float64 oracle by itself (round-4 advice: the 1e-2 between batch sizes is half the whole bf16
+    # budget, a mis-routed small layer could hide in it): the same frame alone in its batch -- the serving route: K split over the chip in
+    # layer3 / layer4 and the three decoder convolutions (hm_dec_ksplit, fixed-order reduce) -- must meet the oracle gate of the batched route
+    rel_alone = float((last[0].double().cpu() - ref[B - 1]).norm() / ref[B - 1].norm())
+    assert 1e-5 < rel_alone < (2e-2 if model_name == "resnet18" else 3e-2), rel_alone
     low = low.double().cpu()
     assert tuple(low.shape) == tuple(ref.shape)
     rels = [float((low[b] - ref[b]).norm() / ref[b].norm()) for b in range(B)]
