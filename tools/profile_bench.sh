@@ -25,6 +25,7 @@ for s in $SETS; do
     config3)  passes gpurun_out/prof_c3 tools/train_bf16_probe.py 1024 bf16 ;;
     hm16)     passes gpurun_out/prof_hm tools/hm_bf16_probe.py 256 64 bf16 ;;
     stage1)   passes gpurun_out/prof_st1 tools/stage1_probe.py 32 f32 ;;
+    rgbdef)   passes gpurun_out/prof_rgbdef tools/from_rgb_probe.py 1024 default ;;
     all)      passes gpurun_out/prof_all bench.py --steps 2 --warmup 1 --full-steps 1 --train-steps 1 --no-cpu-baseline --no-kernel-timing ;;
   esac
 done

@@ -66,6 +66,12 @@ def main():
     if os.path.isdir(SRC):
         one(tag + "_stage1_f32", "python3 tools/stage1_probe.py 32 f32", "stage-1 training step of the position heatmap estimator, fp32, B = 32 stereo frames: "
             "train-mode forward, loss, backward, Adam; 1 warm-up + 2 timed steps", traffic_json=False)
+    SRC = os.path.join(REPO, "gpurun_out", "prof_rgbdef")
+    if os.path.isdir(SRC):
+        one(tag + "_from_rgb_default", "python3 tools/from_rgb_probe.py 1024 default", "[r5] the lifting head's training step FROM RGB as train.py runs it: the two "
+            "frozen estimators in train mode (batch-statistics BatchNorm per eye on the bf16 channels-last kernels: stem statistics pass + fused stem, "
+            "bn_colstats / bn_finish / bn_apply per BatchNorm, backbone over the whole batch, decoder in chunks of 256), then the bf16-storage step of the head; "
+            "B = 1024, 2 warm-up + 2 timed steps", traffic_json=False)
     SRC = os.path.join(REPO, "gpurun_out", "prof_all")
     if os.path.isdir(SRC):
         one(tag + "_all_legs", ALL_CMD, "every leg: fp32 headline, bf16x3 / bf16 fast modes, full pipeline in both modes, EgoCap / 128x128 geometry, "
