@@ -132,8 +132,9 @@ static inline hipError_t bn_batch_bf16s_launch(__bf16* z, const __bf16* res, lon
     const int NC = 2 * C;
     if (NC < 128 || NC > 1024 || (NC & (NC - 1)) != 0 || R < 2) return hipErrorInvalidValue;
     const int rstep = 256 / (NC >> 3);
-    // blocks: ~64 row steps each at least, at most MAX_PARTS
-    long per = 64L * rstep;
+    // workgroups: about 1024 of them (four per CU: the kernel is a stream), each at least 8 row steps, at most MAX_PARTS.  (64 row steps each left
+    // a 32-frame batch 16-128 workgroups per launch -- the reference's own training batch: 18 us per BatchNorm where 6 suffice)
+    long per = std::max<long>(8L * rstep, ((R + 1023) / 1024 + rstep - 1) / rstep * rstep);
     long nblk = (R + per - 1) / per;
     if (nblk > BnBatchScratch::MAX_PARTS) { per = ((R + BnBatchScratch::MAX_PARTS - 1) / BnBatchScratch::MAX_PARTS + rstep - 1) / rstep * rstep; nblk = (R + per - 1) / per; }
     hipLaunchKernelGGL(bn_colstats_bf16s_kernel, dim3((unsigned)nblk), dim3(256), 0, s, (const __bf16*)z, R, NC, per, ws.part);

@@ -2283,7 +2283,7 @@ extern "C" int egotap_train_adamw_multi(const void* table, int nseg, const float
                                         double beta2, double eps, double weight_decay, int step, void* stream) {
     EGO_CHECK(table && g && m && v && nseg >= 1 && span >= 1 && step >= 1, "egotap_train_adamw_multi: bad argument");
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2s = sqrt(1.0 - pow(beta2, (double)step));
-    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const long*)table, nseg, g, m, v,
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)(((span + 3) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const long*)table, nseg, g, m, v,
                        (long)span, (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)bc1, (float)bc2s);
     EGO_HIP(hipGetLastError());
     return EGOTAP_OK;

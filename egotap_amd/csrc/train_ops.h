@@ -106,28 +106,64 @@ static __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p
 
 // the same update for MANY tensors in one launch: gradients, exp_avg and exp_avg_sq live in flat arenas with one layout (segment s
 // covers arena elements [off_s, off_s + n_s)), the parameters stay where the framework allocated them.  table[s] = {off_s, n_s, param
-// pointer}, sorted by offset; a thread finds its segment by binary search (a few steps against ~28 bytes of HBM traffic per element).
+// pointer}, sorted by offset.
+// [r5] One thread = FOUR consecutive arena elements (segment offsets are multiples of 4 in both wrappers' arenas: 16-byte loads and stores
+// wherever the four lie inside one segment and the parameter pointer is 16-byte aligned, element by element otherwise), and the segment is
+// found once per WAVE on the scalar unit (binary search on the wave's first element) and then walked forward per lane.  The round-1 form -- one
+// element per thread, a 7-step binary search of global loads in front of every 28 bytes of traffic -- ran at 2.2 TB/s: 1.17 ms for the head's 97 M
+// parameters, 6 % of a training step at the reference's batch of 32.  Same expressions per element: same bits.
 static __global__ __launch_bounds__(256) void adamw_multi_kernel(const long* __restrict__ table, int nseg, const float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v, long span, float lr, float b1,
                                                           float b2, float eps, float wd, float bc1, float bc2_sqrt) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= span) return;
+    const long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    // wave-uniform start: the first lane's element (lanes are consecutive)
+    const long w0 = ((long)__builtin_amdgcn_readfirstlane((int)(i0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)i0);
     int lo = 0, hi = nseg - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (table[3 * mid] <= i) lo = mid; else hi = mid - 1;
+        if (table[3 * mid] <= w0) lo = mid; else hi = mid - 1;
     }
-    const long off = table[3 * lo], n = table[3 * lo + 1];
-    if (i < off || i >= off + n) return;                       // alignment padding between segments
-    float* p = (float*)table[3 * lo + 2] + (i - off);
-    const float gi = g[i];
-    float pi = *p * (1.0f - lr * wd);
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
-    *p = pi;
+    if (i0 >= span) return;
+    int sg = lo;
+    while (sg + 1 < nseg && table[3 * (sg + 1)] <= i0) ++sg;   // (a wave spans 1024 elements: a few steps where tiny tensors follow each other)
+    auto upd = [&](float* p, long i) __attribute__((always_inline)) {
+        const float gi = g[i];
+        float pi = *p * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        *p = pi;
+    };
+    const long off = table[3 * sg], n = table[3 * sg + 1];
+    float* pb = (float*)table[3 * sg + 2];
+    if (i0 >= off && i0 + 4 <= off + n && (((size_t)(pb + (i0 - off))) & 15) == 0 && i0 + 4 <= span) {
+        float* p = pb + (i0 - off);
+        const f32x4 g4 = *(const f32x4*)(g + i0), m4 = *(const f32x4*)(m + i0), v4 = *(const f32x4*)(v + i0);
+        f32x4 p4 = *(const f32x4*)p, mo, vo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pi = p4[e] * (1.0f - lr * wd);
+            const float mi = b1 * m4[e] + (1.0f - b1) * g4[e];
+            const float vi = b2 * v4[e] + (1.0f - b2) * g4[e] * g4[e];
+            mo[e] = mi;
+            vo[e] = vi;
+            pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+            p4[e] = pi;
+        }
+        *(f32x4*)(m + i0) = mo;
+        *(f32x4*)(v + i0) = vo;
+        *(f32x4*)p = p4;
+        return;
+    }
+    for (int e = 0; e < 4; ++e) {                               // a segment's ragged end, alignment padding, or the start of the next segment
+        const long i = i0 + e;
+        if (i >= span) return;
+        while (sg + 1 < nseg && table[3 * (sg + 1)] <= i) ++sg;
+        const long o2 = table[3 * sg], n2 = table[3 * sg + 1];
+        if (i >= o2 && i < o2 + n2) upd((float*)table[3 * sg + 2] + (i - o2), i);
+    }
 }
 
 // ----------------------------------------------------------------------------- LayerNorm (training)

@@ -228,6 +228,48 @@ def test_adamw_matches_torch():
     _close(p, ref.detach().double(), 1e-6)
 
 
+def test_adamw_multi_tensor_launch_matches_torch_on_ragged_segments():
+    """egotap_train_adamw_multi (one launch for every tensor whose gradient lives in one arena; [r5] four elements per thread, 16-byte accesses
+    inside a segment): tensors of 3 / 1 / 1024 / 7 / 65 / 4099 / 30000 elements at 64-element-aligned arena offsets (padding between them), one
+    PARAMETER that is a 4-byte-aligned view (element-wise path), two steps against torch.optim.AdamW; padding and neighbours untouched."""
+    from egotap_amd.training import EgotapAdamW
+    sizes = [3, 1, 1024, 7, 65, 4099, 30000, 130]
+    offs, o = [], 0
+    for n in sizes:
+        offs.append(o)
+        o += (n + 63) // 64 * 64
+    arena = torch.zeros(o, device="cuda")
+    backing = torch.zeros(sum(sizes) + 16, device="cuda")          # parameter 5 is a view at an odd element offset: 4-byte aligned only
+    ps, refs = [], []
+    for i, n in enumerate(sizes):
+        init = _rand((n,), 300 + i)
+        if i == 5:
+            view = backing[1:1 + n]
+            view.copy_(init.cuda())
+            prm = torch.nn.Parameter(view)
+            assert prm.data_ptr() % 16 != 0
+        else:
+            prm = torch.nn.Parameter(init.cuda())
+        prm.grad = arena[offs[i]:offs[i] + n]
+        ps.append(prm)
+        refs.append(torch.nn.Parameter(init.clone()))
+    opt = EgotapAdamW(ps, lr=2e-3, eps=1e-4, weight_decay=0.01)
+    ref_opt = torch.optim.AdamW(refs, lr=2e-3, eps=1e-4, weight_decay=0.01)
+    for step in range(2):
+        arena.fill_(float("nan"))                                   # the padding between segments is never read into an update
+        for i, n in enumerate(sizes):
+            gr = _rand((n,), 400 + 10 * step + i, -0.1, 0.1)
+            arena[offs[i]:offs[i] + n] = gr.cuda()
+            refs[i].grad = gr.clone()
+        opt.step()
+        ref_opt.step()
+    torch.cuda.synchronize()
+    assert opt._flat, "the arena launch was not taken"
+    for i in range(len(sizes)):
+        _close(ps[i].detach(), refs[i].detach().double(), 1e-6)
+    assert float(backing[0]) == 0.0 and float(backing[1 + sizes[5]:].abs().max()) == 0.0      # the view's neighbours
+
+
 def test_pu_chain_and_pose_head_backward():
     """SkelNet(PU) + pose head: forward in training mode and full backward vs autograd of the oracle"""
     from egotap_amd import lib as L, train_ops as T
