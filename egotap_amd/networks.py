@@ -97,6 +97,9 @@ class EgoTAPAutoEncoder(nn.Module):
         self._bound_sig = None
         self._ws = None
         self._zeros = {}
+        # several processes on one GPU (rehearsals, tests): per-step propagation-unit kernels instead of the one-launch recurrence.  An OPTION of the
+        # model (opt.shared_device); the EGOTAP_SHARED_DEVICE=1 environment switch remains for launchers that cannot reach opt
+        self._shared_device = bool(getattr(opt, "shared_device", False))
 
     # -- C-ABI plumbing ---------------------------------------------------------------------------
     def _ensure_handle(self):
@@ -107,7 +110,7 @@ class EgoTAPAutoEncoder(nn.Module):
             h = C.c_void_p()
             _lib.check(_lib.load().egotap_create(C.byref(cfg), C.byref(h)))
             self._handle = h
-            if os.environ.get("EGOTAP_SHARED_DEVICE", "0") == "1":      # several processes on one GPU (rehearsals, tests): see set_pu_chain
+            if self._shared_device or os.environ.get("EGOTAP_SHARED_DEVICE", "0") == "1":      # several processes on one GPU: see set_pu_chain
                 _lib.check(_lib.load().egotap_set_pu_chain(h, 0))
         return self._handle
 
