@@ -121,7 +121,7 @@ struct LiftParams {   // resolved raw pointers of net_AutoEncoder
 };
 
 struct HmParams {   // resolved raw pointers of one heatmap estimator (net_HeatMap / net_RotHeatMap)
-    struct Bn { const float *g, *b, *m, *v; };
+    struct Bn { const float *g, *b, *m, *v; long long* nbt; };      // nbt: num_batches_tracked where bound (EGOTAP_I64), else null; m / v are written by the batch-statistics forward
     const float* stem_w; Bn stem_bn;
     struct Block { const float *w1, *w2, *wd; Bn bn1, bn2, bnd; } blk[4][6];
     int nblk[4];        // BasicBlocks per stage (resnet18: 2,2,2,2; resnet34: 3,4,6,3)
@@ -1049,8 +1049,10 @@ static int hm_resolve(Handle* h, int net) {
     HmParams& p = h->hp[net];
     const std::string bb = "backbone.backbone.backbone.";
     auto bn = [&](const std::string& k) {
+        auto n = h->bound[net].find(k + ".num_batches_tracked");
+        long long* nbt = (n != h->bound[net].end() && n->second.dtype == EGOTAP_I64 && n->second.numel == 1) ? (long long*)n->second.ptr : nullptr;
         return HmParams::Bn{P(h, net, k + ".weight", ok), P(h, net, k + ".bias", ok), P(h, net, k + ".running_mean", ok),
-                            P(h, net, k + ".running_var", ok)};
+                            P(h, net, k + ".running_var", ok), nbt};
     };
     p.stem_w = P(h, net, bb + "conv1.weight", ok);
     p.stem_bn = bn(bb + "bn1");
@@ -1204,7 +1206,7 @@ static size_t hm_pack_plan(const HmParams* p, const int* nblk, PackTable* T, lon
     };
     struct Pending { HmParams::Bn bn; int C, Np; } pend[PackTable::MAXB];
     auto bseg = [&](const HmParams::Bn& bn, int C, int Np) { if (nb < PackTable::MAXB) pend[nb] = Pending{bn, C, Np}; ++nb; };
-    static const HmParams::Bn nobn{nullptr, nullptr, nullptr, nullptr};
+    static const HmParams::Bn nobn{nullptr, nullptr, nullptr, nullptr, nullptr};
     auto npad = [](int c) { return c <= 64 ? 64 : c <= 128 ? 128 : (c + 255) / 256 * 256; };
     int cin = 64;
     for (int i = 0; i < 4; ++i) {
@@ -1287,27 +1289,10 @@ struct HmBf16Bufs {
     float* dec_slab; size_t dec_split_floats;       // ... of the decoder's 3x3 convolutions at serving batches
     const float *ones, *zeros;                      // batch-statistics mode: unit scale / zero shift (1024 floats each) for the raw-output epilogue
 };
-struct HmBnBatch {                                  // batch-statistics mode: where the finish kernel finds each BatchNorm's buffers
+struct HmBnBatch {                                  // batch-statistics mode: the scratch every BatchNorm of the forward reuses (stream-ordered)
     BnBatchScratch scr;
-    Handle* h; int net;
 };
 static inline int hm_ilog2(long v) { int l = 0; while ((1L << l) < v) ++l; return l; }
-// running_mean / running_var (mutable) and num_batches_tracked of the BatchNorm whose weight tensor is `g`: looked up by pointer in the bound set
-static bool hm_bn_buffers(Handle* h, int net, const float* g, float** rm, float** rv, long long** nbt) {
-    for (auto& kv : h->bound[net]) {
-        if (kv.second.ptr != (const void*)g) continue;
-        const std::string& k = kv.first;
-        if (k.size() < 7 || k.compare(k.size() - 7, 7, ".weight") != 0) continue;
-        const std::string base = k.substr(0, k.size() - 7);
-        auto m = h->bound[net].find(base + ".running_mean"), v = h->bound[net].find(base + ".running_var"), n = h->bound[net].find(base + ".num_batches_tracked");
-        if (m == h->bound[net].end() || v == h->bound[net].end()) continue;
-        *rm = (float*)m->second.ptr; *rv = (float*)v->second.ptr;
-        *nbt = (n != h->bound[net].end() && n->second.dtype == EGOTAP_I64 && n->second.numel == 1) ? (long long*)n->second.ptr : nullptr;
-        return true;
-    }
-    return false;
-}
-
 static hipError_t hm_bf16_backbone(Handle* h, const HmParams& p, const PackTable& PT, int& li, int& bi, const HmBf16Bufs& q, const float* left, const float* right, int B,
                                    int S0, const HmBnBatch* bnb, hipStream_t s) {
     const int N2 = 2 * B, cus = device_cu_count();
@@ -1323,10 +1308,8 @@ static hipError_t hm_bf16_backbone(Handle* h, const HmParams& p, const PackTable
         int grid = 0;
         hipError_t e = stem_pool_bf16s_launch_mode<1>(left, right, p.stem_w, nullptr, nullptr, nullptr, nullptr, (__bf16*)bnb->scr.part, S0, N2, cus, s, &grid);
         if (e != hipSuccess) return e;
-        float *rm, *rv; long long* nbt;
-        if (!hm_bn_buffers(bnb->h, bnb->net, p.stem_bn.g, &rm, &rv, &nbt)) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(bn_finish_bf16s_kernel, dim3(64), dim3(128), 0, s, (const float*)bnb->scr.part, grid, 64, (double)B * (S0 / 2) * (S0 / 2), p.stem_bn.g, p.stem_bn.b, rm, rv,
-                           nbt, bnb->scr.sc, bnb->scr.sh);
+        hipLaunchKernelGGL(bn_finish_bf16s_kernel, dim3(64), dim3(128), 0, s, (const float*)bnb->scr.part, grid, 64, (double)B * (S0 / 2) * (S0 / 2), p.stem_bn.g, p.stem_bn.b,
+                           (float*)p.stem_bn.m, (float*)p.stem_bn.v, p.stem_bn.nbt, bnb->scr.sc, bnb->scr.sh);
         e = stem_pool_bf16s_launch_mode<2>(left, right, p.stem_w, bnb->scr.sc, bnb->scr.sh, nullptr, nullptr, q.P0, S0, N2, cus, s);
         if (e != hipSuccess) return e;
     }
@@ -1371,9 +1354,7 @@ static hipError_t hm_bf16_backbone(Handle* h, const HmParams& p, const PackTable
         };
         hipError_t e = run();
         if (e != hipSuccess || !bnb) return e;
-        float *rm, *rv; long long* nbt;
-        if (!hm_bn_buffers(bnb->h, bnb->net, bn.g, &rm, &rv, &nbt)) return hipErrorInvalidValue;
-        return bn_batch_bf16s_launch(o, res_, (long)B * side * side, c, bn.g, bn.b, rm, rv, nbt, relu_, bnb->scr, s);
+        return bn_batch_bf16s_launch(o, res_, (long)B * side * side, c, bn.g, bn.b, (float*)bn.m, (float*)bn.v, bn.nbt, relu_, bnb->scr, s);
     };
     const int sides[4] = {s64, s32, s16, s8};
     const __bf16* x = q.P0;
@@ -1745,7 +1726,7 @@ extern "C" int egotap_hm_forward_bnbatch(egotap_handle h, int net, const float* 
     q.split_slab = (float*)(base + w.SPLIT); q.split_floats = HM_BN_SPLIT_FLOATS;
     q.dec_slab = (float*)(base + w.DEC);     q.dec_split_floats = ((size_t)40 << 20) / 4;
     q.ones = (const float*)(base + w.ONES);  q.zeros = (const float*)(base + w.ZEROS);
-    HmBnBatch bnb{BnBatchScratch{(float*)(base + w.PART), (float*)(base + w.SC), (float*)(base + w.SH)}, h, net};
+    HmBnBatch bnb{BnBatchScratch{(float*)(base + w.PART), (float*)(base + w.SC), (float*)(base + w.SH)}};
     const int cus = device_cu_count();
     EGO_HIP(zero_fill(q.ZP, 256, s));
     EGO_HIP(zero_fill((void*)q.zeros, 4096, s));
