@@ -127,15 +127,39 @@ class EgoTAPAutoEncoderModel(nn.Module):
             return False, False
         return bool(self.net_HeatMap.training), bool(self.net_RotHeatMap.training)
 
+    @staticmethod
+    def _adjacent_channel_slices(parts):
+        """True when the tensors are consecutive dim-1 slices of ONE contiguous fp32 CUDA [B, C, S, S] tensor that holds nothing else per frame"""
+        a = parts[0]
+        if not all(t is not None and t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 for t in parts):
+            return False
+        S2 = a.shape[2] * a.shape[3]
+        ctot = sum(t.shape[1] for t in parts)
+        want_stride = (ctot * S2, S2, a.shape[3], 1)
+        off = a.storage_offset()
+        base = a.untyped_storage().data_ptr()
+        for t in parts:
+            if t.untyped_storage().data_ptr() != base or tuple(t.stride()) != want_stride or t.shape[0] != a.shape[0] or tuple(t.shape[2:]) != tuple(a.shape[2:]) \
+                    or t.storage_offset() != off:
+                return False
+            off += t.shape[1] * S2
+        return True
+
     def forward_heatmap(self):
         p = self.net_AutoEncoder.preset
         J = p.n_joints_hm
         if getattr(self.opt, "use_gt_heatmap", False):
+            parts = (self.gt_heatmap_left, self.gt_heatmap_right, self.gt_limb_heatmap_left, self.gt_limb_heatmap_right)
             if getattr(self, "_gt_cat", None) is not None and self.gt_heatmap_left.data_ptr() == self._gt_cat.data_ptr():
                 cat = self._gt_cat                     # synthesised in place in the head's layout: no torch.cat
+            elif self._adjacent_channel_slices(parts):
+                # [r5] the four maps already ARE consecutive channel slices of one fp32 [B, 6J, S, S] tensor (a loader that renders into the
+                # head's layout, bench.py's resident inputs): the concatenation of egotap_autoencoder_model.py:195-216 is that tensor -- a view,
+                # not a 1.4 GB copy per 1024-frame step
+                a = parts[0]
+                cat = a.as_strided((a.shape[0], sum(t.shape[1] for t in parts), a.shape[2], a.shape[3]), a.stride(), a.storage_offset())
             else:
-                cat = torch.cat((self.gt_heatmap_left, self.gt_heatmap_right, self.gt_limb_heatmap_left,
-                                 self.gt_limb_heatmap_right), dim=1).float().contiguous()
+                cat = torch.cat(parts, dim=1).float().contiguous()
         else:
             left = self.input_rgb_left.float().contiguous()
             right = self.input_rgb_right.float().contiguous()

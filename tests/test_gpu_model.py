@@ -76,6 +76,20 @@ def test_wrapper_gt_heatmap_path():
     direct = m.net_AutoEncoder.predict_pose(hm.cuda())
     torch.cuda.synchronize()
     assert torch.equal(m.pred_pose, direct)
+    cat_copy = m.pred_heatmap_cat
+    # [r5] maps that already ARE consecutive channel slices of one resident tensor in the head's layout: the concatenation is a view of it (no copy),
+    # same values and same pose; any other arrangement (a different order, a gap, another dtype) still goes through torch.cat
+    base = hm.cuda()
+    views = {"gt_heatmap_left": base[:, :15], "gt_heatmap_right": base[:, 15:30], "gt_limb_heatmap_left": base[:, 30:60], "gt_limb_heatmap_right": base[:, 60:]}
+    m.set_input(dict(data, **views))
+    with torch.no_grad():
+        m.forward(evaluate=True)
+    torch.cuda.synchronize()
+    assert m.pred_heatmap_cat.data_ptr() == base.data_ptr() and torch.equal(m.pred_heatmap_cat, cat_copy) and torch.equal(m.pred_pose, direct)
+    m.set_input(dict(data, **dict(views, gt_heatmap_left=base[:, 15:30], gt_heatmap_right=base[:, :15])))      # swapped eyes: not the tensor's own order
+    with torch.no_grad():
+        m.forward(evaluate=True)
+    assert m.pred_heatmap_cat.data_ptr() != base.data_ptr() and torch.equal(m.pred_heatmap_cat[:, :15], base[:, 15:30])
 
 
 def test_wrapper_synthesises_gt_heatmaps_from_joints():
