@@ -162,6 +162,30 @@ def test_host_side_argument_checks_of_the_newer_entry_points():
         assert lib.egotap_pose_metrics(None, None, 4, 16, None, None, None, None) == 1
         assert lib.egotap_attention(None, None, 1, 64, 1, 0, None) == 1
         assert lib.egotap_hmtrain_conv_wgrad(None, None, None, 1, 8, 8, 16, 3, 1, 0, 0, 0, 0, None, 0, None) == 1
+        # [r5] the batch-statistics forward of a frozen estimator: workspace = whole-batch backbone maps + one decoder chunk (grows with both),
+        # bf16 precision only, at least two frames, no launch on any refusal
+        n1, n2, n3 = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        L.check(lib.egotap_hm_forward_bnbatch_workspace_bytes(h, 64, 16, C.byref(n1)))
+        L.check(lib.egotap_hm_forward_bnbatch_workspace_bytes(h, 64, 64, C.byref(n2)))
+        L.check(lib.egotap_hm_forward_bnbatch_workspace_bytes(h, 128, 16, C.byref(n3)))
+        assert 0 < n1.value < n2.value and n1.value < n3.value
+        assert n3.value - n1.value == 64 * (64 * 64 * 128 * 2) * (1 + 4 * (1 + 0.5 + 0.25 + 0.125))      # 8.5 MB of bf16 backbone maps per frame
+        off, num = C.c_size_t(), C.c_int64()
+        L.check(lib.egotap_hm_forward_bnbatch_intermediate(h, 64, 16, b"layer4", C.byref(off), C.byref(num)))
+        assert num.value == 64 * 8 * 8 * 1024 and off.value % 256 == 0
+        assert lib.egotap_hm_forward_bnbatch_intermediate(h, 64, 16, b"nope", C.byref(off), C.byref(num)) == 1
+        L.check(lib.egotap_set_precision(h, 0))
+        assert lib.egotap_hm_forward_bnbatch(h, 1, C.c_void_p(256), C.c_void_p(256), 4, C.c_void_p(256), 30 * 4096, 0, C.c_void_p(256), 1 << 40, None) == 1
+        assert b"EGOTAP_PREC_BF16" in lib.egotap_last_error()
+        L.check(lib.egotap_set_precision(h, 2))
+        assert lib.egotap_hm_forward_bnbatch(h, 1, C.c_void_p(256), C.c_void_p(256), 1, C.c_void_p(256), 30 * 4096, 0, C.c_void_p(256), 1 << 40, None) == 1      # one frame
+        L.check(lib.egotap_hm_forward_bnbatch(h, 1, None, None, 0, None, 0, 0, None, 0, None))                                                                     # batch 0: no-op
+        assert lib.egotap_hm_forward_bnbatch(h, 0, C.c_void_p(256), C.c_void_p(256), 4, C.c_void_p(256), 30 * 4096, 0, C.c_void_p(256), 1 << 40, None) == 1      # the lifting head's id
+        assert lib.egotap_hm_forward_bnbatch(h, 1, C.c_void_p(256), C.c_void_p(256), 4, C.c_void_p(256), 30 * 4096, 0, C.c_void_p(256), 1 << 40, None) == 3      # nothing bound
+        # attention: any sequence that is a multiple of 4 from 32 on is a shape the fp32 kernel takes (null pointers are still refused first)
+        assert lib.egotap_attention_f32(None, None, 1, 144, 8, None) == 1 and b"null" in lib.egotap_last_error()
+        assert lib.egotap_attention_f32(C.c_void_p(256), C.c_void_p(256), 1, 30, 8, None) == 1 and b"at least 32" in lib.egotap_last_error()
+        L.check(lib.egotap_set_precision(h, 0))
     finally:
         lib.egotap_destroy(h)
     # Python wrappers refuse CPU tensors (no CPU fallback) and inconsistent shapes

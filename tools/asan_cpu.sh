@@ -5,7 +5,7 @@
 # test-suite's ABI tests run against that library: everything the ABI does before its first kernel launch -- create / bind /
 # resolve / workspace sizing / intermediates / the error paths of every entry point.  CPU build container only: GPU sanitizers are
 # not available on the pool.  Exit code 0 = no sanitizer report.
-#   usage: tools/asan_cpu.sh        (about 5 minutes: four translation units at -O1 -g)
+#   usage: tools/asan_cpu.sh        (about 5 minutes: four translation units; host pass at -O1 -g)
 set -euo pipefail
 cd "$(dirname "$0")/.."
 REPO=$PWD
@@ -15,7 +15,9 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 CLANG=/opt/rocm/lib/llvm/bin/clang
 RT=$($CLANG -print-file-name=libclang_rt.asan-x86_64.so)
 [ -f "$RT" ] || { echo "asan runtime not found ($RT)"; exit 2; }
-FLAGS="-O1 -g --offload-arch=gfx950 -std=c++17 -fPIC -I$REPO/include -I$REPO/egotap_amd/csrc -Xarch_host -fsanitize=address,undefined -Xarch_host -fno-omit-frame-pointer -Xarch_host -fno-sanitize-recover=undefined"
+# [r5] the DEVICE pass is compiled exactly as the product is (-O3, no debug info): at -O1 -g hipcc 7.2's ADCE pass crashes on gemm_bf16s64_kernel;
+# only the host pass gets -O1 -g and the sanitizers
+FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -I$REPO/include -I$REPO/egotap_amd/csrc -Xarch_host -O1 -Xarch_host -g -Xarch_host -fsanitize=address,undefined -Xarch_host -fno-omit-frame-pointer -Xarch_host -fno-sanitize-recover=undefined"
 pids=()
 for part in 0 1 2 3; do
   $HIPCC $FLAGS -DEGOTAP_PART=$part -c egotap_amd/csrc/egotap_abi.hip -o "$OUT/part$part.o" &

@@ -71,5 +71,34 @@ for Bh in (136, 256):
     bad += nd + (0 if same_frames else 1)
     del est, outs
     torch.cuda.empty_cache()
+# [r5] the batch-statistics forward of a frozen estimator (egotap_hm_forward_bnbatch): the stem's statistics pass, the column-statistics /
+# finish / apply kernels, the backbone over the whole batch and the chunked decoder -- from the same buffers the same bits, five times,
+# at the bench's batch (1024 frames, chunks of 256) and at a batch that leaves the last chunk ragged
+for Bh, chunk in ((1024, 256), (200, 64)):
+    est, _ = hm_net("pos")
+    est.set_precision("bf16")
+    l = torch.from_numpy(synth_input("det_bn_l", (8, 3, 256, 256), -2.0, 2.0)).cuda().repeat(Bh // 8, 1, 1, 1).contiguous()
+    r = torch.from_numpy(synth_input("det_bn_r", (8, 3, 256, 256), -2.0, 2.0)).cuda().repeat(Bh // 8, 1, 1, 1).contiguous()
+    bufs0 = {k: v.detach().clone() for k, v in est.named_buffers()}
+    outs, stats = [], []
+    for _ in range(5):
+        with torch.no_grad():
+            for k, v in est.named_buffers():
+                v.copy_(bufs0[k])
+        o = torch.empty((Bh, 2 * est.num_heatmap, 64, 64), device="cuda")
+        est.forward_bnbatch_into(l, r, o, chunk=chunk)
+        torch.cuda.synchronize()
+        outs.append(o)
+        stats.append({k: v.detach().clone() for k, v in est.named_buffers()})
+    nd = sum(0 if torch.equal(outs[0], o) else 1 for o in outs[1:])
+    ns = sum(0 if all(torch.equal(stats[0][k], st[k]) for k in st) else 1 for st in stats[1:])
+    print(f"batch-statistics bf16 estimator B = {Bh}, chunk {chunk}: {nd} of 4 repeats differ in the heatmaps, {ns} in the running statistics; finite: {bool(torch.isfinite(outs[0]).all())}")
+    bad += nd + ns + (0 if bool(torch.isfinite(outs[0]).all()) else 1)
+    with torch.no_grad():
+        for k, v in est.named_buffers():
+            v.copy_(bufs0[k])
+    est.set_precision("f32")
+    del est, outs, stats, l, r
+    torch.cuda.empty_cache()
 print("DETERMINISM", "OK" if bad == 0 else f"FAILED ({bad})")
 sys.exit(0 if bad == 0 else 1)
