@@ -30,32 +30,49 @@ struct TnSCfg {
     static constexpr int LDS_BYTES = NS * STAGE;
 };
 
-// X-operand loaders for the TN kernel: address of 8 consecutive columns (16 bytes) k .. k+7 of row m
+// X-operand loaders for the TN kernel: address of 8 consecutive columns (16 bytes) k .. k+7 of row m = base + rowpart(m) + kpart(k) (elements).
+// [r5] The column of a lane's DMA piece is fixed for the whole kernel (k0 of the workgroup's tile + the lane's chunk), so kpart is computed ONCE
+// per lane; only rowpart runs per DMA instruction.  Through round 4 the gather loaders recomputed ptr(m, k) -- five integer divisions by run-time
+// divisors, ~100 VALU instructions -- in front of every one of the kernel's DMA issues: the fc1 weight gradients ran at MFMA busy 0.35-0.37.
 struct TXPlain {
     const __bf16* A;
     long lda;
+    __device__ __forceinline__ const __bf16* base() const { return A; }
+    __device__ __forceinline__ long kpart(int k) const { return k; }
+    __device__ __forceinline__ long rowpart(int m) const { return (long)m * lda; }
     __device__ __forceinline__ const __bf16* ptr(int m, int k) const { return A + (long)m * lda + k; }
 };
 struct TXTokens {            // rows gathered as XTokens (fc1 of the position encoder)
     const __bf16* Y;
     int T, D, seq, side, ppd, grid;
-    __device__ __forceinline__ const __bf16* ptr(int m, int k) const {
-        const int b = m / T, i = m - b * T;
+    __device__ __forceinline__ const __bf16* base() const { return Y; }
+    __device__ __forceinline__ long kpart(int k) const {
         const int s = k / D, c = k - s * D;
         const int prl = s / ppd, pcl = s - prl * ppd;
-        return Y + ((long)b * seq + (long)(ppd * (i / grid) + prl) * side + ppd * (i % grid) + pcl) * D + c;
+        return (long)(prl * side + pcl) * D + c;
     }
+    __device__ __forceinline__ long rowpart(int m) const {
+        const int b = m / T, i = m - b * T;
+        const int gr = i / grid;
+        return ((long)b * seq + (long)(ppd * gr) * side + ppd * (i - gr * grid)) * D;
+    }
+    __device__ __forceinline__ const __bf16* ptr(int m, int k) const { return Y + rowpart(m) + kpart(k); }
 };
 struct TXRot {               // rows gathered as XRot (fc1 of the rotation encoder)
     const __bf16* hm;
     int C, J, HW;
-    __device__ __forceinline__ const __bf16* ptr(int m, int k) const {
+    __device__ __forceinline__ const __bf16* base() const { return hm; }
+    __device__ __forceinline__ long kpart(int k) const {
+        const int cs = k / HW;
+        return (long)cs * J * HW + (k - cs * HW);
+    }
+    __device__ __forceinline__ long rowpart(int m) const {
         const int T = 2 * J;
         const int b = m / T, t = m - b * T;
         const int eye = t / J, j = t - eye * J;
-        const int cs = k / HW;
-        return hm + (long)(b * C + 2 * J + eye * 2 * J + j) * HW + (long)cs * J * HW + (k - cs * HW);
+        return (long)(b * C + 2 * J + eye * 2 * J + j) * HW;
     }
+    __device__ __forceinline__ const __bf16* ptr(int m, int k) const { return hm + rowpart(m) + kpart(k); }
 };
 
 // FAST (plain X operand, M a multiple of 32: every 32-row step of every split is whole): the DMA addresses are a wave-uniform 64-bit base
@@ -143,6 +160,9 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
         ybase = uniform64((unsigned long long)(size_t)dY + ((unsigned long long)m_lo * ldy + n0) * 2);
         xbase = uniform64((unsigned long long)(size_t)xl.A + ((unsigned long long)m_lo * xl.lda + k0) * 2);
     }
+    // the lane's two column pieces of the X tile, fixed for the kernel (general path)
+    const __bf16* const xk0 = xl.base() + xl.kpart(k0 + c0 * 8);
+    const __bf16* const xk1 = xl.base() + xl.kpart(k0 + c1 * 8);
     auto issue_y = [&](int st) __attribute__((always_inline)) {
         const unsigned sa = lds0 + st * STAGE + wid * 1024;
         if constexpr (FAST) {
@@ -171,8 +191,8 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
         const int mb = m_lo + lx * BKM;
         const bool in = lx < total;
         const int ma = mb + r0, mc = mb + r1;
-        dma1(in && ma < m_hi ? xl.ptr(ma, k0 + c0 * 8) : zeros + c0 * 8, sa);
-        dma1(in && mc < m_hi ? xl.ptr(mc, k0 + c1 * 8) : zeros + c1 * 8, sa + 8 * 1024);
+        dma1(in && ma < m_hi ? xk0 + xl.rowpart(ma) : zeros + c0 * 8, sa);
+        dma1(in && mc < m_hi ? xk1 + xl.rowpart(mc) : zeros + c1 * 8, sa + 8 * 1024);
         ++lx;
     };
 
