@@ -41,6 +41,7 @@ struct TXPlain {
     __device__ __forceinline__ long kpart(int k) const { return k; }
     __device__ __forceinline__ long rowpart(int m) const { return (long)m * lda; }
     __device__ __forceinline__ const __bf16* ptr(int m, int k) const { return A + (long)m * lda + k; }
+    long span(int M) const { return (long)M * lda; }      // (host) elements the M rows span from base()
 };
 struct TXTokens {            // rows gathered as XTokens (fc1 of the position encoder)
     const __bf16* Y;
@@ -57,6 +58,7 @@ struct TXTokens {            // rows gathered as XTokens (fc1 of the position en
         return ((long)b * seq + (long)(ppd * gr) * side + ppd * (i - gr * grid)) * D;
     }
     __device__ __forceinline__ const __bf16* ptr(int m, int k) const { return Y + rowpart(m) + kpart(k); }
+    long span(int M) const { return (long)((M + T - 1) / T) * seq * D; }
 };
 struct TXRot {               // rows gathered as XRot (fc1 of the rotation encoder)
     const __bf16* hm;
@@ -73,6 +75,7 @@ struct TXRot {               // rows gathered as XRot (fc1 of the rotation encod
         return (long)(b * C + 2 * J + eye * 2 * J + j) * HW;
     }
     __device__ __forceinline__ const __bf16* ptr(int m, int k) const { return hm + rowpart(m) + kpart(k); }
+    long span(int M) const { return (long)((M + 2 * J - 1) / (2 * J)) * C * HW; }
 };
 
 // FAST (plain X operand, M a multiple of 32: every 32-row step of every split is whole): the DMA addresses are a wave-uniform 64-bit base
@@ -154,11 +157,19 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
     auto dma_s = [&](unsigned voff, unsigned long long sbase, unsigned lds_addr) __attribute__((always_inline)) {
         asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
+    constexpr bool PLAINX = std::is_same<XL, TXPlain>::value;
     if constexpr (FAST) {
         oy0 = (unsigned)(((long)r0 * ldy + c0 * 8) * 2); oy1 = (unsigned)(((long)r1 * ldy + c1 * 8) * 2);
-        ox0 = (unsigned)(((long)r0 * xl.lda + c0 * 8) * 2); ox1 = (unsigned)(((long)r1 * xl.lda + c1 * 8) * 2);
         ybase = uniform64((unsigned long long)(size_t)dY + ((unsigned long long)m_lo * ldy + n0) * 2);
-        xbase = uniform64((unsigned long long)(size_t)xl.A + ((unsigned long long)m_lo * xl.lda + k0) * 2);
+        if constexpr (PLAINX) {
+            ox0 = (unsigned)(((long)r0 * xl.lda + c0 * 8) * 2); ox1 = (unsigned)(((long)r1 * xl.lda + c1 * 8) * 2);
+            xbase = uniform64((unsigned long long)(size_t)xl.A + ((unsigned long long)m_lo * xl.lda + k0) * 2);
+        } else {
+            // [r5] gathered rows (fc1 of the two encoders): every row whole and in range, the tensor under 4 GB -> wave-uniform tensor base + one
+            // 32-bit byte offset per lane = the lane's fixed column part + the row's gather offset; no 64-bit pointer selects, no zero page
+            ox0 = (unsigned)(xl.kpart(k0 + c0 * 8) * 2); ox1 = (unsigned)(xl.kpart(k0 + c1 * 8) * 2);
+            xbase = uniform64((unsigned long long)(size_t)xl.base());
+        }
     }
     // the lane's two column pieces of the X tile, fixed for the kernel (general path)
     const __bf16* const xk0 = xl.base() + xl.kpart(k0 + c0 * 8);
@@ -181,10 +192,17 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
     };
     auto issue_x = [&](int st) __attribute__((always_inline)) {
         const unsigned sa = lds0 + st * STAGE + PART + wid * 1024;
-        if constexpr (FAST) {
+        if constexpr (FAST && PLAINX) {
             const unsigned long long b = xbase + (unsigned long long)min(lx, total - 1) * (BKM * 2) * xl.lda;
             dma_s(ox0, b, sa);
             dma_s(ox1, b, sa + 8 * 1024);
+            ++lx;
+            return;
+        }
+        if constexpr (FAST && !PLAINX) {
+            const int mb = m_lo + min(lx, total - 1) * BKM;
+            dma_s(ox0 + (unsigned)(xl.rowpart(mb + r0) * 2), xbase, sa);
+            dma_s(ox1 + (unsigned)(xl.rowpart(mb + r1) * 2), xbase, sa + 8 * 1024);
             ++lx;
             return;
         }
@@ -336,11 +354,10 @@ static hipError_t gemm_tn_bf16s_launch(const __bf16* dY, long ldy, const XL& xl,
     bool fast = false;
 #if !(defined(EGOTAP_ABL) && (EGOTAP_ABL & 16))      // A/B: the general addressing everywhere
     if constexpr (std::is_same<XL, TXPlain>::value) fast = M % Cfg::BKM == 0 && (long)32 * (ldy > xl.lda ? ldy : xl.lda) * 2 < (1L << 31) && xl.lda % 8 == 0;
+    else fast = M % Cfg::BKM == 0 && (long)32 * ldy * 2 < (1L << 31) && xl.span(M) * 2 < (1L << 32);      // gathered rows: 32-bit byte offsets from the tensor base
 #endif
     auto kern = gemm_tn_bf16s_kernel<XL>;
-    if constexpr (std::is_same<XL, TXPlain>::value) {
-        if (fast) kern = gemm_tn_bf16s_kernel<XL, true>;
-    }
+    if (fast) kern = gemm_tn_bf16s_kernel<XL, true>;
     static bool attr_done[2] = {false, false};
     if (!attr_done[fast]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);

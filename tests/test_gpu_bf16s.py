@@ -344,3 +344,46 @@ def test_patch_embedding_on_the_bf16_storage_gemm(preset, hm, B):
     got = outs[0].double().cpu().view(B, seq, D)
     err = float((got - emb).abs().max())
     assert err < 2e-5 * float(emb.abs().max()) + 1e-6, err
+
+
+@pytest.mark.parametrize("B", [16, 3])
+def test_fc1_weight_gradients_on_gathered_rows(B):
+    """egotap_bf16_fc1_wgrad (weight gradient of fc1 of both encoders: dW[n, k] = sum over rows of dz[row, n] X[row, k], X gathered by the
+    TXTokens / TXRot loaders of gemm_tn_bf16s.h -- net_architecture.py:388-406, 690-694) against float64 on the same bf16 operands.
+    B = 16: 480 rows = whole 32-row steps -> [r5] the scalar-base form of the gather (wave-uniform tensor base + one 32-bit lane offset);
+    B = 3: 90 rows, ragged last step -> the general form (per-lane pointers, zero page)."""
+    from egotap_amd import bf16s
+    from gpu_util import lift_net
+    net, _, p = lift_net("UnrealEgo")
+    h = net._ensure_handle()
+    T, D, seq, side, ppd, grid, J = p.tokens, p.vit_dim, p.seq, p.side, p.ppd, p.grid, p.n_joints_hm
+    HW = p.hm_size * p.hm_size
+    g = torch.Generator().manual_seed(17)
+    tokens = (torch.randn(B * seq, D, generator=g) * 0.5).bfloat16()
+    hmb = (torch.rand(B, p.in_channels, HW, generator=g)).bfloat16()
+    dz = (torch.randn(B * T, 2048, generator=g) * 0.1).bfloat16()
+    # position encoder: row (b, i), k = (patch s of heatmap i, channel c)
+    tok = tokens.double().view(B, side, side, D)
+    rows = []
+    for i in range(T):
+        r0, c0 = ppd * (i // grid), ppd * (i % grid)
+        rows.append(tok[:, r0:r0 + ppd, c0:c0 + ppd, :].reshape(B, ppd * ppd * D))
+    Xp = torch.stack(rows, 1).reshape(B * T, ppd * ppd * D)
+    # limb encoder: row (b, eye J + j), k = (cos | sin, pixel)
+    hmd = hmb.double()
+    rows = []
+    for eye in range(2):
+        for j in range(J):
+            rows.append(torch.cat([hmd[:, 2 * J + eye * 2 * J + j], hmd[:, 2 * J + eye * 2 * J + J + j]], 1))
+    Xr = torch.stack(rows, 1).reshape(B * T, 2 * HW)
+    for which, src, X in ((0, tokens, Xp), (1, hmb, Xr)):
+        K = X.shape[1]
+        dw = torch.full((2048, K), float("nan"), device="cuda")
+        bf16s.fc1_wgrad(h, which, dz.cuda(), src.cuda(), dw, B)
+        again = torch.full((2048, K), float("nan"), device="cuda")
+        bf16s.fc1_wgrad(h, which, dz.cuda(), src.cuda(), again, B)
+        torch.cuda.synchronize()
+        assert torch.equal(dw, again)
+        ref = dz.double().T @ X
+        err = float((dw.double().cpu() - ref).abs().max())
+        assert err < 2e-5 * float(ref.abs().max()) + 1e-5, (which, B, err, float(ref.abs().max()))
