@@ -801,6 +801,21 @@ extern "C" int egotap_lift_debug_stop(egotap_handle h, int stage) {
 }
 #endif
 
+// fc1 of an encoder (rows gathered from the ViT tokens / the limb heatmaps) as an NT product: [r5] on the 64-deep kernel where its shape rules hold
+// (D, HW multiples of 64: a K-tile inside one token / map), the 32-deep kernel otherwise or when egotap_debug_gemm_bk pins it; same k order per
+// output element: same bits
+template <class Epi>
+static hipError_t fc1_nt(Handle* h, int which, const __bf16* src, const __bf16* w, long K, const Epi& ep, int BT, int cus, hipStream_t s) {
+    const int HW = h->cfg.hm_size * h->cfg.hm_size;
+    const bool deep = g_gemm_bf16s_bk != 32 && K % 64 == 0 && K >= 128 && (which == 0 ? h->D % 64 == 0 : HW % 64 == 0) && (long)256 * K * 2 < (1L << 31);
+    if (which == 0) {
+        if (deep) return gemm_bf16s64_launch_x(X64Tokens{src, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, w, K, ep, BT, 2048, (int)K, cus, s);
+        return gemm_bf16s_launch(XTokens{src, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, w, K, ep, BT, 2048, (int)K, cus, s);
+    }
+    if (deep) return gemm_bf16s64_launch_x(X64Rot{src, h->C, h->J, HW}, w, K, ep, BT, 2048, (int)K, cus, s);
+    return gemm_bf16s_launch(XRot{src, h->C, h->J, HW}, w, K, ep, BT, 2048, (int)K, cus, s);
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 static hipError_t launch_ln(const float* x, float* y, const float* g, const float* b, int rows, float eps, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
@@ -929,7 +944,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
             const XTokens xt{Yb, h->T, D, h->seq, h->side, h->ppd, h->grid};
             const int sp = gemm_bf16s_ksplit(BT, 2048, K1, cu, SPLITK_FLOATS);
             if (sp > 1) EGO_HIP(gemm_bf16s_splitk_launch(xt, Wb, (long)K1, bnf(p.pos_fc[0], Z1), SPK, sp, BT, 2048, K1, cu, s));
-            else EGO_HIP(gemm_bf16s_launch(xt, Wb, (long)K1, bnf(p.pos_fc[0], Z1), BT, 2048, K1, cu, s));
+            else EGO_HIP(fc1_nt(h, 0, Yb, Wb, (long)K1, bnf(p.pos_fc[0], Z1), BT, cu, s));
             EGO_HIP((fc_gemm(h, "pos_fc2", ALoadPlain{Z1, 2048}, segmat1(p.pos_fc[1].w, 512, 2048), bn(p.pos_fc[1]), Z2, 512, BT, 512, 2048, SPK, s)));
             EGO_HIP((fc_gemm(h, "pos_fc3", ALoadPlain{Z2, 512}, segmat1(p.pos_fc[2].w, hid, 512), bn(p.pos_fc[2]), POSZ, hid, BT, hid, 512, SPK, s)));
         }
@@ -942,7 +957,7 @@ extern "C" int egotap_lift_forward(egotap_handle h, const float* hm, int B, floa
             const XRot xr{hmb, h->C, J, HW};
             const int sp = gemm_bf16s_ksplit(BT, 2048, 2 * HW, cu, SPLITK_FLOATS);
             if (sp > 1) EGO_HIP(gemm_bf16s_splitk_launch(xr, Wb, 2L * HW, bnf(p.rot_fc[0], Z1), SPK, sp, BT, 2048, 2 * HW, cu, s));
-            else EGO_HIP(gemm_bf16s_launch(xr, Wb, 2L * HW, bnf(p.rot_fc[0], Z1), BT, 2048, 2 * HW, cu, s));
+            else EGO_HIP(fc1_nt(h, 1, hmb, Wb, 2L * HW, bnf(p.rot_fc[0], Z1), BT, cu, s));
             EGO_HIP((fc_gemm(h, "rot_fc2", ALoadPlain{Z1, 2048}, segmat1(p.rot_fc[1].w, 512, 2048), bn(p.rot_fc[1]), Z2, 512, BT, 512, 2048, SPK, s)));
             EGO_HIP((fc_gemm(h, "rot_fc3", ALoadPlain{Z2, 512}, segmat1(p.rot_fc[2].w, hid, 512), bn(p.rot_fc[2]), ROTZ, hid, BT, hid, 512, SPK, s)));
         }
@@ -3066,10 +3081,7 @@ extern "C" int egotap_bf16_patch_fwd(egotap_handle h, const void* hmb, const voi
 extern "C" int egotap_bf16_fc1_fwd(egotap_handle h, int which, const void* src, const void* w, const float* bias, float* z, int B, void* stream) {
     EGO_CHECK(h && src && w && bias && z && (which == 0 || which == 1), "egotap_bf16_fc1_fwd: bad argument");
     const int BT = B * h->T, S = h->cfg.hm_size, K = which == 0 ? h->ppd * h->ppd * h->D : 2 * S * S;
-    hipError_t e;
-    if (which == 0) e = gemm_bf16s_launch(XTokens{(const __bf16*)src, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, (const __bf16*)w, (long)K, SEpiF32{bias, z, 2048L}, BT, 2048, K, device_cu_count(), (hipStream_t)stream);
-    else e = gemm_bf16s_launch(XRot{(const __bf16*)src, h->C, h->J, S * S}, (const __bf16*)w, (long)K, SEpiF32{bias, z, 2048L}, BT, 2048, K, device_cu_count(), (hipStream_t)stream);
-    EGO_HIP(e);
+    EGO_HIP(fc1_nt(h, which, (const __bf16*)src, (const __bf16*)w, (long)K, SEpiF32{bias, z, 2048L}, BT, device_cu_count(), (hipStream_t)stream));
     return EGOTAP_OK;
 }
 #endif
@@ -3095,8 +3107,8 @@ extern "C" int egotap_bf16_fc1_dgrad_tokens(egotap_handle h, const void* dz, con
     const int BT = B * h->T, K1 = h->ppd * h->ppd * h->D;
     hipStream_t s = (hipStream_t)stream;
     EGO_HIP(zero_fill(dtok, (size_t)B * h->seq * h->D * 2, s));
-    EGO_HIP(gemm_bf16s_launch(XPlain{(const __bf16*)dz, 2048L}, (const __bf16*)wt, 2048L, SEpiScatterTokens{(__bf16*)dtok, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, BT, K1, 2048,
-                              device_cu_count(), s));
+    EGO_HIP(gemm_bf16s_plain_launch(XPlain{(const __bf16*)dz, 2048L}, (const __bf16*)wt, 2048L, SEpiScatterTokens{(__bf16*)dtok, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, BT, K1,
+                                    2048, device_cu_count(), s));      // [r5] the 64-deep kernel where its shape rules hold (plain operand)
     return EGOTAP_OK;
 }
 #endif

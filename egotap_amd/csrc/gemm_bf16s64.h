@@ -103,6 +103,40 @@ struct X64ConvE {
     }
 };
 
+// [r5] fc1 of the two encoders on this kernel: rows gathered as gemm_bf16s.h's XTokens / XRot gather them (net_architecture.py:388-406, 690-694).
+// D and HW are multiples of 64, so a 64-deep K-tile lies inside one patch token / one map: 128 contiguous bytes per row.
+struct X64Tokens {
+    static constexpr bool SBASE = false;
+    const __bf16* Y;
+    int T, D, seq, side, ppd, grid;
+    struct Row { const __bf16* p; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int b = m / T, i = m - b * T;
+        return Row{Y + ((long)b * seq + (long)(ppd * (i / grid)) * side + ppd * (i % grid)) * D};
+    }
+    __device__ __forceinline__ const __bf16* ptr(const Row& r, int kt, int chunk) const {       // kt wave-uniform: scalar arithmetic
+        const int k0 = kt * 64, s = k0 / D, c = k0 - s * D;
+        const int prl = s / ppd, pcl = s - prl * ppd;
+        return r.p + (long)(prl * side + pcl) * D + c + chunk * 8;
+    }
+};
+struct X64Rot {
+    static constexpr bool SBASE = false;
+    const __bf16* hm;
+    int C, J, HW;
+    struct Row { const __bf16* p; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int T = 2 * J;
+        const int b = m / T, t = m - b * T;
+        const int eye = t / J, j = t - eye * J;
+        return Row{hm + (long)(b * C + 2 * J + eye * 2 * J + j) * HW};
+    }
+    __device__ __forceinline__ const __bf16* ptr(const Row& r, int kt, int chunk) const {
+        const int k0 = kt * 64, cs = k0 / HW;
+        return r.p + (long)cs * J * HW + (k0 - cs * HW) + chunk * 8;
+    }
+};
+
 // Epilogues whose per-column constants are just the bias (Col = SBias8 or f32x4 read from `bias`): the kernel stages the wave's 64 bias
 // values in its (idle) epilogue patch by one 4-byte LDS DMA per tile, issued in the tile's first phase and counted like every other DMA.
 // The epilogue then starts with two LDS reads instead of a global load whose wait -- vmcnt is in order -- drained every DMA in flight

@@ -387,3 +387,40 @@ def test_fc1_weight_gradients_on_gathered_rows(B):
         ref = dz.double().T @ X
         err = float((dw.double().cpu() - ref).abs().max())
         assert err < 2e-5 * float(ref.abs().max()) + 1e-5, (which, B, err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B", [3, 20])
+def test_fc1_forward_on_the_64_deep_kernel_has_the_bits_of_the_32_deep_one(B):
+    """[r5] egotap_bf16_fc1_fwd (fc1 of both encoders: rows gathered from the ViT tokens / the limb heatmaps) runs on the 64-deep GEMM through the
+    X64Tokens / X64Rot loaders (gemm_bf16s64.h); pinned to the 32-deep kernel (egotap_debug_gemm_bk(32), XTokens / XRot) it must give the SAME bits --
+    one k order per output element -- and both must equal float64 on the same bf16 operands.  B = 3: a ragged 90-row tile; B = 20: 600 rows."""
+    from egotap_amd import bf16s, lib
+    from gpu_util import lift_net
+    L = lib.load()
+    net, _, p = lift_net("UnrealEgo")
+    h = net._ensure_handle()
+    T, D, seq, side, ppd, grid, J = p.tokens, p.vit_dim, p.seq, p.side, p.ppd, p.grid, p.n_joints_hm
+    HW = p.hm_size * p.hm_size
+    g = torch.Generator().manual_seed(23)
+    tokens = (torch.randn(B * seq, D, generator=g) * 0.5).bfloat16()
+    hmb = torch.rand(B, p.in_channels, HW, generator=g).bfloat16()
+    bias = torch.randn(2048, generator=g)
+    tok = tokens.double().view(B, side, side, D)
+    Xp = torch.stack([tok[:, ppd * (i // grid):ppd * (i // grid) + ppd, ppd * (i % grid):ppd * (i % grid) + ppd, :].reshape(B, ppd * ppd * D) for i in range(T)], 1)
+    hmd = hmb.double()
+    Xr = torch.stack([torch.cat([hmd[:, 2 * J + e * 2 * J + j], hmd[:, 2 * J + e * 2 * J + J + j]], 1) for e in range(2) for j in range(J)], 1)
+    for which, src, X in ((0, tokens, Xp.reshape(B * T, -1)), (1, hmb, Xr.reshape(B * T, -1))):
+        K = X.shape[1]
+        w = (torch.randn(2048, K, generator=g) * 0.02).bfloat16()
+        outs = {}
+        try:
+            for bk in (32, 0):
+                lib.check(L.egotap_debug_gemm_bk(bk))
+                outs[bk] = bf16s.fc1_fwd(h, which, src.cuda(), w.cuda(), bias.cuda(), B, T).clone()
+        finally:
+            lib.check(L.egotap_debug_gemm_bk(0))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[32], outs[0]), which
+        ref = X @ w.double().T + bias.double()
+        err = float((outs[0].double().cpu() - ref).abs().max())
+        assert err < 2e-5 * float(ref.abs().max()) + 1e-5, (which, B, err)
