@@ -3447,6 +3447,8 @@ static int lift_backward16(Handle* h, const float* hm, const float* dpose, int B
 extern "C" int egotap_lift_forward_train(egotap_handle h, const float* hm, int B, float* pose, void* saved, size_t saved_bytes, void* ws,
                                          size_t ws_bytes, void* stream) {
     EGO_CHECK(h && hm && pose && saved && ws && B > 0, "egotap_lift_forward_train: bad argument");
+    EGO_CHECK(h->seq % 32 == 0, "egotap_lift_forward_train: training needs a ViT sequence that is a multiple of 32 (heatmap sides 64, 128, ...: every shipped configuration); "
+              "this head has %d tokens (heatmap side %d) -- evaluation runs at any side that is a multiple of 16", h->seq, h->cfg.hm_size);
     EGO_RC(lift_resolve(h));
     if (lift_train_bf16s(h)) return lift_forward_train16(h, hm, B, pose, saved, saved_bytes, ws, ws_bytes, stream);
     LiftTrainPlan t; LiftBwdPlan w;

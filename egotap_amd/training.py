@@ -618,6 +618,9 @@ class PoseLossFn(torch.autograd.Function):
 
 def lift_train_forward(net, hm):
     """training-mode forward of EgoTAPAutoEncoder through the HIP operators, differentiable w.r.t. net.parameters()"""
+    if net.preset.seq % 32 != 0:
+        raise NotImplementedError(f"training the lifting head needs a ViT sequence that is a multiple of 32 (heatmap sides 64, 128: every shipped script); "
+                                  f"--load_size_heatmap {net.preset.hm_size} gives {net.preset.seq} tokens -- evaluation runs at any side that is a multiple of 16")
     params = dict(net.named_parameters())
     # net.bf16_storage = False keeps fp32 tensors in HBM under the bf16 arithmetic (round 1's path: operands converted per launch)
     bf16 = getattr(net, "precision", "f32") == "bf16"
