@@ -1308,12 +1308,28 @@ struct HmBnBatch {                                  // batch-statistics mode: th
     BnBatchScratch scr;
 };
 static inline int hm_ilog2(long v) { int l = 0; while ((1L << l) < v) ++l; return l; }
+// [r5] the zero page of a convolution operand addressed from a scalar origin (gemm_bf16s64.h, X64ConvES / X64Conv3S) has to lie within 4 GB of the map:
+// 256 bytes of zeros right behind every map a 3x3 convolution reads (in the eval-mode workspace the unused upper half of the map's fp32 slot; in the
+// batch-statistics workspace 256 bytes taken with the map), written by one launch at the head of the backbone / of each decoder pass.
+static inline __bf16* hm_zero_tail(const __bf16* map, size_t bytes) { return (__bf16*)((char*)map + ((bytes + 255) & ~(size_t)255)); }
+struct ZeroPages { void* p[24]; };
+static __global__ __launch_bounds__(64) void zero_pages_kernel(ZeroPages z) { ((float*)z.p[blockIdx.x])[threadIdx.x] = 0.f; }
 static hipError_t hm_bf16_backbone(Handle* h, const HmParams& p, const PackTable& PT, int& li, int& bi, const HmBf16Bufs& q, const float* left, const float* right, int B,
                                    int S0, const HmBnBatch* bnb, hipStream_t s) {
     const int N2 = 2 * B, cus = device_cu_count();
     const int s64 = S0 / 4, s32 = S0 / 8, s16 = S0 / 16, s8 = S0 / 32;
     char* reg = q.reg;
     __bf16* ZP = q.ZP;
+    {
+        ZeroPages z{};
+        int n = 0;
+        z.p[n++] = hm_zero_tail(q.P0, (size_t)B * s64 * s64 * 128 * 2);
+        for (int i = 0; i < 4; ++i) {
+            const size_t side = (size_t)S0 / (4u << i), bytes = (size_t)B * side * side * 2 * HM_CH[i] * 2;
+            for (__bf16* m : {q.A[i], q.Ta[i], q.Tb[i], q.Td[i]}) z.p[n++] = hm_zero_tail(m, bytes);
+        }
+        hipLaunchKernelGGL(zero_pages_kernel, dim3(n), dim3(64), 0, s, z);
+    }
     // E1 + E2: stem conv7x7/2 + BN + ReLU + max-pool in one kernel (stem_bf16s.h): bf16 [B * s64^2, 2 x 64], image n = 2b + eye in the eye's column half
     if (!bnb) {
         hipError_t e = stem_pool_bf16s_launch(left, right, p.stem_w, p.stem_bn.g, p.stem_bn.b, p.stem_bn.m, p.stem_bn.v, q.P0, S0, N2, cus, s);
@@ -1351,6 +1367,15 @@ static hipError_t hm_bf16_backbone(Handle* h, const HmParams& p, const PackTable
             const SEpiBnBf16<false> ep{SC, SH, res, o, c, hm_ilog2(side), relu};
             if (sg.slab == 64) {      // [r4] layer3 / layer4's stride-1 convolutions on the 64-deep GEMM (the plan checked the shape rules)
                 if (taps != 9 || cin % 64 != 0 || Np != c) return hipErrorInvalidValue;
+                const long si = (long)side * stride;
+                const __bf16* org;
+                unsigned in_off, zero_off;
+                const size_t in_bytes = (size_t)(N2 / 2) * si * si * 2 * cin * 2;
+                if (s64_conv_origin(in, in_bytes, (size_t)(si + 1) * 2 * cin * 2, hm_zero_tail(in, in_bytes), org, in_off, zero_off)) {   // [r5] scalar origin + lane offsets
+                    const X64ConvES xs{org, in_off, zero_off, cin, hm_ilog2(side), stride};
+                    if (c == 128) return gemm_bf16s64_launch_x<X64ConvES, SEpiBnBf16<false>, 1>(xs, WPl, 9L * cin, ep, (int)M, Np, 9 * cin, cus, s);
+                    return gemm_bf16s64_launch_x(xs, WPl, 9L * cin, ep, (int)M, Np, 9 * cin, cus, s);
+                }
                 const X64ConvE xl{in, ZP, cin, hm_ilog2(side), stride};
                 if (c == 128) return gemm_bf16s64_launch_x<X64ConvE, SEpiBnBf16<false>, 1>(xl, WPl, 9L * cin, ep, (int)M, Np, 9 * cin, cus, s);   // layer2: 256 x 128 tile
                 return gemm_bf16s64_launch_x(xl, WPl, 9L * cin, ep, (int)M, Np, 9 * cin, cus, s);
@@ -1442,11 +1467,23 @@ static hipError_t hm_bf16_decoder(Handle* h, const HmParams& p, const PackTable&
         }
         if (sg.slab != 64 || Cp % 64 != 0 || Cout % 256 != 0) return hipErrorInvalidValue;
         GemmTimer t(h, s, role, "gemm_bf16s64_kernel<X64Conv3>", 2.0 * M * Cout * 9.0 * Cin);
+        const SEpiConvBf16<false> ep{cv.b, o, (long)Cout, Cout, 1};
+        const __bf16* org;
+        unsigned in_off, zero_off;
+        if (s64_conv_origin(in, (size_t)M * Cp * 2, (size_t)(side + 1) * Cp * 2, hm_zero_tail(in, (size_t)M * Cp * 2), org, in_off, zero_off))      // [r5] scalar origin + lane offsets
+            return gemm_bf16s64_launch_x(X64Conv3S{org, in_off, zero_off, Cp, hm_ilog2(side)}, (const __bf16*)(reg + sg.dst_w), 9L * Cp, ep, (int)M, Cout, 9 * Cp, cus, s);
         const X64Conv3 xl{in, ZP, Cp, hm_ilog2(side)};
-        return gemm_bf16s64_launch_x(xl, (const __bf16*)(reg + sg.dst_w), 9L * Cp, SEpiConvBf16<false>{cv.b, o, (long)Cout, Cout, 1}, (int)M, Cout, 9 * Cp, cus, s);
+        return gemm_bf16s64_launch_x(xl, (const __bf16*)(reg + sg.dst_w), 9L * Cp, ep, (int)M, Cout, 9 * Cp, cus, s);
     };
     const __bf16 *A1 = lv[0], *A2 = lv[1], *A3 = lv[2], *A4 = lv[3];
 #define HMD(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
+    {
+        ZeroPages z{};
+        z.p[0] = hm_zero_tail(C3, (size_t)B * p16 * HM_CAT3P * 2);
+        z.p[1] = hm_zero_tail(C2, (size_t)B * p32 * 1280 * 2);
+        z.p[2] = hm_zero_tail(C1, (size_t)B * p64 * 640 * 2);
+        hipLaunchKernelGGL(zero_pages_kernel, dim3(3), dim3(64), 0, s, z);
+    }
     HMD(zero_fill(C3, (size_t)B * p16 * HM_CAT3P * 2, s));                    // channels 1544..1599 of the first concat are padding
     HMD(conv1("hm.layer4_1x1", A4, B * p8, p.l1x1[3], 1024, 1024, T4, 1024));
     HMD(up2(T4, C3, 1024, s8, HM_CAT3P));
@@ -1653,16 +1690,17 @@ static HmBnWs hm_bn_ws(const Handle* h, int B, int chunk) {
     const size_t S0 = (size_t)h->cfg.hm_size * 4, s64 = S0 / 4, s32 = S0 / 8, s16 = S0 / 16, s8 = S0 / 32;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = al256(o + bytes); return r; };
-    w.P0 = take((size_t)B * s64 * s64 * 128 * 2);
+    constexpr size_t ZT = 256;                                  // the zero page behind every map a 3x3 convolution reads (hm_zero_tail)
+    w.P0 = take((size_t)B * s64 * s64 * 128 * 2 + ZT);
     for (int i = 0; i < 4; ++i) {
         const size_t side = S0 / (4u << i), bytes = (size_t)B * side * side * 2 * HM_CH[i] * 2;
-        for (int k = 0; k < 4; ++k) w.S[i][k] = take(bytes);
+        for (int k = 0; k < 4; ++k) w.S[i][k] = take(bytes + ZT);
     }
     const size_t c = (size_t)chunk;
     w.T4 = take(c * s8 * s8 * 1024 * 2);
-    w.C3 = take(c * s16 * s16 * HM_CAT3P * 2); w.Y3 = take(c * s16 * s16 * 1024 * 2);
-    w.C2 = take(c * s32 * s32 * 1280 * 2);     w.Y2 = take(c * s32 * s32 * 512 * 2);
-    w.C1 = take(c * s64 * s64 * 640 * 2);      w.Y1 = take(c * s64 * s64 * 512 * 2);
+    w.C3 = take(c * s16 * s16 * HM_CAT3P * 2 + ZT); w.Y3 = take(c * s16 * s16 * 1024 * 2);
+    w.C2 = take(c * s32 * s32 * 1280 * 2 + ZT);     w.Y2 = take(c * s32 * s32 * 512 * 2);
+    w.C1 = take(c * s64 * s64 * 640 * 2 + ZT);      w.Y1 = take(c * s64 * s64 * 512 * 2);
     const int nblk_[4] = {hm_nblk(h, 0), hm_nblk(h, 1), hm_nblk(h, 2), hm_nblk(h, 3)};
     w.WALL = take(hm_pack_plan(nullptr, nblk_, nullptr) + 256);
     w.DEC = take((size_t)40 << 20);
@@ -2892,6 +2930,12 @@ extern "C" int egotap_hmtrain_upsample_fwd(const float* x, float* y, int N, int 
 // EGOTAP_PREC_BF16 with bf16 tensors in HBM: activations are written as bf16 by their producers, weights are rounded once per
 // step; every GEMM reads bf16 through the LDS DMA (gemm_bf16s.h).  Single operators first (tests, tools), the whole step below.
 #if EGOTAP_IN(3)
+int g_conv_addressing = 0;           // the one definition (gemm_bf16s64.h)
+extern "C" int egotap_debug_conv_addressing(int mode) {
+    EGO_CHECK(mode == 0 || mode == 1, "egotap_debug_conv_addressing: mode must be 0 (scalar origin where it fits) or 1 (per-lane pointers)");
+    g_conv_addressing = mode;
+    return EGOTAP_OK;
+}
 int g_gemm_bf16s_bk = 0;             // the one definition (gemm_bf16s64.h declares it for every part)
 extern "C" int egotap_debug_gemm_bk(int bk) {
     EGO_CHECK(bk == 0 || bk == 32 || bk == 64, "egotap_debug_gemm_bk: 0 (by shape), 32 or 64");

@@ -103,6 +103,62 @@ struct X64ConvE {
     }
 };
 
+// [r5] SCALAR-ORIGIN forms of the two convolution loaders: the same rows, taps and zero page, addressed as ONE wave-uniform 64-bit origin
+// (at or below everything the loader touches: the map's first pixel minus one image row + 1 pixels, or the zero page, whichever is lower) + a 32-bit
+// lane offset -- the global_load_lds s[base] form the plain operands use -- instead of a 64-bit pointer per lane picked by a 64-bit select.  The
+// launcher takes this form when everything lies inside 4 GB of the origin (every shipped chunk size); same bytes fetched, same bits out.
+//   row(m)        -> byte offset of the row's centre pixel (+ eye slice) from the origin, and its 9-bit tap mask
+//   ktile(kt,...) -> wave-uniform: signed byte offset of the K-tile's tap / slab from the centre pixel, and the tap
+struct X64Conv3S {
+    static constexpr bool SBASE = false, SORG = true;
+    const __bf16* org;
+    unsigned in_off, zero_off;     // bytes from org to the map / to the zero page
+    int Cp, log2S;
+    struct Row { unsigned off; unsigned mask; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int S = 1 << log2S, x = m & (S - 1), y = (m >> log2S) & (S - 1);
+        unsigned mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            if (y + dy >= 0 && y + dy < S && x + dx >= 0 && x + dx < S) mask |= 1u << t;
+        }
+        return Row{in_off + (unsigned)m * (unsigned)(Cp * 2), mask};
+    }
+    __device__ __forceinline__ void ktile(int kt, int& koff, int& tap) const {
+        const int slab = (kt * 7282) >> 16;
+        tap = kt - 9 * slab;
+        const int dy = ((tap * 11) >> 5) - 1, dx = tap - 3 * (dy + 1) - 1;
+        koff = (((dy << log2S) + dx) * Cp + 64 * slab) * 2;
+    }
+};
+struct X64ConvES {
+    static constexpr bool SBASE = false, SORG = true;
+    const __bf16* org;
+    unsigned in_off, zero_off;
+    int C, log2So, stride;
+    struct Row { unsigned off; unsigned mask; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int So = 1 << log2So, xo = m & (So - 1), yo = (m >> log2So) & (So - 1), n = m >> (2 * log2So);
+        const int Si = So * stride, yi = yo * stride, xi = xo * stride;
+        unsigned mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            if (yi + dy >= 0 && yi + dy < Si && xi + dx >= 0 && xi + dx < Si) mask |= 1u << t;
+        }
+        return Row{in_off + (((unsigned)(n >> 1) * (unsigned)(Si * Si) + (unsigned)(yi * Si + xi)) * 2u + (unsigned)(n & 1)) * (unsigned)(C * 2), mask};
+    }
+    __device__ __forceinline__ void ktile(int kt, int& koff, int& tap) const {
+        const int slab = (kt * 7282) >> 16;
+        tap = kt - 9 * slab;
+        const int dy = ((tap * 11) >> 5) - 1, dx = tap - 3 * (dy + 1) - 1;
+        koff = ((dy * (stride << log2So) + dx) * (2 * C) + 64 * slab) * 2;
+    }
+};
+template <class XL, class = void> struct s64_sorg { static constexpr bool value = false; };
+template <class XL> struct s64_sorg<XL, std::enable_if_t<XL::SORG>> { static constexpr bool value = true; };
+
 // [r5] fc1 of the two encoders on this kernel: rows gathered as gemm_bf16s.h's XTokens / XRot gather them (net_architecture.py:388-406, 690-694).
 // D and HW are multiples of 64, so a 64-deep K-tile lies inside one patch token / one map: 128 contiguous bytes per row.
 struct X64Tokens {
@@ -242,6 +298,10 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
             else st.kt = KT - 1;                     // stream exhausted: keep re-reading the last K-tile into a region nobody reads
         }
     };
+    unsigned long long xorg = 0;                     // scalar-origin loaders: the origin, and this lane's offset into the zero page
+    unsigned zoff = 0;
+    const unsigned dch16 = (unsigned)dchunk * 16;
+    if constexpr (s64_sorg<XL>::value) { xorg = uniform64((unsigned long long)(size_t)xl.org); zoff = xl.zero_off + dch16; }
     auto dma1v = [&](const __bf16* g, unsigned lds_addr) __attribute__((always_inline)) {
         asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
@@ -251,6 +311,15 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
             const unsigned long long kb = xbase[a] + (unsigned long long)s_xa[a].kt * (BK * 2);
             dma1(xo[a][0], kb, sa);
             dma1(xo[a][1], kb, sa + 8 * 1024);
+        } else if constexpr (s64_sorg<XL>::value) {
+            int koff, tap;
+            xl.ktile(s_xa[a].kt, koff, tap);                                   // scalar unit
+            const unsigned kc = (unsigned)koff + dch16;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const typename XL::Row& r = xrow.r[a][g];
+                dma1(((r.mask >> tap) & 1u) ? r.off + kc : zoff, xorg, sa + g * 8 * 1024);
+            }
         } else {
             dma1v(xl.ptr(xrow.r[a][0], s_xa[a].kt, dchunk), sa);
             dma1v(xl.ptr(xrow.r[a][1], s_xa[a].kt, dchunk), sa + 8 * 1024);
@@ -524,6 +593,21 @@ static hipError_t gemm_bf16s64_launch(const __bf16* X, long ldx, const __bf16* W
     if (M <= 0) return hipSuccess;
     if (!gemm_bf16s64_ok(M, N, K, ldx, ldw)) return hipErrorInvalidValue;
     return gemm_bf16s64_launch_x(X64Plain{X, ldx}, Wb, ldw, epi, M, N, K, num_cu, stream);
+}
+
+// Scalar-origin addressing of a convolution operand (X64Conv3S / X64ConvES): the origin is the lower of (map - reach) and the zero page; false when
+// the map's end or the zero page lies 4 GB or more above it (the caller keeps the per-lane pointer form).  g_conv_addressing
+// (egotap_debug_conv_addressing; defined once, in part 3 of the library): 0 = scalar origin where it fits (default), 1 = per-lane pointers always.
+extern int g_conv_addressing;
+static inline bool s64_conv_origin(const __bf16* in, size_t bytes, size_t reach, const __bf16* zero, const __bf16*& org, unsigned& in_off, unsigned& zero_off) {
+    const unsigned long long a = (unsigned long long)(size_t)in, z = (unsigned long long)(size_t)zero;
+    if (g_conv_addressing == 1 || a < reach) return false;
+    const unsigned long long lo = a - reach < z ? a - reach : z, hi = a + bytes > z + 256 ? a + bytes : z + 256;
+    if (hi - lo >= (1ull << 32) - 4096) return false;
+    org = (const __bf16*)(size_t)lo;
+    in_off = (unsigned)(a - lo);
+    zero_off = (unsigned)(z - lo);
+    return true;
 }
 
 // Dispatch of a plain-operand NT product: the 64-deep kernel where its shape rules hold, the 32-deep one otherwise (ragged K, narrow

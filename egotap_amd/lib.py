@@ -41,6 +41,7 @@ _PROTOS = {
     "egotap_pu_chain_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "egotap_debug_pu_drop_workgroups": (C.c_int, [C.c_void_p, C.c_int]),
     "egotap_debug_gemm_bk": (C.c_int, [C.c_int]),
+    "egotap_debug_conv_addressing": (C.c_int, [C.c_int]),
     "egotap_set_weight_scratch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "egotap_set_act_scratch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "egotap_hm_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),

@@ -27,6 +27,11 @@ int egotap_lift_debug_stop(egotap_handle h, int stage);
  * 32 / 64 = always that one (64 fails on shapes it does not take).  Both run the same MFMAs in the same k order: bit-identical results. */
 int egotap_debug_gemm_bk(int bk);
 
+/* ---- measurement / test switch (process wide): how the 64-deep GEMM addresses a convolution operand (csrc/gemm_bf16s64.h): 0 (default) = one
+ * wave-uniform origin + 32-bit lane offsets where map and zero page lie within 4 GB of each other, 1 = a 64-bit pointer per lane always.  The same
+ * bytes are fetched either way: bit-identical results. */
+int egotap_debug_conv_addressing(int mode);
+
 /* ---- host-side planning, exposed for unit tests ---- */
 /* (test aid, host only: no device call) the number of partial slabs a weight-gradient launch splits its contraction into, and the slabs per split:
  * workgroups in a row on the busiest CU x slabs each + a fixed part per workgroup + the traffic of the slab reduction, within slab_bytes of

@@ -171,7 +171,8 @@ def test_hm_forward_bf16_large_batch_routes_layers_2_to_4_through_the_64_deep_ge
     GEMM with the X64ConvE loader (stride 1 and 2, 64-channel weight slabs); below ~130 frames layer4 still takes the 32-deep kernel's
     split-K path, so the small-batch tests never reach it.  B = 136: against the same forward pinned to the 32-deep kernels
     (egotap_debug_gemm_bk(32): another summation order, so bf16 roundings flip -- relative L2 of a few 1e-3, a wrong tap / slab / eye
-    would be O(1)), run-to-run bits, and the last frame against the float64 oracle."""
+    would be O(1)), run-to-run bits, and the last frame against the float64 oracle.  [r5] The default addressing of the convolution operands
+    (X64ConvES / X64Conv3S: one wave-uniform origin + 32-bit lane offsets) against the per-lane pointer form: the same bits."""
     from gpu_util import hm_net
     from oracle import hm_ref as H
     from egotap_amd import lib
@@ -191,10 +192,14 @@ def test_hm_forward_bf16_large_batch_routes_layers_2_to_4_through_the_64_deep_ge
         lib.check(L.egotap_debug_gemm_bk(0))
         new = net(lc, rc)
         again = net(lc, rc)
+        lib.check(L.egotap_debug_conv_addressing(1))       # [r5] per-lane pointers instead of a scalar origin + lane offsets: the same bytes fetched
+        by_pointer = net(lc, rc)
     finally:
+        lib.check(L.egotap_debug_conv_addressing(0))
         lib.check(L.egotap_debug_gemm_bk(0))
         net.set_precision("f32")
     assert torch.equal(new, again)
+    assert torch.equal(new, by_pointer)
     assert not torch.equal(new, old)                        # the two routings are different kernels
     new, old = new.double().cpu(), old.double().cpu()
     rel_route = float((new - old).norm() / old.norm())
