@@ -29,6 +29,21 @@ constexpr int BUF = 2 * TILEB + LSB;               // Q image | dO image | lse, 
 __device__ __forceinline__ void dma16(const void* g, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
 }
+// [r5] the same DMA with the address as a wave-uniform 64-bit base (scalar registers) + a 32-bit byte offset per lane: every tile of these kernels is
+// "uniform tile origin + a lane pattern fixed for the whole kernel", so the per-lane 64-bit add (and the 64-bit address operand) of the flat form is dropped.
+// -DEGOTAP_ATT_DMA_FLAT keeps the per-lane pointer form (A/B: profiles/r05_attention_ab.log).
+__device__ __forceinline__ unsigned long long uniform64(const void* p) {
+    const unsigned long long v = (unsigned long long)(size_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ void dma16s(unsigned voff, unsigned long long sbase, unsigned lds_addr) {
+#ifdef EGOTAP_ATT_DMA_FLAT
+    dma16((const char*)(size_t)sbase + voff, lds_addr);
+#else
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+#endif
+}
 __device__ __forceinline__ void dma4(const void* g, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
 }
@@ -141,16 +156,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_bf16s2_kernel(const _
     for (int e = 0; e < 8; ++e) dma16(qkv + (long)k0 * ld3 + 2 * D + dma_src(e, lane, ld3), lds0 + vimg + 1024 * e);
 
     // DMA duty per tile: 8-row group `wid` of the Q tile and of the dO tile (two pieces each); wave 0 also fetches lse | delta
-    const int oq0 = dma_src(2 * wid, lane, ld3), oq1 = dma_src(2 * wid + 1, lane, ld3);
-    const int od0 = dma_src(2 * wid, lane, D), od1 = dma_src(2 * wid + 1, lane, D);
+    const unsigned oq0 = 2u * dma_src(2 * wid, lane, ld3), oq1 = 2u * dma_src(2 * wid + 1, lane, ld3);      // byte offsets from the tile's first row
+    const unsigned od0 = 2u * dma_src(2 * wid, lane, D), od1 = 2u * dma_src(2 * wid + 1, lane, D);
     auto issue = [&](int qt, unsigned boff) __attribute__((always_inline)) {
-        const __bf16* qs = qkv + (long)(qt * 32) * ld3;
-        const __bf16* ds = dob + (long)(qt * 32) * D;
+        const unsigned long long qs = uniform64(qkv + (long)(qt * 32) * ld3);
+        const unsigned long long ds = uniform64(dob + (long)(qt * 32) * D);
         const unsigned a = lds0 + boff + 2048 * wid;
-        dma16(qs + oq0, a);
-        dma16(qs + oq1, a + 1024);
-        dma16(ds + od0, a + TILEB);
-        dma16(ds + od1, a + TILEB + 1024);
+        dma16s(oq0, qs, a);
+        dma16s(oq1, qs, a + 1024);
+        dma16s(od0, ds, a + TILEB);
+        dma16s(od1, ds, a + TILEB + 1024);
         if (wid == 0) dma4((lane < 32 ? lsep : delp - 32) + qt * 32 + lane, lds0 + boff + 2 * TILEB);
     };
     const LaneAddr la = lane_addr(lane);
@@ -250,19 +265,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_bf16s2_kernel(const __
     const int q0 = min(qb * 32, N - 32);
     const long orow = ((long)b * N + q0 + l31) * D + h * DH;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sm2;
-    int ok[4];                                                 // this wave's 4 K pieces of a step (the V pieces sit D elements further)
+    unsigned ok[4];                                            // this wave's 4 K pieces of a step, in bytes from the step's first row (the V pieces sit D elements further)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int e = 4 * wid + i;
-        ok[i] = 32 * (e >> 3) * ld3 + D + dma_src(e & 7, lane, ld3);
+        ok[i] = 2u * (unsigned)(32 * (e >> 3) * ld3 + D + dma_src(e & 7, lane, ld3));
     }
     auto issue = [&](int kt, unsigned boff) __attribute__((always_inline)) {
-        const __bf16* src = qkv + (long)(kt * 64) * ld3;
+        const unsigned long long src = uniform64(qkv + (long)(kt * 64) * ld3);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned a = lds0 + boff + 1024 * (4 * wid + i);         // piece e of the step: image e >> 3, piece e & 7 = byte 1024 e
-            dma16(src + ok[i], a);
-            dma16(src + ok[i] + D, a + 2 * TILEB);
+            dma16s(ok[i], src, a);
+            dma16s(ok[i], src + 2ull * D, a + 2 * TILEB);
         }
     };
     issue(0, 0);
@@ -389,17 +404,17 @@ __global__ __launch_bounds__(64 * NW, 3) void attention_bf16s3_kernel(const __bf
     const int q0 = min(qb * 32, N - 32);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sm3;
     constexpr int PPW = (8 + NW - 1) / NW;                     // pieces per wave: wave w takes pieces w, w + NW, ... < 8 of the K and of the V image
-    int ok[PPW];
+    unsigned ok[PPW];                                          // bytes from the tile's first row
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) ok[i] = D + dma_src(min(wid + i * NW, 7), lane, ld3);
+    for (int i = 0; i < PPW; ++i) ok[i] = 2u * (unsigned)(D + dma_src(min(wid + i * NW, 7), lane, ld3));
     auto issue = [&](int kt, unsigned boff) __attribute__((always_inline)) {
-        const __bf16* src = qkv + (long)(kt * 32) * ld3;
+        const unsigned long long src = uniform64(qkv + (long)(kt * 32) * ld3);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             if (wid + i * NW < 8) {                             // wave-uniform
                 const unsigned a = lds0 + boff + 1024 * (wid + i * NW);
-                dma16(src + ok[i], a);
-                dma16(src + ok[i] + D, a + TILEB);
+                dma16s(ok[i], src, a);
+                dma16s(ok[i], src + 2ull * D, a + TILEB);
             }
         }
     };

@@ -30,7 +30,7 @@ struct ALoadPlain {
     // address of the 4 floats load() returns: loaders that are pure address math can feed the global -> LDS DMA (gemm_f32_dma.h)
     static constexpr bool HAS_PTR = true;
     __device__ __forceinline__ const float* ptr(const Row& r, int k) const { return r.p + k; }
-    __host__ bool dma_ok() const { return lda % 4 == 0 && ((uintptr_t)A & 15) == 0; }
+    __host__ bool dma_ok() const { return lda % 4 == 0 && lda < (1L << 21) && ((uintptr_t)A & 15) == 0; }
 };
 
 // ViT patch embedding input: token (b, pr, pc) of the tiled (grid*hm)^2 image, K = 16*16

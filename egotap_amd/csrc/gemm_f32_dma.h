@@ -55,18 +55,43 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
     const int drow = lane >> 2, dchunk = (lane & 3) ^ (lane >> 4);
     typename ALoad::Row ra0, ra1;
     const float *pb0, *pb1;
+    // [r5] plain row-major operands: a wave-uniform 64-bit base per tile (scalar registers) + a 32-bit byte offset per lane -- the global_load_lds
+    // s[base] form -- instead of a 64-bit pointer per lane (-DEGOTAP_F32_DMA_FLAT keeps the pointer form for the A/B).  W is always plain rows.
+#ifdef EGOTAP_F32_DMA_FLAT
+    constexpr bool SBA = false, SBW = false;
+#else
+    constexpr bool SBA = std::is_same<ALoad, ALoadPlain>::value, SBW = true;
+#endif
+    unsigned long long abase = 0, wbase = 0;
+    unsigned ao0 = 0, ao1 = 0;
+    auto uniform64 = [](const void* p) __attribute__((always_inline)) {
+        const unsigned long long v = (unsigned long long)(size_t)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    const unsigned wo0 = (unsigned)(((long)(wid * 16 + drow) * W.ld + dchunk * 4) * 4), wo1 = (unsigned)(((long)((wid + 8) * 16 + drow) * W.ld + dchunk * 4) * 4);
     int l_tile = 0, l_kt = 0;
     auto set_rows = [&](int i) __attribute__((always_inline)) {
         int tm, tn;
         tile_of(i, tm, tn);
+        if constexpr (SBA) {
+            abase = uniform64(al.A + (long)tm * BM * al.lda);
+            const long ld = al.lda * 4;                                                                      // bytes per row
+            ao0 = (unsigned)((long)(min(tm * BM + wid * 16 + drow, M - 1) - tm * BM) * ld + dchunk * 16);
+            ao1 = (unsigned)((long)(min(tm * BM + (wid + 8) * 16 + drow, M - 1) - tm * BM) * ld + dchunk * 16);
+        } else {
         ra0 = al.row(min(tm * BM + wid * 16 + drow, M - 1));
         ra1 = al.row(min(tm * BM + (wid + 8) * 16 + drow, M - 1));
+        }
         // the segment of W is uniform over a tile (seg % 256 == 0): scalar selects, no indexed (vector) load of W.p[] whose
         // vmcnt wait would drain the DMA pipeline at every tile switch
         const int n0 = tn * BN, sidx = n0 / W.seg;
         const float* wp = (sidx == 0 ? W.p[0] : (sidx == 1 ? W.p[1] : W.p[2])) + (long)(n0 - sidx * W.seg) * W.ld;
+        if constexpr (SBW) wbase = uniform64(wp);
+        else {
         pb0 = wp + (long)(wid * 16 + drow) * W.ld + dchunk * 4;
         pb1 = wp + (long)((wid + 8) * 16 + drow) * W.ld + dchunk * 4;
+        }
     };
     set_rows(0);
     // The DMA goes through inline asm: the compiler's waitcnt pass treats __builtin_amdgcn_global_load_lds as a store to LDS that
@@ -79,13 +104,16 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
     };
     // one slab of this block's slab stream -> stage st.  Unconditional (past the end it re-reads the last slab into a stage
     // nobody reads) so that the number of DMA instructions in flight is a constant the waits below can count on.
+    auto dma1s = [&](unsigned voff, unsigned long long sbase, unsigned lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+    };
     auto dma_part = [&](int st, int part) __attribute__((always_inline)) {       // one of the four DMA instructions of a slab
         const unsigned sa = lds0 + st * Cfg::STAGE + wid * 1024;
         const int k0 = l_kt * BK;
-        if (part == 0) dma1(al.ptr(ra0, k0 + dchunk * 4), sa);
-        else if (part == 1) dma1(al.ptr(ra1, k0 + dchunk * 4), sa + 8 * 1024);
-        else if (part == 2) dma1(pb0 + k0, sa + BM * ROWB);
-        else dma1(pb1 + k0, sa + BM * ROWB + 8 * 1024);
+        if (part == 0) { if constexpr (SBA) dma1s(ao0, abase + (unsigned long long)k0 * 4, sa); else dma1(al.ptr(ra0, k0 + dchunk * 4), sa); }
+        else if (part == 1) { if constexpr (SBA) dma1s(ao1, abase + (unsigned long long)k0 * 4, sa + 8 * 1024); else dma1(al.ptr(ra1, k0 + dchunk * 4), sa + 8 * 1024); }
+        else if (part == 2) { if constexpr (SBW) dma1s(wo0, wbase + (unsigned long long)k0 * 4, sa + BM * ROWB); else dma1(pb0 + k0, sa + BM * ROWB); }
+        else { if constexpr (SBW) dma1s(wo1, wbase + (unsigned long long)k0 * 4, sa + BM * ROWB + 8 * 1024); else dma1(pb1 + k0, sa + BM * ROWB + 8 * 1024); }
     };
     auto dma_advance = [&]() __attribute__((always_inline)) {
         if (l_tile < my_n && ++l_kt == KT) {
@@ -274,6 +302,7 @@ static hipError_t gemm_f32_dma_launch(const ALoad& al, const SegMat& W, const Ep
     using Cfg = DmaF32Cfg;
     if (M <= 0) return hipSuccess;
     if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0 || !al.dma_ok() || W.ld % 4 != 0) return hipErrorInvalidValue;
+    if (W.ld >= (1L << 21) || K >= (1 << 21)) return hipErrorInvalidValue;      // 256 rows of an operand within the 32-bit lane offsets of the scalar-base DMA
     auto kern = gemm_f32_dma_kernel<ALoad, Epi>;
     static bool attr_done = false;
     if (!attr_done) {
