@@ -19,6 +19,7 @@
 // become MFMA operands, fixed summation order, no atomics -> bitwise reproducible.
 #pragma once
 #include "attention_bf16s.h"
+#include "lds_dma.h"
 
 namespace att2 {
 using namespace attnbf;
@@ -32,11 +33,7 @@ __device__ __forceinline__ void dma16(const void* g, unsigned lds_addr) {
 // [r5] the same DMA with the address as a wave-uniform 64-bit base (scalar registers) + a 32-bit byte offset per lane: every tile of these kernels is
 // "uniform tile origin + a lane pattern fixed for the whole kernel", so the per-lane 64-bit add (and the 64-bit address operand) of the flat form is dropped.
 // -DEGOTAP_ATT_DMA_FLAT keeps the per-lane pointer form (A/B: profiles/r05_attention_ab.log).
-__device__ __forceinline__ unsigned long long uniform64(const void* p) {
-    const unsigned long long v = (unsigned long long)(size_t)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
+__device__ __forceinline__ unsigned long long uniform64(const void* p) { return lds_dma_base(p); }      // lds_dma.h
 __device__ __forceinline__ void dma16s(unsigned voff, unsigned long long sbase, unsigned lds_addr) {
 #ifdef EGOTAP_ATT_DMA_FLAT
     dma16((const char*)(size_t)sbase + voff, lds_addr);

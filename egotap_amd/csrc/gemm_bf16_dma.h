@@ -16,6 +16,7 @@
 // per-wave transpose patch is 16 rows (two passes per 32x32 block) to leave LDS for the fourth stage.
 #pragma once
 #include "gemm_bf16.h"
+#include "lds_dma.h"
 
 struct DmaCfg {
     static constexpr int BM = 256, BN = 256, BK = 32, WM = 4, WN = 2, THREADS = 512, NS = 4, TM = 2, TN = 4;
@@ -60,19 +61,23 @@ __global__ __launch_bounds__(DmaCfg::THREADS, 2) void gemm_bf16_dma_kernel(const
     // DMA duty of this wave per slab: 16-row chunks wid and wid + 8 of A and of W.  Lane -> (row lane >> 2 of the chunk, chunk
     // position lane & 3), which holds logical chunk (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ (lane >> 4).
     const int drow = lane >> 2, dchunk = (lane & 3) ^ (lane >> 4);
-    const __bf16 *pa0, *pa1, *pb0, *pb1;
+    // [r5] wave-uniform 64-bit base per tile (scalar registers) + 32-bit byte offset per lane: the global_load_lds s[base] form
+    unsigned long long abase = 0, wbase = 0;
+    unsigned ao0 = 0, ao1 = 0;
+    auto uniform64 = [](const void* p) __attribute__((always_inline)) { return lds_dma_base(p); };      // lds_dma.h
+    const unsigned wo0 = (unsigned)(((long)(wid * 16 + drow) * W.ld + dchunk * 8) * 2), wo1 = (unsigned)(((long)((wid + 8) * 16 + drow) * W.ld + dchunk * 8) * 2);
     int l_tile = 0, l_kt = 0;
     auto set_rows = [&](int i) __attribute__((always_inline)) {
         int tm, tn;
         tile_of(i, tm, tn);
-        pa0 = A + (long)min(tm * BM + wid * 16 + drow, M - 1) * lda + dchunk * 8;
-        pa1 = A + (long)min(tm * BM + (wid + 8) * 16 + drow, M - 1) * lda + dchunk * 8;
+        abase = uniform64(A + (long)tm * BM * lda);
+        ao0 = (unsigned)(((long)(min(tm * BM + wid * 16 + drow, M - 1) - tm * BM) * lda + dchunk * 8) * 2);
+        ao1 = (unsigned)(((long)(min(tm * BM + (wid + 8) * 16 + drow, M - 1) - tm * BM) * lda + dchunk * 8) * 2);
         // the segment of W is uniform over a tile (seg % 256 == 0): scalar selects, no indexed (vector) load of W.p[] whose
         // vmcnt wait would drain the DMA pipeline at every tile switch
         const int n0 = tn * BN, sidx = n0 / W.seg;
         const __bf16* wp = (sidx == 0 ? W.p[0] : (sidx == 1 ? W.p[1] : W.p[2])) + (long)(n0 - sidx * W.seg) * W.ld;
-        pb0 = wp + (long)(wid * 16 + drow) * W.ld + dchunk * 8;
-        pb1 = wp + (long)((wid + 8) * 16 + drow) * W.ld + dchunk * 8;
+        wbase = uniform64(wp);
     };
     set_rows(0);
     // The DMA goes through inline asm: the compiler's waitcnt pass treats __builtin_amdgcn_global_load_lds as a store to LDS that
@@ -80,18 +85,19 @@ __global__ __launch_bounds__(DmaCfg::THREADS, 2) void gemm_bf16_dma_kernel(const
     // these instructions is counted by hand (constant number in flight, see the loop).  M0 (the LDS base of the DMA) is a reserved
     // register: the compiler keeps no value in it across statements, so writing it here needs no clobber.
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_dma;
-    auto dma1 = [&](const __bf16* g, unsigned lds_addr) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+    auto dma1 = [&](unsigned voff, unsigned long long sbase, unsigned lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
     // one slab of this block's slab stream -> stage st.  Unconditional (past the end it re-reads the last slab into a stage
     // nobody reads) so that the number of DMA instructions in flight is a constant the waits below can count on.
     auto dma = [&](int st) __attribute__((always_inline)) {
         const unsigned sa = lds0 + st * Cfg::STAGE + wid * 1024;
         const int k0 = l_kt * BK;
-        dma1(pa0 + k0, sa);
-        dma1(pa1 + k0, sa + 8 * 1024);
-        dma1(pb0 + k0, sa + BM * ROWB);
-        dma1(pb1 + k0, sa + BM * ROWB + 8 * 1024);
+        const unsigned long long ka = abase + (unsigned long long)k0 * 2, kw = wbase + (unsigned long long)k0 * 2;
+        dma1(ao0, ka, sa);
+        dma1(ao1, ka, sa + 8 * 1024);
+        dma1(wo0, kw, sa + BM * ROWB);
+        dma1(wo1, kw, sa + BM * ROWB + 8 * 1024);
         if (l_tile < my_n && ++l_kt == KT) {
             l_kt = 0;
             if (++l_tile < my_n) set_rows(l_tile);
@@ -190,7 +196,7 @@ static hipError_t gemm_bf16_dma_launch(const __bf16* A, long lda, const SegMatB&
                                        int num_cu, hipStream_t stream) {
     using Cfg = DmaCfg;
     if (M <= 0) return hipSuccess;
-    if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0 || lda % 8 != 0 || W.ld % 8 != 0) return hipErrorInvalidValue;
+    if (N % Cfg::BN != 0 || K % Cfg::BK != 0 || W.seg % Cfg::BN != 0 || lda % 8 != 0 || W.ld % 8 != 0 || lda >= (1L << 22) || W.ld >= (1L << 22)) return hipErrorInvalidValue;
     auto kern = gemm_bf16_dma_kernel<Epi>;
     static bool attr_done = false;
     if (!attr_done) {

@@ -261,10 +261,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
     struct Stream { int tile, kt; };                 // position of an issue stream: (tile index of this workgroup, K-tile inside it)
     Stream s_xa[2] = {{0, 0}, {0, 0}}, s_wb[2] = {{0, 0}, {0, 0}};
     unsigned long long xbase[2], wbase[2];           // wave-uniform bases of the streams' current tiles (bytes)
-    auto uniform64 = [](unsigned long long v) __attribute__((always_inline)) {
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return ((unsigned long long)hi << 32) | lo;
-    };
+    auto uniform64 = [](unsigned long long v) __attribute__((always_inline)) { return lds_dma_base(v); };      // lds_dma.h
     auto set_x = [&](int a, int i) __attribute__((always_inline)) {
         int tm, tn;
         tile_of(i, tm, tn);

@@ -9,6 +9,7 @@
 #pragma once
 #include <type_traits>
 #include "gemm_f32.h"
+#include "lds_dma.h"
 
 struct DmaF32Cfg {
     static constexpr int BM = 256, BN = 256, BK = 16, WM = 4, WN = 2, THREADS = 512, NS = 4, TM = 2, TN = 4;
@@ -64,11 +65,7 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
 #endif
     unsigned long long abase = 0, wbase = 0;
     unsigned ao0 = 0, ao1 = 0;
-    auto uniform64 = [](const void* p) __attribute__((always_inline)) {
-        const unsigned long long v = (unsigned long long)(size_t)p;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return ((unsigned long long)hi << 32) | lo;
-    };
+    auto uniform64 = [](const void* p) __attribute__((always_inline)) { return lds_dma_base(p); };      // lds_dma.h
     const unsigned wo0 = (unsigned)(((long)(wid * 16 + drow) * W.ld + dchunk * 4) * 4), wo1 = (unsigned)(((long)((wid + 8) * 16 + drow) * W.ld + dchunk * 4) * 4);
     int l_tile = 0, l_kt = 0;
     auto set_rows = [&](int i) __attribute__((always_inline)) {

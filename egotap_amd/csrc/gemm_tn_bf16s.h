@@ -21,6 +21,7 @@
 
 #include "gemm_bf16s.h"
 #include "gemm_tn_bf16.h"
+#include "lds_dma.h"
 
 struct TnSCfg {
     static constexpr int BN = 256, BK = 256, BKM = 32, NS = 4, THREADS = 512;
@@ -150,10 +151,7 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
     // landing in a stage nobody reads)
     unsigned oy0 = 0, oy1 = 0, ox0 = 0, ox1 = 0;
     unsigned long long ybase = 0, xbase = 0;
-    auto uniform64 = [](unsigned long long v) __attribute__((always_inline)) {
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return ((unsigned long long)hi << 32) | lo;
-    };
+    auto uniform64 = [](unsigned long long v) __attribute__((always_inline)) { return lds_dma_base(v); };      // lds_dma.h
     auto dma_s = [&](unsigned voff, unsigned long long sbase, unsigned lds_addr) __attribute__((always_inline)) {
         asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };

@@ -12,6 +12,7 @@
 #pragma once
 #include "common.h"
 #include "gemm_f32.h"
+#include "lds_dma.h"
 
 template <int BN_, int BK_, int BKM_, int WN_, int WK_>
 struct TnCfg {
@@ -282,14 +283,25 @@ static __global__ __launch_bounds__(TnDmaCfg::THREADS) void gemm_tn_f32_dma_kern
         asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
     // wave w stages rows w, w + 8, w + 16, w + 24 of both operands: 8 DMA instructions per wave and slab
-    const float* ga = dY + (long)(m_lo + wid) * ldy + n0 + lane * 4;
-    const float* gb = X + (long)(m_lo + wid) * ldx + k0 + lane * 4;
+    // [r5] a staged row is one wave instruction: wave-uniform row address (scalar registers) + 16 bytes per lane -- the global_load_lds s[base]
+    // form instead of a 64-bit pointer per lane (-DEGOTAP_TNF32_DMA_FLAT keeps the pointer form for the A/B)
+    auto dma1s = [&](unsigned voff, const float* base, unsigned lds_addr) __attribute__((always_inline)) {
+#ifdef EGOTAP_TNF32_DMA_FLAT
+        dma1((const float*)((const char*)base + voff), lds_addr);
+#else
+        const unsigned long long sb = lds_dma_base(base);      // lds_dma.h
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+#endif
+    };
+    const float* ga = dY + (long)(m_lo + wid) * ldy + n0;
+    const float* gb = X + (long)(m_lo + wid) * ldx + k0;
+    const unsigned lo16 = lane * 16;
     auto dma_slab = [&](int s, int buf) __attribute__((always_inline)) {
         const unsigned sa = lds0 + (unsigned)(buf * SF + wid * LDA) * 4u, sb = lds0 + (unsigned)(buf * SF + BKM * LDA + wid * LDB) * 4u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            dma1(ga + ((long)s * BKM + 8 * q) * ldy, sa + (unsigned)(8 * q * LDA) * 4u);
-            dma1(gb + ((long)s * BKM + 8 * q) * ldx, sb + (unsigned)(8 * q * LDB) * 4u);
+            dma1s(lo16, ga + ((long)s * BKM + 8 * q) * ldy, sa + (unsigned)(8 * q * LDA) * 4u);
+            dma1s(lo16, gb + ((long)s * BKM + 8 * q) * ldx, sb + (unsigned)(8 * q * LDB) * 4u);
         }
     };
 
