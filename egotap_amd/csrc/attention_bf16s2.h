@@ -28,7 +28,7 @@ constexpr int LSB = 256;                           // 32 log-sum-exp + 32 delta 
 constexpr int BUF = 2 * TILEB + LSB;               // Q image | dO image | lse, delta
 
 __device__ __forceinline__ void dma16(const void* g, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
 }
 // [r5] the same DMA with the address as a wave-uniform 64-bit base (scalar registers) + a 32-bit byte offset per lane: every tile of these kernels is
 // "uniform tile origin + a lane pattern fixed for the whole kernel", so the per-lane 64-bit add (and the 64-bit address operand) of the flat form is dropped.
@@ -38,11 +38,11 @@ __device__ __forceinline__ void dma16s(unsigned voff, unsigned long long sbase, 
 #ifdef EGOTAP_ATT_DMA_FLAT
     dma16((const char*)(size_t)sbase + voff, lds_addr);
 #else
-    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
 #endif
 }
 __device__ __forceinline__ void dma4(const void* g, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
 }
 
 // element offset (row * ld + column) this lane fetches for DMA piece e (0..7) of a 32 x 128 tile whose rows are ld elements apart:

@@ -97,7 +97,7 @@ static __global__ __launch_bounds__(Conv64Cfg::THREADS, 1) void conv64_direct_bf
                 const int gy = y0 - 1 + ((dma_info[jj] >> 20) & 15), gx = x0 - 1 + ((dma_info[jj] >> 24) & 63);
                 const bool ok = !(dma_info[jj] >> 30) && gy >= 0 && gy < S && gx >= 0 && gx < S;
                 const __bf16* g = ok ? corner + (dma_info[jj] & 0xfffff) : zero;
-                asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds0 + b * Cfg::HALO_BYTES + j * 1024)) : "memory");
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds0 + b * Cfg::HALO_BYTES + j * 1024)) : "memory");
             }
         }
     };

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
     // inline asm: the compiler's waitcnt pass would drain vmcnt(0) before every LDS read after __builtin_amdgcn_global_load_lds;
     // the waits are counted by hand below (a constant number of DMA instructions per phase, unconditionally)
     auto dma1 = [&](unsigned voff, unsigned long long sbase, unsigned lds_addr) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
     auto advance = [&](Stream& st, int which, bool is_x) __attribute__((always_inline)) {
         if (__builtin_expect(st.tile < my_n && ++st.kt == KT, 0)) {          // (rare: the common path falls through without a taken branch)
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
     const unsigned dch16 = (unsigned)dchunk * 16;
     if constexpr (s64_sorg<XL>::value) { xorg = uniform64((unsigned long long)(size_t)xl.org); zoff = xl.zero_off + dch16; }
     auto dma1v = [&](const __bf16* g, unsigned lds_addr) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
     auto issue_x = [&](int a, int buf) __attribute__((always_inline)) {        // XA_a of the stream's next K-tile -> K-tile buffer buf
         const unsigned sa = lds0 + buf * KBUF + (a ? Cfg::O_XA1 : Cfg::O_XA0) + wid * 1024;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(S64Cfg::THREADS, 2) void gemm_bf16s64_kernel(XL xl,
         // (no bias: the DMA still runs, from any valid 256 bytes -- the count per phase is a compile-time constant -- and is never read)
         const unsigned long long b = has_bias ? uniform64((unsigned long long)(size_t)bias_g + (unsigned long long)(tn * BN + wc * 64) * 4)
                                               : uniform64((unsigned long long)(size_t)Wb);
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" ::"v"((unsigned)(lane * 4)), "s"(b), "s"(__builtin_amdgcn_readfirstlane(patch_lds)) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"((unsigned)(lane * 4)), "s"(b), "s"(__builtin_amdgcn_readfirstlane(patch_lds)) : "memory");
     };
     // per-column constants of this lane: staged in the patch during the tile's first K-tile (LDS operations of a wave stay in order: the
     // epilogue's patch writes cannot overtake these reads), or from global memory for the epilogues with other constants / no bias

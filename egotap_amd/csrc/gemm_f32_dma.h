@@ -97,12 +97,12 @@ __global__ __launch_bounds__(DmaF32Cfg::THREADS, 2) void gemm_f32_dma_kernel(ALo
     // register: the compiler keeps no value in it across statements, so writing it here needs no clobber.
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_dmaf;
     auto dma1 = [&](const float* g, unsigned lds_addr) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
     // one slab of this block's slab stream -> stage st.  Unconditional (past the end it re-reads the last slab into a stage
     // nobody reads) so that the number of DMA instructions in flight is a constant the waits below can count on.
     auto dma1s = [&](unsigned voff, unsigned long long sbase, unsigned lds_addr) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
     auto dma_part = [&](int st, int part) __attribute__((always_inline)) {       // one of the four DMA instructions of a slab
         const unsigned sa = lds0 + st * Cfg::STAGE + wid * 1024;

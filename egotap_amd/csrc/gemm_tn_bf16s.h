@@ -144,7 +144,7 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
     const int c0 = (lane & 31) ^ fsw(r0), c1 = (lane & 31) ^ fsw(r1);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_t;
     auto dma1 = [&](const __bf16* g, unsigned lds_addr) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
     int ly = 0, lx = 0;            // next step of the dY / X issue streams; past the end they keep re-reading the zero page
     // FAST: lane offsets (bytes) from the step's wave-uniform base; past the end the streams re-read the split's last step (valid memory,
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(TnSCfg::THREADS, 2) void gemm_tn_bf16s_kernel(const
     unsigned long long ybase = 0, xbase = 0;
     auto uniform64 = [](unsigned long long v) __attribute__((always_inline)) { return lds_dma_base(v); };      // lds_dma.h
     auto dma_s = [&](unsigned voff, unsigned long long sbase, unsigned lds_addr) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
     constexpr bool PLAINX = std::is_same<XL, TXPlain>::value;
     if constexpr (FAST) {

@@ -280,7 +280,7 @@ static __global__ __launch_bounds__(TnDmaCfg::THREADS) void gemm_tn_f32_dma_kern
     // the DMA goes through inline asm and vmcnt is waited for by hand (see gemm_f32_dma.h for why)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_tnd;
     auto dma1 = [&](const float* g, unsigned lds_addr) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
     // wave w stages rows w, w + 8, w + 16, w + 24 of both operands: 8 DMA instructions per wave and slab
     // [r5] a staged row is one wave instruction: wave-uniform row address (scalar registers) + 16 bytes per lane -- the global_load_lds s[base]
@@ -290,7 +290,7 @@ static __global__ __launch_bounds__(TnDmaCfg::THREADS) void gemm_tn_f32_dma_kern
         dma1((const float*)((const char*)base + voff), lds_addr);
 #else
         const unsigned long long sb = lds_dma_base(base);      // lds_dma.h
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
 #endif
     };
     const float* ga = dY + (long)(m_lo + wid) * ldy + n0;
