@@ -28,7 +28,6 @@
 #include <type_traits>
 
 #include "gemm_bf16.h"
-#include "lds_dma.h"
 
 typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
 
@@ -382,31 +381,13 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
 #endif
     typename XL::Row xr0, xr1;
     const __bf16 *pw0, *pw1;
-    // [r5] plain row-major operands (W always, X when the loader is XPlain): a wave-uniform 64-bit base per tile (scalar registers) + a 32-bit byte
-    // offset per lane -- the global_load_lds s[base] form of gemm_bf16s64.h -- instead of a 64-bit pointer per lane (-DEGOTAP_BF16S_DMA_FLAT: A/B)
-#ifdef EGOTAP_BF16S_DMA_FLAT
-    constexpr bool SBX = false, SBW = false;
-#else
-    constexpr bool SBX = std::is_same<XL, XPlain>::value, SBW = true;
-#endif
-    unsigned long long xbase = 0, wbase = 0;
-    unsigned xo0 = 0, xo1 = 0;
-    auto uniform64 = [](const void* p) __attribute__((always_inline)) { return lds_dma_base(p); };      // lds_dma.h
-    const unsigned wo0 = (unsigned)(((long)((wid % (BN / 16)) * 16 + drow) * ldw + dchunk * 8) * 2);
-    const unsigned wo1 = NI == 4 ? (unsigned)(((long)((wid + 8) * 16 + drow) * ldw + dchunk * 8) * 2) : wo0;
     int lx_tile = 0, lx_kt = 0, lw_tile = 0, lw_kt = 0;       // position of the X / W issue streams (the W stream runs one phase ahead)
     int xkb = 0;                                               // k offset of the X stream's tile (split * K; 0 without split-K)
     auto set_x = [&](int i) __attribute__((always_inline)) {
         int tm, tn;
         tile_of(i, tm, tn);
-        if constexpr (SBX) {
-            xbase = uniform64(xl.A + (long)tm * BM * xl.lda);
-            xo0 = (unsigned)(((long)(min(tm * BM + wid * 16 + drow, M - 1) - tm * BM) * xl.lda + dchunk * 8) * 2);
-            xo1 = (unsigned)(((long)(min(tm * BM + (wid + 8) * 16 + drow, M - 1) - tm * BM) * xl.lda + dchunk * 8) * 2);
-        } else {
-            xr0 = xl.row(min(tm * BM + wid * 16 + drow, M - 1));
-            xr1 = xl.row(min(tm * BM + (wid + 8) * 16 + drow, M - 1));
-        }
+        xr0 = xl.row(min(tm * BM + wid * 16 + drow, M - 1));
+        xr1 = xl.row(min(tm * BM + (wid + 8) * 16 + drow, M - 1));
         xkb = ksplit > 1 ? (tn / tiles_n_real) * K : 0;
     };
     auto set_w = [&](int i) __attribute__((always_inline)) {
@@ -415,11 +396,8 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
         long koff = 0;
         if (ksplit > 1) { const int sp = tn / tiles_n_real; tn -= sp * tiles_n_real; koff = (long)sp * K; }
         constexpr int WBLK = BN / 16;                // 16-row blocks of the W part
-        if constexpr (SBW) wbase = uniform64(Wb + (long)(tn * BN) * ldw + koff);
-        else {
-            pw0 = Wb + (long)(tn * BN + (wid % WBLK) * 16 + drow) * ldw + koff + dchunk * 8;
-            pw1 = NI == 4 ? Wb + (long)(tn * BN + (wid + 8) * 16 + drow) * ldw + koff + dchunk * 8 : pw0;
-        }
+        pw0 = Wb + (long)(tn * BN + (wid % WBLK) * 16 + drow) * ldw + koff + dchunk * 8;
+        pw1 = NI == 4 ? Wb + (long)(tn * BN + (wid + 8) * 16 + drow) * ldw + koff + dchunk * 8 : pw0;
     };
     set_x(0);
     set_w(0);
@@ -429,19 +407,11 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
     auto dma1 = [&](const __bf16* g, unsigned lds_addr) __attribute__((always_inline)) {
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
     };
-    auto dma1s = [&](unsigned voff, unsigned long long sbase, unsigned lds_addr) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
-    };
     auto issue_w = [&](int st) __attribute__((always_inline)) {        // W part of the next K-tile of the W stream -> stage st
         const unsigned sa = lds0 + st * STAGE + PART + (wid % (BN / 16)) * 1024;
         const int k0 = lw_kt * BK;
-        if constexpr (SBW) {
-            dma1s(wo0, wbase + (unsigned long long)k0 * 2, sa);
-            if constexpr (NI == 4) dma1s(wo1, wbase + (unsigned long long)k0 * 2, sa + 8 * 1024);
-        } else {
-            dma1(pw0 + k0, sa);
-            if constexpr (NI == 4) dma1(pw1 + k0, sa + 8 * 1024);
-        }
+        dma1(pw0 + k0, sa);
+        if constexpr (NI == 4) dma1(pw1 + k0, sa + 8 * 1024);
         if (lw_tile < my_n && ++lw_kt == KT) {
             lw_kt = 0;
             if (++lw_tile < my_n) set_w(lw_tile);
@@ -451,13 +421,8 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
     auto issue_x = [&](int st) __attribute__((always_inline)) {
         const unsigned sa = lds0 + st * STAGE + wid * 1024;
         const int k0 = lx_kt * BK + xkb;
-        if constexpr (SBX) {
-            dma1s(xo0, xbase + (unsigned long long)k0 * 2, sa);
-            dma1s(xo1, xbase + (unsigned long long)k0 * 2, sa + 8 * 1024);
-        } else {
-            dma1(xl.ptr(xr0, k0, dchunk * 8), sa);
-            dma1(xl.ptr(xr1, k0, dchunk * 8), sa + 8 * 1024);
-        }
+        dma1(xl.ptr(xr0, k0, dchunk * 8), sa);
+        dma1(xl.ptr(xr1, k0, dchunk * 8), sa + 8 * 1024);
         if (lx_tile < my_n && ++lx_kt == KT) {
             lx_kt = 0;
             if (++lx_tile < my_n) set_x(lx_tile);
@@ -662,15 +627,12 @@ __global__ __launch_bounds__(SCfg::THREADS, 2) void gemm_bf16s_kernel(XL xl, con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing (dummy) DMAs must not outlive the workgroup's LDS
 }
 
-// 32-bit lane offsets of the scalar-base DMA: 256 rows of an operand lie within 4 GB of the tile's first row
-template <class XL> static inline bool s_dma_span_ok(const XL&, long ldw) { return ldw < (1L << 22); }
-template <> inline bool s_dma_span_ok<XPlain>(const XPlain& xl, long ldw) { return ldw < (1L << 22) && xl.lda < (1L << 22); }
 template <class XL, class Epi, int NI = 4>
 static hipError_t gemm_bf16s_launch(const XL& xl, const __bf16* Wb, long ldw, const Epi& epi, int M, int N, int K, int num_cu, hipStream_t stream) {
     using Cfg = SCfg;
     constexpr int BN = 64 * NI;
     if (M <= 0) return hipSuccess;
-    if (N % BN != 0 || K % Cfg::BK != 0 || ldw % 8 != 0 || !s_dma_span_ok(xl, ldw)) return hipErrorInvalidValue;
+    if (N % BN != 0 || K % Cfg::BK != 0 || ldw % 8 != 0) return hipErrorInvalidValue;
     auto kern = gemm_bf16s_kernel<XL, Epi, NI>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -720,7 +682,7 @@ static hipError_t gemm_bf16s_splitk_launch(const XL& xl, const __bf16* Wb, long 
                                            hipStream_t stream) {
     using Cfg = SCfg;
     if (M <= 0) return hipSuccess;
-    if (N % 256 != 0 || ksplit < 2 || K % (ksplit * Cfg::BK) != 0 || ldw % 8 != 0 || !s_dma_span_ok(xl, ldw)) return hipErrorInvalidValue;
+    if (N % 256 != 0 || ksplit < 2 || K % (ksplit * Cfg::BK) != 0 || ldw % 8 != 0) return hipErrorInvalidValue;
     auto kern = gemm_bf16s_kernel<XL, SEpiRawF32, 4>;
     static bool attr_done = false;
     if (!attr_done) {

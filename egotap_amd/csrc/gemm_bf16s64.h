@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "gemm_bf16s.h"
+#include "lds_dma.h"
 
 struct S64Cfg {
     static constexpr int BM = 256, BN = 256, BK = 64, THREADS = 512;
