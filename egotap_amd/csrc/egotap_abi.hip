@@ -599,38 +599,67 @@ static constexpr size_t SPLITK_FLOATS = (size_t)1 << 24;
 // The fitted constants below (0.2319 us per 16-deep K step of a 256 x 256 tile = 0.92 x 157.3 TF over 256 CUs, 5 us per round; the per-slab times inside
 // gemm_f32_splitk_plan / gemm_f32_direct_estimate_us) were measured on the 256-CU MI355X; `cus` only scales the round counts.  On another part they
 // would still pick a CORRECT kernel, not necessarily the faster one.
-enum { GS_BIG = 0, GS_DIRECT_A, GS_DIRECT_S, GS_SPLIT_S, GS_SPLIT_A };
-struct SmallRoute { int kind, splits; };
-static SmallRoute gemm_small_route(const Handle* h, bool plain_loader, int M, int N, int K, int wseg, int cus) {
+enum { GS_BIG = 0, GS_DIRECT_A, GS_DIRECT_S, GS_SPLIT_S, GS_SPLIT_A, GS_HYBRID };
+struct SmallRoute { int kind, splits, head_rows; };
+// epilogues that do not index their operands by the output ROW: a product may be cut into row ranges without touching the functor (GS_HYBRID)
+template <class E> struct epi_row_free : std::false_type {};
+template <> struct epi_row_free<EpiBias> : std::true_type {};
+template <> struct epi_row_free<EpiBiasGelu> : std::true_type {};
+template <> struct epi_row_free<EpiBnLrelu> : std::true_type {};
+template <> struct epi_row_free<EpiNone> : std::true_type {};
+static SmallRoute gemm_small_route(const Handle* h, bool plain_loader, int M, int N, int K, int wseg, int cus, bool row_free = false) {
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const long fill = (h && h->precision != EGOTAP_PREC_F32) ? 64 : 160;
-    if (N % 128 != 0 || K % 32 != 0 || wseg % 128 != 0) return SmallRoute{GS_BIG, 1};
+    if (N % 128 != 0 || K % 32 != 0 || wseg % 128 != 0) return SmallRoute{GS_BIG, 1, 0};
     if (tiles256 >= fill) {
         // [r4] fp32, plain operands, fewer than four rounds of 256 x 256 tiles: the 256 x 256 kernel runs WHOLE rounds at 0.92 of the matrix
         // pipe (B = 8, N = 4096: 288 tiles = two rounds for 1.1 rounds of work, 484 us) -- the 128 x 128 kernel with its epilogue inside takes
         // 415 us there.  Both estimates are fitted to tools/gemm_small_vs_big_probe.py and name the faster kernel at 46 of its 48 points.
         if (plain_loader && h && h->precision == EGOTAP_PREC_F32 && tiles256 < 4L * cus) {
-            const double t_big = (double)((tiles256 + cus - 1) / cus) * (K * 0.2319 + 5.0);
-            if (gemm_f32_direct_estimate_us<TileA>(M, N, K, cus) < t_big) return SmallRoute{GS_DIRECT_A, 1};
+            const double t_round = K * 0.2319 + 5.0;
+            const double t_big = (double)((tiles256 + cus - 1) / cus) * t_round;
+            const double t_direct = gemm_f32_direct_estimate_us<TileA>(M, N, K, cus);
+            // [r5] GS_HYBRID: the tile rows that fill WHOLE rounds of the 256 x 256 kernel run there, the rows past them as a product of their own
+            // (a few tiles: K split over the idle CUs) -- B = 8, N = 4096: one round of 256 tiles + 32 tiles split two ways, ~290 us for the 375 the
+            // 128 x 128 kernel took.  Only for epilogues that do not index by row (the functor is passed on unchanged).
+            if (row_free && N % 256 == 0 && tiles256 > cus) {
+                const int tn = N / 256, mh = (int)((tiles256 / cus) * cus / tn);      // whole tile rows inside the whole rounds
+                const int Mt = M - mh * 256;
+                if (mh >= 1 && Mt > 0) {
+                    const long tt = (long)((Mt + 255) / 256) * tn;
+                    const double t_head = (double)(((long)mh * tn + cus - 1) / cus) * t_round;
+                    const double t_tail = 4.0 + (tt >= fill ? std::min((double)((tt + cus - 1) / cus) * t_round, gemm_f32_direct_estimate_us<TileA>(Mt, N, K, cus))
+                                                            : gemm_f32_splitk_plan<TileA>(Mt, N, K, SPLITK_FLOATS, cus).us);
+                    if (t_head + t_tail < std::min(t_big, t_direct)) return SmallRoute{GS_HYBRID, 1, mh * 256};
+                }
+            }
+            if (t_direct < t_big) return SmallRoute{GS_DIRECT_A, 1, 0};
         }
-        return SmallRoute{GS_BIG, 1};
+        return SmallRoute{GS_BIG, 1, 0};
     }
     const SplitPlan pa = gemm_f32_splitk_plan<TileA>(M, N, K, SPLITK_FLOATS, cus);
     if (M <= 640) {   // [r4] one frame (576 rows = 4.5 tiles of 128 rows): the 64-row tile when its plan is estimated faster -- nine row tiles exactly, up
         // to one workgroup per CU without a split (qkv: 216 tiles, epilogue in the kernel: no partials, no reduce launch).  Measured: B = 1 forward
         // -33 us; from two frames on the 64-row tile loses what it gains (its slab is shorter than a load's round trip), so the rule stops here.
         const SplitPlan ps = gemm_f32_splitk_plan<TileS>(M, N, K, SPLITK_FLOATS, cus);
-        if (ps.us < pa.us) return SmallRoute{ps.splits == 1 ? GS_DIRECT_S : GS_SPLIT_S, ps.splits};
+        if (ps.us < pa.us) return SmallRoute{ps.splits == 1 ? GS_DIRECT_S : GS_SPLIT_S, ps.splits, 0};
     }
-    return SmallRoute{GS_SPLIT_A, pa.splits};
+    return SmallRoute{GS_SPLIT_A, pa.splits, 0};
 }
 template <class AL, class Epi>
 static hipError_t gemm_small(Handle* h, const char* role, const AL& al, const SegMat& W, const Epi& epi, float* C, long ldc,
                              int M, int N, int K, float* P, hipStream_t s) {
     const int cus = device_cu_count();
-    const SmallRoute r = gemm_small_route(h, std::is_same<AL, ALoadPlain>::value, M, N, K, W.seg, cus);
+    const SmallRoute r = gemm_small_route(h, std::is_same<AL, ALoadPlain>::value, M, N, K, W.seg, cus, epi_row_free<Epi>::value);
+    if constexpr (std::is_same<AL, ALoadPlain>::value && epi_row_free<Epi>::value) {
+        if (r.kind == GS_HYBRID) {      // whole rounds of 256 x 256 tiles, then the remaining rows routed as a product of their own (never GS_HYBRID again: fewer tiles than CUs)
+            hipError_t e = gemm_big(h, role, al, W, epi, C, ldc, r.head_rows, N, K, s);
+            if (e != hipSuccess) return e;
+            return gemm_small(h, role, ALoadPlain{al.A + (long)r.head_rows * al.lda, al.lda}, W, epi, C + (long)r.head_rows * ldc, ldc, M - r.head_rows, N, K, P, s);
+        }
+    }
     switch (r.kind) {
-        case GS_BIG: return gemm_big(h, role, al, W, epi, C, ldc, M, N, K, s);
+        case GS_BIG: case GS_HYBRID: return gemm_big(h, role, al, W, epi, C, ldc, M, N, K, s);
         case GS_DIRECT_A: return gemm<TileA>(h, role, al, W, epi, C, ldc, M, N, K, s);
         case GS_DIRECT_S: return gemm<TileS>(h, role, al, W, epi, C, ldc, M, N, K, s);
         case GS_SPLIT_S: {

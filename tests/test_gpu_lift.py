@@ -244,7 +244,7 @@ def test_every_gemm_routing_regime_matches_the_golden(tag, preset):
     try:
         for mode, gate in (("f32", TOL), ("bf16x3", TOL)):
             net.set_precision(mode)
-            for B in (1, 3, 7, 30, 31, 34, 35, 36, 63, 106, 107, 108, 129):
+            for B in (1, 3, 7, 8, 12, 20, 30, 31, 34, 35, 36, 63, 106, 107, 108, 129):      # [r5] 8 ... 36: whole rounds of 256 x 256 tiles + a split tail (fc1 / qkv)
                 x = two.repeat((B + 1) // 2, 1, 1, 1)[:B].contiguous()
                 out = net.predict_pose(x).cpu().numpy()
                 ref = np.tile(g["pose"], ((B + 1) // 2, 1, 1))[:B]
