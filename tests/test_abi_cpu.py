@@ -186,6 +186,9 @@ def test_host_side_argument_checks_of_the_newer_entry_points():
         assert lib.egotap_attention_f32(None, None, 1, 144, 8, None) == 1 and b"null" in lib.egotap_last_error()
         assert lib.egotap_attention_f32(C.c_void_p(256), C.c_void_p(256), 1, 30, 8, None) == 1 and b"at least 32" in lib.egotap_last_error()
         L.check(lib.egotap_set_precision(h, 0))
+        # [r5] the measurement switch of the convolution operands' addressing (host state only): 0 / 1, anything else refused by name
+        assert lib.egotap_debug_conv_addressing(2) == 1 and b"mode must be 0" in lib.egotap_last_error()
+        assert lib.egotap_debug_conv_addressing(1) == 0 and lib.egotap_debug_conv_addressing(0) == 0
     finally:
         lib.egotap_destroy(h)
     # Python wrappers refuse CPU tensors (no CPU fallback) and inconsistent shapes

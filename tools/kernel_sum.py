@@ -1,3 +1,5 @@
+"""Per-kernel digest of a `rocprofv3 --kernel-trace --stats --output-format csv -d <dir>` run: launches, average and total microseconds per
+forward.  usage: kernel_sum.py <dir> <number of forwards the run made>"""
 import csv,sys,glob
 f=glob.glob(sys.argv[1]+"/**/*kernel_stats.csv",recursive=True)[0]
 n=float(sys.argv[2])
