@@ -838,9 +838,15 @@ static hipError_t fc1_nt(Handle* h, int which, const __bf16* src, const __bf16* 
     const int HW = h->cfg.hm_size * h->cfg.hm_size;
     const bool deep = g_gemm_bf16s_bk != 32 && K % 64 == 0 && K >= 128 && (which == 0 ? h->D % 64 == 0 : HW % 64 == 0) && (long)256 * K * 2 < (1L << 31);
     if (which == 0) {
+        // [r5] tensors under 4 GB (every shipped batch): scalar origin + 32-bit lane offsets (X64TokensS / X64RotS); the pointer loaders otherwise
+        const size_t tok_bytes = (size_t)(BT / h->T) * h->seq * h->D * 2;
+        if (deep && g_conv_addressing == 0 && tok_bytes < ((size_t)1 << 32) - 4096)
+            return gemm_bf16s64_launch_x(X64TokensS{src, 0u, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, w, K, ep, BT, 2048, (int)K, cus, s);
         if (deep) return gemm_bf16s64_launch_x(X64Tokens{src, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, w, K, ep, BT, 2048, (int)K, cus, s);
         return gemm_bf16s_launch(XTokens{src, h->T, h->D, h->seq, h->side, h->ppd, h->grid}, w, K, ep, BT, 2048, (int)K, cus, s);
     }
+    const size_t hm_bytes = (size_t)(BT / (2 * h->J)) * h->C * HW * 2;
+    if (deep && g_conv_addressing == 0 && hm_bytes < ((size_t)1 << 32) - 4096) return gemm_bf16s64_launch_x(X64RotS{src, 0u, h->C, h->J, HW}, w, K, ep, BT, 2048, (int)K, cus, s);
     if (deep) return gemm_bf16s64_launch_x(X64Rot{src, h->C, h->J, HW}, w, K, ep, BT, 2048, (int)K, cus, s);
     return gemm_bf16s_launch(XRot{src, h->C, h->J, HW}, w, K, ep, BT, 2048, (int)K, cus, s);
 }

@@ -157,6 +157,42 @@ struct X64ConvES {
         koff = ((dy * (stride << log2So) + dx) * (2 * C) + 64 * slab) * 2;
     }
 };
+// [r5] the fc1 gathers in the same form: a row's byte offset from the tensor + a wave-uniform offset per K-tile (every lane valid: mask 1, tap 0)
+struct X64TokensS {
+    static constexpr bool SBASE = false, SORG = true;
+    const __bf16* org;               // = Y
+    unsigned zero_off;               // unused (no lane is ever invalid)
+    int T, D, seq, side, ppd, grid;
+    struct Row { unsigned off; unsigned mask; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int b = m / T, i = m - b * T;
+        return Row{(unsigned)(((long)b * seq + (long)(ppd * (i / grid)) * side + ppd * (i % grid)) * D * 2), 1u};
+    }
+    __device__ __forceinline__ void ktile(int kt, int& koff, int& tap) const {
+        const int k0 = kt * 64, s = k0 / D, c = k0 - s * D;
+        const int prl = s / ppd, pcl = s - prl * ppd;
+        koff = ((prl * side + pcl) * D + c) * 2;
+        tap = 0;
+    }
+};
+struct X64RotS {
+    static constexpr bool SBASE = false, SORG = true;
+    const __bf16* org;               // = hm
+    unsigned zero_off;
+    int C, J, HW;
+    struct Row { unsigned off; unsigned mask; };
+    __device__ __forceinline__ Row row(int m) const {
+        const int T = 2 * J;
+        const int b = m / T, t = m - b * T;
+        const int eye = t / J, j = t - eye * J;
+        return Row{(unsigned)((long)(b * C + 2 * J + eye * 2 * J + j) * HW * 2), 1u};
+    }
+    __device__ __forceinline__ void ktile(int kt, int& koff, int& tap) const {
+        const int k0 = kt * 64, cs = k0 / HW;
+        koff = (cs * J * HW + (k0 - cs * HW)) * 2;
+        tap = 0;
+    }
+};
 template <class XL, class = void> struct s64_sorg { static constexpr bool value = false; };
 template <class XL> struct s64_sorg<XL, std::enable_if_t<XL::SORG>> { static constexpr bool value = true; };
 

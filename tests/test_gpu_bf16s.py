@@ -417,10 +417,13 @@ def test_fc1_forward_on_the_64_deep_kernel_has_the_bits_of_the_32_deep_one(B):
             for bk in (32, 0):
                 lib.check(L.egotap_debug_gemm_bk(bk))
                 outs[bk] = bf16s.fc1_fwd(h, which, src.cuda(), w.cuda(), bias.cuda(), B, T).clone()
+            lib.check(L.egotap_debug_conv_addressing(1))      # [r5] the 64-deep kernel's gather by per-lane pointers (X64Tokens / X64Rot) instead of a scalar origin
+            outs["ptr"] = bf16s.fc1_fwd(h, which, src.cuda(), w.cuda(), bias.cuda(), B, T).clone()
         finally:
+            lib.check(L.egotap_debug_conv_addressing(0))
             lib.check(L.egotap_debug_gemm_bk(0))
         torch.cuda.synchronize()
-        assert torch.equal(outs[32], outs[0]), which
+        assert torch.equal(outs[32], outs[0]) and torch.equal(outs["ptr"], outs[0]), which
         ref = X @ w.double().T + bias.double()
         err = float((outs[0].double().cpu() - ref).abs().max())
         assert err < 2e-5 * float(ref.abs().max()) + 1e-5, (which, B, err)
